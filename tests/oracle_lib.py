@@ -1,0 +1,122 @@
+"""ctypes wrapper around oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (the checker, never the
+product).  Builds the oracle on first use if the .so is missing (gcc only, seconds)."""
+import ctypes as C, pathlib, subprocess
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+P = 0xFFFFFFFF00000001
+_u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        for name in ("orc_gl_mul", "orc_gl_mul_slow", "orc_gl_add", "orc_gl_sub", "orc_gl_pow"):
+            getattr(L, name).restype = C.c_uint64
+            getattr(L, name).argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_gl_inv.restype = C.c_uint64; L.orc_gl_inv.argtypes = [C.c_uint64]
+        L.orc_gl_root.restype = C.c_uint64; L.orc_gl_root.argtypes = [C.c_uint]
+        L.orc_bitrev.restype = C.c_uint32; L.orc_bitrev.argtypes = [C.c_uint32, C.c_uint]
+        L.orc_f3_mul.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_f3_inv.argtypes = [_u64p, _u64p]
+        L.orc_f3_pow.argtypes = [_u64p, C.c_uint64, _u64p]
+        L.orc_ntt.argtypes = [_u64p, _u64p, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_lde.argtypes = [_u64p, C.c_uint32, C.c_uint32, _u64p, C.c_uint32]
+        L.orc_poseidon.argtypes = [_u64p, _u64p, _u64p, C.c_int]
+        L.orc_linearhash.argtypes = [_u64p, C.c_size_t, _u64p]
+        L.orc_merkle_n_nodes.restype = C.c_uint64; L.orc_merkle_n_nodes.argtypes = [C.c_uint64]
+        L.orc_merkelize.argtypes = [_u64p, C.c_uint32, C.c_uint64, _u64p]
+        L.orc_merkle_proof.restype = C.c_int
+        L.orc_merkle_proof.argtypes = [_u64p, C.c_uint64, C.c_uint64, _u64p]
+        L.orc_merkle_root_from_proof.argtypes = [_u64p, C.c_uint32, _u64p, C.c_int, C.c_uint64, _u64p]
+        L.orc_tr_sizeof.restype = C.c_size_t
+        L.orc_tr_init.argtypes = [C.c_void_p]
+        L.orc_tr_put.argtypes = [C.c_void_p, _u64p, C.c_size_t]
+        L.orc_tr_get1.restype = C.c_uint64; L.orc_tr_get1.argtypes = [C.c_void_p]
+        L.orc_tr_get_field.argtypes = [C.c_void_p, _u64p]
+        L.orc_tr_get_permutations.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _u64p]
+
+    # -- field
+    def mul(self, a, b): return self.lib.orc_gl_mul(a, b)
+    def add(self, a, b): return self.lib.orc_gl_add(a, b)
+    def sub(self, a, b): return self.lib.orc_gl_sub(a, b)
+    def inv(self, a): return self.lib.orc_gl_inv(a)
+    def pow(self, a, e): return self.lib.orc_gl_pow(a, e)
+    def root(self, k): return self.lib.orc_gl_root(k)
+    def f3_mul(self, a, b):
+        o = np.zeros(3, np.uint64); self.lib.orc_f3_mul(_a(a), _a(b), o); return o
+    def f3_inv(self, a):
+        o = np.zeros(3, np.uint64); self.lib.orc_f3_inv(_a(a), o); return o
+    def f3_pow(self, a, e):
+        o = np.zeros(3, np.uint64); self.lib.orc_f3_pow(_a(a), e, o); return o
+
+    # -- transforms (row-major [1<<nbits][n_pols])
+    def ntt(self, src, n_pols, nbits, inverse=False):
+        src = _a(src); dst = np.empty_like(src)
+        self.lib.orc_ntt(src, dst, n_pols, nbits, int(inverse)); return dst
+    def lde(self, src, n_pols, nbits, nbits_ext):
+        src = _a(src); dst = np.empty((1 << nbits_ext) * n_pols, np.uint64)
+        self.lib.orc_lde(src, n_pols, nbits, dst, nbits_ext); return dst
+
+    # -- hashing
+    def poseidon(self, inp, cap, n_out=4):
+        o = np.zeros(n_out, np.uint64); self.lib.orc_poseidon(_a(inp), _a(cap), o, n_out); return o
+    def linearhash(self, v):
+        v = _a(v); o = np.zeros(4, np.uint64); self.lib.orc_linearhash(v, v.size, o); return o
+    def n_nodes(self, height): return self.lib.orc_merkle_n_nodes(height)
+    def merkelize(self, buff, width, height):
+        nodes = np.zeros(self.n_nodes(height) * 4, np.uint64)
+        self.lib.orc_merkelize(_a(buff), width, height, nodes); return nodes
+    def merkle_proof(self, nodes, height, idx):
+        path = np.zeros(64 * 4, np.uint64)
+        d = self.lib.orc_merkle_proof(nodes, height, idx, path); return path[:4 * d].copy()
+    def root_from_proof(self, row, path, idx):
+        row = _a(row); path = _a(path); r = np.zeros(4, np.uint64)
+        self.lib.orc_merkle_root_from_proof(row, row.size, path, path.size // 4, idx, r); return r
+
+    def transcript(self):
+        return Transcript(self)
+
+
+class Transcript:
+    def __init__(self, o):
+        self.o = o; self.buf = C.create_string_buffer(o.lib.orc_tr_sizeof())
+        o.lib.orc_tr_init(self.buf)
+    def put(self, v):
+        v = _a(v); self.o.lib.orc_tr_put(self.buf, v, v.size)
+    def get1(self): return self.o.lib.orc_tr_get1(self.buf)
+    def get_field(self):
+        o = np.zeros(3, np.uint64); self.o.lib.orc_tr_get_field(self.buf, o); return o
+    def get_permutations(self, n, nbits):
+        o = np.zeros(n, np.uint64); self.o.lib.orc_tr_get_permutations(self.buf, n, nbits, o); return o
+
+
+def _a(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64).reshape(-1))
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle")])
+
+
+_cached = None
+def load():
+    global _cached
+    if _cached is None:
+        so = ROOT / "oracle" / "liboracle.so"
+        if not so.exists():
+            build()
+        _cached = Oracle(C.CDLL(str(so)))
+    return _cached
+
+
+def splitmix64_stream(seed, n):
+    """x_i = splitmix64(seed, i) mod p -- the synthetic input of BASELINE config 2."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return np.where(z >= np.uint64(P), z - np.uint64(P), z)
