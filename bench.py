@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X.
+
+Workload (config.workload): BASELINE config 2, "2^24-point Goldilocks radix-2 forward+inverse NTT
+on one MI355X": one column, n = 2^24, x_i = splitmix64(seed, i) mod p, resident in HBM before the
+timed region.  One step = forward NTT then inverse NTT of that column (2 transforms).
+
+  value    = Goldilocks NTT throughput, GElem/s = n_gpus * 2 * 2^24 * steps / time (whole job)
+  roofline = dominant kernel (ntt_pass_kernel, 3 launches per transform): achieved =
+             ALGORITHMIC bytes per launch (16 B/element/transform, SURVEY 8d, divided over the
+             transform's passes) / average launch duration measured with HIP events on the launch
+             stream; `pass_hbm_frac` additionally rates the bytes each pass really moves (16 B per
+             element per pass) against the 8 TB/s peak.
+  cpu_baseline = the CPU oracle (a port of the reference algorithm, fft.rs:39-83) on the same
+             2^24 column, one step, timed on rank 0's host cores.
+
+N > 1: one process per GPU, each transforming its own column (independent replicas: a single NTT
+does not shard without an all-to-all that no BASELINE config needs -- DESIGN.md (e)); no data-path
+collective, barrier + max-over-ranks timing only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+NBITS = 24
+SEED = 0x9E3779B97F4A7C15
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nbits", type=int, default=NBITS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import zkgpu_loader, oracle_lib
+    zk = zkgpu_loader.load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    zk.init(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = zk.lib()
+    nbits, n = args.nbits, 1 << args.nbits
+    x_host = oracle_lib.splitmix64_stream(SEED + rank, n)            # synthetic input (generator only)
+    dev = torch.device("cuda", local_rank)
+    x = torch.from_numpy(x_host.view(np.int64)).to(dev)              # resident in HBM
+    X = torch.empty_like(x); y = torch.empty_like(x); tmp = torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    vp = C.c_void_p
+
+    def step():
+        rc = lib.zk_gl_ntt_dev(vp(x.data_ptr()), vp(X.data_ptr()), vp(tmp.data_ptr()), 1, nbits, 0, vp(stream))
+        rc |= lib.zk_gl_ntt_dev(vp(X.data_ptr()), vp(y.data_ptr()), vp(tmp.data_ptr()), 1, nbits, 1, vp(stream))
+        if rc:
+            raise RuntimeError(lib.zk_last_error().decode())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not torch.equal(x, y):                                         # inverse(forward(x)) == x, bit exact
+        raise SystemExit("bench: NTT round trip is not bit-exact")
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                                     # HIP events on the launch stream
+    if dist is not None:
+        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        passes = lib.zk_gl_ntt_passes(nbits)
+        launches = 2 * passes * args.steps
+        launch_us = dev_ms * 1e3 / launches
+        alg_bytes_per_launch = 16.0 * n / passes                       # 16 B/element/transform over its passes
+        achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
+        pass_gbs = 16.0 * n / (launch_us * 1e-6) / 1e9
+        value = world * 2.0 * n * args.steps / wall / 1e9
+        out = {
+            "metric": "Goldilocks NTT GElems/s + BN254 G1 MSM Mpts/s; starky prove ms at 2^24 rows",
+            "value": round(value, 3), "unit": "GElem/s (Goldilocks NTT, 2^%d, fwd+inv)" % nbits,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks, canonical)",
+            "data": "synthetic (splitmix64 mod p)",
+            "config": {"workload": "BASELINE config 2: 2^%d-point Goldilocks forward+inverse NTT, 1 column, "
+                                   "HBM-resident" % nbits, "nbits": nbits, "n_pols": 1,
+                       "passes_per_transform": passes, "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "launch_us": round(launch_us, 2),
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            orc = oracle_lib.load()
+            t0 = time.perf_counter()
+            Xc = orc.ntt(x_host, 1, nbits, False)
+            yc = orc.ntt(Xc, 1, nbits, True)
+            cpu_s = time.perf_counter() - t0
+            assert np.array_equal(yc, x_host)
+            assert np.array_equal(Xc, X.cpu().numpy().view(np.uint64)), "GPU forward NTT != CPU oracle"
+            out["cpu_baseline"] = {"value": round(2.0 * n / cpu_s / 1e9, 5), "unit": "GElem/s", "cores": 1,
+                                   "kind": "port", "sample": "1 step (fwd+inv) of the same 2^%d column, "
+                                   "oracle/oracle.c orc_ntt, %.2f s" % (nbits, cpu_s)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

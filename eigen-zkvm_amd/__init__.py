@@ -1,0 +1,186 @@
+"""eigen-zkvm_amd -- MI355X-native backend for eigen-zkvm's starky hot path.
+
+This module is only a thin ctypes binding over the C ABI of ``libzkgpu.so`` (include/zkgpu.h);
+the product is the HIP library.  Names mirror the reference's Rust seams: ``fft``/``ifft``/
+``interpolate`` (starky/src/fft_p.rs:242-355), ``Poseidon.hash`` (poseidon_opt.rs:76),
+``LinearHash.hash`` (linearhash.rs:79), ``MerkleTreeGL`` (merklehash.rs:293-457).
+
+There is NO CPU fallback: importing works without a GPU (so symbols can be inspected), but every
+compute call goes to the HIP kernels and raises ``ZkError`` if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+import pathlib
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libzkgpu.so"
+P = 0xFFFFFFFF00000001
+
+EXPORTS = [
+    "zk_init", "zk_last_error", "zk_device_count", "zk_gl_modulus", "zk_gl_root_of_unity",
+    "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download", "zk_dev_sync",
+    "zk_gl_ntt", "zk_gl_lde", "zk_gl_ntt_dev", "zk_gl_lde_dev", "zk_gl_ntt_passes",
+    "zk_gl_poseidon", "zk_gl_linearhash", "zk_gl_linearhash_rows_dev",
+    "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes",
+    "zk_merkle_depth", "zk_merkle_group_proof", "zk_merkle_elements_dev", "zk_merkle_nodes_dev",
+    "zk_merkle_free",
+]
+
+
+class ZkError(RuntimeError):
+    pass
+
+
+def _load():
+    if not LIB_PATH.exists():
+        raise ZkError(f"{LIB_PATH} is missing: build it with `make -C eigen-zkvm_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    u64p, vp = C.POINTER(C.c_uint64), C.c_void_p
+    sig = {
+        "zk_init": (C.c_int, [C.c_int]),
+        "zk_last_error": (C.c_char_p, []),
+        "zk_device_count": (C.c_int, []),
+        "zk_gl_modulus": (C.c_uint64, []),
+        "zk_gl_root_of_unity": (C.c_uint64, [C.c_uint32]),
+        "zk_dev_alloc": (vp, [C.c_size_t]),
+        "zk_dev_free": (C.c_int, [vp]),
+        "zk_dev_upload": (C.c_int, [vp, vp, C.c_size_t]),
+        "zk_dev_download": (C.c_int, [vp, vp, C.c_size_t]),
+        "zk_dev_sync": (C.c_int, []),
+        "zk_gl_ntt": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int]),
+        "zk_gl_lde": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32]),
+        "zk_gl_ntt_dev": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]),
+        "zk_gl_lde_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp]),
+        "zk_gl_ntt_passes": (C.c_int, [C.c_uint32]),
+        "zk_gl_poseidon": (C.c_int, [vp, vp, vp, C.c_uint32]),
+        "zk_gl_linearhash": (C.c_int, [vp, C.c_size_t, vp]),
+        "zk_gl_linearhash_rows_dev": (C.c_int, [vp, C.c_uint32, C.c_uint64, vp, vp]),
+        "zk_merkle_n_nodes": (C.c_uint64, [C.c_uint64]),
+        "zk_gl_merkelize": (vp, [vp, C.c_uint32, C.c_uint64]),
+        "zk_gl_merkelize_dev": (vp, [vp, C.c_uint32, C.c_uint64, vp]),
+        "zk_merkle_root": (C.c_int, [vp, vp]),
+        "zk_merkle_nodes": (C.c_int, [vp, vp]),
+        "zk_merkle_depth": (C.c_uint32, [vp]),
+        "zk_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_merkle_elements_dev": (vp, [vp]),
+        "zk_merkle_nodes_dev": (vp, [vp]),
+        "zk_merkle_free": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise ZkError(lib().zk_last_error().decode() or "libzkgpu call failed")
+
+
+def _np(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64).reshape(-1))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def init(device=0):
+    _check(lib().zk_init(device))
+
+
+# ---- fft_p.rs seams (host buffers) -----------------------------------------------------------
+def fft(buffsrc, n_pols, nbits):
+    """fft_p::fft (fft_p.rs:242): natural-order batched NTT of a row-major [1<<nbits][n_pols] matrix."""
+    src = _np(buffsrc); dst = np.empty_like(src)
+    _check(lib().zk_gl_ntt(_ptr(src), _ptr(dst), n_pols, nbits, 0)); return dst
+
+
+def ifft(buffsrc, n_pols, nbits):
+    """fft_p::ifft (fft_p.rs:246)."""
+    src = _np(buffsrc); dst = np.empty_like(src)
+    _check(lib().zk_gl_ntt(_ptr(src), _ptr(dst), n_pols, nbits, 1)); return dst
+
+
+def interpolate(buffsrc, n_pols, nbits, nbitsext):
+    """fft_p::interpolate (fft_p.rs:255): coset LDE, shift 49."""
+    src = _np(buffsrc); dst = np.zeros((1 << nbitsext) * n_pols, np.uint64)
+    _check(lib().zk_gl_lde(_ptr(src), n_pols, nbits, _ptr(dst), nbitsext)); return dst
+
+
+# ---- poseidon_opt.rs / linearhash.rs seams ---------------------------------------------------
+def poseidon_hash(inp, init_state, out=4):
+    """Poseidon::hash(inp, init_state, out) (poseidon_opt.rs:76); wrong lengths are errors (:81-96)."""
+    inp, cap = _np(inp), _np(init_state)
+    if inp.size != 8:
+        raise ZkError(f"Wrong inputs length {inp.size} != 8")
+    if cap.size != 4:
+        raise ZkError(f"Capacity inputs length {cap.size} != 4")
+    o = np.zeros(out, np.uint64)
+    _check(lib().zk_gl_poseidon(_ptr(inp), _ptr(cap), _ptr(o), out)); return o
+
+
+def linearhash(flatvals):
+    """LinearHash::hash(flatvals, 0) (linearhash.rs:79)."""
+    v = _np(flatvals); o = np.zeros(4, np.uint64)
+    _check(lib().zk_gl_linearhash(_ptr(v), v.size, _ptr(o))); return o
+
+
+# ---- merklehash.rs seam -----------------------------------------------------------------------
+class MerkleTreeGL:
+    """trait MerkleTree for the GL hash (traits.rs:24-55, merklehash.rs:293-457); device resident."""
+
+    def __init__(self):
+        self._h = None; self.width = 0; self.height = 0
+
+    def merkelize(self, buff, width, height):
+        buff = _np(buff)
+        if buff.size != width * height:
+            raise ZkError("merkelize: buffer size != width*height")
+        self.free()
+        h = lib().zk_gl_merkelize(_ptr(buff), width, height)
+        if not h:
+            raise ZkError(lib().zk_last_error().decode())
+        self._h, self.width, self.height = h, width, height
+
+    def merkelize_dev(self, d_ptr, width, height, stream=0):
+        self.free()
+        h = lib().zk_gl_merkelize_dev(C.c_void_p(d_ptr), width, height, C.c_void_p(stream))
+        if not h:
+            raise ZkError(lib().zk_last_error().decode())
+        self._h, self.width, self.height = h, width, height
+
+    def root(self):
+        o = np.zeros(4, np.uint64); _check(lib().zk_merkle_root(self._h, _ptr(o))); return o
+
+    def nodes(self):
+        o = np.zeros(lib().zk_merkle_n_nodes(self.height) * 4, np.uint64)
+        _check(lib().zk_merkle_nodes(self._h, _ptr(o))); return o
+
+    def get_group_proof(self, idx):
+        d = lib().zk_merkle_depth(self._h)
+        row = np.zeros(self.width, np.uint64); path = np.zeros(max(1, d) * 4, np.uint64)
+        _check(lib().zk_merkle_group_proof(self._h, idx, _ptr(row), _ptr(path)))
+        return row, path[:4 * d].reshape(d, 4)
+
+    def free(self):
+        if self._h:
+            lib().zk_merkle_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

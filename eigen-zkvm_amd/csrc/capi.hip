@@ -1,0 +1,234 @@
+// C ABI of libzkgpu (include/zkgpu.h): thin extern "C" wrappers, error capture, host<->device
+// staging for the host-pointer entry points, and the Merkle tree handle.
+#include "zk_internal.h"
+#include "../../include/zkgpu.h"
+#include <mutex>
+#include <vector>
+#include <cstring>
+
+namespace zk {
+
+static thread_local std::string t_err;
+void set_error(const std::string& msg) { t_err = msg; }
+
+namespace {
+
+std::mutex g_ws_mu;
+DevBuf g_ws_a, g_ws_b, g_ws_c;  // grow-only staging for the host-pointer API
+
+template <class F>
+int guard(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { set_error(e.what()); return -1; }
+    catch (...) { set_error("unknown error"); return -1; }
+}
+
+__global__ void gather_proof_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width,
+                                    u64 height, u64 idx, u64* __restrict__ out /* width + depth*4 */) {
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < width; i += blockDim.x) out[i] = elements[idx * width + i];
+    if (t == 0) {  // merklehash.rs:64-76 merkle_gen_merkle_proof
+        u64 n = height, off = 0, id = idx; u32 d = 0;
+        while (n > 1) {
+            const u64* sib = nodes + 4 * (off + (id ^ 1));
+            for (int k = 0; k < 4; ++k) out[width + 4 * d + k] = sib[k];
+            u64 next = (n - 1) / 2 + 1;
+            off += next * 2; n = next; id >>= 1; ++d;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace zk
+
+using namespace zk;
+
+struct zk_merkle {
+    const u64* d_elements = nullptr;  // [height][width]
+    DevBuf owned_elements;            // set when the tree owns its rows
+    DevBuf nodes;                     // merkle_n_nodes(height) * 4 words
+    DevBuf proof;                     // staging for group proofs
+    uint32_t width = 0, depth = 0;
+    uint64_t height = 0, n_nodes = 0;
+    hipStream_t stream = nullptr;
+};
+
+static uint32_t tree_depth(uint64_t height) {
+    uint32_t d = 0; uint64_t n = height;
+    while (n > 1) { n = (n - 1) / 2 + 1; ++d; }
+    return d;
+}
+
+extern "C" {
+
+int zk_init(int device) { return guard([&] { ZK_HIP(hipSetDevice(device)); }); }
+const char* zk_last_error(void) { return t_err.c_str(); }
+int zk_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+uint64_t zk_gl_modulus(void) { return GL_P; }
+uint64_t zk_gl_root_of_unity(uint32_t k) { return k <= 32 ? gl::hroot(k) : 0; }
+
+void* zk_dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (guard([&] { ZK_HIP(hipMalloc(&p, bytes ? bytes : 8)); }) != 0) return nullptr;
+    return p;
+}
+int zk_dev_free(void* p) { return guard([&] { ZK_HIP(hipFree(p)); }); }
+int zk_dev_upload(void* d, const void* h, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }); }
+int zk_dev_download(void* h, const void* d, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }); }
+int zk_dev_sync(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); }); }
+
+int zk_gl_ntt_passes(uint32_t nbits) { return ntt_num_passes(nbits); }
+
+int zk_gl_ntt_dev(const uint64_t* d_src, uint64_t* d_dst, uint64_t* d_tmp, uint32_t n_pols, uint32_t nbits,
+                  int inverse, void* stream) {
+    return guard([&] {
+        ZK_REQUIRE(nbits <= 32, "zk_gl_ntt: nbits > 32");
+        ZK_REQUIRE(d_tmp != nullptr || ntt_num_passes(nbits) == 1 || n_pols == 0, "zk_gl_ntt_dev: d_tmp required");
+        ntt_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, inverse != 0, (hipStream_t)stream);
+    });
+}
+
+int zk_gl_lde_dev(const uint64_t* d_src, uint32_t n_pols, uint32_t nbits, uint64_t* d_dst, uint64_t* d_tmp,
+                  uint32_t nbits_ext, void* stream) {
+    return guard([&] {
+        ZK_REQUIRE(d_tmp != nullptr || n_pols == 0, "zk_gl_lde_dev: d_tmp required");
+        lde_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, nbits_ext, (hipStream_t)stream);
+    });
+}
+
+int zk_gl_ntt(const uint64_t* src, uint64_t* dst, uint32_t n_pols, uint32_t nbits, int inverse) {
+    return guard([&] {
+        ZK_REQUIRE(nbits <= 32, "zk_gl_ntt: nbits > 32");
+        if (n_pols == 0) return;
+        ZK_REQUIRE(src && dst && src != dst, "zk_gl_ntt: bad buffers (dst may not alias src)");
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        const size_t bytes = ((size_t)1 << nbits) * n_pols * sizeof(u64);
+        g_ws_a.reserve(bytes); g_ws_b.reserve(bytes); g_ws_c.reserve(bytes);
+        ZK_HIP(hipMemcpy(g_ws_a.p, src, bytes, hipMemcpyHostToDevice));
+        ntt_dev(g_ws_a.u(), g_ws_b.u(), g_ws_c.u(), n_pols, nbits, inverse != 0, nullptr);
+        ZK_HIP(hipMemcpy(dst, g_ws_b.p, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+int zk_gl_lde(const uint64_t* src, uint32_t n_pols, uint32_t nbits, uint64_t* dst, uint32_t nbits_ext) {
+    return guard([&] {
+        ZK_REQUIRE(nbits_ext <= 32 && nbits <= nbits_ext, "zk_gl_lde: need nbits <= nbits_ext <= 32");
+        if (n_pols == 0) return;  // fft_p.rs:262-264: empty source is a no-op
+        ZK_REQUIRE(src && dst, "zk_gl_lde: null buffer");
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        const size_t in_bytes = ((size_t)1 << nbits) * n_pols * sizeof(u64);
+        const size_t out_bytes = ((size_t)1 << nbits_ext) * n_pols * sizeof(u64);
+        g_ws_a.reserve(in_bytes); g_ws_b.reserve(out_bytes); g_ws_c.reserve(out_bytes);
+        ZK_HIP(hipMemcpy(g_ws_a.p, src, in_bytes, hipMemcpyHostToDevice));
+        lde_dev(g_ws_a.u(), g_ws_b.u(), g_ws_c.u(), n_pols, nbits, nbits_ext, nullptr);
+        ZK_HIP(hipMemcpy(dst, g_ws_b.p, out_bytes, hipMemcpyDeviceToHost));
+    });
+}
+
+int zk_gl_poseidon(const uint64_t in[8], const uint64_t cap[4], uint64_t* out, uint32_t n_out) {
+    return guard([&] {
+        // poseidon_opt.rs:81-96 rejects wrong input/capacity lengths; with fixed-size C arrays the
+        // remaining argument error is the output count.
+        ZK_REQUIRE(in && cap && out, "zk_gl_poseidon: null buffer");
+        ZK_REQUIRE(n_out >= 1 && n_out <= 12, "zk_gl_poseidon: n_out must be 1..12");
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        g_ws_a.reserve(24 * sizeof(u64));
+        u64 h[12];
+        memcpy(h, in, 64); memcpy(h + 8, cap, 32);
+        ZK_HIP(hipMemcpy(g_ws_a.p, h, 96, hipMemcpyHostToDevice));
+        poseidon_dev(g_ws_a.u(), g_ws_a.u() + 8, g_ws_a.u() + 12, (int)n_out, nullptr);
+        ZK_HIP(hipMemcpy(out, g_ws_a.u() + 12, n_out * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+
+int zk_gl_linearhash_rows_dev(const uint64_t* d_rows, uint32_t width, uint64_t height, uint64_t* d_digests, void* stream) {
+    return guard([&] { linearhash_rows_dev((const u64*)d_rows, width, height, (u64*)d_digests, (hipStream_t)stream); });
+}
+
+int zk_gl_linearhash(const uint64_t* v, size_t n, uint64_t out[4]) {
+    return guard([&] {
+        ZK_REQUIRE(out && (v || n == 0), "zk_gl_linearhash: null buffer");
+        ZK_REQUIRE(n < (1ull << 32), "zk_gl_linearhash: row too wide");
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        g_ws_a.reserve((n + 8) * sizeof(u64));
+        if (n) ZK_HIP(hipMemcpy(g_ws_a.p, v, n * sizeof(u64), hipMemcpyHostToDevice));
+        u64* d_out = g_ws_a.u() + n;
+        linearhash_rows_dev(g_ws_a.u(), (uint32_t)n, 1, d_out, nullptr);
+        ZK_HIP(hipMemcpy(out, d_out, 32, hipMemcpyDeviceToHost));
+    });
+}
+
+uint64_t zk_merkle_n_nodes(uint64_t height) { return height ? merkle_n_nodes(height) : 0; }
+
+static zk_merkle_t* make_tree(const u64* d_rows, zk_merkle_t* t, uint32_t width, uint64_t height, hipStream_t st) {
+    t->d_elements = d_rows; t->width = width; t->height = height;
+    t->n_nodes = merkle_n_nodes(height); t->depth = tree_depth(height); t->stream = st;
+    t->nodes.reserve(t->n_nodes * 32);
+    t->proof.reserve(((size_t)width + 4 * (size_t)t->depth + 4) * sizeof(u64));
+    merkelize_dev(d_rows, width, height, t->nodes.u(), st);
+    return t;
+}
+
+zk_merkle_t* zk_gl_merkelize(const uint64_t* buff, uint32_t width, uint64_t height) {
+    zk_merkle_t* t = nullptr;
+    int rc = guard([&] {
+        ZK_REQUIRE(buff && width >= 1 && height >= 1, "zk_gl_merkelize: empty matrix");
+        t = new zk_merkle();
+        const size_t bytes = (size_t)width * height * sizeof(u64);
+        t->owned_elements.reserve(bytes);
+        ZK_HIP(hipMemcpy(t->owned_elements.p, buff, bytes, hipMemcpyHostToDevice));
+        make_tree(t->owned_elements.u(), t, width, height, nullptr);
+        ZK_HIP(hipStreamSynchronize(nullptr));
+    });
+    if (rc != 0) { delete t; return nullptr; }
+    return t;
+}
+
+zk_merkle_t* zk_gl_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream) {
+    zk_merkle_t* t = nullptr;
+    int rc = guard([&] {
+        ZK_REQUIRE(d_buff && width >= 1 && height >= 1, "zk_gl_merkelize_dev: empty matrix");
+        t = new zk_merkle();
+        make_tree((const u64*)d_buff, t, width, height, (hipStream_t)stream);
+    });
+    if (rc != 0) { delete t; return nullptr; }
+    return t;
+}
+
+int zk_merkle_root(const zk_merkle_t* t, uint64_t out[4]) {
+    return guard([&] {
+        ZK_REQUIRE(t && out, "zk_merkle_root: null");
+        ZK_HIP(hipStreamSynchronize(t->stream));
+        ZK_HIP(hipMemcpy(out, t->nodes.u() + 4 * (t->n_nodes - 1), 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int zk_merkle_nodes(const zk_merkle_t* t, uint64_t* out) {
+    return guard([&] {
+        ZK_REQUIRE(t && out, "zk_merkle_nodes: null");
+        ZK_HIP(hipStreamSynchronize(t->stream));
+        ZK_HIP(hipMemcpy(out, t->nodes.p, t->n_nodes * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+uint32_t zk_merkle_depth(const zk_merkle_t* t) { return t ? t->depth : 0; }
+
+int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {
+    return guard([&] {
+        ZK_REQUIRE(t && row_out && (path_out || t->depth == 0), "zk_merkle_group_proof: null");
+        ZK_REQUIRE(idx < t->height, "MerkleTreeError: access invalid node");  // merklehash.rs:431-433
+        hipLaunchKernelGGL(gather_proof_kernel, dim3(1), dim3(64), 0, t->stream, t->d_elements, t->nodes.u(),
+                           t->width, t->height, idx, t->proof.u());
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(t->stream));
+        ZK_HIP(hipMemcpy(row_out, t->proof.p, t->width * sizeof(u64), hipMemcpyDeviceToHost));
+        if (t->depth)
+            ZK_HIP(hipMemcpy(path_out, t->proof.u() + t->width, (size_t)t->depth * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->d_elements : nullptr; }
+const uint64_t* zk_merkle_nodes_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->nodes.p : nullptr; }
+int zk_merkle_free(zk_merkle_t* t) { delete t; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// Goldilocks NTT / iNTT / LDE for gfx950 (MI355X).
+//
+// Replaces starky/src/fft_p.rs:174-355 (_fft, fft, ifft, interpolate) and fft_worker.rs:25-72.
+// Same contract: row-major [1<<nbits][n_pols] matrix of canonical u64, natural order in and out,
+// forward root w = MG.0[nbits] (constant.rs:54-68), inverse = 1/N * NTT with w^-1
+// (== the reference's (n-BR(i))%n input permutation, fft_p.rs:124-142), LDE on the coset
+// 49*<w_ext> (fft_p.rs:255-355).
+//
+// Design (not the reference's bit-reverse + blocked butterflies + transposes):
+//   * Stockham auto-sort decomposition N = R_1*R_2*...; every pass reads R rows of `inner`
+//     contiguous words (row stride N/R * n_pols) and writes runs of >= s*n_pols contiguous words,
+//     so there is no bit-reversal pass and no transpose pass; natural order falls out.
+//       pass with stride s (product of earlier radices), L = N/s, p < L/R, q < s:
+//         out[(p*R + k)*s + q] = w_L^(p*k) * sum_j in[j*N/R + p*s + q] * w_R^(j*k)
+//   * one workgroup = one tile of R (<=256) points x C = 4096/R adjacent lanes (a lane is one
+//     (row-within-stride, column) pair, i.e. one contiguous u64 of the matrix row range);
+//     each thread owns 16 points: radix-2^LOGA DIF in registers -> twiddle -> ONE LDS
+//     transpose -> radix-2^LOGB DIF in registers -> inter-pass twiddle -> store.
+//     A 2^24 transform is three such passes (8+8+8 bits), 2 LDS accesses / element / pass.
+//   * twiddles w_N^e come from a two-level table (4096 + N/4096 entries, L2 resident); the
+//     per-thread chain over the 16 outputs needs 2 lookups + 1 multiply per element.
+//   * HBM-bound: 16 B / element / pass; bytes per transform = 16 * passes * N * n_pols.
+#include "zk_internal.h"
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace zk {
+
+namespace {
+
+constexpr int TW_LO_BITS = 12;
+constexpr int TW_LO = 1 << TW_LO_BITS;
+
+struct PassParams {
+    const u64* in;
+    u64* out;
+    const u64* w256;   // w_256^e, e < 256 (direction-specific)
+    const u64* tw_lo;  // w_N^i, i < 4096
+    const u64* tw_hi;  // w_N^(4096 i)
+    const u64* sc_lo;  // optional output scaling c * g^k (k = output row): g^i * c, i < 4096
+    const u64* sc_hi;  // g^(4096 i)
+    u64 sc_step;       // g^(RA * s)
+    u64 out_scale;     // plain constant scaling (1 = none), used when sc_lo == nullptr
+    u64 inner;         // (N/R) * n_pols : contiguous words per transform-axis index j
+    u64 valid_in;      // words of `in` that exist; beyond that the input is implicit zero (LDE)
+    u64 s_np;          // s * n_pols
+    u32 np;
+    u32 log_s;
+    u32 has_tw;        // L > R (not the last pass)
+};
+
+__host__ __device__ constexpr int bitrev_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// 2^LOG-point DIF NTT in registers, natural order in; X[k] ends up in x[bitrev(k)].
+// Twiddle w_{2h}^j = w_256^(j * 128/h): uniform addresses -> scalar loads.
+template <int LOG>
+__device__ __forceinline__ void ntt_reg(u64 (&x)[1 << LOG], const u64* __restrict__ w256) {
+    constexpr int n = 1 << LOG;
+#pragma unroll
+    for (int lh = LOG - 1; lh >= 0; --lh) {
+        const int half = 1 << lh;
+#pragma unroll
+        for (int blk = 0; blk < n; blk += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                u64 a = x[blk + j], b = x[blk + j + half];
+                x[blk + j] = gl::add(a, b);
+                u64 d = gl::sub(a, b);
+                x[blk + j + half] = (j == 0) ? d : gl::mul(d, w256[j * (128 / half)]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e) {
+    return gl::mul(hi[e >> TW_LO_BITS], lo[e & (TW_LO - 1)]);
+}
+
+template <int LOGA, int LOGB, bool KMODE>
+__global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
+    constexpr int LOGR = LOGA + LOGB, R = 1 << LOGR, RA = 1 << LOGA, RB = 1 << LOGB;
+    constexpr int C = 4096 / R;                // lanes per tile
+    constexpr int GA = 16 / RA, GB = 16 / RB;  // independent sub-transforms per thread
+    constexpr int TG = R / 16;                 // threads along the transform axis
+    constexpr int PAD = KMODE ? 512 / R : 0;   // words; spreads kappa_a rows over banks (KMODE reads)
+    constexpr int ROW = RB * C + PAD;
+    static_assert(LOGR >= 4 && LOGR <= 8 && LOGA <= 4 && LOGB <= 4, "tile shape");
+    __shared__ u64 lds[RA * ROW];
+
+    const int t = threadIdx.x;
+    const u64 u0 = (u64)blockIdx.x * C;
+
+    {   // ---- sub-step A: RA-point transforms over ja (j = ja*RB + jb), twiddle w_R^(jb*ka)
+        const int c = t % C, ta = t / C;
+        const u64 u = u0 + c;
+        const bool live = u < P.inner;
+        u64 x[GA][RA];
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+#pragma unroll
+            for (int ja = 0; ja < RA; ++ja) {
+                const u64 idx = (u64)(ja * RB + ta * GA + g) * P.inner + u;
+                x[g][ja] = (live && idx < P.valid_in) ? P.in[idx] : 0;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GA; ++g) ntt_reg<LOGA>(x[g], P.w256);
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+            const int jb = ta * GA + g;
+#pragma unroll
+            for (int ka = 0; ka < RA; ++ka) {
+                u64 v = x[g][bitrev_c(ka, LOGA)];
+                if (LOGB > 0 && ka > 0) v = gl::mul(v, P.w256[(jb * ka) << (8 - LOGR)]);
+                lds[ka * ROW + jb * C + c] = v;
+            }
+        }
+    }
+    __syncthreads();
+    {   // ---- sub-step B: RB-point transforms over jb -> kappa = RA*kb + ka
+        int c, tb;
+        if (KMODE) { tb = t % TG; c = t / TG; } else { c = t % C; tb = t / C; }
+        const u64 u = u0 + c;
+        u64 y[GB][RB];
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int ka = tb + g * TG;
+#pragma unroll
+            for (int jb = 0; jb < RB; ++jb) y[g][jb] = lds[ka * ROW + jb * C + c];
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) ntt_reg<LOGB>(y[g], P.w256);
+        if (u >= P.inner) return;
+
+        const u64 p = u / P.s_np, rem = u - p * P.s_np;
+        u64* __restrict__ outp = P.out + p * R * P.s_np + rem;
+        u64 tw_step = 1;
+        if (P.has_tw) tw_step = tab2(P.tw_lo, P.tw_hi, (p * RA) << P.log_s);
+        const u64 row_q = P.sc_lo ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const int ka = tb + g * TG;
+            u64 f = P.out_scale;
+            if (P.has_tw) f = tab2(P.tw_lo, P.tw_hi, (p * ka) << P.log_s);
+            if (P.sc_lo) f = tab2(P.sc_lo, P.sc_hi, ((u64)ka << P.log_s) + row_q);
+            const bool scaled = P.has_tw || P.sc_lo || P.out_scale != 1;
+            const u64 fstep = P.sc_lo ? P.sc_step : tw_step;
+#pragma unroll
+            for (int kb = 0; kb < RB; ++kb) {
+                u64 v = y[g][bitrev_c(kb, LOGB)];
+                if (scaled) {
+                    v = gl::mul(v, f);
+                    if (kb + 1 < RB) f = gl::mul(f, fstep);
+                }
+                outp[(u64)(RA * kb + ka) * P.s_np] = v;
+            }
+        }
+    }
+}
+
+// Direct evaluation for transforms shorter than one register tile (nbits < 4): out[k][c] =
+// scale(k) * sum_{i < n_in} in[i][c] * w^(i k).  A handful of rows; never on a hot path.
+__global__ void ntt_small_kernel(const u64* in, u64* out, u32 np, u32 n_in, u32 n, u64 w, u64 g, u64 cst) {
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n * np) return;
+    const u32 k = tid / np, c = tid % np;
+    const u64 wk = gl::pow(w, k);
+    u64 acc = 0, cur = 1;
+    for (u32 i = 0; i < n_in; ++i) { acc = gl::add(acc, gl::mul(in[(u64)i * np + c], cur)); cur = gl::mul(cur, wk); }
+    out[(u64)k * np + c] = gl::mul(acc, gl::mul(cst, gl::pow(g, k)));
+}
+
+// ---- host side: tables + plan -------------------------------------------------------------
+struct Tables { u64 *w256 = nullptr, *lo = nullptr, *hi = nullptr; };
+struct ScaleTables { u64 *lo = nullptr, *hi = nullptr; };
+
+std::mutex g_mu;
+std::map<std::pair<int, std::pair<u32, int>>, Tables> g_tables;      // (device,(nbits,inverse))
+std::map<std::pair<int, std::pair<u32, u32>>, ScaleTables> g_scales;  // (device,(nbits,g))
+
+u64* upload(const std::vector<u64>& v) {
+    u64* d = nullptr;
+    ZK_HIP(hipMalloc((void**)&d, v.size() * sizeof(u64)));
+    ZK_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(u64), hipMemcpyHostToDevice));
+    return d;
+}
+
+void two_level(u64 base, u64 cst, u32 nbits, std::vector<u64>& lo, std::vector<u64>& hi) {
+    lo.resize(TW_LO);
+    u64 c = cst;
+    for (int i = 0; i < TW_LO; ++i) { lo[i] = c; c = gl::hmul(c, base); }
+    size_t nh = nbits > (u32)TW_LO_BITS ? (size_t)1 << (nbits - TW_LO_BITS) : 1;
+    hi.resize(nh);
+    u64 step = gl::hpow(base, TW_LO);
+    c = 1;
+    for (size_t i = 0; i < nh; ++i) { hi[i] = c; c = gl::hmul(c, step); }
+}
+
+Tables get_tables(u32 nbits, bool inverse) {
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, std::make_pair(nbits, (int)inverse));
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) return it->second;
+    u64 w = gl::hroot(nbits), w8 = gl::hroot(8);
+    if (inverse) { w = gl::hinv(w); w8 = gl::hinv(w8); }
+    std::vector<u64> t256(256), lo, hi;
+    u64 c = 1;
+    for (int i = 0; i < 256; ++i) { t256[i] = c; c = gl::hmul(c, w8); }
+    two_level(w, 1, nbits, lo, hi);
+    Tables T; T.w256 = upload(t256); T.lo = upload(lo); T.hi = upload(hi);
+    g_tables[key] = T;
+    return T;
+}
+
+ScaleTables get_scale(u32 nbits, u64 g, u64 cst) {  // cst * g^k, k < 2^nbits
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, std::make_pair(nbits, (u32)g));
+    auto it = g_scales.find(key);
+    if (it != g_scales.end()) return it->second;
+    std::vector<u64> lo, hi;
+    two_level(g, cst, nbits, lo, hi);
+    ScaleTables S; S.lo = upload(lo); S.hi = upload(hi);
+    g_scales[key] = S;
+    return S;
+}
+
+template <int LOGA, int LOGB>
+void launch_pass(const PassParams& P, bool kmode, hipStream_t st) {
+    constexpr int C = 4096 >> (LOGA + LOGB);
+    const u64 blocks = (P.inner + C - 1) / C;
+    ZK_REQUIRE(blocks < (1ull << 31), "ntt: grid too large");
+    if (kmode) hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, true>), dim3((u32)blocks), dim3(256), 0, st, P);
+    else       hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, false>), dim3((u32)blocks), dim3(256), 0, st, P);
+    ZK_HIP(hipGetLastError());
+}
+
+void launch_pass_logr(int logr, const PassParams& P, bool kmode, hipStream_t st) {
+    switch (logr) {
+        case 4: launch_pass<2, 2>(P, kmode, st); break;
+        case 5: launch_pass<3, 2>(P, kmode, st); break;
+        case 6: launch_pass<3, 3>(P, kmode, st); break;
+        case 7: launch_pass<4, 3>(P, kmode, st); break;
+        case 8: launch_pass<4, 4>(P, kmode, st); break;
+        default: throw Error("ntt: unsupported pass radix");
+    }
+}
+
+// radices of the passes of a 2^nbits transform (each 4..8 bits); empty for nbits < 4
+std::vector<int> plan(u32 nbits) {
+    std::vector<int> r;
+    if (nbits < 4) return r;
+    int np = (nbits + 7) / 8;
+    int base = nbits / np, extra = nbits % np;
+    for (int i = 0; i < np; ++i) r.push_back(base + (i < extra ? 1 : 0));
+    return r;
+}
+
+// One transform of size 2^nbits whose input holds `valid_rows` rows (rest implicit zero).
+// bufs: sequence of distinct buffers the passes ping-pong through, bufs[0] = input,
+// bufs.back() = output.  scale: optional (g, cst) output scaling cst*g^row; out_scale: constant.
+struct Scale { bool on = false; u64 g = 1, cst = 1; };
+
+void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land in `a` */
+                   u32 n_pols, u32 nbits, u64 valid_rows, bool inverse, Scale sc, u64 out_scale, hipStream_t st) {
+    const u64 n = 1ull << nbits;
+    if (nbits < 4) {
+        u64 w = gl::hroot(nbits);
+        if (inverse) w = gl::hinv(w);
+        u64 cst = sc.on ? sc.cst : out_scale;
+        u64 g = sc.on ? sc.g : 1;
+        u32 total = (u32)(n * n_pols);
+        hipLaunchKernelGGL(ntt_small_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, a, n_pols,
+                           (u32)valid_rows, (u32)n, w, g, cst);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+    const std::vector<int> radices = plan(nbits);
+    const int np = (int)radices.size();
+    Tables T = get_tables(nbits, inverse);
+    ScaleTables S;
+    if (sc.on) S = get_scale(nbits, sc.g, sc.cst);
+    u32 log_s = 0;
+    const u64* cur = in;
+    for (int i = 0; i < np; ++i) {
+        const int logr = radices[i];
+        u64* dstbuf = ((np - 1 - i) % 2 == 0) ? a : b;
+        const bool last = (i == np - 1);
+        PassParams P{};
+        P.in = cur; P.out = dstbuf;
+        P.w256 = T.w256; P.tw_lo = T.lo; P.tw_hi = T.hi;
+        P.sc_lo = (last && sc.on) ? S.lo : nullptr;
+        P.sc_hi = (last && sc.on) ? S.hi : nullptr;
+        const int loga = (logr + 1) / 2;
+        P.sc_step = (last && sc.on) ? gl::hpow(sc.g, (1ull << loga) << log_s) : 1;
+        P.out_scale = (last && !sc.on) ? out_scale : 1;
+        P.inner = (n >> logr) * n_pols;
+        P.valid_in = (i == 0) ? valid_rows * n_pols : n * n_pols;
+        P.s_np = ((u64)1 << log_s) * n_pols;
+        P.np = n_pols;
+        P.log_s = log_s;
+        P.has_tw = last ? 0 : 1;
+        const bool kmode = P.s_np < 16;
+        launch_pass_logr(logr, P, kmode, st);
+        cur = dstbuf;
+        log_s += logr;
+    }
+}
+
+}  // namespace
+
+int ntt_num_passes(uint32_t nbits) { return nbits < 4 ? 1 : (int)plan(nbits).size(); }
+
+void ntt_dev(const u64* d_src, u64* d_dst, u64* d_tmp, uint32_t n_pols, uint32_t nbits, bool inverse, hipStream_t st) {
+    ZK_REQUIRE(nbits <= 32, "ntt: nbits > 32");
+    if (n_pols == 0) return;
+    ZK_REQUIRE(d_src != d_dst, "ntt: dst may not alias src");
+    u64 out_scale = inverse ? gl::hinv((1ull << nbits) % GL_P) : 1;
+    run_transform(d_src, d_dst, d_tmp, n_pols, nbits, 1ull << nbits, inverse, Scale{}, out_scale, st);
+}
+
+void lde_dev(const u64* d_src, u64* d_dst, u64* d_tmp, uint32_t n_pols, uint32_t nbits, uint32_t nbits_ext, hipStream_t st) {
+    ZK_REQUIRE(nbits_ext <= 32 && nbits <= nbits_ext, "lde: need nbits <= nbits_ext <= 32");
+    if (n_pols == 0) return;  // fft_p.rs:262-264
+    ZK_REQUIRE(d_src != d_dst, "lde: dst may not alias src");
+    const u64 n = 1ull << nbits;
+    // coefficients * 49^i / N  (fft_p.rs:144-172): the inverse transform's last pass applies it.
+    Scale sc; sc.on = true; sc.g = 49; sc.cst = gl::hinv(n % GL_P);
+    const int fwd_passes = ntt_num_passes(nbits_ext);
+    // forward transform must end in d_dst; its input (the coefficient buffer) must differ from
+    // the first forward pass's output: forward pass i writes (fwd_passes-1-i)%2==0 ? dst : tmp.
+    u64* first_fwd_out = ((fwd_passes - 1) % 2 == 0) ? d_dst : d_tmp;
+    u64* coef = (first_fwd_out == d_dst) ? d_tmp : d_dst;
+    u64* other = (coef == d_dst) ? d_tmp : d_dst;
+    run_transform(d_src, coef, other, n_pols, nbits, n, true, sc, 1, st);
+    run_transform(coef, d_dst, d_tmp, n_pols, nbits_ext, n, false, Scale{}, 1, st);
+}
+
+}  // namespace zk
