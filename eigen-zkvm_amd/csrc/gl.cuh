@@ -18,13 +18,27 @@ typedef unsigned int u32;
 
 namespace gl {
 
-__host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {  // field_gl.rs:385-388
-    u64 s = a + b;
-    return (s < a || s >= GL_P) ? s - GL_P : s;  // wrapped s - p == s + 2^32 - 1 (mod 2^64)
+// add/sub are written on 32-bit limbs with explicit carries: on gfx950 v_add_co/v_addc_co are
+// double-rate VALU ops while 64-bit compares + selects are not (tools/ubench_valu.hip,
+// tools/field_probe.hip measured the variants: -20 % cycles on an NTT-shaped workload).
+__device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ u64 add(u64 a, u64 b) {  // field_gl.rs:385-388; canonical in -> canonical out
+    u32 c0, c1, d0, d1;
+    u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
+    u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+    u32 t0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &d0);  // t = s - p = s + 2^32 - 1 (mod 2^64)
+    u32 t1 = __builtin_addc(s1, 0u, d0, &d1);           // d1 <=> s >= p
+    const bool sel = (c1 | d1) != 0;
+    return mk64(sel ? t0 : s0, sel ? t1 : s1);
 }
-__host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {  // field_gl.rs:395-403
-    u64 d = a - b;
-    return a < b ? d + GL_P : d;
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {  // field_gl.rs:395-403
+    u32 b0, b1, e0, e1;
+    u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &b0);
+    u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b0, &b1);
+    u32 m = 0u - b1;                                      // borrow ? 2^32 - 1 : 0;  d + p == d - (2^32 - 1)
+    u32 r0 = __builtin_subc(d0, m, 0u, &e0);
+    u32 r1 = __builtin_subc(d1, 0u, e0, &e1);
+    return mk64(r0, r1);
 }
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? GL_P - a : 0; }
 
@@ -38,8 +52,32 @@ __host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
     if (t2 < t1) t2 += GL_EPS;
     return t2 >= GL_P ? t2 - GL_P : t2;
 }
-__device__ __forceinline__ u64 mul(u64 a, u64 b) {  // field_gl.rs:454-458 (observable value)
-    return reduce128(a * b, __umul64hi(a, b));
+// a*b mod p, any u64 inputs, canonical output (field_gl.rs:454-458, observable value).
+//   product : four v_mad_u64_u32 (the compiler's a*b + __umul64hi(a,b) spends seven multiplies)
+//   reduce  : x = lo + r2*2^64 + r3*2^96 = lo - r3 + r2*(2^32-1); the r2 term is ONE
+//             v_mad_u64_u32 whose carry-out (vcc) selects the +2^32-1 fix-up.
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    const u32 r2 = (u32)p3, r3 = (u32)(p3 >> 32);
+    u32 bw0, bw1, e0, e1;
+    u32 t0 = __builtin_subc((u32)p0, r3, 0u, &bw0);      // t = lo - r3
+    u32 t1 = __builtin_subc((u32)p2, 0u, bw0, &bw1);
+    const u32 mb = 0u - bw1;                             // borrowed: t -= 2^32 - 1
+    t0 = __builtin_subc(t0, mb, 0u, &e0);
+    t1 = __builtin_subc(t1, 0u, e0, &e1);
+    const u64 t = mk64(t0, t1);
+    u64 u; u32 m;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
+                 : "=&v"(u), "=v"(m) : "v"(r2), "v"(t) : "vcc");
+    u += m;                                              // carried: u += 2^32 - 1 (cannot carry again)
+    u32 d0, d1;
+    const u32 v0 = __builtin_addc((u32)u, 0xFFFFFFFFu, 0u, &d0);
+    const u32 v1 = __builtin_addc((u32)(u >> 32), 0u, d0, &d1);  // d1 <=> u >= p
+    return mk64(d1 ? v0 : (u32)u, d1 ? v1 : (u32)(u >> 32));
 }
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __device__ __forceinline__ u64 pow(u64 a, u64 e) {  // field_gl.rs:467-479
