@@ -34,6 +34,33 @@ SEED = 0x9E3779B97F4A7C15
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def shard_units(n_units, rank, world):
+    """Independent proving units (sub-proofs / columns sets) owned by `rank`: round-robin, so that
+    every rank gets floor or ceil of n_units/world and no unit is proved twice."""
+    return list(range(rank, n_units, world))
+
+
+def max_over_ranks(dist, values, device):
+    """MAX-reduce a list of floats over all ranks (the only collective on the bench path)."""
+    import torch
+    t = torch.tensor(values, device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def gather_roots(dist, root4, device):
+    """All-gather of each rank's 4-word Merkle root (32 B): the one exchange step of sharded
+    aggregation.  Returns a [world][4] list."""
+    import torch
+    t = torch.tensor([int(v) for v in root4], dtype=torch.int64, device=device)
+    if dist is None:
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,10 +124,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                                     # HIP events on the launch stream
-    if dist is not None:
-        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
+    wall, dev_ms = max_over_ranks(dist, [wall, dev_ms], dev)
 
     if rank == 0:
         passes = lib.zk_gl_ntt_passes(nbits)

@@ -1,0 +1,49 @@
+"""The N>1 path of bench.py on CPU: world_size-2 gloo processes exercise unit sharding, the
+max-over-ranks timing reduction and the 32-byte root all-gather (the only collectives on the path)."""
+import os, sys, pathlib
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    mine = bench.shard_units(8, rank, world)
+    wall, ms = bench.max_over_ranks(dist, [1.0 + rank, 10.0 - rank], dev)
+    roots = bench.gather_roots(dist, [rank + 1, 2, 3, (1 << 62) + rank], dev)
+    dist.barrier()
+    q.put((rank, mine, wall, ms, roots))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_reductions():
+    world, port = 2, 29541
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    units = sorted(u for r in res for u in r[1])
+    assert units == list(range(8))                       # every unit proved exactly once
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
+    for r in res:
+        assert r[2] == 2.0 and r[3] == 10.0              # MAX over ranks
+        assert r[4] == [[1, 2, 3, 1 << 62], [2, 2, 3, (1 << 62) + 1]]
+
+
+def test_single_rank_helpers_without_dist():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert bench.max_over_ranks(None, [3.5, 1.0], torch.device("cpu")) == [3.5, 1.0]
+    assert bench.gather_roots(None, [1, 2, 3, 4], torch.device("cpu")) == [[1, 2, 3, 4]]
