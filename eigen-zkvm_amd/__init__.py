@@ -25,7 +25,18 @@ EXPORTS = [
     "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes",
     "zk_merkle_depth", "zk_merkle_group_proof", "zk_merkle_elements_dev", "zk_merkle_nodes_dev",
     "zk_merkle_free",
+    "zk_transcript_new", "zk_transcript_put", "zk_transcript_put_dev", "zk_transcript_get_field",
+    "zk_transcript_get_field_dev", "zk_transcript_get_fields1", "zk_transcript_get_permutations",
+    "zk_transcript_free",
+    "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
+    "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
 ]
+
+
+class EvalDesc(C.Structure):
+    """zk_eval_desc (include/zkgpu.h)"""
+    _fields_ = [("d_buf", C.c_void_p), ("width", C.c_uint64), ("offset", C.c_uint64),
+                ("dim", C.c_uint32), ("prime", C.c_uint32)]
 
 
 class ZkError(RuntimeError):
@@ -67,6 +78,22 @@ def _load():
         "zk_merkle_elements_dev": (vp, [vp]),
         "zk_merkle_nodes_dev": (vp, [vp]),
         "zk_merkle_free": (C.c_int, [vp]),
+        "zk_transcript_new": (vp, []),
+        "zk_transcript_put": (C.c_int, [vp, vp, C.c_size_t]),
+        "zk_transcript_put_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "zk_transcript_get_field": (C.c_int, [vp, vp]),
+        "zk_transcript_get_field_dev": (C.c_int, [vp, vp, vp]),
+        "zk_transcript_get_fields1": (C.c_int, [vp, vp]),
+        "zk_transcript_get_permutations": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "zk_transcript_free": (C.c_int, [vp]),
+        "zk_fri_fold_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp]),
+        "zk_fri_transpose_dev": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, vp]),
+        "zk_stark_x_table_dev": (C.c_int, [C.c_uint32, C.c_uint64, vp, vp]),
+        "zk_stark_zh_inv_dev": (C.c_int, [C.c_uint32, C.c_uint32, vp, vp]),
+        "zk_stark_xdivxsub_dev": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, vp]),
+        "zk_stark_lev_dev": (C.c_int, [vp, C.c_uint32, C.c_int, vp, vp, vp, vp]),
+        "zk_stark_evals_dev": (C.c_int, [C.POINTER(EvalDesc), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
+        "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -184,3 +211,130 @@ class MerkleTreeGL:
             self.free()
         except Exception:
             pass
+
+
+# ---- device buffers (HBM-resident words) ---------------------------------------------------------
+class DevArray:
+    """n u64 words in HBM (zk_dev_alloc); `.ptr` is the raw device address."""
+
+    def __init__(self, n_words, src=None, zero=False):
+        self.n = int(n_words)
+        self.ptr = lib().zk_dev_alloc(max(1, self.n) * 8)
+        if not self.ptr:
+            raise ZkError(lib().zk_last_error().decode())
+        if src is not None:
+            a = _np(src)
+            assert a.size == self.n
+            _check(lib().zk_dev_upload(self.ptr, _ptr(a), self.n * 8))
+        elif zero:
+            z = np.zeros(self.n, np.uint64)
+            _check(lib().zk_dev_upload(self.ptr, _ptr(z), self.n * 8))
+
+    @classmethod
+    def from_host(cls, a):
+        a = _np(a)
+        return cls(a.size, a)
+
+    def to_host(self):
+        _check(lib().zk_dev_sync())
+        o = np.empty(self.n, np.uint64)
+        if self.n:
+            _check(lib().zk_dev_download(_ptr(o), self.ptr, self.n * 8))
+        return o
+
+    def free(self):
+        if self.ptr:
+            lib().zk_dev_free(self.ptr); self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- transcript.rs seam ----------------------------------------------------------------------------
+class TranscriptGL:
+    """trait Transcript (traits.rs:57-63) / TranscriptGL (transcript.rs:8-103); state on the device."""
+
+    def __init__(self):
+        self._h = lib().zk_transcript_new()
+        if not self._h:
+            raise ZkError(lib().zk_last_error().decode())
+
+    def put(self, es):
+        v = _np(es)
+        _check(lib().zk_transcript_put(self._h, _ptr(v), v.size))
+
+    def put_dev(self, dev, n=None, stream=0):
+        _check(lib().zk_transcript_put_dev(self._h, dev.ptr, dev.n if n is None else n, stream))
+
+    def get_field(self):
+        o = np.zeros(3, np.uint64); _check(lib().zk_transcript_get_field(self._h, _ptr(o))); return o
+
+    def get_field_dev(self, dev, stream=0):
+        _check(lib().zk_transcript_get_field_dev(self._h, dev.ptr, stream))
+
+    def get_fields1(self):
+        o = np.zeros(1, np.uint64); _check(lib().zk_transcript_get_fields1(self._h, _ptr(o))); return int(o[0])
+
+    def get_permutations(self, n, nbits):
+        o = np.zeros(n, np.uint64)
+        _check(lib().zk_transcript_get_permutations(self._h, n, nbits, _ptr(o))); return o
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().zk_transcript_free(self._h); self._h = None
+        except Exception:
+            pass
+
+
+# ---- fri.rs / stark_gen.rs glue (device resident operands) ---------------------------------------
+def fri_fold(d_pol, pol_bits, step_bits, d_special_x, shift_inv, stream=0):
+    """one step of FRI::prove's fold loop (fri.rs:101-126)"""
+    out = DevArray(3 << step_bits)
+    _check(lib().zk_fri_fold_dev(d_pol.ptr, pol_bits, step_bits, d_special_x.ptr, shift_inv, out.ptr, stream))
+    return out
+
+
+def fri_transpose(d_pol, n, tbits, stream=0):
+    """get_transposed_buffer (fri.rs:299-317)"""
+    out = DevArray(3 * n)
+    _check(lib().zk_fri_transpose_dev(d_pol.ptr, n, tbits, out.ptr, stream)); return out
+
+
+def x_table(nbits, shift=1, stream=0):
+    out = DevArray(1 << nbits)
+    _check(lib().zk_stark_x_table_dev(nbits, shift, out.ptr, stream)); return out
+
+
+def zh_inv(nbits, extend_bits, stream=0):
+    out = DevArray(1 << extend_bits)
+    _check(lib().zk_stark_zh_inv_dev(nbits, extend_bits, out.ptr, stream)); return out
+
+
+def xdivxsub(d_xi, mulw, nbits_ext, stream=0):
+    out = DevArray(3 << nbits_ext)
+    _check(lib().zk_stark_xdivxsub_dev(d_xi.ptr, mulw, nbits_ext, out.ptr, stream)); return out
+
+
+def lev(d_xi, nbits, prime, stream=0):
+    out, t1, t2 = DevArray(3 << nbits), DevArray(3 << nbits), DevArray(3 << nbits)
+    _check(lib().zk_stark_lev_dev(d_xi.ptr, nbits, int(prime), out.ptr, t1.ptr, t2.ptr, stream))
+    _check(lib().zk_dev_sync())
+    return out
+
+
+def evals(descs, nbits, ext, d_lev, d_lpev, stream=0):
+    """descs: list of (DevArray buf, width, offset, dim, prime)"""
+    arr = (EvalDesc * len(descs))(*[EvalDesc(b.ptr, w, o, d, int(p)) for (b, w, o, d, p) in descs])
+    out = DevArray(3 * len(descs))
+    _check(lib().zk_stark_evals_dev(arr, len(descs), nbits, ext, d_lev.ptr, d_lpev.ptr, out.ptr, stream))
+    _check(lib().zk_dev_sync())
+    return out
+
+
+def qsplit(d_qq1, nbits, nbits_ext, q_dim, q_deg, stream=0):
+    out = DevArray((1 << nbits_ext) * q_dim * q_deg, zero=True)
+    _check(lib().zk_stark_qsplit_dev(d_qq1.ptr, nbits, q_dim, q_deg, out.ptr, stream)); return out

@@ -53,6 +53,11 @@ struct zk_merkle {
     hipStream_t stream = nullptr;
 };
 
+struct zk_transcript {
+    DevBuf state;  // TranscriptState (poseidon.hip)
+    DevBuf io;     // staging for host-word put / get
+};
+
 static uint32_t tree_depth(uint64_t height) {
     uint32_t d = 0; uint64_t n = height;
     while (n > 1) { n = (n - 1) / 2 + 1; ++d; }
@@ -225,6 +230,84 @@ int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out,
         if (t->depth)
             ZK_HIP(hipMemcpy(path_out, t->proof.u() + t->width, (size_t)t->depth * 32, hipMemcpyDeviceToHost));
     });
+}
+
+// ---- transcript ------------------------------------------------------------------------------
+zk_transcript_t* zk_transcript_new(void) {
+    zk_transcript_t* t = nullptr;
+    int rc = guard([&] {
+        t = new zk_transcript();
+        t->state.reserve(transcript_state_bytes());
+        t->io.reserve(4096 * sizeof(u64));
+        transcript_init_dev(t->state.p, nullptr);
+    });
+    if (rc != 0) { delete t; return nullptr; }
+    return t;
+}
+int zk_transcript_put_dev(zk_transcript_t* t, const uint64_t* d_src, size_t n, void* stream) {
+    return guard([&] { ZK_REQUIRE(t, "transcript: null"); transcript_put_dev(t->state.p, (const u64*)d_src, n, (hipStream_t)stream); });
+}
+int zk_transcript_put(zk_transcript_t* t, const uint64_t* src, size_t n) {
+    return guard([&] {
+        ZK_REQUIRE(t && (src || n == 0), "transcript: null");
+        if (n == 0) return;
+        t->io.reserve(n * sizeof(u64));
+        ZK_HIP(hipMemcpy(t->io.p, src, n * sizeof(u64), hipMemcpyHostToDevice));
+        transcript_put_dev(t->state.p, t->io.u(), n, nullptr);
+        ZK_HIP(hipStreamSynchronize(nullptr));
+    });
+}
+int zk_transcript_get_field_dev(zk_transcript_t* t, uint64_t* d_out3, void* stream) {
+    return guard([&] { ZK_REQUIRE(t && d_out3, "transcript: null"); transcript_get_dev(t->state.p, (u64*)d_out3, 3, (hipStream_t)stream); });
+}
+static int transcript_get_host(zk_transcript_t* t, uint64_t* out, uint32_t n_words) {
+    return guard([&] {
+        ZK_REQUIRE(t && out, "transcript: null");
+        transcript_get_dev(t->state.p, t->io.u(), n_words, nullptr);
+        ZK_HIP(hipMemcpy(out, t->io.p, n_words * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+int zk_transcript_get_field(zk_transcript_t* t, uint64_t out[3]) { return transcript_get_host(t, out, 3); }
+int zk_transcript_get_fields1(zk_transcript_t* t, uint64_t* out) { return transcript_get_host(t, out, 1); }
+int zk_transcript_get_permutations(zk_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out) {
+    return guard([&] {
+        ZK_REQUIRE(t && out, "transcript: null");
+        t->io.reserve((size_t)n * sizeof(u64) + 64);
+        transcript_permutations_dev(t->state.p, n, nbits, t->io.u(), nullptr);
+        ZK_HIP(hipMemcpy(out, t->io.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+    });
+}
+int zk_transcript_free(zk_transcript_t* t) { delete t; return 0; }
+
+// ---- FRI / stark_gen glue ----------------------------------------------------------------------
+int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits, const uint64_t* d_special_x,
+                    uint64_t shift_inv, uint64_t* d_out, void* stream) {
+    return guard([&] { fri_fold_dev((const u64*)d_pol, pol_bits, step_bits, (const u64*)d_special_x, shift_inv, (u64*)d_out, (hipStream_t)stream); });
+}
+int zk_fri_transpose_dev(const uint64_t* d_pol, uint64_t n, uint32_t tbits, uint64_t* d_out, void* stream) {
+    return guard([&] { fri_transpose_dev((const u64*)d_pol, n, tbits, (u64*)d_out, (hipStream_t)stream); });
+}
+int zk_stark_x_table_dev(uint32_t nbits, uint64_t shift, uint64_t* d_out, void* stream) {
+    return guard([&] { ZK_REQUIRE(nbits <= 32, "x_table: nbits > 32"); x_table_dev(nbits, shift, (u64*)d_out, (hipStream_t)stream); });
+}
+int zk_stark_zh_inv_dev(uint32_t nbits, uint32_t extend_bits, uint64_t* d_out, void* stream) {
+    return guard([&] { ZK_REQUIRE(extend_bits <= 16, "zh_inv: extend_bits > 16"); zh_inv_dev(nbits, extend_bits, (u64*)d_out, (hipStream_t)stream); });
+}
+int zk_stark_xdivxsub_dev(const uint64_t* d_xi, uint64_t mulw, uint32_t nbits_ext, uint64_t* d_out, void* stream) {
+    return guard([&] { ZK_REQUIRE(nbits_ext <= 32, "xdivxsub: nbits_ext > 32"); xdivxsub_dev((const u64*)d_xi, mulw, nbits_ext, (u64*)d_out, (hipStream_t)stream); });
+}
+int zk_stark_lev_dev(const uint64_t* d_xi, uint32_t nbits, int prime, uint64_t* d_out, uint64_t* d_tmp, uint64_t* d_tmp2, void* stream) {
+    return guard([&] { lev_dev((const u64*)d_xi, nbits, prime != 0, (u64*)d_out, (u64*)d_tmp, (u64*)d_tmp2, (hipStream_t)stream); });
+}
+int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const uint64_t* d_LEv,
+                       const uint64_t* d_LpEv, uint64_t* d_out, void* stream) {
+    return guard([&] {
+        static_assert(sizeof(zk_eval_desc) == sizeof(EvalDescHost), "eval descriptor layout");
+        evals_dev((const EvalDescHost*)descs, n_ev, nbits, ext, (const u64*)d_LEv, (const u64*)d_LpEv, (u64*)d_out, (hipStream_t)stream);
+    });
+}
+int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, uint64_t* d_qq2, void* stream) {
+    return guard([&] { qsplit_dev((const u64*)d_qq1, nbits, q_dim, q_deg, (u64*)d_qq2, (hipStream_t)stream); });
 }
 
 const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->d_elements : nullptr; }

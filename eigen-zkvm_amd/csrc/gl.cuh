@@ -21,8 +21,16 @@ namespace gl {
 // add/sub are written on 32-bit limbs with explicit carries: on gfx950 v_add_co/v_addc_co are
 // double-rate VALU ops while 64-bit compares + selects are not (tools/ubench_valu.hip,
 // tools/field_probe.hip measured the variants: -20 % cycles on an NTT-shaped workload).
+//
+// GL_OPAQUE: every operation makes its operands opaque to the optimiser first.  Without it hipcc
+// (ROCm 7.2, LLVM 22) folds a producer's plain add/sub into a consumer's carry op
+// ("addcarry (add x, y), 0, cc -> addcarry x, y, cc") although the carry-OUT is used, which changes
+// the carry and silently corrupts e.g. add(sub(a, b), 0) -- found by tests/test_gpu_stark_steps.py,
+// reproduced in tools/dbg/dbg_f3b.hip.  The empty asm costs no instruction.
+#define GL_OPAQUE(x) asm("" : "+v"(x))
 __device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 __device__ __forceinline__ u64 add(u64 a, u64 b) {  // field_gl.rs:385-388; canonical in -> canonical out
+    GL_OPAQUE(a); GL_OPAQUE(b);
     u32 c0, c1, d0, d1;
     u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
     u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
@@ -32,6 +40,7 @@ __device__ __forceinline__ u64 add(u64 a, u64 b) {  // field_gl.rs:385-388; cano
     return mk64(sel ? t0 : s0, sel ? t1 : s1);
 }
 __device__ __forceinline__ u64 sub(u64 a, u64 b) {  // field_gl.rs:395-403
+    GL_OPAQUE(a); GL_OPAQUE(b);
     u32 b0, b1, e0, e1;
     u32 d0 = __builtin_subc((u32)a, (u32)b, 0u, &b0);
     u32 d1 = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b0, &b1);
@@ -57,6 +66,7 @@ __host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
 //   reduce  : x = lo + r2*2^64 + r3*2^96 = lo - r3 + r2*(2^32-1); the r2 term is ONE
 //             v_mad_u64_u32 whose carry-out (vcc) selects the +2^32-1 fix-up.
 __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    GL_OPAQUE(a); GL_OPAQUE(b);
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 p0 = (u64)a0 * b0;
     const u64 p1 = (u64)a0 * b1 + (p0 >> 32);

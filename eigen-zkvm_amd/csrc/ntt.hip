@@ -21,6 +21,7 @@
 //     per-thread chain over the 16 outputs needs 2 lookups + 1 multiply per element.
 //   * HBM-bound: 16 B / element / pass; bytes per transform = 16 * passes * N * n_pols.
 #include "zk_internal.h"
+#include "ntt_reg.cuh"
 #include <map>
 #include <mutex>
 #include <vector>
@@ -49,33 +50,6 @@ struct PassParams {
     u32 log_s;
     u32 has_tw;        // L > R (not the last pass)
 };
-
-__host__ __device__ constexpr int bitrev_c(int x, int bits) {
-    int r = 0;
-    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
-    return r;
-}
-
-// 2^LOG-point DIF NTT in registers, natural order in; X[k] ends up in x[bitrev(k)].
-// Twiddle w_{2h}^j = w_256^(j * 128/h): uniform addresses -> scalar loads.
-template <int LOG>
-__device__ __forceinline__ void ntt_reg(u64 (&x)[1 << LOG], const u64* __restrict__ w256) {
-    constexpr int n = 1 << LOG;
-#pragma unroll
-    for (int lh = LOG - 1; lh >= 0; --lh) {
-        const int half = 1 << lh;
-#pragma unroll
-        for (int blk = 0; blk < n; blk += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; ++j) {
-                u64 a = x[blk + j], b = x[blk + j + half];
-                x[blk + j] = gl::add(a, b);
-                u64 d = gl::sub(a, b);
-                x[blk + j + half] = (j == 0) ? d : gl::mul(d, w256[j * (128 / half)]);
-            }
-        }
-    }
-}
 
 __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e) {
     return gl::mul(hi[e >> TW_LO_BITS], lo[e & (TW_LO - 1)]);
@@ -316,6 +290,8 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
 }  // namespace
 
 int ntt_num_passes(uint32_t nbits) { return nbits < 4 ? 1 : (int)plan(nbits).size(); }
+
+const u64* ntt_w256_table(bool inverse) { return get_tables(8, inverse).w256; }
 
 void ntt_dev(const u64* d_src, u64* d_dst, u64* d_tmp, uint32_t n_pols, uint32_t nbits, bool inverse, hipStream_t st) {
     ZK_REQUIRE(nbits <= 32, "ntt: nbits > 32");

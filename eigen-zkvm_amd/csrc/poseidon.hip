@@ -191,6 +191,57 @@ __global__ void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, i
     for (int k = 0; k < 12; ++k) if (k < n_out) out[k] = st[k];
 }
 
+// ---- TranscriptGL (transcript.rs:8-103), device resident ---------------------------------------
+// The Fiat-Shamir sponge lives in HBM next to the data it absorbs (roots, evals, final
+// polynomial) and next to the kernels that consume its challenges, so a proof is one stream of
+// launches with no host round trip until the query indices are needed.  One lane does the work
+// (a sponge is inherently serial); state layout = TranscriptState below.
+struct TranscriptState { u64 state[4]; u64 pending[8]; u64 out[12]; u32 n_pending, out_pos, n_out, _pad; };
+
+__device__ void tr_update(TranscriptState* t) {  // transcript.rs:15-24
+    u64 st[12];
+    for (int i = 0; i < 8; ++i) st[i] = (u32)i < t->n_pending ? t->pending[i] : 0;
+    for (int i = 0; i < 4; ++i) st[8 + i] = t->state[i];
+    poseidon_perm(st);
+    for (int i = 0; i < 12; ++i) t->out[i] = st[i];
+    for (int i = 0; i < 4; ++i) t->state[i] = st[i];
+    t->n_pending = 0; t->out_pos = 0; t->n_out = 12;
+}
+__device__ u64 tr_get1(TranscriptState* t) {     // transcript.rs:54-62
+    if (t->out_pos >= t->n_out) tr_update(t);
+    return t->out[t->out_pos++];
+}
+__global__ void tr_init_kernel(TranscriptState* t) {
+    if (threadIdx.x | blockIdx.x) return;
+    for (int i = 0; i < 4; ++i) t->state[i] = 0;
+    t->n_pending = 0; t->out_pos = 0; t->n_out = 0;
+}
+__global__ void tr_put_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n) {  // transcript.rs:25-33,64-71
+    if (threadIdx.x | blockIdx.x) return;
+    for (u64 i = 0; i < n; ++i) {
+        t->n_out = 0; t->out_pos = 0;
+        t->pending[t->n_pending++] = src[i];
+        if (t->n_pending == 8) tr_update(t);
+    }
+}
+__global__ void tr_get_kernel(TranscriptState* t, u64* __restrict__ dst, u32 n_words) {  // get_field = 3 words
+    if (threadIdx.x | blockIdx.x) return;
+    for (u32 i = 0; i < n_words; ++i) dst[i] = tr_get1(t);
+}
+__global__ void tr_permutations_kernel(TranscriptState* t, u32 n, u32 nbits, u64* __restrict__ dst) {  // transcript.rs:73-102
+    if (threadIdx.x | blockIdx.x) return;
+    u64 field = 0; u32 cur_bit = 63;  // force a fetch on first use
+    for (u32 i = 0; i < n; ++i) {
+        u64 a = 0;
+        for (u32 j = 0; j < nbits; ++j) {
+            if (cur_bit == 63) { field = tr_get1(t); cur_bit = 0; }
+            if ((field >> cur_bit) & 1) a += 1ull << j;
+            ++cur_bit;
+        }
+        dst[i] = a;
+    }
+}
+
 bool g_consts_loaded[64] = {};
 
 void ensure_constants() {
@@ -205,6 +256,27 @@ void ensure_constants() {
 }
 
 }  // namespace
+
+size_t transcript_state_bytes() { return sizeof(TranscriptState); }
+void transcript_init_dev(void* d_t, hipStream_t st) {
+    ensure_constants();
+    hipLaunchKernelGGL(tr_init_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t);
+    ZK_HIP(hipGetLastError());
+}
+void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(tr_put_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_src, n);
+    ZK_HIP(hipGetLastError());
+}
+void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st) {
+    hipLaunchKernelGGL(tr_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_dst, n_words);
+    ZK_HIP(hipGetLastError());
+}
+void transcript_permutations_dev(void* d_t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st) {
+    ZK_REQUIRE(nbits >= 1 && nbits <= 63, "get_permutations: nbits out of range");
+    hipLaunchKernelGGL(tr_permutations_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, n, nbits, d_dst);
+    ZK_HIP(hipGetLastError());
+}
 
 void poseidon_dev(const u64* d_in8, const u64* d_cap4, u64* d_out, int n_out, hipStream_t st) {
     ensure_constants();

@@ -1,0 +1,227 @@
+// Per-stage glue kernels of the starky prover for gfx950: FRI folding and transposition, the
+// x/(x-xi) tables, evaluation (opening) dot products, quotient split, vanishing-inverse and
+// domain tables.  All operands are device resident; F3G = 3 consecutive canonical u64.
+//
+// Replaces (file:line under /root/reference/starky/src):
+//   fri.rs:101-126 (fold, single-threaded `for g` there), fri.rs:299-317 (get_transposed_buffer),
+//   stark_gen.rs:231-249 (x_n, x_2ns, build_Zh_Inv :575-592), :375-396 (Q split),
+//   :416-430 (LEv/LpEv), :432-466 (evals), :481-522 (xDivXSubXi via sequential batch_inverse,
+//   polutils.rs:35-53 -- here every point is inverted independently: same field elements).
+#include "zk_internal.h"
+#include "ntt_reg.cuh"
+
+namespace zk {
+
+namespace {
+
+using gl::f3;
+
+__device__ __forceinline__ f3 ld3(const u64* __restrict__ p) { return f3{{p[0], p[1], p[2]}}; }
+__device__ __forceinline__ void st3(u64* __restrict__ p, f3 v) { p[0] = v.v[0]; p[1] = v.v[1]; p[2] = v.v[2]; }
+__device__ __forceinline__ f3 f3_pow(f3 a, u64 e) {
+    f3 r{{1, 0, 0}};
+    while (e) { if (e & 1) r = gl::f3_mul(r, a); a = gl::f3_mul(a, a); e >>= 1; }
+    return r;
+}
+// multiplication by the generator x of GF(p^3) = GF(p)[x]/(x^3 - x - 1)
+__device__ __forceinline__ f3 mul_x(f3 a) { return f3{{a.v[2], gl::add(a.v[0], a.v[2]), a.v[1]}}; }
+
+// ---- FRI fold (fri.rs:112-126) ------------------------------------------------------------
+// pol2[g] = P_g(special_x * sinv_g), P_g = interpolant of {pol[i*n2 + g]}_i on <w_NX>,
+// sinv_g = shift_inv * w_polbits^-g.  One lane per g; limb by limb: a base-field size-NX inverse
+// DFT in registers, Horner at the extension point, recombination with powers of x.
+template <int LOGNX>
+__global__ __launch_bounds__(256) void fri_fold_kernel(const u64* __restrict__ pol, u64 pol2_n, const u64* __restrict__ w256inv,
+                                                       u64 shift_inv, u64 wi, u64 nx_inv, const u64* __restrict__ special_x,
+                                                       u64* __restrict__ out) {
+    constexpr int NX = 1 << LOGNX;
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= pol2_n) return;
+    const u64 sinv = gl::mul(shift_inv, gl::pow(wi, g));
+    const f3 y = gl::f3_muls(ld3(special_x), sinv);
+    f3 S[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        u64 x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = pol[((u64)i * pol2_n + g) * 3 + l];
+        ntt_reg<LOGNX>(x, w256inv);  // coefficient k (times NX) sits in x[bitrev(k)]
+        f3 acc{{x[bitrev_c(NX - 1, LOGNX)], 0, 0}};
+#pragma unroll
+        for (int k = NX - 2; k >= 0; --k) {
+            acc = gl::f3_mul(acc, y);
+            acc.v[0] = gl::add(acc.v[0], x[bitrev_c(k, LOGNX)]);
+        }
+        S[l] = acc;
+    }
+    f3 r = gl::f3_add(S[0], gl::f3_add(mul_x(S[1]), mul_x(mul_x(S[2]))));
+    st3(out + 3 * g, gl::f3_muls(r, nx_inv));
+}
+
+__global__ void copy3_kernel(const u64* __restrict__ in, u64 n, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// fri.rs:299-317: out[(i*h + j)*3 ..] = pol[(j*w + i)*3 ..]
+__global__ void fri_transpose_kernel(const u64* __restrict__ pol, u64 n, u32 tbits, u64* __restrict__ out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // destination element index
+    if (t >= n) return;
+    const u64 w = 1ull << tbits, h = n >> tbits;
+    const u64 i = t / h, j = t % h;
+    st3(out + 3 * t, ld3(pol + 3 * (j * w + i)));
+}
+
+// ---- domain tables -------------------------------------------------------------------------
+__global__ void x_table_kernel(u64 shift, u64 w, u64 n, u64* __restrict__ out) {   // stark_gen.rs:231-247
+    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = gl::mul(shift, gl::pow(w, k));
+}
+__global__ void zh_inv_kernel(u64 sn, u64 we, u32 n, u64* __restrict__ out) {      // stark_gen.rs:575-592
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = gl::inv(gl::sub(gl::mul(sn, gl::pow(we, j)), 1));
+}
+// x/(x - xi*mulw) for x = 49*w_ext^k                                            stark_gen.rs:481-522
+__global__ __launch_bounds__(256) void xdivxsub_kernel(const u64* __restrict__ xi, u64 mulw, u64 w_ext, u64 n, u64* __restrict__ out) {
+    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const f3 z = gl::f3_muls(ld3(xi), mulw);
+    const u64 x = gl::mul(49, gl::pow(w_ext, k));
+    const f3 den{{gl::sub(x, z.v[0]), gl::neg(z.v[1]), gl::neg(z.v[2])}};
+    st3(out + 3 * k, gl::f3_muls(gl::f3_inv(den), x));
+}
+// LEv[i] = (xi * mulw / 49)^i                                                   stark_gen.rs:416-427
+__global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi, u64 mul_c, u64 n, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st3(out + 3 * i, f3_pow(gl::f3_muls(ld3(xi), mul_c), i));
+}
+
+// ---- evals (stark_gen.rs:432-466) ----------------------------------------------------------
+struct EvalDesc { const u64* buf; u64 width; u64 offset; u32 dim; u32 prime; };
+constexpr int EV_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void evals_partial_kernel(const EvalDesc* __restrict__ descs, u32 nbits, u32 ext,
+                                                            const u64* __restrict__ LEv, const u64* __restrict__ LpEv,
+                                                            u64* __restrict__ partial /* [n_ev][EV_BLOCKS][3] */) {
+    const EvalDesc d = descs[blockIdx.y];
+    const u64 N = 1ull << nbits;
+    const u64* __restrict__ L = d.prime ? LpEv : LEv;
+    f3 acc{{0, 0, 0}};
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (u64)gridDim.x * blockDim.x) {
+        const u64* c = d.buf + (k << ext) * d.width + d.offset;
+        const f3 l = ld3(L + 3 * k);
+        acc = gl::f3_add(acc, d.dim == 1 ? gl::f3_muls(l, c[0]) : gl::f3_mul(ld3(c), l));
+    }
+    __shared__ u64 red[256 * 3];
+    red[threadIdx.x * 3] = acc.v[0]; red[threadIdx.x * 3 + 1] = acc.v[1]; red[threadIdx.x * 3 + 2] = acc.v[2];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s) * 3)));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st3(partial + ((u64)blockIdx.y * gridDim.x + blockIdx.x) * 3, ld3(red));
+}
+__global__ void evals_final_kernel(const u64* __restrict__ partial, u32 n_ev, u32 nblk, u64* __restrict__ out) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ev) return;
+    f3 acc{{0, 0, 0}};
+    for (u32 b = 0; b < nblk; ++b) acc = gl::f3_add(acc, ld3(partial + ((u64)e * nblk + b) * 3));
+    st3(out + 3 * e, acc);
+}
+
+// ---- Q split (stark_gen.rs:375-391) ---------------------------------------------------------
+__global__ void qsplit_kernel(const u64* __restrict__ qq1, u32 nbits, u32 q_dim, u32 q_deg, u64 shift_inv_n, u64* __restrict__ qq2) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // over N * q_deg * q_dim source cells
+    const u64 N = 1ull << nbits;
+    if (t >= N * q_deg * q_dim) return;
+    const u32 k = t % q_dim;
+    const u64 row = t / q_dim;          // p*N + i
+    const u64 p = row >> nbits, i = row & (N - 1);
+    qq2[i * q_dim * q_deg + q_dim * p + k] = gl::mul(qq1[t], gl::pow(shift_inv_n, p));
+}
+
+inline dim3 grid1(u64 n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+void fri_fold_dev(const u64* d_pol, uint32_t pol_bits, uint32_t step_bits, const u64* d_special_x, u64 shift_inv, u64* d_out, hipStream_t st) {
+    ZK_REQUIRE(step_bits <= pol_bits && pol_bits <= 32, "fri_fold: need step_bits <= pol_bits <= 32");
+    const uint32_t r = pol_bits - step_bits;
+    const u64 n2 = 1ull << step_bits;
+    if (r == 0) {  // fri.rs:113-114: step 0 copies
+        hipLaunchKernelGGL(copy3_kernel, grid1(n2 * 3), dim3(256), 0, st, d_pol, n2 * 3, d_out);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
+    ZK_REQUIRE(r <= 6, "fri_fold: reduction of more than 6 bits per step is not supported");
+    const u64* w256inv = ntt_w256_table(true);
+    const u64 wi = gl::hinv(gl::hroot(pol_bits)), nx_inv = gl::hinv(1ull << r);
+#define ZK_FOLD(L) hipLaunchKernelGGL((fri_fold_kernel<L>), grid1(n2), dim3(256), 0, st, d_pol, n2, w256inv, shift_inv, wi, nx_inv, d_special_x, d_out)
+    switch (r) {
+        case 1: ZK_FOLD(1); break; case 2: ZK_FOLD(2); break; case 3: ZK_FOLD(3); break;
+        case 4: ZK_FOLD(4); break; case 5: ZK_FOLD(5); break; default: ZK_FOLD(6); break;
+    }
+#undef ZK_FOLD
+    ZK_HIP(hipGetLastError());
+}
+
+void fri_transpose_dev(const u64* d_pol, uint64_t n, uint32_t tbits, u64* d_out, hipStream_t st) {
+    ZK_REQUIRE((n >> tbits) >= 1, "fri_transpose: bad shape");
+    hipLaunchKernelGGL(fri_transpose_kernel, grid1(n), dim3(256), 0, st, d_pol, n, tbits, d_out);
+    ZK_HIP(hipGetLastError());
+}
+
+void x_table_dev(uint32_t nbits, u64 shift, u64* d_out, hipStream_t st) {
+    const u64 n = 1ull << nbits;
+    hipLaunchKernelGGL(x_table_kernel, grid1(n), dim3(256), 0, st, shift, gl::hroot(nbits), n, d_out);
+    ZK_HIP(hipGetLastError());
+}
+
+void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st) {
+    u64 sn = 49;
+    for (uint32_t i = 0; i < nbits; ++i) sn = gl::hmul(sn, sn);
+    const uint32_t n = 1u << extend_bits;
+    hipLaunchKernelGGL(zh_inv_kernel, grid1(n), dim3(256), 0, st, sn, gl::hroot(extend_bits), n, d_out);
+    ZK_HIP(hipGetLastError());
+}
+
+void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st) {
+    const u64 n = 1ull << nbits_ext;
+    hipLaunchKernelGGL(xdivxsub_kernel, grid1(n), dim3(256), 0, st, d_xi, mulw, gl::hroot(nbits_ext), n, d_out);
+    ZK_HIP(hipGetLastError());
+}
+
+void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp, u64* d_tmp2, hipStream_t st) {
+    const u64 n = 1ull << nbits;
+    u64 c = gl::hinv(49);
+    if (prime) c = gl::hmul(c, gl::hroot(nbits));
+    hipLaunchKernelGGL(lev_pow_kernel, grid1(n), dim3(256), 0, st, d_xi, c, n, d_tmp);
+    ZK_HIP(hipGetLastError());
+    ntt_dev(d_tmp, d_out, d_tmp2, 3, nbits, true, st);  // FFT::ifft over F3G == per-limb iNTT (base-field roots)
+}
+
+void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv,
+               u64* d_out, hipStream_t st) {
+    if (n_ev == 0) return;
+    static_assert(sizeof(EvalDescHost) == sizeof(EvalDesc), "descriptor layout");
+    EvalDesc* d_desc; u64* d_partial;
+    ZK_HIP(hipMallocAsync((void**)&d_desc, n_ev * sizeof(EvalDesc), st));
+    ZK_HIP(hipMallocAsync((void**)&d_partial, (size_t)n_ev * EV_BLOCKS * 24, st));
+    ZK_HIP(hipMemcpyAsync(d_desc, descs, n_ev * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, n_ev), dim3(256), 0, st, d_desc, nbits, ext, d_LEv, d_LpEv, d_partial);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(evals_final_kernel, grid1(n_ev, 64), dim3(64), 0, st, d_partial, n_ev, (u32)EV_BLOCKS, d_out);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipFreeAsync(d_desc, st));
+    ZK_HIP(hipFreeAsync(d_partial, st));
+}
+
+void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st) {
+    const u64 N = 1ull << nbits;
+    const u64 shift_inv_n = gl::hpow(gl::hinv(49), N);
+    hipLaunchKernelGGL(qsplit_kernel, grid1(N * q_deg * q_dim), dim3(256), 0, st, d_qq1, nbits, q_dim, q_deg, shift_inv_n, d_qq2);
+    ZK_HIP(hipGetLastError());
+}
+
+}  // namespace zk

@@ -54,4 +54,23 @@ uint64_t merkle_n_nodes(uint64_t height);
 // nodes: merkle_n_nodes(height)*4 words, zero-filled by this call; leaves from [height][width] rows
 void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
 
+// ---- device-resident transcript (poseidon.hip; transcript.rs:8-103) ----
+size_t transcript_state_bytes();
+void transcript_init_dev(void* d_t, hipStream_t st);
+void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st);
+void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st);
+void transcript_permutations_dev(void* d_t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st);
+
+// ---- prover glue (stark.hip) ----
+const u64* ntt_w256_table(bool inverse);  // w_256^(+-e), e < 256, device pointer (ntt.hip)
+struct EvalDescHost { const u64* buf; uint64_t width; uint64_t offset; uint32_t dim; uint32_t prime; };
+void fri_fold_dev(const u64* d_pol, uint32_t pol_bits, uint32_t step_bits, const u64* d_special_x, u64 shift_inv, u64* d_out, hipStream_t st);
+void fri_transpose_dev(const u64* d_pol, uint64_t n, uint32_t tbits, u64* d_out, hipStream_t st);
+void x_table_dev(uint32_t nbits, u64 shift, u64* d_out, hipStream_t st);
+void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st);
+void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st);
+void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp, u64* d_tmp2, hipStream_t st);
+void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv, u64* d_out, hipStream_t st);
+void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
+
 }  // namespace zk

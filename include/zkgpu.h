@@ -83,6 +83,48 @@ const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t);       /* device po
 const uint64_t* zk_merkle_nodes_dev(const zk_merkle_t* t);          /* device pointer of nodes  */
 int zk_merkle_free(zk_merkle_t* t);
 
+/* ---- Transcript (trait Transcript, starky/src/traits.rs:57-63; TranscriptGL,
+ *      starky/src/transcript.rs:8-103).  The sponge state lives on the device: absorbing a root,
+ *      the evals or the last FRI polynomial and drawing a challenge need no host round trip.     */
+typedef struct zk_transcript zk_transcript_t;
+zk_transcript_t* zk_transcript_new(void);                                        /* T::new()            */
+int zk_transcript_put(zk_transcript_t* t, const uint64_t* src, size_t n);        /* put(), host words   */
+int zk_transcript_put_dev(zk_transcript_t* t, const uint64_t* d_src, size_t n, void* stream);
+int zk_transcript_get_field(zk_transcript_t* t, uint64_t out[3]);                /* get_field() -> host */
+int zk_transcript_get_field_dev(zk_transcript_t* t, uint64_t* d_out3, void* stream);
+int zk_transcript_get_fields1(zk_transcript_t* t, uint64_t* out);                /* get_fields1()       */
+int zk_transcript_get_permutations(zk_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out);
+int zk_transcript_free(zk_transcript_t* t);
+
+/* ---- FRI (starky/src/fri.rs:84-184) ----------------------------------------------------------
+ * one folding step (fri.rs:101-126): d_pol [1<<pol_bits][3] -> d_out [1<<step_bits][3];
+ * d_special_x = the step's challenge (3 device words); shift_inv = (49^-1)^(2^(nBitsExt-pol_bits)).
+ * pol_bits - step_bits <= 6.  step_bits == pol_bits copies (step 0 of the reference).            */
+int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits,
+                    const uint64_t* d_special_x, uint64_t shift_inv, uint64_t* d_out, void* stream);
+/* get_transposed_buffer (fri.rs:299-317): [n] F3G -> [1<<tbits][n>>tbits][3] words */
+int zk_fri_transpose_dev(const uint64_t* d_pol, uint64_t n, uint32_t tbits, uint64_t* d_out, void* stream);
+
+/* ---- stark_gen glue (starky/src/stark_gen.rs) --------------------------------------------------
+ * x_n / x_2ns tables (:231-247): out[k] = shift * MG.0[nbits]^k                                    */
+int zk_stark_x_table_dev(uint32_t nbits, uint64_t shift, uint64_t* d_out, void* stream);
+/* build_Zh_Inv (:575-592): out[j] = 1/(49^(2^nbits) * MG.0[ext]^j - 1), j < 2^ext                 */
+int zk_stark_zh_inv_dev(uint32_t nbits, uint32_t extend_bits, uint64_t* d_out, void* stream);
+/* xDivXSubXi / xDivXSubWXi (:481-522): out[k] = x/(x - xi*mulw), x = 49*MG.0[nbits_ext]^k, [Next][3];
+ * mulw = 1 for xi, MG.0[nBits] for w*xi                                                            */
+int zk_stark_xdivxsub_dev(const uint64_t* d_xi, uint64_t mulw, uint32_t nbits_ext, uint64_t* d_out, void* stream);
+/* LEv / LpEv (:416-430): iNTT_N of ((xi[*w])/49)^i -> [N][3]; d_tmp, d_tmp2: N*3 words each        */
+int zk_stark_lev_dev(const uint64_t* d_xi, uint32_t nbits, int prime, uint64_t* d_out, uint64_t* d_tmp,
+                     uint64_t* d_tmp2, void* stream);
+/* evals (:432-466): out[e] = sum_k cell_e[(k<<ext)*width + offset] * L_e[k]; L_e = LpEv if prime   */
+typedef struct { const uint64_t* d_buf; uint64_t width; uint64_t offset; uint32_t dim; uint32_t prime; } zk_eval_desc;
+int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext,
+                       const uint64_t* d_LEv, const uint64_t* d_LpEv, uint64_t* d_out, void* stream);
+/* Q split (:375-391): qq2[i][p*q_dim+k] = qq1[p*N+i][k] * (49^-N)^p ; qq2 is [Next][q_dim*q_deg]
+ * and must be zero-filled by the caller beyond row N                                               */
+int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg,
+                        uint64_t* d_qq2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

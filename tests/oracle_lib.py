@@ -36,6 +36,17 @@ class Oracle:
         L.orc_tr_get1.restype = C.c_uint64; L.orc_tr_get1.argtypes = [C.c_void_p]
         L.orc_tr_get_field.argtypes = [C.c_void_p, _u64p]
         L.orc_tr_get_permutations.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _u64p]
+        L.orc_f3_ntt.argtypes = [_u64p, C.c_uint, C.c_int]
+        L.orc_fri_fold.argtypes = [_u64p, C.c_uint, C.c_uint, _u64p, C.c_uint64, _u64p]
+        L.orc_fri_transpose.argtypes = [_u64p, C.c_uint64, C.c_uint, _u64p]
+        L.orc_f3_batch_inverse.argtypes = [_u64p, C.c_uint64, _u64p]
+        L.orc_xdivxsub.argtypes = [_u64p, C.c_uint, _u64p]
+        L.orc_zh_inv.argtypes = [C.c_uint, C.c_uint, _u64p]
+        L.orc_lev.argtypes = [_u64p, C.c_uint, C.c_int, _u64p]
+        L.orc_eval_dot.argtypes = [_u64p, C.c_uint64, C.c_uint64, C.c_uint, C.c_uint, C.c_uint, _u64p, _u64p]
+        L.orc_qsplit.argtypes = [_u64p, C.c_uint, C.c_uint, C.c_uint, _u64p]
+        L.orc_calculate_z.restype = C.c_int
+        L.orc_calculate_z.argtypes = [_u64p, _u64p, C.c_uint64, _u64p]
 
     # -- field
     def mul(self, a, b): return self.lib.orc_gl_mul(a, b)
@@ -77,6 +88,31 @@ class Oracle:
 
     def transcript(self):
         return Transcript(self)
+
+    # -- prover glue (oracle/stark_steps.c)
+    def f3_ntt(self, v, bits, inverse=False):
+        v = _a(v).copy(); self.lib.orc_f3_ntt(v, bits, int(inverse)); return v
+    def fri_fold(self, pol, pol_bits, step_bits, special_x, shift_inv):
+        o = np.zeros(3 << step_bits, np.uint64)
+        self.lib.orc_fri_fold(_a(pol), pol_bits, step_bits, _a(special_x), shift_inv, o); return o
+    def fri_transpose(self, pol, n, tbits):
+        o = np.zeros(3 * n, np.uint64); self.lib.orc_fri_transpose(_a(pol), n, tbits, o); return o
+    def f3_batch_inverse(self, v):
+        v = _a(v); o = np.zeros_like(v); self.lib.orc_f3_batch_inverse(v, v.size // 3, o); return o
+    def xdivxsub(self, xi, nbits_ext):
+        o = np.zeros(3 << nbits_ext, np.uint64); self.lib.orc_xdivxsub(_a(xi), nbits_ext, o); return o
+    def zh_inv(self, nbits, ext):
+        o = np.zeros(1 << ext, np.uint64); self.lib.orc_zh_inv(nbits, ext, o); return o
+    def lev(self, xi, nbits, prime):
+        o = np.zeros(3 << nbits, np.uint64); self.lib.orc_lev(_a(xi), nbits, int(prime), o); return o
+    def eval_dot(self, buf, width, offset, dim, nbits, ext, L):
+        o = np.zeros(3, np.uint64); self.lib.orc_eval_dot(_a(buf), width, offset, dim, nbits, ext, _a(L), o); return o
+    def qsplit(self, qq1, nbits, nbits_ext, q_dim, q_deg):
+        o = np.zeros((1 << nbits_ext) * q_dim * q_deg, np.uint64)
+        self.lib.orc_qsplit(_a(qq1), nbits, q_dim, q_deg, o); return o
+    def calculate_z(self, num, den):
+        num = _a(num); z = np.zeros_like(num)
+        ok = self.lib.orc_calculate_z(num, _a(den), num.size // 3, z); return z, bool(ok)
 
 
 class Transcript:
