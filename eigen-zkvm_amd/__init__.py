@@ -30,7 +30,31 @@ EXPORTS = [
     "zk_transcript_free",
     "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
+    "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
 ]
+
+# include/zkgpu.h enums
+OP_ADD, OP_SUB, OP_MUL, OP_COPY = 0, 1, 2, 3
+(OPND_TMP, OPND_MEM, OPND_NUMBER, OPND_PUBLIC, OPND_CHALLENGE, OPND_EVAL, OPND_X, OPND_ZI,
+ OPND_XDIVXSUBXI, OPND_XDIVXSUBWXI) = range(10)
+
+
+class Operand(C.Structure):
+    """zk_operand"""
+    _fields_ = [("kind", C.c_uint8), ("dim", C.c_uint8), ("prime", C.c_uint8), ("buf", C.c_uint8),
+                ("id", C.c_uint32), ("stride", C.c_uint32), ("_pad", C.c_uint32), ("value", C.c_uint64)]
+
+
+class Instr(C.Structure):
+    """zk_instr"""
+    _fields_ = [("op", C.c_uint32), ("_pad", C.c_uint32), ("dest", Operand), ("src", Operand * 2)]
+
+
+class EvalCtx(C.Structure):
+    """zk_eval_ctx"""
+    _fields_ = [("bufs", C.c_void_p * 16), ("publics", C.c_void_p), ("challenges", C.c_void_p),
+                ("evals", C.c_void_p), ("x", C.c_void_p), ("zi", C.c_void_p), ("zi_mask", C.c_uint64),
+                ("xdivxsubxi", C.c_void_p), ("xdivxsubwxi", C.c_void_p)]
 
 
 class EvalDesc(C.Structure):
@@ -94,6 +118,10 @@ def _load():
         "zk_stark_lev_dev": (C.c_int, [vp, C.c_uint32, C.c_int, vp, vp, vp, vp]),
         "zk_stark_evals_dev": (C.c_int, [C.POINTER(EvalDesc), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
         "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+        "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
+        "zk_program_source": (C.c_char_p, [vp]),
+        "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
+        "zk_program_free": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -333,6 +361,50 @@ def evals(descs, nbits, ext, d_lev, d_lpev, stream=0):
     _check(lib().zk_stark_evals_dev(arr, len(descs), nbits, ext, d_lev.ptr, d_lpev.ptr, out.ptr, stream))
     _check(lib().zk_dev_sync())
     return out
+
+
+# ---- interpreter.rs seam: compiled step programs ---------------------------------------------------
+def opnd(kind, id=0, dim=1, prime=False, buf=0, stride=0, value=0):
+    return Operand(kind, dim, int(prime), buf, id, stride, 0, value)
+
+
+def instr(op, dest, src0, src1=None):
+    i = Instr(); i.op = op; i.dest = dest; i.src[0] = src0
+    i.src[1] = src1 if src1 is not None else Operand()
+    return i
+
+
+class Program:
+    """compile_code + Block::eval (interpreter.rs:187-225, :91-175) as one run-time compiled kernel."""
+
+    def __init__(self, instrs):
+        arr = (Instr * len(instrs))(*instrs)
+        self._h = lib().zk_program_compile(arr, len(instrs))
+        if not self._h:
+            raise ZkError(lib().zk_last_error().decode())
+
+    @property
+    def source(self):
+        return lib().zk_program_source(self._h).decode()
+
+    def run(self, bufs, nbits_domain, next_, publics=None, challenges=None, evals=None, x=None, zi=None,
+            xdiv=None, xdivw=None, stream=0):
+        c = EvalCtx()
+        for k, b in bufs.items():
+            c.bufs[k] = b.ptr
+        p = lambda d: d.ptr if d is not None else None
+        c.publics, c.challenges, c.evals, c.x = p(publics), p(challenges), p(evals), p(x)
+        c.zi, c.zi_mask = p(zi), (zi.n - 1 if zi is not None else 0)
+        c.xdivxsubxi, c.xdivxsubwxi = p(xdiv), p(xdivw)
+        _check(lib().zk_program_run_dev(self._h, C.byref(c), nbits_domain, next_, stream))
+        _check(lib().zk_dev_sync())
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().zk_program_free(self._h); self._h = None
+        except Exception:
+            pass
 
 
 def qsplit(d_qq1, nbits, nbits_ext, q_dim, q_deg, stream=0):

@@ -10,9 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ZK-JIT-BEGIN  (the region up to ZK-JIT-END is also the prelude of the run-time compiled
+// constraint kernels, csrc/expr_jit.hip; keep it free of #include and host-only code)
 typedef unsigned long long u64;
 typedef unsigned int u32;
-
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL
 
@@ -97,23 +98,6 @@ __device__ __forceinline__ u64 pow(u64 a, u64 e) {  // field_gl.rs:467-479
 }
 __device__ __forceinline__ u64 inv(u64 a) { return pow(a, GL_P - 2); }  // field_gl.rs:415-449
 
-// host-side twins (used only to build twiddle tables at context creation)
-inline u64 hmul(u64 a, u64 b) {
-    unsigned __int128 x = (unsigned __int128)a * b;
-    return reduce128((u64)x, (u64)(x >> 64));
-}
-inline u64 hpow(u64 a, u64 e) {
-    u64 r = 1;
-    while (e) { if (e & 1) r = hmul(r, a); a = hmul(a, a); e >>= 1; }
-    return r;
-}
-inline u64 hinv(u64 a) { return hpow(a, GL_P - 2); }
-inline u64 hroot(unsigned k) {  // MG.0[k], starky/src/constant.rs:54-68
-    u64 w = hpow(7, 0xFFFFFFFFULL);
-    for (unsigned n = 32; n > k; --n) w = hmul(w, w);
-    return w;
-}
-
 // GF(p^3) = GF(p)[x]/(x^3 - x - 1)  (starky/src/f3g.rs).  Device values never carry the
 // reference's runtime `dim` tag: the width (1 or 3 words) is a static property of each buffer.
 struct f3 { u64 v[3]; };
@@ -143,6 +127,25 @@ __device__ __forceinline__ f3 f3_inv(f3 x) {  // f3g.rs:207-235
     u64 i2 = sub(ba, cc);
     u64 i3 = add(sub(ac, bb), cc);
     return f3{{mul(i1, ti), mul(i2, ti), mul(i3, ti)}};
+}
+
+// ZK-JIT-END
+
+// host-side twins (used only to build twiddle tables at context creation)
+inline u64 hmul(u64 a, u64 b) {
+    unsigned __int128 x = (unsigned __int128)a * b;
+    return reduce128((u64)x, (u64)(x >> 64));
+}
+inline u64 hpow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = hmul(r, a); a = hmul(a, a); e >>= 1; }
+    return r;
+}
+inline u64 hinv(u64 a) { return hpow(a, GL_P - 2); }
+inline u64 hroot(unsigned k) {  // MG.0[k], starky/src/constant.rs:54-68
+    u64 w = hpow(7, 0xFFFFFFFFULL);
+    for (unsigned n = 32; n > k; --n) w = hmul(w, w);
+    return w;
 }
 
 }  // namespace gl

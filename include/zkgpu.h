@@ -125,6 +125,47 @@ int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits,
 int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg,
                         uint64_t* d_qq2, void* stream);
 
+/* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
+ * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
+ * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as
+ * interpreter.rs get_ref/set_ref/eval_map do (:286-524): section cells become
+ * (buffer slot, column offset, row stride, prime); tmp/number/public/challenge/eval/x/Zi/xDivXSub*
+ * keep their meaning.  zk_program_compile translates it to a gfx950 kernel (hipRTC) once;
+ * zk_program_run_dev evaluates it for every row i of the domain, reading rows (i + next*prime) % N.
+ * Value widths (the F3G dim) are inferred from the operands: dim-1 op dim-1 -> 1, anything with a
+ * dim-3 operand -> 3 (f3g.rs:323-449); a dim-3 result written to a section cell occupies 3 words,
+ * a dim-1 result 1 word (interpreter.rs:149-159).                                                */
+enum { ZK_OP_ADD = 0, ZK_OP_SUB = 1, ZK_OP_MUL = 2, ZK_OP_COPY = 3 };
+enum { ZK_OPND_TMP = 0, ZK_OPND_MEM = 1, ZK_OPND_NUMBER = 2, ZK_OPND_PUBLIC = 3, ZK_OPND_CHALLENGE = 4,
+       ZK_OPND_EVAL = 5, ZK_OPND_X = 6, ZK_OPND_ZI = 7, ZK_OPND_XDIVXSUBXI = 8, ZK_OPND_XDIVXSUBWXI = 9 };
+typedef struct {
+    uint8_t kind;     /* ZK_OPND_*                                                            */
+    uint8_t dim;      /* MEM: width of the cell (1 or 3); ignored for the other kinds          */
+    uint8_t prime;    /* MEM: read row (i + next) % N                                          */
+    uint8_t buf;      /* MEM: slot in zk_eval_ctx.bufs                                         */
+    uint32_t id;      /* TMP: id; MEM: column offset; PUBLIC/CHALLENGE/EVAL: index             */
+    uint32_t stride;  /* MEM: words per row of the section                                     */
+    uint32_t _pad;
+    uint64_t value;   /* NUMBER: canonical value                                               */
+} zk_operand;
+typedef struct { uint32_t op; uint32_t _pad; zk_operand dest; zk_operand src[2]; } zk_instr;
+typedef struct {
+    uint64_t* bufs[16];            /* device base pointers of the sections the program touches  */
+    const uint64_t* publics;       /* [n_publics]                                               */
+    const uint64_t* challenges;    /* [8][3]  (constant.rs:39-50)                               */
+    const uint64_t* evals;         /* [n_evals][3]                                              */
+    const uint64_t* x;             /* x_n or x_2ns, [N]                                         */
+    const uint64_t* zi;            /* ZHInv table, [zi_mask + 1]                                */
+    uint64_t zi_mask;
+    const uint64_t* xdivxsubxi;    /* [N][3]                                                    */
+    const uint64_t* xdivxsubwxi;   /* [N][3]                                                    */
+} zk_eval_ctx;
+typedef struct zk_program zk_program_t;
+zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr);    /* needs no GPU */
+const char* zk_program_source(const zk_program_t* p);                         /* generated HIP text */
+int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, void* stream);
+int zk_program_free(zk_program_t* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,99 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Pure-Python restatement of the reference's constraint
+interpreter for small domains: starky/src/interpreter.rs:91-175 (Block::eval), :228-234 (get_i),
+:236-283 (get_value) and the F3G runtime-dim arithmetic of starky/src/f3g.rs:323-449.
+
+A value is a tuple of 1 or 3 ints (the reference's F3G with dim 1 or 3).  A program is a list of
+(op, dest, src0, src1) with operands given as dicts:
+  {"kind": "tmp", "id": k}
+  {"kind": "mem", "buf": name, "id": column, "stride": width, "dim": 1|3, "prime": bool}
+  {"kind": "number", "value": v} | {"kind": "public"|"challenge"|"eval", "id": k}
+  {"kind": "x"} | {"kind": "Zi"} | {"kind": "xDivXSubXi"} | {"kind": "xDivXSubWXi"}
+Rows are evaluated sequentially, as the reference does inside a chunk (stark_gen.rs:752-783).
+"""
+P = 0xFFFFFFFF00000001
+
+
+def f3_mul(a, b):  # f3g.rs:420-430
+    A = (a[0] + a[1]) * (b[0] + b[1]) % P
+    B = (a[0] + a[2]) * (b[0] + b[2]) % P
+    C = (a[1] + a[2]) * (b[1] + b[2]) % P
+    D, E, F = a[0] * b[0] % P, a[1] * b[1] % P, a[2] * b[2] % P
+    G = (D - E) % P
+    return ((C + G - F) % P, (A + C - E - E - D) % P, (B - G) % P)
+
+
+def v_add(a, b):  # f3g.rs:323-361
+    if len(a) == 3 and len(b) == 3:
+        return tuple((x + y) % P for x, y in zip(a, b))
+    if len(a) == 3:
+        return ((a[0] + b[0]) % P, a[1], a[2])
+    if len(b) == 3:
+        return ((b[0] + a[0]) % P, b[1], b[2])
+    return ((a[0] + b[0]) % P,)
+
+
+def v_sub(a, b):  # f3g.rs:370-398
+    if len(a) == 3 and len(b) == 3:
+        return tuple((x - y) % P for x, y in zip(a, b))
+    if len(a) == 3:
+        return ((a[0] - b[0]) % P, a[1], a[2])
+    if len(b) == 3:
+        return ((a[0] - b[0]) % P, (-b[1]) % P, (-b[2]) % P)
+    return ((a[0] - b[0]) % P,)
+
+
+def v_mul(a, b):  # f3g.rs:407-449
+    if len(a) == 3 and len(b) == 3:
+        return f3_mul(a, b)
+    if len(a) == 3:
+        return tuple(x * b[0] % P for x in a)
+    if len(b) == 3:
+        return tuple(x * a[0] % P for x in b)
+    return (a[0] * b[0] % P,)
+
+
+def run(program, bufs, n, next_, publics=(), challenges=(), evals=(), x=None, zi=None, xdiv=None, xdivw=None):
+    """bufs: dict name -> flat list of ints (mutated in place)."""
+    def get(o, i, tmp):
+        k = o["kind"]
+        if k == "tmp":
+            return tmp[o["id"]]
+        if k == "mem":
+            row = (i + (next_ if o.get("prime") else 0)) % n                     # interpreter.rs:228-234
+            base = o["id"] + row * o["stride"]
+            b = bufs[o["buf"]]
+            return (b[base],) if o.get("dim", 1) == 1 else (b[base], b[base + 1], b[base + 2])
+        if k == "number":
+            return (o["value"] % P,)
+        if k == "public":
+            return (publics[o["id"]],)
+        if k == "challenge":
+            return tuple(challenges[o["id"]])
+        if k == "eval":
+            return tuple(evals[o["id"]])
+        if k == "x":
+            return (x[i],)
+        if k == "Zi":
+            return (zi[i % len(zi)],)
+        if k == "xDivXSubXi":
+            return tuple(xdiv[3 * i:3 * i + 3])
+        if k == "xDivXSubWXi":
+            return tuple(xdivw[3 * i:3 * i + 3])
+        raise ValueError(k)
+
+    for i in range(n):
+        tmp = {}
+        for op, dest, s0, s1 in program:
+            a = get(s0, i, tmp)
+            if op == "copy":
+                r = a
+            else:
+                b = get(s1, i, tmp)
+                r = {"add": v_add, "sub": v_sub, "mul": v_mul}[op](a, b)
+            if dest["kind"] == "tmp":
+                tmp[dest["id"]] = r
+            else:                                                                   # interpreter.rs:143-166
+                base = dest["id"] + i * dest["stride"]
+                buf = bufs[dest["buf"]]
+                for j, v in enumerate(r):
+                    buf[base + j] = v

@@ -1,0 +1,104 @@
+"""Constraint-evaluation programs: run-time compiled gfx950 kernels (zk_program_*) vs the Python
+restatement of the reference interpreter (oracle/interp.py)."""
+import pathlib
+import sys
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+P = 0xFFFFFFFF00000001
+
+BUF = {"cm1": 0, "const": 1, "q": 2, "cm3": 3}
+
+
+def _conv(zk, o):
+    """oracle operand dict -> zk_operand"""
+    k = o["kind"]
+    if k == "tmp":
+        return zk.opnd(zk.OPND_TMP, id=o["id"])
+    if k == "mem":
+        return zk.opnd(zk.OPND_MEM, id=o["id"], dim=o.get("dim", 1), prime=o.get("prime", False),
+                       buf=BUF[o["buf"]], stride=o["stride"])
+    if k == "number":
+        return zk.opnd(zk.OPND_NUMBER, value=o["value"] % P)
+    return zk.opnd({"public": zk.OPND_PUBLIC, "challenge": zk.OPND_CHALLENGE, "eval": zk.OPND_EVAL, "x": zk.OPND_X,
+                    "Zi": zk.OPND_ZI, "xDivXSubXi": zk.OPND_XDIVXSUBXI, "xDivXSubWXi": zk.OPND_XDIVXSUBWXI}[k],
+                   id=o.get("id", 0))
+
+
+def _compile(zk, program):
+    ops = {"add": zk.OP_ADD, "sub": zk.OP_SUB, "mul": zk.OP_MUL, "copy": zk.OP_COPY}
+    return zk.Program([zk.instr(ops[op], _conv(zk, d), _conv(zk, a), _conv(zk, b) if b else None)
+                       for op, d, a, b in program])
+
+
+def T(i): return {"kind": "tmp", "id": i}
+def M(buf, col, stride, dim=1, prime=False): return {"kind": "mem", "buf": buf, "id": col, "stride": stride, "dim": dim, "prime": prime}
+def N(v): return {"kind": "number", "value": v}
+
+
+def _fib_like_program():
+    """Shape of a step-4 program: Fibonacci transition constraints combined with the challenge vc,
+    multiplied by Zi, written to q (dim 3); plus a dim-1 and a dim-3 intermediate column."""
+    ch = lambda i: {"kind": "challenge", "id": i}
+    return [
+        ("mul", T(0), M("cm1", 0, 2), M("cm1", 0, 2)),                 # l1^2
+        ("mul", T(1), M("cm1", 1, 2), M("cm1", 1, 2)),                 # l2^2
+        ("add", T(2), T(0), T(1)),
+        ("sub", T(3), M("cm1", 0, 2, prime=True), T(2)),              # l1' - (l1^2 + l2^2)
+        ("sub", T(4), M("cm1", 1, 2, prime=True), M("cm1", 0, 2)),    # l2' - l1
+        ("sub", T(5), N(1), M("const", 0, 1)),                         # 1 - L_last
+        ("mul", T(6), T(3), T(5)),
+        ("mul", T(7), T(4), T(5)),
+        ("mul", T(8), ch(4), T(6)),                                    # dim 3 * dim 1
+        ("add", T(9), T(8), T(7)),                                     # dim 3 + dim 1
+        ("mul", T(10), ch(4), T(9)),                                   # dim 3 * dim 3
+        ("sub", T(11), {"kind": "public", "id": 0}, T(10)),            # dim 1 - dim 3
+        ("add", T(12), T(11), {"kind": "x"}),
+        ("copy", M("cm3", 0, 4), T(2), None),                          # dim-1 write
+        ("copy", M("cm3", 1, 4, dim=3), T(9), None),                   # dim-3 write
+        ("mul", T(13), M("cm3", 1, 4, dim=3), M("cm3", 0, 4)),         # read back own writes
+        ("add", T(14), T(12), T(13)),
+        ("mul", M("q", 0, 3, dim=3), T(14), {"kind": "Zi"}),
+    ]
+
+
+def test_program_compiles_without_gpu(zk):
+    prog = _compile(zk, _fib_like_program())
+    src = prog.source
+    assert "zk_eval_kernel" in src and "gl::f3_mul" in src and "mul31" in src and "sub13" in src
+    assert src.count("= gl::mul(") == 4
+
+
+def test_program_rejects_bad_code(zk):
+    with pytest.raises(zk.ZkError, match="tmp read before write"):
+        _compile(zk, [("add", T(1), T(0), N(1))])
+    with pytest.raises(zk.ZkError, match="written and read at the next row"):
+        _compile(zk, [("copy", M("cm3", 0, 4), N(1), None), ("copy", T(0), M("cm3", 0, 4, prime=True), None)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,ext", [(3, 1), (6, 1), (8, 2)])
+def test_program_matches_reference_interpreter(zk, orc, nbits, ext):
+    import interp
+    assert zk.lib().zk_device_count() >= 1
+    zk.init(0)
+    rng = np.random.default_rng(nbits * 10 + ext)
+    n = 1 << (nbits + ext); nxt = 1 << ext
+    program = _fib_like_program()
+    cm1 = rng.integers(0, P, size=2 * n, dtype=np.uint64)
+    const = rng.integers(0, 2, size=n, dtype=np.uint64)
+    chal = rng.integers(0, P, size=24, dtype=np.uint64)
+    pub = rng.integers(0, P, size=2, dtype=np.uint64)
+    zi = orc.zh_inv(nbits, ext)
+    d = {"cm1": zk.DevArray.from_host(cm1), "const": zk.DevArray.from_host(const),
+         "q": zk.DevArray(3 * n, zero=True), "cm3": zk.DevArray(4 * n, zero=True)}
+    x = zk.x_table(nbits + ext, 49)
+    _compile(zk, program).run({BUF[k]: v for k, v in d.items()}, nbits + ext, nxt, publics=zk.DevArray.from_host(pub),
+                              challenges=zk.DevArray.from_host(chal), x=x, zi=zk.DevArray.from_host(zi))
+    bufs = {"cm1": [int(v) for v in cm1], "const": [int(v) for v in const], "q": [0] * (3 * n), "cm3": [0] * (4 * n)}
+    interp.run(program, bufs, n, nxt, publics=[int(v) for v in pub], challenges=chal.reshape(8, 3).astype(object).tolist(),
+               x=[int(v) for v in x.to_host()], zi=[int(v) for v in zi])
+    assert [int(v) for v in d["q"].to_host()] == bufs["q"]
+    assert [int(v) for v in d["cm3"].to_host()] == bufs["cm3"]
