@@ -93,7 +93,49 @@ def run(program, bufs, n, next_, publics=(), challenges=(), evals=(), x=None, zi
             if dest["kind"] == "tmp":
                 tmp[dest["id"]] = r
             else:                                                                   # interpreter.rs:143-166
-                base = dest["id"] + i * dest["stride"]
+                row = (i + (next_ if dest.get("prime") else 0)) % n                 # get_i on the destination too
+                base = dest["id"] + row * dest["stride"]
                 buf = bufs[dest["buf"]]
                 for j, v in enumerate(r):
                     buf[base + j] = v
+
+
+def run_at(program, bufs, n, next_, i, **kw):
+    """Evaluate the program at the single row i and return its last destination value
+    (compile_code(..., ret = true) + Block::eval, interpreter.rs:218-223; stark_gen.rs:558-572)."""
+    last = {}
+    prog2 = list(program)
+    # capture: run on a shadow that records the final destination
+    res = {}
+    def rec_run():
+        tmp_bufs = bufs
+        # re-implement the row loop for one row, recording the last written value
+        def get(o, tmp):
+            k = o["kind"]
+            if k == "tmp":
+                return tmp[o["id"]]
+            if k == "mem":
+                row = (i + (next_ if o.get("prime") else 0)) % n
+                base = o["id"] + row * o["stride"]
+                b = tmp_bufs[o["buf"]]
+                return (b[base],) if o.get("dim", 1) == 1 else (b[base], b[base + 1], b[base + 2])
+            if k == "number":
+                return (o["value"] % P,)
+            if k == "public":
+                return (kw["publics"][o["id"]],)
+            if k == "challenge":
+                return tuple(kw["challenges"][o["id"]])
+            if k == "x":
+                return (kw["x"][i],)
+            raise ValueError(k)
+        tmp = {}
+        r = None
+        for op, dest, s0, s1 in prog2:
+            a = get(s0, tmp)
+            r = a if op == "copy" else {"add": v_add, "sub": v_sub, "mul": v_mul}[op](a, get(s1, tmp))
+            if dest["kind"] == "tmp":
+                tmp[dest["id"]] = r
+            else:
+                raise ValueError("public calculator writes to a section")
+        return r
+    return rec_run()

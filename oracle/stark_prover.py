@@ -1,0 +1,451 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's GL-hash eSTARK prover and
+verifier, small sizes only (the row evaluator is pure Python):
+
+  setup      starky/src/stark_setup.rs:27-66
+  stark_gen  starky/src/stark_gen.rs:193-557 (+ helpers :575-750), operand addressing
+             interpreter.rs:286-524, FRI starky/src/fri.rs:84-184
+  verify     starky/src/stark_verify.rs:20-250, fri.rs:186-297
+  zkin JSON  starky/src/serializer.rs:140-264, digest.rs:84-112
+
+Heavy primitives (NTT/LDE, Poseidon, Merkle, transcript, FRI fold...) come from liboracle.so.
+"""
+import json
+import pathlib
+import sys
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+sys.path.insert(0, str(HERE.parent / "tests"))
+import interp          # noqa: E402
+import starkinfo as SI  # noqa: E402
+import oracle_lib       # noqa: E402
+
+P = 0xFFFFFFFF00000001
+
+
+def parse_pil_number(s):  # types.rs:221-233
+    v = int(s, 16) if s.startswith("0x") else int(s)
+    return v % P
+
+
+def load_trace(path, n_cols):
+    a = np.fromfile(path, dtype="<u8")                                   # polsarray.rs:137-217
+    assert a.size % n_cols == 0
+    return a
+
+
+# ---- operand resolution (interpreter.rs get_ref / set_ref / eval_map) ------------------------------
+def resolve(node, info, dom):
+    t = node["type_"]
+    if t == "tmp":
+        return {"kind": "tmp", "id": node["id"]}
+    if t == "const":
+        return {"kind": "mem", "buf": "const_" + dom, "id": node["id"], "stride": info["n_constants"], "dim": 1, "prime": node["prime"]}
+    if t in ("cm", "tmpExp"):
+        pol_id = (info["cm_n"] if dom == "n" else info["cm_2ns"])[node["id"]] if t == "cm" else info["tmpexp_n"][node["id"]]
+        p = info["var_pol_map"][pol_id]
+        return {"kind": "mem", "buf": p["section"], "id": p["section_pos"], "stride": info["map_sectionsN"][p["section"]],
+                "dim": p["dim"], "prime": node["prime"]}
+    if t == "q":
+        return {"kind": "mem", "buf": "q_2ns", "id": node["id"], "stride": info["q_dim"], "dim": info["q_dim"], "prime": False}
+    if t == "f":
+        return {"kind": "mem", "buf": "f_2ns", "id": node["id"], "stride": 3, "dim": 3, "prime": False}
+    if t == "number":
+        return {"kind": "number", "value": parse_pil_number(node["value"])}
+    if t in ("public", "challenge", "eval"):
+        return {"kind": t, "id": node["id"]}
+    if t in ("x", "Zi", "xDivXSubXi", "xDivXSubWXi"):
+        return {"kind": t}
+    raise ValueError("Invalid reference type " + t)
+
+
+def compile_segment(seg, info, dom):
+    """Segment.first -> [(op, dest, src0, src1)] (interpreter.rs:187-225; only `first` runs, stark_gen.rs:761-782)"""
+    out = []
+    for c in seg["first"]:
+        src = [resolve(s, info, dom) for s in c["src"]]
+        out.append((c["op"], resolve(c["dest"], info, dom), src[0], src[1] if len(src) > 1 else None))
+    return out
+
+
+class Ctx:
+    pass
+
+
+def setup(pil_json, const_path, stark_struct, orc):
+    """StarkSetup::new: LDE + Merkle of the constants, then codegen."""
+    n_const = pil_json["nConstants"]
+    nbits, nbits_ext = stark_struct["nBits"], stark_struct["nBitsExt"]
+    const_n = load_trace(const_path, n_const)
+    const_2ns = orc.lde(const_n, n_const, nbits, nbits_ext)
+    const_tree = orc.merkelize(const_2ns, n_const, 1 << nbits_ext)
+    info, prog, _ = SI.generate(pil_json, stark_struct)
+    return {"const_n": const_n, "const_2ns": const_2ns, "const_tree": const_tree, "starkinfo": info, "program": prog}
+
+
+def group_proof(orc, nodes, elements, width, height, idx):
+    row = [int(v) for v in elements[idx * width:(idx + 1) * width]]
+    path = orc.merkle_proof(nodes, height, idx).reshape(-1, 4)
+    return row, [[int(x) for x in lvl] for lvl in path]
+
+
+def stark_gen(cm_path, su, stark_struct, orc):
+    info, prog = su["starkinfo"], su["program"]
+    nbits, nbits_ext = stark_struct["nBits"], stark_struct["nBitsExt"]
+    ext = nbits_ext - nbits
+    N, Next = 1 << nbits, 1 << nbits_ext
+    sN = info["map_sectionsN"]
+    bufs = {"cm1_n": [int(v) for v in load_trace(cm_path, info["n_cm1"])],
+            "const_n": [int(v) for v in su["const_n"]], "const_2ns": [int(v) for v in su["const_2ns"]]}
+    assert len(bufs["cm1_n"]) == N * sN["cm1_n"]
+    for s in ("cm2_n", "cm3_n", "tmpexp_n"):
+        bufs[s] = [0] * (sN[s] * N)
+    for s in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns"):
+        bufs[s] = [0] * (sN[s] * Next)
+    bufs["q_2ns"] = [0] * (info["q_dim"] * Next)
+    bufs["f_2ns"] = [0] * (3 * Next)
+    w, w_ext = orc.root(nbits), orc.root(nbits_ext)
+    x_n, x_2ns = [pow(w, k, P) for k in range(N)], [49 * pow(w_ext, k, P) % P for k in range(Next)]
+    zi = [int(v) for v in orc.zh_inv(nbits, ext)]
+    challenge = [[0, 0, 0] for _ in range(8)]
+    evals = []
+    publics = []
+    for i, pe in enumerate(info["publics"]):                                 # stark_gen.rs:256-270
+        if pe["polType"] == "cmP":
+            publics.append(bufs["cm1_n"][pe["idx"] * sN["cm1_n"] + pe["polId"]])
+        elif pe["polType"] == "imP":                                         # calculate_exp_at_point :558-572
+            code = compile_segment(prog["publics_code"][i], info, "n")
+            v = interp.run_at(code, bufs, N, 1, pe["idx"], publics=publics, challenges=challenge, x=x_n)
+            assert len(v) == 1
+            publics.append(v[0])
+        else:
+            raise ValueError("Invalid public type " + pe["polType"])
+    tr = orc.transcript()
+    for p in publics:
+        tr.put([p])
+
+    def run(seg_name, dom):
+        n, nxt = (N, 1) if dom == "n" else (Next, 1 << ext)
+        interp.run(compile_segment(prog[seg_name], info, dom), bufs, n, nxt, publics=publics, challenges=challenge,
+                   evals=evals, x=x_n if dom == "n" else x_2ns, zi=zi, xdiv=bufs.get("xDivXSubXi"), xdivw=bufs.get("xDivXSubWXi"))
+
+    def extend_and_merkelize(sec):                                           # stark_gen.rs:709-732
+        width = sN[sec + "_n"]
+        e = orc.lde(np.array(bufs[sec + "_n"], np.uint64), width, nbits, nbits_ext) if width else np.zeros(0, np.uint64)
+        bufs[sec + "_2ns"] = [int(v) for v in e]
+        return {"nodes": orc.merkelize(e, width, Next), "elements": e, "width": width}
+
+    tree1 = extend_and_merkelize("cm1")
+    tr.put(tree1["nodes"][-4:])
+    challenge[0] = [int(v) for v in tr.get_field()]
+    challenge[1] = [int(v) for v in tr.get_field()]
+    run("step2prev", "n")
+    n_cm = info["n_cm1"]
+    for pu in info["pu_ctx"]:                                               # stark_gen.rs:300-308
+        f = get_pol(bufs, info, info["exp2pol"][pu["f_exp_id"]], N).reshape(-1, 3)
+        t = get_pol(bufs, info, info["exp2pol"][pu["t_exp_id"]], N).reshape(-1, 3)
+        h1, h2 = calculate_h1h2([tuple(int(v) for v in r) for r in f], [tuple(int(v) for v in r) for r in t])
+        set_pol(bufs, info, info["cm_n"][n_cm], [v for r in h1 for v in r], N); n_cm += 1
+        set_pol(bufs, info, info["cm_n"][n_cm], [v for r in h2 for v in r], N); n_cm += 1
+    tree2 = extend_and_merkelize("cm2")
+    tr.put(tree2["nodes"][-4:])
+    challenge[2] = [int(v) for v in tr.get_field()]
+    challenge[3] = [int(v) for v in tr.get_field()]
+    run("step3prev", "n")
+    n_cm = info["n_cm1"] + info["n_cm2"]
+    for o in info["pu_ctx"] + info["pe_ctx"] + info["ci_ctx"]:               # stark_gen.rs:329-353
+        num, den = get_pol(bufs, info, info["exp2pol"][o["num_id"]], N), get_pol(bufs, info, info["exp2pol"][o["den_id"]], N)
+        z, ok = orc.calculate_z(num, den)
+        assert ok, "z does not close"
+        set_pol(bufs, info, info["cm_n"][n_cm], [int(v) for v in z], N)
+        n_cm += 1
+    run("step3", "n")
+    tree3 = extend_and_merkelize("cm3")
+    tr.put(tree3["nodes"][-4:])
+    challenge[4] = [int(v) for v in tr.get_field()]
+    run("step42ns", "2ns")
+    q_dim, q_deg = info["q_dim"], info["q_deg"]
+    qq1 = orc.ntt(np.array(bufs["q_2ns"], np.uint64), q_dim, nbits_ext, inverse=True)      # :375-396
+    qq2 = orc.qsplit(qq1, nbits, nbits_ext, q_dim, q_deg)
+    cm4 = orc.ntt(qq2, q_dim * q_deg, nbits_ext) if q_deg > 0 else np.zeros(0, np.uint64)
+    bufs["cm4_2ns"] = [int(v) for v in cm4]
+    tree4 = {"nodes": orc.merkelize(cm4, sN["cm4_2ns"], Next), "elements": cm4, "width": sN["cm4_2ns"]}
+    tr.put(tree4["nodes"][-4:])
+    challenge[7] = [int(v) for v in tr.get_field()]                          # xi
+    xi = np.array(challenge[7], np.uint64)
+    LEv, LpEv = orc.lev(xi, nbits, False), orc.lev(xi, nbits, True)
+    for ev in info["ev_map"]:                                                # :432-466
+        if ev["type_"] == "const":
+            buf, width, off, dim = bufs["const_2ns"], info["n_constants"], ev["id"], 1
+        else:
+            p = info["var_pol_map"][info["cm_2ns"][ev["id"]]]
+            buf, width, off, dim = bufs[p["section"]], sN[p["section"]], p["section_pos"], p["dim"]
+        evals.append([int(v) for v in orc.eval_dot(np.array(buf, np.uint64), width, off, dim, nbits, ext, LpEv if ev["prime"] else LEv)])
+    for e in evals:
+        tr.put(e)
+    challenge[5] = [int(v) for v in tr.get_field()]
+    challenge[6] = [int(v) for v in tr.get_field()]
+    bufs["xDivXSubXi"] = [int(v) for v in orc.xdivxsub(xi, nbits_ext)]       # :481-522
+    wxi = np.array([int(v) * w % P for v in challenge[7]], np.uint64)
+    bufs["xDivXSubWXi"] = [int(v) for v in orc.xdivxsub(wxi, nbits_ext)]
+    run("step52ns", "2ns")
+    fri_pol = np.array(bufs["f_2ns"], np.uint64)
+    trees = [tree1, tree2, tree3, tree4, {"nodes": su["const_tree"], "elements": su["const_2ns"], "width": info["n_constants"]}]
+
+    def query_pol(idx):
+        return [group_proof(orc, t["nodes"], t["elements"], t["width"], Next, idx) for t in trees]
+    fri_proof = fri_prove(orc, tr, fri_pol, stark_struct, query_pol)
+    return {"rootC": [int(v) for v in su["const_tree"][-4:]], "root1": [int(v) for v in tree1["nodes"][-4:]],
+            "root2": [int(v) for v in tree2["nodes"][-4:]], "root3": [int(v) for v in tree3["nodes"][-4:]],
+            "root4": [int(v) for v in tree4["nodes"][-4:]], "fri_proof": fri_proof, "evals": evals, "publics": publics}
+
+
+def calculate_h1h2(f, t):                                                    # stark_gen.rs:624-651
+    idx_t = {}
+    s = []
+    for i, e in enumerate(t):
+        idx_t[e] = i
+        s.append((e, i))
+    for e in f:
+        if e not in idx_t:
+            raise ValueError("Number not included: %r" % (e,))
+        s.append((e, idx_t[e]))
+    s.sort(key=lambda a: a[1])                                                # stable, like slice::sort_by
+    return [s[2 * i][0] for i in range(len(f))], [s[2 * i + 1][0] for i in range(len(f))]
+
+
+def get_pol(bufs, info, pol_id, n):                                           # stark_gen.rs:683-707
+    p = info["var_pol_map"][pol_id]
+    b, size, off = bufs[p["section"]], info["map_sectionsN"][p["section"]], p["section_pos"]
+    out = np.zeros(3 * n, np.uint64)
+    for i in range(n):
+        for k in range(p["dim"]):
+            out[3 * i + k] = b[off + i * size + k]
+    return out
+
+
+def set_pol(bufs, info, pol_id, pol3, n):                                     # stark_gen.rs:594-622
+    p = info["var_pol_map"][pol_id]
+    b, size, off = bufs[p["section"]], info["map_sectionsN"][p["section"]], p["section_pos"]
+    for i in range(n):
+        for k in range(p["dim"]):
+            b[off + i * size + k] = pol3[3 * i + k]
+
+
+def fri_prove(orc, tr, pol, stark_struct, query_pol):                         # fri.rs:84-184
+    steps = [s["nBits"] for s in stark_struct["steps"]]
+    pol_bits = stark_struct["nBitsExt"]
+    shift_inv = pow(49, P - 2, P)
+    trees, queries = [], [{"root": None, "pol_queries": []} for _ in steps]
+    for si, step_bits in enumerate(steps):
+        special_x = tr.get_field()
+        pol = orc.fri_fold(pol, pol_bits, step_bits, special_x, shift_inv)
+        if si < len(steps) - 1:
+            nxt = steps[si + 1]
+            n_groups, group_size = 1 << nxt, (1 << step_bits) >> nxt
+            tb = orc.fri_transpose(pol, 1 << step_bits, nxt)
+            nodes = orc.merkelize(tb, 3 * group_size, n_groups)
+            trees.append({"nodes": nodes, "elements": tb, "width": 3 * group_size, "height": n_groups})
+            queries[si + 1]["root"] = [int(v) for v in nodes[-4:]]
+            tr.put(nodes[-4:])
+        else:
+            tr.put(pol)                                                        # every coefficient, 3 words each
+        for _ in range(pol_bits - step_bits):
+            shift_inv = shift_inv * shift_inv % P
+        pol_bits = step_bits
+    ys = [int(v) for v in tr.get_permutations(stark_struct["nQueries"], steps[0])]
+    for si in range(len(steps)):
+        for y in ys:
+            if si == 0:
+                queries[si]["pol_queries"].append(query_pol(y))
+            else:
+                t = trees[si - 1]
+                queries[si]["pol_queries"].append([group_proof(orc, t["nodes"], t["elements"], t["width"], t["height"], y)])
+        if si < len(steps) - 1:
+            ys = [y % (1 << steps[si + 1]) for y in ys]
+    return {"queries": queries, "last": [[int(v) for v in pol[3 * i:3 * i + 3]] for i in range(len(pol) // 3)]}
+
+
+# ---- serializer.rs:140-264 ---------------------------------------------------------------------------
+def _digest(d):                                                               # digest.rs:84-112
+    return str(d[0]) if d[1] == 0 and d[2] == 0 and d[3] == 0 else [str(v) for v in d]
+
+
+def to_zkin(proof):
+    z = {"rootC": _digest(proof["rootC"])}
+    for k in ("root1", "root2", "root3", "root4"):
+        z[k] = _digest(proof[k])
+    z["evals"] = [[str(v) for v in e] for e in proof["evals"]]
+    qs = proof["fri_proof"]["queries"]
+    sib = lambda path: [[str(v) for v in lvl] for lvl in path]                # from_basefield(v) = [v,0,0,0] -> one string
+    for i in range(1, len(qs)):
+        z["s%d_root" % i] = _digest(qs[i]["root"])
+        z["s%d_vals" % i] = [[str(v) for v in q[0][0]] for q in qs[i]["pol_queries"]]
+        z["s%d_siblings" % i] = [sib(q[0][1]) for q in qs[i]["pol_queries"]]
+    names = ["1", "2", "3", "4", "C"]
+    for j, nm in enumerate(names):
+        z["s0_vals" + nm] = [[str(v) for v in q[j][0]] for q in qs[0]["pol_queries"]]
+    for j, nm in enumerate(names):
+        z["s0_siblings" + nm] = [sib(q[j][1]) for q in qs[0]["pol_queries"]]
+    z["finalPol"] = [[str(v) for v in e] for e in proof["fri_proof"]["last"]]
+    z["publics"] = [str(p) for p in proof["publics"]]
+    return z
+
+
+# ---- stark_verify.rs ---------------------------------------------------------------------------------
+def f3(v):
+    return tuple(int(x) for x in v)
+
+
+def f3_pow(a, e):
+    r = (1, 0, 0)
+    while e:
+        if e & 1:
+            r = interp.f3_mul(r, a)
+        a = interp.f3_mul(a, a); e >>= 1
+    return r
+
+
+def f3_inv(orc, a):
+    return f3(orc.f3_inv(np.array(a, np.uint64)))
+
+
+def execute_code(code, ctx):                                                  # stark_verify.rs:156-250
+    tmp = {}
+    def get(r):
+        t = r["type_"]
+        if t == "tmp": return tmp[r["id"]]
+        if t in ("tree1", "tree2", "tree3", "tree4"):
+            arr = ctx[t]; p = r["tree_pos"]
+            return (arr[p],) if r["dim"] == 1 else (arr[p], arr[p + 1], arr[p + 2])
+        if t == "const": return (ctx["consts"][r["id"]],)
+        if t == "eval": return f3(ctx["evals"][r["id"]])
+        if t == "number": return (parse_pil_number(r["value"]),)
+        if t == "public": return (ctx["publics"][r["id"]],)
+        if t == "challenge": return f3(ctx["challenge"][r["id"]])
+        if t == "xDivXSubXi": return ctx["xDivXSubXi"]
+        if t == "xDivXSubWXi": return ctx["xDivXSubWXi"]
+        if t == "x": return f3(ctx["challenge"][7])
+        if t == "Z": return ctx["Zp"] if r["prime"] else ctx["Z"]
+        raise ValueError("Invalid reference type, get: " + t)
+    for c in code:
+        s = [get(x) for x in c["src"]]
+        op = c["op"]
+        if op == "add": r = interp.v_add(s[0], s[1])
+        elif op == "sub": r = interp.v_sub(s[0], s[1])
+        elif op == "mul": r = interp.v_mul(s[0], s[1])
+        elif op == "muladd": r = interp.v_add(interp.v_mul(s[0], s[1]), s[2])
+        elif op == "copy": r = s[0]
+        else: raise ValueError(op)
+        assert c["dest"]["type_"] == "tmp"
+        tmp[c["dest"]["id"]] = r
+    return get(code[-1]["dest"])
+
+
+def v_eq(a, b):                                                                # f3g.rs:95-103 _eq
+    a = tuple(a) + (0,) * (3 - len(a)); b = tuple(b) + (0,) * (3 - len(b))
+    return a == b
+
+
+def stark_verify(proof, const_root, info, prog, stark_struct, orc):
+    nbits, nbits_ext = stark_struct["nBits"], stark_struct["nBitsExt"]
+    N = 1 << nbits
+    tr = orc.transcript()
+    ch = [[0, 0, 0] for _ in range(8)]
+    for p in proof["publics"]:
+        tr.put([p])
+    tr.put(proof["root1"]); ch[0] = f3(tr.get_field()); ch[1] = f3(tr.get_field())
+    tr.put(proof["root2"]); ch[2] = f3(tr.get_field()); ch[3] = f3(tr.get_field())
+    tr.put(proof["root3"]); ch[4] = f3(tr.get_field())
+    tr.put(proof["root4"]); ch[7] = f3(tr.get_field())
+    for e in proof["evals"]:
+        tr.put(e)
+    ch[5] = f3(tr.get_field()); ch[6] = f3(tr.get_field())
+    w = orc.root(nbits)
+    x_n = f3_pow(ch[7], N)
+    ctx = {"evals": proof["evals"], "publics": proof["publics"], "challenge": ch,
+           "Z": interp.v_sub(x_n, (1,)), "Zp": interp.v_sub(f3_pow(interp.v_mul(ch[7], (w,)), N), (1,))}
+    res = execute_code(prog["verifier_code"]["first"], ctx)
+    x_acc, q = (1,), (0,)
+    for i in range(info["q_deg"]):
+        q = interp.v_add(q, interp.v_mul(x_acc, f3(proof["evals"][info["ev_idx"]["cm"][(0, info["qs"][i])]])))
+        x_acc = interp.v_mul(x_acc, x_n)
+    if not v_eq(res, interp.v_mul(q, ctx["Z"])):
+        return False
+    w_ext = orc.root(nbits_ext)
+    roots = [proof["root1"], proof["root2"], proof["root3"], proof["root4"], const_root]
+
+    def check_query(query, idx):                                               # stark_verify.rs:80-136
+        for (row, path), root in zip(query, roots):
+            got = orc.root_from_proof(np.array(row, np.uint64), np.array(path, np.uint64).reshape(-1), idx)
+            if [int(v) for v in got] != [int(v) for v in root]:
+                raise ValueError("FRIVerifierFailed")
+        x = 49 * pow(w_ext, idx, P) % P
+        q = {"tree1": query[0][0], "tree2": query[1][0], "tree3": query[2][0], "tree4": query[3][0], "consts": query[4][0],
+             "evals": proof["evals"], "publics": proof["publics"], "challenge": ch}
+        q["xDivXSubXi"] = interp.v_mul((x,), f3_inv(orc, interp.v_sub((x,), ch[7])))
+        q["xDivXSubWXi"] = interp.v_mul((x,), f3_inv(orc, interp.v_sub((x,), interp.v_mul(ch[7], (w,)))))
+        return [execute_code(prog["verifier_query_code"]["first"], q)]
+    return fri_verify(orc, tr, proof["fri_proof"], stark_struct, check_query)
+
+
+def fri_verify(orc, tr, fp, stark_struct, check_query):                        # fri.rs:186-297
+    steps = [s["nBits"] for s in stark_struct["steps"]]
+    nq = stark_struct["nQueries"]
+    special_x = []
+    for si in range(len(steps)):
+        special_x.append(f3(tr.get_field()))
+        if si < len(steps) - 1:
+            tr.put(fp["queries"][si + 1]["root"])
+        else:
+            for e in fp["last"]:
+                tr.put(e)
+    ys = [int(v) for v in tr.get_permutations(nq, steps[0])]
+    pol_bits, shift = stark_struct["nBitsExt"], 49
+    for si, step_bits in enumerate(steps):
+        item = fp["queries"][si]
+        for i in range(nq):
+            if si == 0:
+                pgroup = check_query(item["pol_queries"][i], ys[i])
+            else:
+                row, path = item["pol_queries"][i][0]
+                got = orc.root_from_proof(np.array(row, np.uint64), np.array(path, np.uint64).reshape(-1), ys[i])
+                if [int(v) for v in got] != item["root"]:
+                    return False
+                pgroup = [tuple(row[k:k + 3]) for k in range(0, len(row), 3)]                 # split3
+            flat = np.array([v for e in pgroup for v in (tuple(e) + (0,) * (3 - len(e)))], np.uint64)
+            bits = (len(pgroup) - 1).bit_length()
+            coef = orc.f3_ntt(flat, bits, inverse=True).reshape(-1, 3)
+            sinv = pow(shift * pow(orc.root(pol_bits), ys[i], P) % P, P - 2, P)
+            pt = interp.v_mul(special_x[si], (sinv,))
+            ev = f3(coef[-1])                                                                  # eval_pol
+            for k in range(len(coef) - 2, -1, -1):
+                ev = interp.v_add(interp.f3_mul(ev, pt), f3(coef[k]))
+            if si < len(steps) - 1:
+                nxt_groups = 1 << steps[si + 1]
+                gi = ys[i] // nxt_groups
+                row = fp["queries"][si + 1]["pol_queries"][i][0][0]
+                if not v_eq(ev, tuple(row[3 * gi:3 * gi + 3])):
+                    return False
+            elif not v_eq(ev, tuple(fp["last"][ys[i]])):
+                return False
+        for _ in range(pol_bits - step_bits):
+            shift = shift * shift % P
+        pol_bits = step_bits
+        if si < len(steps) - 1:
+            ys = [y % (1 << steps[si + 1]) for y in ys]
+    in_bits, max_deg_bits = stark_struct["nBitsExt"], stark_struct["nBits"]
+    max_deg = 0 if pol_bits < (in_bits - max_deg_bits) else 1 << (pol_bits - (in_bits - max_deg_bits))
+    last = np.array([v for e in fp["last"] for v in e], np.uint64)
+    coef = orc.f3_ntt(last, pol_bits, inverse=True).reshape(-1, 3)
+    return all(not any(int(v) for v in coef[i]) for i in range(max_deg + 1, len(coef)))
+
+
+def prove_files(pil_path, const_path, cm_path, struct_path):
+    orc = oracle_lib.load()
+    pil = json.load(open(pil_path)); ss = json.load(open(struct_path))
+    su = setup(pil, const_path, ss, orc)
+    proof = stark_gen(cm_path, su, ss, orc)
+    return su, proof, ss
