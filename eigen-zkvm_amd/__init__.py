@@ -31,6 +31,7 @@ EXPORTS = [
     "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
     "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
+    "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
 ]
 
 # include/zkgpu.h enums
@@ -122,6 +123,9 @@ def _load():
         "zk_program_source": (C.c_char_p, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
         "zk_program_free": (C.c_int, [vp]),
+        "zk_stark_get_pol_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
+        "zk_stark_set_pol_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
+        "zk_stark_calculate_z_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -226,9 +230,9 @@ class MerkleTreeGL:
 
     def get_group_proof(self, idx):
         d = lib().zk_merkle_depth(self._h)
-        row = np.zeros(self.width, np.uint64); path = np.zeros(max(1, d) * 4, np.uint64)
+        row = np.zeros(max(1, self.width), np.uint64); path = np.zeros(max(1, d) * 4, np.uint64)
         _check(lib().zk_merkle_group_proof(self._h, idx, _ptr(row), _ptr(path)))
-        return row, path[:4 * d].reshape(d, 4)
+        return row[:self.width], path[:4 * d].reshape(d, 4)
 
     def free(self):
         if self._h:

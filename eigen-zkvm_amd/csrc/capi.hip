@@ -177,11 +177,11 @@ static zk_merkle_t* make_tree(const u64* d_rows, zk_merkle_t* t, uint32_t width,
 zk_merkle_t* zk_gl_merkelize(const uint64_t* buff, uint32_t width, uint64_t height) {
     zk_merkle_t* t = nullptr;
     int rc = guard([&] {
-        ZK_REQUIRE(buff && width >= 1 && height >= 1, "zk_gl_merkelize: empty matrix");
+        ZK_REQUIRE((buff || width == 0) && height >= 1, "zk_gl_merkelize: empty matrix");
         t = new zk_merkle();
         const size_t bytes = (size_t)width * height * sizeof(u64);
-        t->owned_elements.reserve(bytes);
-        ZK_HIP(hipMemcpy(t->owned_elements.p, buff, bytes, hipMemcpyHostToDevice));
+        t->owned_elements.reserve(bytes ? bytes : 8);
+        if (bytes) ZK_HIP(hipMemcpy(t->owned_elements.p, buff, bytes, hipMemcpyHostToDevice));
         make_tree(t->owned_elements.u(), t, width, height, nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
     });
@@ -192,7 +192,7 @@ zk_merkle_t* zk_gl_merkelize(const uint64_t* buff, uint32_t width, uint64_t heig
 zk_merkle_t* zk_gl_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream) {
     zk_merkle_t* t = nullptr;
     int rc = guard([&] {
-        ZK_REQUIRE(d_buff && width >= 1 && height >= 1, "zk_gl_merkelize_dev: empty matrix");
+        ZK_REQUIRE((d_buff || width == 0) && height >= 1, "zk_gl_merkelize_dev: empty matrix");
         t = new zk_merkle();
         make_tree((const u64*)d_buff, t, width, height, (hipStream_t)stream);
     });
@@ -308,6 +308,24 @@ int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits,
 }
 int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, uint64_t* d_qq2, void* stream) {
     return guard([&] { qsplit_dev((const u64*)d_qq1, nbits, q_dim, q_deg, (u64*)d_qq2, (hipStream_t)stream); });
+}
+
+int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, uint64_t* d_out3, void* stream) {
+    return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, (hipStream_t)stream); });
+}
+int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const uint64_t* d_in3, void* stream) {
+    return guard([&] { pol_set_dev((u64*)d_buf, width, offset, dim, n, (const u64*)d_in3, (hipStream_t)stream); });
+}
+int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream) {
+    return guard([&] {
+        ZK_REQUIRE(n >= 1, "calculate_Z: empty polynomial");
+        DevBuf work; work.reserve((n + n / 1024 + 8) * 24);
+        u64 h[3];
+        calculate_z_dev((const u64*)d_num3, (const u64*)d_den3, n, (u64*)d_z3, work.u(), work.u() + 3 * (n + n / 1024 + 4), (hipStream_t)stream);
+        ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        ZK_HIP(hipMemcpy(h, work.u() + 3 * (n + n / 1024 + 4), 24, hipMemcpyDeviceToHost));
+        ZK_REQUIRE(h[0] == 1 && h[1] == 0 && h[2] == 0, "calculate_Z: z does not close (grand product != 1)");
+    });
 }
 
 const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->d_elements : nullptr; }

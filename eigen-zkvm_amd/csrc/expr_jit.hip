@@ -46,7 +46,7 @@ struct Val { std::string name; int dim; };
 struct Gen {
     std::ostringstream body;
     std::map<uint32_t, Val> tmp;                                   // tmp id -> current SSA value
-    std::map<std::pair<uint32_t, uint32_t>, Val> fwd;              // (buf, column) -> value written this row
+    std::map<std::pair<uint32_t, uint32_t>, Val> fwd, fwd_prime;   // (buf, column) -> value this lane wrote at row i / i+next
     std::map<std::pair<uint32_t, uint32_t>, bool> written, prime_read;
     int n_val = 0;
 
@@ -68,6 +68,8 @@ struct Gen {
                     auto it = fwd.find(key);
                     if (it != fwd.end() && it->second.dim == o.dim) return it->second;
                 } else {
+                    auto it = fwd_prime.find(key);   // this lane computed the next-row value itself (e.g. t' of a plookup)
+                    if (it != fwd_prime.end() && it->second.dim == o.dim) return it->second;
                     prime_read[key] = true;
                 }
                 e << "c.bufs[" << (int)o.buf << "] + " << (o.prime ? "ip" : "i") << " * " << o.stride << "ull + " << o.id;
@@ -96,13 +98,15 @@ struct Gen {
     void store(const zk_operand& d, const Val& v) {
         if (d.kind == ZK_OPND_TMP) { tmp[d.id] = v; return; }                      // interpreter.rs:149-152
         ZK_REQUIRE(d.kind == ZK_OPND_MEM && d.buf < 16, "eval program: destination must be tmp or a section cell");
-        ZK_REQUIRE(!d.prime, "eval program: primed destination");
+        // A primed destination (set_ref -> eval_map with prime, interpreter.rs:331-345) stores the value of row
+        // i+next into row i+next's cell; the lane of that row stores the same field element there.
         std::ostringstream e;
-        e << "(c.bufs[" << (int)d.buf << "] + i * " << d.stride << "ull + " << d.id << ")";
+        e << "(c.bufs[" << (int)d.buf << "] + " << (d.prime ? "ip" : "i") << " * " << d.stride << "ull + " << d.id << ")";
         if (v.dim == 1) body << "    " << e.str() << "[0] = " << v.name << ";\n";   // interpreter.rs:149-152
         else body << "    { u64* p = " << e.str() << "; p[0] = " << v.name << ".v[0]; p[1] = " << v.name << ".v[1]; p[2] = "
                   << v.name << ".v[2]; }\n";                                          // interpreter.rs:153-159
         auto key = std::make_pair((uint32_t)d.buf, d.id);
+        if (d.prime) { fwd_prime[key] = v; return; }
         fwd[key] = v; written[key] = true;
     }
 

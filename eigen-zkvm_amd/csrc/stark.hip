@@ -141,9 +141,114 @@ __global__ void qsplit_kernel(const u64* __restrict__ qq1, u32 nbits, u32 q_dim,
     qq2[i * q_dim * q_deg + q_dim * p + k] = gl::mul(qq1[t], gl::pow(shift_inv_n, p));
 }
 
+// ---- get_pol / set_pol (stark_gen.rs:594-622, :683-707): one column of a section <-> [n][3] ------
+__global__ void pol_get_kernel(const u64* __restrict__ buf, u64 width, u64 offset, u32 dim, u64 n, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64* c = buf + i * width + offset;
+    out[3 * i] = c[0]; out[3 * i + 1] = dim == 3 ? c[1] : 0; out[3 * i + 2] = dim == 3 ? c[2] : 0;
+}
+__global__ void pol_set_kernel(u64* __restrict__ buf, u64 width, u64 offset, u32 dim, u64 n, const u64* __restrict__ in) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64* c = buf + i * width + offset;
+    c[0] = in[3 * i];
+    if (dim == 3) { c[1] = in[3 * i + 1]; c[2] = in[3 * i + 2]; }
+}
+
+// ---- calculate_Z (stark_gen.rs:653-666): z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1] -----------
+// The reference's sequential prefix product becomes a three-phase scan over chunks of 1024 rows;
+// every den is inverted on its own (the reference's batch_inverse yields the same field elements).
+constexpr int Z_ITEMS = 4, Z_CHUNK = 256 * Z_ITEMS;
+
+__device__ __forceinline__ f3 block_scan_excl(f3 v, u64* lds /* 256*3 */, f3* total) {
+    // Hillis-Steele inclusive scan of 256 products, returned as exclusive prefix
+    const int t = threadIdx.x;
+    st3(lds + 3 * t, v);
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        f3 cur = ld3(lds + 3 * t);
+        f3 prev = t >= off ? ld3(lds + 3 * (t - off)) : f3{{1, 0, 0}};
+        __syncthreads();
+        st3(lds + 3 * t, gl::f3_mul(cur, prev));
+        __syncthreads();
+    }
+    *total = ld3(lds + 3 * 255);
+    f3 ex = t ? ld3(lds + 3 * (t - 1)) : f3{{1, 0, 0}};
+    __syncthreads();
+    return ex;
+}
+
+__global__ __launch_bounds__(256) void z_ratio_kernel(const u64* __restrict__ num, const u64* __restrict__ den, u64 n,
+                                                      u64* __restrict__ ratio, u64* __restrict__ block_tot) {
+    __shared__ u64 lds[256 * 3];
+    const u64 base = (u64)blockIdx.x * Z_CHUNK + (u64)threadIdx.x * Z_ITEMS;
+    f3 prod{{1, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < Z_ITEMS; ++k) {
+        const u64 i = base + k;
+        if (i < n) {
+            f3 r = gl::f3_mul(ld3(num + 3 * i), gl::f3_inv(ld3(den + 3 * i)));
+            st3(ratio + 3 * i, r);
+            prod = gl::f3_mul(prod, r);
+        }
+    }
+    f3 total;
+    block_scan_excl(prod, lds, &total);
+    if (threadIdx.x == 0) st3(block_tot + 3 * blockIdx.x, total);
+}
+__global__ void z_block_offsets_kernel(u64* __restrict__ block_tot, u64 n_blocks) {  // exclusive scan, in place
+    if (threadIdx.x | blockIdx.x) return;
+    f3 acc{{1, 0, 0}};
+    for (u64 b = 0; b < n_blocks; ++b) { f3 t = ld3(block_tot + 3 * b); st3(block_tot + 3 * b, acc); acc = gl::f3_mul(acc, t); }
+    st3(block_tot + 3 * n_blocks, acc);  // grand product: must be 1 (stark_gen.rs:663-664)
+}
+__global__ __launch_bounds__(256) void z_apply_kernel(const u64* __restrict__ ratio, const u64* __restrict__ block_off, u64 n,
+                                                      u64* __restrict__ z) {
+    __shared__ u64 lds[256 * 3];
+    const u64 base = (u64)blockIdx.x * Z_CHUNK + (u64)threadIdx.x * Z_ITEMS;
+    f3 r[Z_ITEMS], prod{{1, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < Z_ITEMS; ++k) {
+        r[k] = base + k < n ? ld3(ratio + 3 * (base + k)) : f3{{1, 0, 0}};
+        prod = gl::f3_mul(prod, r[k]);
+    }
+    f3 total;
+    f3 acc = gl::f3_mul(block_scan_excl(prod, lds, &total), ld3(block_off + 3 * blockIdx.x));
+#pragma unroll
+    for (int k = 0; k < Z_ITEMS; ++k) {
+        if (base + k < n) st3(z + 3 * (base + k), acc);
+        acc = gl::f3_mul(acc, r[k]);
+    }
+}
+
 inline dim3 grid1(u64 n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 }  // namespace
+
+void pol_get_dev(const u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, u64* d_out, hipStream_t st) {
+    ZK_REQUIRE(dim == 1 || dim == 3, "get_pol: Invalid dim");
+    hipLaunchKernelGGL(pol_get_kernel, grid1(n), dim3(256), 0, st, d_buf, width, offset, dim, n, d_out);
+    ZK_HIP(hipGetLastError());
+}
+void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const u64* d_in, hipStream_t st) {
+    ZK_REQUIRE(dim == 1 || dim == 3, "set_pol: Invalid dim");
+    hipLaunchKernelGGL(pol_set_kernel, grid1(n), dim3(256), 0, st, d_buf, width, offset, dim, n, d_in);
+    ZK_HIP(hipGetLastError());
+}
+// d_work: (n + n/1024 + 2) * 3 words of scratch; d_check receives the grand product (3 words)
+void calculate_z_dev(const u64* d_num, const u64* d_den, uint64_t n, u64* d_z, u64* d_work, u64* d_check, hipStream_t st) {
+    const u64 nb = (n + Z_CHUNK - 1) / Z_CHUNK;
+    u64* ratio = d_work;
+    u64* tot = d_work + 3 * n;
+    hipLaunchKernelGGL(z_ratio_kernel, dim3((unsigned)nb), dim3(256), 0, st, d_num, d_den, n, ratio, tot);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(z_block_offsets_kernel, dim3(1), dim3(64), 0, st, tot, nb);
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(z_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, ratio, tot, n, d_z);
+    ZK_HIP(hipGetLastError());
+    ZK_HIP(hipMemcpyAsync(d_check, tot + 3 * nb, 24, hipMemcpyDeviceToDevice, st));
+}
 
 void fri_fold_dev(const u64* d_pol, uint32_t pol_bits, uint32_t step_bits, const u64* d_special_x, u64 shift_inv, u64* d_out, hipStream_t st) {
     ZK_REQUIRE(step_bits <= pol_bits && pol_bits <= 32, "fri_fold: need step_bits <= pol_bits <= 32");

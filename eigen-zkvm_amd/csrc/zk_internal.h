@@ -71,6 +71,9 @@ void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st
 void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st);
 void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp, u64* d_tmp2, hipStream_t st);
 void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv, u64* d_out, hipStream_t st);
+void pol_get_dev(const u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, u64* d_out, hipStream_t st);
+void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const u64* d_in, hipStream_t st);
+void calculate_z_dev(const u64* d_num, const u64* d_den, uint64_t n, u64* d_z, u64* d_work, u64* d_check, hipStream_t st);
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
 
 }  // namespace zk

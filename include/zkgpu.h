@@ -125,6 +125,16 @@ int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits,
 int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg,
                         uint64_t* d_qq2, void* stream);
 
+/* get_pol / set_pol (:594-622, :683-707): column `offset` (1 or 3 words wide) of a [n][width] section
+ * <-> a dense [n][3] polynomial (dim-1 columns are zero padded)                                    */
+int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n,
+                         uint64_t* d_out3, void* stream);
+int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n,
+                         const uint64_t* d_in3, void* stream);
+/* calculate_Z (:653-666): z[0] = 1, z[i] = z[i-1]*num[i-1]/den[i-1] over [n][3] operands; synchronises
+ * and fails ("z does not close") when z[n-1]*num[n-1]/den[n-1] != 1, as the reference asserts (:663-664) */
+int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream);
+
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
  * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as

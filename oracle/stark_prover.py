@@ -153,6 +153,7 @@ def stark_gen(cm_path, su, stark_struct, orc):
     tr.put(tree2["nodes"][-4:])
     challenge[2] = [int(v) for v in tr.get_field()]
     challenge[3] = [int(v) for v in tr.get_field()]
+    bufs["tmpexp_n"] = [0] * len(bufs["tmpexp_n"])      # output-only section of the step: starts from zero (stark_gen.rs:944-951)
     run("step3prev", "n")
     n_cm = info["n_cm1"] + info["n_cm2"]
     for o in info["pu_ctx"] + info["pe_ctx"] + info["ci_ctx"]:               # stark_gen.rs:329-353
@@ -161,6 +162,7 @@ def stark_gen(cm_path, su, stark_struct, orc):
         assert ok, "z does not close"
         set_pol(bufs, info, info["cm_n"][n_cm], [int(v) for v in z], N)
         n_cm += 1
+    bufs["tmpexp_n"] = [0] * len(bufs["tmpexp_n"])
     run("step3", "n")
     tree3 = extend_and_merkelize("cm3")
     tr.put(tree3["nodes"][-4:])
