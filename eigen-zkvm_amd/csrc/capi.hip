@@ -81,6 +81,7 @@ int zk_dev_free(void* p) { return guard([&] { ZK_HIP(hipFree(p)); }); }
 int zk_dev_upload(void* d, const void* h, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }); }
 int zk_dev_download(void* h, const void* d, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }); }
 int zk_dev_sync(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); }); }
+int zk_dev_memset(void* d, int value, size_t n) { return guard([&] { if (n) ZK_HIP(hipMemset(d, value, n)); }); }
 
 int zk_gl_ntt_passes(uint32_t nbits) { return ntt_num_passes(nbits); }
 

@@ -265,8 +265,7 @@ def _ints(a):
 
 def _zero(d):
     if d.n:
-        z = np.zeros(d.n, np.uint64)
-        _check(lib().zk_dev_upload(d.ptr, _ptr(z), d.n * 8))
+        _check(lib().zk_dev_memset(d.ptr, 0, d.n * 8))
 
 
 def _group_proof(tree, idx):

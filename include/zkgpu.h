@@ -37,6 +37,7 @@ int zk_dev_free(void* d_ptr);
 int zk_dev_upload(void* d_dst, const void* h_src, size_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, size_t bytes);
 int zk_dev_sync(void);
+int zk_dev_memset(void* d_ptr, int value, size_t bytes);
 
 /* ---- NTT / LDE ---------------------------------------------------------------------------
  * replaces fft_p::fft / fft_p::ifft (starky/src/fft_p.rs:242-253):

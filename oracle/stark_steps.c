@@ -148,3 +148,4 @@ int orc_calculate_z(const uint64_t *num, const uint64_t *den, uint64_t n, uint64
     free(di);
     return chk.v[0] == 1 && chk.v[1] == 0 && chk.v[2] == 0;
 }
+

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Times full GL-hash STARK proofs of the synthetic wide-Fibonacci PIL on one MI355X.
+usage: python tools/prove_bench.py --nbits 16 18 20 [--w 10] [--verify]
+Prints one JSON line per size: setup (const LDE+Merkle, JIT compile) and stark_gen wall time."""
+import argparse, json, pathlib, sys, time
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
+import importlib
+import zkgpu_loader, synth_pil
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nbits", type=int, nargs="+", default=[16])
+    ap.add_argument("--w", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--verify", action="store_true", help="check the proof with the oracle's restated verifier")
+    args = ap.parse_args()
+    assert args.w == 10, "only the committed W=10 program fixture is available"
+    zk = zkgpu_loader.load(); zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
+    for nbits in args.nbits:
+        info = synth_pil.rescale(d["starkinfo"], nbits)
+        ss = synth_pil.stark_struct(nbits)
+        cm = synth_pil.wide_fib_trace(nbits, args.w)
+        const = synth_pil.const_trace(nbits)
+        t0 = time.perf_counter()
+        setup = stark.StarkSetup(const, info, d["program"], ss)
+        zk.lib().zk_dev_sync()
+        t_setup = time.perf_counter() - t0
+        times = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            proof = stark.stark_gen(cm, setup)
+            times.append(time.perf_counter() - t0)
+        out = {"workload": "wide-Fibonacci PIL W=%d (%d committed cols), nBits=%d, GL hash, %d queries" % (args.w, 2 * args.w, nbits, ss["nQueries"]),
+               "setup_s": round(t_setup, 3), "stark_gen_ms": [round(t * 1e3, 1) for t in times], "root1": proof["root1"]}
+        if args.verify:
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import stark_prover as SP, oracle_lib
+            orc = oracle_lib.load()
+            vinfo = dict(info); vinfo["ev_idx"] = {"cm": {tuple(k): v for k, v in info["ev_idx"]["cm"]}, "const_": {}}
+            out["verified"] = bool(SP.stark_verify(proof, proof["rootC"], vinfo, d["program"], ss, orc))
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
