@@ -61,6 +61,39 @@ def gather_roots(dist, root4, device):
     return [o.tolist() for o in out]
 
 
+def prove_leg(zk, nbits):
+    """Third component of BASELINE's metric, "starky prove ms at 2^24 rows": one full GL-hash STARK
+    proof (LDE + Poseidon Merkle + constraint evaluation + FRI, stark_gen.rs:193-557) of the synthetic
+    wide-Fibonacci PIL (20 committed columns ~ the Poseidon PIL's 19, tools/synth_pil.py), trace
+    resident in host memory as `zkit stark_prove` has it after loading the .cm file.  The prover
+    program comes from the committed fixture tests/golden/widefib_w10.program.json."""
+    import importlib
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth_pil
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
+    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
+    cm, const = synth_pil.wide_fib_trace(nbits, 10), synth_pil.const_trace(nbits)
+    t0 = time.perf_counter()
+    setup = stark.StarkSetup(const, info, d["program"], ss)
+    zk.lib().zk_dev_sync()
+    setup_s = time.perf_counter() - t0
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        proof = stark.stark_gen(cm, setup)
+        times.append((time.perf_counter() - t0) * 1e3)
+    # Poseidon permutations of one proof: 4 per row of the 20-column tree + one per interior node of
+    # tree1 and tree4 (the zero-width tree2/tree3 cost one per level)
+    n_ext = 1 << (nbits + 1)
+    perms = 4 * n_ext + 2 * n_ext
+    return {"workload": "wide-Fibonacci PIL, 20 committed + 1 constant column, nBits=%d, nBitsExt=%d, GL hash, "
+                        "%d queries, FRI steps %s" % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]]),
+            "ms": round(min(times), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
+            "poseidon_perms_per_proof": perms, "root1": proof["root1"], "includes": "H2D upload of the 2.7 GB trace"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nbits", type=int, default=NBITS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prove", action="store_true", help="skip the stark_prove leg")
+    ap.add_argument("--prove-nbits", type=int, default=24)
     args = ap.parse_args()
 
     import numpy as np
@@ -150,6 +185,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
         }
+        if not args.no_prove and world == 1:
+            out["stark_prove"] = prove_leg(zk, args.prove_nbits)
         if not args.no_cpu_baseline and world >= 1:
             orc = oracle_lib.load()
             t0 = time.perf_counter()

@@ -2,6 +2,7 @@
 // staging for the host-pointer entry points, and the Merkle tree handle.
 #include "zk_internal.h"
 #include "../../include/zkgpu.h"
+#include <map>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -10,6 +11,42 @@ namespace zk {
 
 static thread_local std::string t_err;
 void set_error(const std::string& msg) { t_err = msg; }
+
+// ---- caching device allocator -------------------------------------------------------------------
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void*> g_pool_free;   // size -> idle block
+std::map<void*, size_t> g_pool_size;        // every block handed out by pool_alloc
+}
+void* pool_alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.find(bytes);
+        if (it != g_pool_free.end()) { void* p = it->second; g_pool_free.erase(it); return p; }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+        pool_trim();
+        ZK_HIP(hipMalloc(&p, bytes));
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_size[p] = bytes;
+    return p;
+}
+void pool_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_size.find(p);
+    if (it == g_pool_size.end()) { (void)hipFree(p); return; }
+    g_pool_free.emplace(it->second, p);
+}
+void pool_trim() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& kv : g_pool_free) { (void)hipFree(kv.second); g_pool_size.erase(kv.second); }
+    g_pool_free.clear();
+}
 
 namespace {
 
@@ -74,10 +111,11 @@ uint64_t zk_gl_root_of_unity(uint32_t k) { return k <= 32 ? gl::hroot(k) : 0; }
 
 void* zk_dev_alloc(size_t bytes) {
     void* p = nullptr;
-    if (guard([&] { ZK_HIP(hipMalloc(&p, bytes ? bytes : 8)); }) != 0) return nullptr;
+    if (guard([&] { p = pool_alloc(bytes); }) != 0) return nullptr;
     return p;
 }
-int zk_dev_free(void* p) { return guard([&] { ZK_HIP(hipFree(p)); }); }
+int zk_dev_free(void* p) { return guard([&] { pool_free(p); }); }
+int zk_dev_trim(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); pool_trim(); }); }
 int zk_dev_upload(void* d, const void* h, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }); }
 int zk_dev_download(void* h, const void* d, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }); }
 int zk_dev_sync(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); }); }

@@ -179,6 +179,25 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
 }
 
+// A tree over zero-width rows (tree2 / tree3 of a PIL without plookups or grand products,
+// stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
+// one permutation per level instead of one per node.
+__global__ void zero_tree_chain_kernel(u32 levels, u64* __restrict__ h /* [levels + 1][4] */) {
+    if (threadIdx.x | blockIdx.x) return;
+    u64 cur[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) h[k] = 0;
+    for (u32 l = 0; l < levels; ++l) {
+        u64 st[12];
+        for (int k = 0; k < 4; ++k) { st[k] = cur[k]; st[4 + k] = cur[k]; st[8 + k] = 0; }
+        poseidon_perm(st);
+        for (int k = 0; k < 4; ++k) { cur[k] = st[k]; h[4 * (l + 1) + k] = st[k]; }
+    }
+}
+__global__ void fill_digest_kernel(u64* __restrict__ nodes, u64 n, const u64* __restrict__ h) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * n) nodes[i] = h[i & 3];
+}
+
 __global__ void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, int n_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 st[12];
@@ -307,6 +326,22 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
     const uint64_t nn = merkle_n_nodes(height);
     // absent right siblings on odd levels are the all-zero digest (merklehash.rs:307)
     ZK_HIP(hipMemsetAsync(d_nodes, 0, nn * 32, st));
+    if (width == 0 && (height & (height - 1)) == 0 && height > 1) {  // all-zero leaves, full binary tree
+        uint32_t levels = 0;
+        while ((1ull << levels) < height) ++levels;
+        DevBuf hbuf;  // pooled; returned at scope exit, reuse is stream ordered
+        hbuf.reserve((levels + 1) * 32);
+        u64* d_h = hbuf.u();
+        hipLaunchKernelGGL(zero_tree_chain_kernel, dim3(1), dim3(64), 0, st, levels, d_h);
+        ZK_HIP(hipGetLastError());
+        uint64_t n = height, off = 0;
+        for (uint32_t l = 1; l <= levels; ++l) {  // level l has height >> l nodes, starting after level l-1
+            off += n; n >>= 1;
+            hipLaunchKernelGGL(fill_digest_kernel, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, d_nodes + 4 * off, n, d_h + 4 * l);
+            ZK_HIP(hipGetLastError());
+        }
+        return;
+    }
     linearhash_rows_dev(d_rows, width, height, d_nodes, st);
     uint64_t n64 = height, next = (n64 - 1) / 2 + 1, p_in = 0, p_out = next * 2;
     while (n64 > 1) {  // merklehash.rs:331-343

@@ -310,16 +310,15 @@ void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_
                u64* d_out, hipStream_t st) {
     if (n_ev == 0) return;
     static_assert(sizeof(EvalDescHost) == sizeof(EvalDesc), "descriptor layout");
-    EvalDesc* d_desc; u64* d_partial;
-    ZK_HIP(hipMallocAsync((void**)&d_desc, n_ev * sizeof(EvalDesc), st));
-    ZK_HIP(hipMallocAsync((void**)&d_partial, (size_t)n_ev * EV_BLOCKS * 24, st));
-    ZK_HIP(hipMemcpyAsync(d_desc, descs, n_ev * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, n_ev), dim3(256), 0, st, d_desc, nbits, ext, d_LEv, d_LpEv, d_partial);
+    DevBuf desc, partial;  // pooled blocks; returned to the pool at scope exit, reuse is stream ordered
+    desc.reserve(n_ev * sizeof(EvalDesc));
+    partial.reserve((size_t)n_ev * EV_BLOCKS * 24);
+    ZK_HIP(hipMemcpyAsync(desc.p, descs, n_ev * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
+    ZK_HIP(hipStreamSynchronize(st));  // `descs` is caller-owned pageable memory
+    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, n_ev), dim3(256), 0, st, (const EvalDesc*)desc.p, nbits, ext, d_LEv, d_LpEv, partial.u());
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(evals_final_kernel, grid1(n_ev, 64), dim3(64), 0, st, d_partial, n_ev, (u32)EV_BLOCKS, d_out);
+    hipLaunchKernelGGL(evals_final_kernel, grid1(n_ev, 64), dim3(64), 0, st, partial.u(), n_ev, (u32)EV_BLOCKS, d_out);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipFreeAsync(d_desc, st));
-    ZK_HIP(hipFreeAsync(d_partial, st));
 }
 
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st) {

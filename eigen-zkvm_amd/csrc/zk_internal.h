@@ -25,15 +25,22 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
     do { if (!(cond)) throw zk::Error(std::string(msg)); } while (0)
 
 // ---- device buffers ----
+// Size-keyed free list in front of hipMalloc/hipFree (capi.hip): a prover allocates the same
+// multi-GB sections for every proof, and hipFree/hipMalloc of such buffers costs hundreds of ms and
+// synchronises the device.  pool_free keeps the block (stream-ordered reuse is safe: one stream).
+void* pool_alloc(size_t bytes);
+void pool_free(void* p);
+void pool_trim();  // hipFree everything cached
+
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) pool_free(p); }
     void reserve(size_t n) {  // grow-only workspace
         if (n <= bytes) return;
-        if (p) { ZK_HIP(hipFree(p)); p = nullptr; bytes = 0; }
-        ZK_HIP(hipMalloc(&p, n)); bytes = n;
+        if (p) { pool_free(p); p = nullptr; bytes = 0; }
+        p = pool_alloc(n); bytes = n;
     }
     u64* u() const { return (u64*)p; }
 };

@@ -31,9 +31,11 @@ int zk_device_count(void);          /* number of visible GPUs, <= 0 when none   
 uint64_t zk_gl_modulus(void);       /* 0xFFFFFFFF00000001 (fields/src/field_gl.rs:12)          */
 uint64_t zk_gl_root_of_unity(uint32_t k); /* MG.0[k] (starky/src/constant.rs:54-68), k <= 32   */
 
-/* device memory helpers for callers that keep traces resident in HBM */
+/* device memory helpers for callers that keep traces resident in HBM.  Blocks are cached by size
+ * (a prover re-allocates the same multi-GB sections for every proof); zk_dev_trim returns the cache. */
 void* zk_dev_alloc(size_t bytes);
 int zk_dev_free(void* d_ptr);
+int zk_dev_trim(void);
 int zk_dev_upload(void* d_dst, const void* h_src, size_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, size_t bytes);
 int zk_dev_sync(void);
