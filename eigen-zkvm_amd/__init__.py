@@ -32,6 +32,7 @@ EXPORTS = [
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
     "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
+    "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev",
 ]
 
 # include/zkgpu.h enums
@@ -121,6 +122,8 @@ def _load():
         "zk_stark_lev_dev": (C.c_int, [vp, C.c_uint32, C.c_int, vp, vp, vp, vp]),
         "zk_stark_evals_dev": (C.c_int, [C.POINTER(EvalDesc), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
         "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+        "zk_msm_g1_bn254": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
+        "zk_msm_g1_bn254_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
@@ -410,6 +413,25 @@ class Program:
                 lib().zk_program_free(self._h); self._h = None
         except Exception:
             pass
+
+
+# ---- groth16 multiexp seam (groth16/src/groth16.rs:88-96 -> bellman_ce multiexp) -------------------
+def msm_g1_bn254(bases, scalars):
+    """sum_i scalars[i] * bases[i] on BN254 G1.  bases: n x 8 u64 (affine x||y, Montgomery limbs),
+    scalars: n x 4 u64 canonical.  Returns (point[8] u64 Montgomery affine, is_infinity)."""
+    b, s = _np(bases).reshape(-1), _np(scalars).reshape(-1)
+    n = s.size // 4
+    if b.size != n * 8 or s.size != n * 4:
+        raise ZkError("msm: bases/scalars length mismatch")
+    out, inf = np.zeros(8, np.uint64), C.c_int(0)
+    _check(lib().zk_msm_g1_bn254(_ptr(b), _ptr(s), n, _ptr(out), C.byref(inf)))
+    return out, bool(inf.value)
+
+
+def msm_g1_bn254_dev(d_bases, d_scalars, n, stream=0):
+    """device-resident variant; returns a DevArray of 9 words (x, y, flag in the low 32 bits of word 8)."""
+    out = DevArray(9, zero=True)
+    _check(lib().zk_msm_g1_bn254_dev(d_bases.ptr, d_scalars.ptr, n, out.ptr, stream)); return out
 
 
 def qsplit(d_qq1, nbits, nbits_ext, q_dim, q_deg, stream=0):

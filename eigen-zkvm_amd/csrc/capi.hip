@@ -349,6 +349,27 @@ int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, u
     return guard([&] { qsplit_dev((const u64*)d_qq1, nbits, q_dim, q_deg, (u64*)d_qq2, (hipStream_t)stream); });
 }
 
+int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
+    return guard([&] { msm_g1_bn254_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });
+}
+int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {
+    return guard([&] {
+        ZK_REQUIRE(out && is_infinity, "msm: null output");
+        ZK_REQUIRE(n == 0 || (bases && scalars), "msm: null input");
+        if (n == 0) { memset(out, 0, 64); *is_infinity = 1; return; }  // empty sum
+        DevBuf db, ds, dout;
+        db.reserve(n * 64); ds.reserve(n * 32); dout.reserve(68);
+        ZK_HIP(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
+        ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+        msm_g1_bn254_dev(db.p, ds.p, n, dout.p, nullptr);
+        uint32_t h[17];
+        ZK_HIP(hipStreamSynchronize(nullptr));
+        ZK_HIP(hipMemcpy(h, dout.p, 68, hipMemcpyDeviceToHost));
+        memcpy(out, h, 64);
+        *is_infinity = (int)h[16];
+    });
+}
+
 int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, uint64_t* d_out3, void* stream) {
     return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, (hipStream_t)stream); });
 }

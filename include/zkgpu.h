@@ -138,6 +138,15 @@ int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint3
  * and fails ("z does not close") when z[n-1]*num[n-1]/den[n-1] != 1, as the reference asserts (:663-664) */
 int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream);
 
+/* ---- G1 multi-scalar multiplication (groth16 final wrap) ---------------------------------------
+ * stands behind Groth16::prove (groth16/src/groth16.rs:88-96) -> bellman_ce::create_random_proof ->
+ * multiexp, the seam bellperson occupies under `--features cuda` (groth16.rs:45-57).  Layout as
+ * bellman keeps it: bases n x 64 B affine (x || y), Fq in Montgomery form (R = 2^256), little-endian
+ * limbs; scalars n x 32 B canonical little-endian (FrRepr); out 64 B affine Montgomery, *is_infinity
+ * set when the sum is the point at infinity.  `_dev` takes device pointers (d_out: 68 bytes).       */
+int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
+int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
  * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as

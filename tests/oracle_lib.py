@@ -89,6 +89,34 @@ class Oracle:
     def transcript(self):
         return Transcript(self)
 
+    # -- BN254 G1 (oracle/ec.c); points = 8 u64 words x||y (Montgomery), scalars = 4 words LE
+    def _ec_setup(self):
+        L = self.lib
+        if getattr(self, "_ec_ready", False):
+            return
+        L.orc_bn254_generator.argtypes = [_u64p]
+        L.orc_bn254_on_curve.restype = C.c_int; L.orc_bn254_on_curve.argtypes = [_u64p]
+        L.orc_fq_mul.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_fq_from_mont.argtypes = [_u64p, _u64p]; L.orc_fq_to_mont.argtypes = [_u64p, _u64p]
+        L.orc_bn254_scalar_mul.restype = C.c_int; L.orc_bn254_scalar_mul.argtypes = [_u64p, _u64p, _u64p]
+        L.orc_bn254_make_bases.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
+        L.orc_bn254_msm.restype = C.c_int; L.orc_bn254_msm.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint, _u64p]
+        self._ec_ready = True
+    def bn254_generator(self):
+        self._ec_setup(); o = np.zeros(8, np.uint64); self.lib.orc_bn254_generator(o); return o
+    def bn254_on_curve(self, p):
+        self._ec_setup(); return bool(self.lib.orc_bn254_on_curve(_a(p)))
+    def fq_from_mont(self, a):
+        self._ec_setup(); o = np.zeros(4, np.uint64); self.lib.orc_fq_from_mont(_a(a), o); return o
+    def bn254_scalar_mul(self, p, k):
+        self._ec_setup(); o = np.zeros(8, np.uint64)
+        inf = self.lib.orc_bn254_scalar_mul(_a(p), _a(k), o); return o, bool(inf)
+    def bn254_make_bases(self, n, a, b):
+        self._ec_setup(); o = np.zeros(8 * n, np.uint64); self.lib.orc_bn254_make_bases(n, a, b, o); return o
+    def bn254_msm(self, bases, scalars, c=8):
+        self._ec_setup(); bases = _a(bases); o = np.zeros(8, np.uint64)
+        inf = self.lib.orc_bn254_msm(bases, _a(scalars), bases.size // 8, c, o); return o, bool(inf)
+
     # -- prover glue (oracle/stark_steps.c)
     def f3_ntt(self, v, bits, inverse=False):
         v = _a(v).copy(); self.lib.orc_f3_ntt(v, bits, int(inverse)); return v

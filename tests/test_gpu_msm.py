@@ -1,0 +1,122 @@
+"""Parity of the BN254 G1 multi-scalar multiplication (csrc/msm.hip, through zk_msm_g1_bn254) against
+the CPU oracle's Pippenger (oracle/ec.c) and the closed form  sum s_i [k_i]G == [sum s_i k_i mod r]G.
+Points compare as affine Montgomery limbs, bit exact (the affine form of a group element is unique)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(zk):
+    assert zk.lib().zk_device_count() >= 1, "no GPU visible (the product has no CPU fallback)"
+    zk.init(0)
+
+
+def words(x, n=4):
+    return np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(n)], np.uint64)
+
+
+def rand_scalars(rng, n):
+    raw = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 60) - 1)          # < 2^252 < r : canonical by construction
+    return raw.reshape(-1)
+
+
+def scalar_ints(s):
+    s = s.reshape(-1, 4)
+    return [sum(int(v) << (64 * j) for j, v in enumerate(row)) for row in s]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 33, 64, 65, 1000, 4097])
+def test_msm_matches_oracle_small(zk, orc, n):
+    rng = np.random.default_rng(100 + n)
+    bases = orc.bn254_make_bases(n, 3, 5)
+    scal = rand_scalars(rng, n)
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    exp, einf = orc.bn254_msm(bases, scal, 8)
+    assert inf == einf and np.array_equal(got, exp)
+
+
+def test_msm_edge_scalars(zk, orc):
+    """0, 1, r-1, 2^k boundaries of the 16-bit windows, all-ones windows."""
+    vals = [0, 1, R - 1, R - 2, 2**16 - 1, 2**16, 2**253 % R, (1 << 240) - 1, 0xFFFF << 48, 1 << 255 - 2]
+    vals = [v % R for v in vals]
+    n = len(vals)
+    bases = orc.bn254_make_bases(n, 7, 11)
+    scal = np.concatenate([words(v) for v in vals])
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    k = sum(v * (7 + 11 * i) for i, v in enumerate(vals)) % R
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+
+
+def test_msm_all_zero_scalars_is_infinity(zk, orc):
+    bases = orc.bn254_make_bases(100, 1, 1)
+    _, inf = zk.msm_g1_bn254(bases, np.zeros(400, np.uint64))
+    assert inf
+
+
+def test_msm_empty_is_infinity(zk):
+    _, inf = zk.msm_g1_bn254(np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+    assert inf
+
+
+def test_msm_cancellation_and_duplicates(zk, orc):
+    one = orc.bn254_make_bases(1, 5, 1)
+    # P*9 + P*(r-9) = infinity : exercises P + (-P) in the window combination
+    _, inf = zk.msm_g1_bn254(np.concatenate([one, one]), np.concatenate([words(9), words(R - 9)]))
+    assert inf
+    # the same base 300 times with the same scalar: every add in a bucket is a doubling or P+2P...
+    n = 300
+    bases = np.tile(one, n)
+    scal = np.tile(words(0x0123456789abcdef0123456789abcdef), n)
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(5 * n * 0x0123456789abcdef0123456789abcdef % R))
+    assert inf == einf and np.array_equal(got, exp)
+
+
+def test_msm_same_bucket_pressure(zk, orc):
+    """All scalars share their window digits except the lowest: one bucket per window gets n points."""
+    n = 5000
+    rng = np.random.default_rng(5)
+    base_s = int.from_bytes(rng.bytes(31), "little") & ~0xFFFF
+    vals = [base_s + int(v) for v in rng.integers(0, 4, size=n)]
+    bases = orc.bn254_make_bases(n, 2, 3)
+    scal = np.concatenate([words(v) for v in vals])
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    k = sum(v * (2 + 3 * i) for i, v in enumerate(vals)) % R
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("logn", [16, 20])
+def test_msm_large_closed_form(zk, orc, logn):
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    bases = orc.bn254_make_bases(n, 3, 5)
+    scal = rand_scalars(rng, n)
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    ks = 3 + 5 * np.arange(n, dtype=object)
+    k = int(sum(s * int(ki) for s, ki in zip(scalar_ints(scal), ks)) % R)
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+    if logn == 16:                                   # and the oracle's own Pippenger, another window size
+        exp2, _ = orc.bn254_msm(bases, scal, 13)
+        assert np.array_equal(got, exp2)
+
+
+def test_msm_linearity(zk, orc):
+    """MSM(b, s1) + MSM(b, s2) == MSM(b, s1 + s2 mod r), checked through one more 2-point MSM."""
+    n = 2048
+    rng = np.random.default_rng(77)
+    bases = orc.bn254_make_bases(n, 9, 2)
+    s1, s2 = rand_scalars(rng, n), rand_scalars(rng, n)
+    s12 = np.concatenate([words((a + b) % R) for a, b in zip(scalar_ints(s1), scalar_ints(s2))])
+    p1, i1 = zk.msm_g1_bn254(bases, s1)
+    p2, i2 = zk.msm_g1_bn254(bases, s2)
+    p12, i12 = zk.msm_g1_bn254(bases, s12)
+    assert not (i1 or i2 or i12)
+    both, inf = zk.msm_g1_bn254(np.concatenate([p1, p2]), np.concatenate([words(1), words(1)]))
+    assert not inf and np.array_equal(both, p12)

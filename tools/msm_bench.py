@@ -1,0 +1,20 @@
+"""BN254 G1 MSM timing (device-resident inputs): python tools/msm_bench.py [logn ...]"""
+import sys, time, pathlib
+import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import zkgpu_loader, oracle_lib
+
+zk = zkgpu_loader.load(); zk.init(0)
+orc = oracle_lib.load()
+for logn in [int(a) for a in sys.argv[1:]] or [16, 20, 22]:
+    n = 1 << logn
+    rng = np.random.default_rng(logn)
+    bases = orc.bn254_make_bases(n, 3, 5)
+    scal = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); scal[:, 3] &= np.uint64((1 << 60) - 1)
+    db, ds = zk.DevArray.from_host(bases), zk.DevArray.from_host(scal.reshape(-1))
+    zk.msm_g1_bn254_dev(db, ds, n)
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); o = zk.msm_g1_bn254_dev(db, ds, n); zk.lib().zk_dev_sync(); ts.append(time.perf_counter() - t)
+    print(f"msm 2^{logn}: {min(ts)*1e3:.2f} ms  {n/min(ts)/1e6:.2f} Mpts/s", flush=True)
