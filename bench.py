@@ -94,6 +94,45 @@ def prove_leg(zk, nbits):
             "poseidon_perms_per_proof": perms, "root1": proof["root1"], "includes": "H2D upload of the 2.7 GB trace"}
 
 
+def msm_leg(zk, logn, cpu_baseline):
+    """Second component of BASELINE's metric, "BN254 G1 MSM Mpts/s" (config 4): n = 2^22 uniform scalars
+    below r, bases [k_i]G generated on the device, everything resident in HBM when the clock starts;
+    the result is checked against the closed form [sum s_i k_i mod r]G by the CPU oracle."""
+    n = 1 << logn
+    rng = np.random.default_rng(0x4D534D)
+    k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
+    scal = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    scal[:, 3] &= np.uint64((1 << 60) - 1)                              # < 2^252 < r
+    d_bases = zk.g1_bn254_mul_generator(zk.DevArray.from_host(k))
+    d_scal = zk.DevArray.from_host(scal.reshape(-1))
+    zk.msm_g1_bn254_dev(d_bases, d_scal, n)                             # warm the pool
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        out = zk.msm_g1_bn254_dev(d_bases, d_scal, n)
+        zk.lib().zk_dev_sync()
+        times.append(time.perf_counter() - t0)
+    res = {"workload": "BASELINE config 4: BN254 G1 Pippenger MSM, n=2^%d, c=16, HBM-resident" % logn,
+           "value": round(n / min(times) / 1e6, 2), "unit": "Mpts/s", "ms": round(min(times) * 1e3, 2)}
+    if cpu_baseline:
+        R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+        orc = oracle_lib.load()
+        w = lambda x: np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64)
+        s4 = scal.astype(object)
+        sv = s4[:, 0] + (s4[:, 1] << 64) + (s4[:, 2] << 128) + (s4[:, 3] << 192)
+        exp, _ = orc.bn254_scalar_mul(orc.bn254_generator(), w(int((sv * k.astype(object)).sum() % R)))
+        assert np.array_equal(out.to_host()[:8], exp), "GPU MSM != closed form"
+        m = 1 << 18                                                     # bounded CPU sample of the same inputs
+        hb = np.empty(m * 8, np.uint64)
+        zk._check(zk.lib().zk_dev_download(zk._ptr(hb), d_bases.ptr, m * 64))
+        t0 = time.perf_counter()
+        orc.bn254_msm(hb, scal[:m].reshape(-1), 14)
+        cpu_s = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
+                               "sample": "first 2^18 points of the same input, oracle/ec.c Pippenger c=14, %.2f s" % cpu_s}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +142,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the stark_prove leg")
     ap.add_argument("--prove-nbits", type=int, default=24)
+    ap.add_argument("--no-msm", action="store_true", help="skip the BN254 MSM leg")
+    ap.add_argument("--msm-logn", type=int, default=22)
     args = ap.parse_args()
 
     import numpy as np
@@ -185,6 +226,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
         }
+        if not args.no_msm and world == 1:
+            out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
         if not args.no_prove and world == 1:
             out["stark_prove"] = prove_leg(zk, args.prove_nbits)
         if not args.no_cpu_baseline and world >= 1:

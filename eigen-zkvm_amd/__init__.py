@@ -32,7 +32,7 @@ EXPORTS = [
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
     "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
-    "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev",
+    "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
 ]
 
 # include/zkgpu.h enums
@@ -124,6 +124,7 @@ def _load():
         "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "zk_msm_g1_bn254": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "zk_msm_g1_bn254_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+        "zk_g1_bn254_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
@@ -426,6 +427,12 @@ def msm_g1_bn254(bases, scalars):
     out, inf = np.zeros(8, np.uint64), C.c_int(0)
     _check(lib().zk_msm_g1_bn254(_ptr(b), _ptr(s), n, _ptr(out), C.byref(inf)))
     return out, bool(inf.value)
+
+
+def g1_bn254_mul_generator(d_k, stream=0):
+    """bases[i] = [k_i]G for the n non-zero u64 in d_k; returns a DevArray of n*8 words."""
+    out = DevArray(d_k.n * 8)
+    _check(lib().zk_g1_bn254_mul_generator_dev(d_k.ptr, d_k.n, out.ptr, stream)); return out
 
 
 def msm_g1_bn254_dev(d_bases, d_scalars, n, stream=0):

@@ -352,6 +352,9 @@ int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, u
 int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
     return guard([&] { msm_g1_bn254_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });
 }
+int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {
+    return guard([&] { g1_bn254_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });
+}
 int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {
     return guard([&] {
         ZK_REQUIRE(out && is_infinity, "msm: null output");

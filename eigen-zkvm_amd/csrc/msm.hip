@@ -11,8 +11,8 @@
 //   3. scatter point indices into bucket order (atomic cursors)
 //   4. bucket accumulation: one lane per bucket, XYZZ += affine (8M + 2S per point), points
 //      gathered by index (64 B each)
-//   5. per-window reduction sum_k k*B_k: 256 lanes per window run the running-sum trick on 256
-//      buckets each, a second level combines the 256 partial (S_t, A_t) pairs
+//   5. per-window reduction sum_k k*B_k: radix-16 hierarchy of (S, A) block summaries, 4 levels,
+//      2^16 .. 2^4 lanes; the serial chain per lane is 47 point additions
 //   6. Horner over the windows + conversion to affine (one lane)
 // Field: 8 x 32-bit limbs, CIOS Montgomery multiplication on v_mad_u64_u32 (128 per product).
 // Integer-ALU bound (about 10 Fq products per point and window); HBM traffic is 96 B per point.
@@ -76,7 +76,10 @@ __device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
 }
 __device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
 // Montgomery product a*b*R^-1 mod q (CIOS, 32-bit limbs)
-__device__ __noinline__ fq fq_mul(const fq& a, const fq& b) {
+#ifndef FQ_MUL_ATTR
+#define FQ_MUL_ATTR __forceinline__
+#endif
+__device__ FQ_MUL_ATTR fq fq_mul(const fq& a, const fq& b) {
     u32 t[NL + 2];
 #pragma unroll
     for (int i = 0; i < NL + 2; ++i) t[i] = 0;
@@ -182,7 +185,6 @@ __device__ __forceinline__ xyzz pt_neg(const xyzz& p) {
 }
 
 constexpr int C_BITS = 16, N_WIN = 16, N_BUCKET = 1 << C_BITS;  // 254-bit scalars: 16 windows of 16 bits
-constexpr int RED_T = 256, RED_CHUNK = N_BUCKET / RED_T;
 
 __global__ void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __restrict__ counts) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // one lane per (point, window)
@@ -252,28 +254,27 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restric
     for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(bases, idx[off + k]));
     buckets[key] = acc;
 }
-// level 1 of sum_k k*B_k: lane (w, t) owns buckets [t*256, t*256+256): S = sum B, A = sum (j+1)*B_j
-__global__ __launch_bounds__(64) void msm_reduce1_kernel(const xyzz* __restrict__ buckets, xyzz* __restrict__ S, xyzz* __restrict__ A) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;  // window * 256 + t
-    const xyzz* b = buckets + (u64)g * RED_CHUNK;
+// One level of the radix-16 hierarchy that computes sum_k k*B_k per window.  An item (S, A) stands
+// for a block of m = 16^level consecutive buckets: S = their sum, A = sum (local index) * bucket.
+// 16 neighbouring blocks combine as S' = sum_j S_j, A' = sum_j A_j + m * sum_j j*S_j (running-sum
+// trick for the last term).  Level 0 reads the buckets themselves (A = 0).  After 4 levels the one
+// item left per window holds A = sum_k k*B_k.  Every level keeps 1/16 of the lanes of the one
+// before: 2^16, 2^12, 2^8, 2^4 -- the serial chain per lane is 47 additions, not 65536.
+__global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __restrict__ S_in, const xyzz* __restrict__ A_in,
+                                                              xyzz* __restrict__ S_out, xyzz* __restrict__ A_out,
+                                                              u32 n_out, int level) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_out) return;
+    const xyzz* s = S_in + (u64)g * 16;
     xyzz run = pt_inf(), acc = pt_inf();
-    for (int j = RED_CHUNK - 1; j >= 0; --j) { run = pt_add(run, b[j]); acc = pt_add(acc, run); }
-    S[g] = run; A[g] = acc;
-}
-// level 2: window = sum_t [ (A_t - S_t) + 256*t*S_t ]
-__global__ __launch_bounds__(64) void msm_reduce2_kernel(const xyzz* __restrict__ S, const xyzz* __restrict__ A, xyzz* __restrict__ win) {
-    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= N_WIN) return;
-    xyzz run = pt_inf(), acc2 = pt_inf(), sumA = pt_inf();
-    for (int t = RED_T - 1; t >= 0; --t) {
-        run = pt_add(run, S[w * RED_T + t]);   // suffix sums of S
-        acc2 = pt_add(acc2, run);              // -> sum (t+1) S_t
-        sumA = pt_add(sumA, A[w * RED_T + t]);
+    for (int j = 15; j >= 1; --j) { run = pt_add(run, s[j]); acc = pt_add(acc, run); }
+    run = pt_add(run, s[0]);
+    if (level > 0) {
+        for (int k = 0; k < 4 * level; ++k) acc = pt_dbl(acc);
+        const xyzz* a = A_in + (u64)g * 16;
+        for (int j = 0; j < 16; ++j) acc = pt_add(acc, a[j]);
     }
-    // sum_t t*S_t = acc2 - sumS ; times 256
-    xyzz hi = pt_add(acc2, pt_neg(run));
-    for (int k = 0; k < 8; ++k) hi = pt_dbl(hi);
-    win[w] = pt_add(pt_add(sumA, pt_neg(run)), hi);
+    S_out[g] = run; A_out[g] = acc;
 }
 __global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 16 words + flag */) {
     if (threadIdx.x | blockIdx.x) return;
@@ -290,17 +291,44 @@ __global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__
     out[16] = 0;
 }
 
+// synthetic bases for benches/tests: P_i = [k_i]G, G = (1, 2); k_i 64-bit, non-zero
+__global__ __launch_bounds__(64) void g1_mul_generator_kernel(const u64* __restrict__ k, u64 n, u32* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aff g;
+    for (int j = 0; j < NL; ++j) g.x.l[j] = FQ_ONE(j);
+    g.y = fq_dbl(g.x);
+    const u64 e = k[i];
+    xyzz acc = pt_inf();
+    for (int b = 63; b >= 0; --b) {
+        acc = pt_dbl(acc);
+        if ((e >> b) & 1) acc = pt_madd(acc, g);
+    }
+    u32* o = out + i * 16;
+    if (pt_is_inf(acc)) { for (int j = 0; j < 16; ++j) o[j] = 0; return; }
+    fq izzz = fq_inv(acc.ZZZ), t = fq_mul(acc.ZZ, izzz), izz = fq_sqr(t);
+    fq x = fq_mul(acc.X, izz), y = fq_mul(acc.Y, izzz);
+    for (int j = 0; j < 8; ++j) { o[j] = x.l[j]; o[8 + j] = y.l[j]; }
+}
+
 }  // namespace
+
+void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(g1_mul_generator_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_k, n, (u32*)d_bases);
+    ZK_HIP(hipGetLastError());
+}
 
 // d_out: 17 u32 words (x, y Montgomery, infinity flag)
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;
-    DevBuf counts, offsets, cursors, tops, idx, buckets, S, A, win;
+    DevBuf counts, offsets, cursors, tops, idx, buckets, S0, A0, S1, A1;
     counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
     idx.reserve((size_t)n * N_WIN * 4);
-    buckets.reserve(n_keys * sizeof(xyzz)); S.reserve(N_WIN * RED_T * sizeof(xyzz)); A.reserve(N_WIN * RED_T * sizeof(xyzz));
-    win.reserve(N_WIN * sizeof(xyzz));
+    buckets.reserve(n_keys * sizeof(xyzz));
+    S0.reserve(n_keys / 16 * sizeof(xyzz)); A0.reserve(n_keys / 16 * sizeof(xyzz));
+    S1.reserve(n_keys / 256 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));
     ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
     ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
     const u64 total = n * N_WIN;
@@ -318,9 +346,16 @@ void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, vo
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, (const u32*)d_bases,
                        (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (xyzz*)buckets.p);
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_reduce1_kernel, dim3(N_WIN * RED_T / 64), dim3(64), 0, st, (const xyzz*)buckets.p, (xyzz*)S.p, (xyzz*)A.p);
-    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)S.p, (const xyzz*)A.p, (xyzz*)win.p);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)win.p, (u32*)d_out);
+    // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
+    const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
+    u32 n_out = (u32)(n_keys / 16);
+    for (int level = 0; level < C_BITS / 4; ++level, n_out /= 16) {
+        xyzz* s_out = (xyzz*)(level & 1 ? S1.p : S0.p); xyzz* a_out = (xyzz*)(level & 1 ? A1.p : A0.p);
+        hipLaunchKernelGGL(msm_reduce_level_kernel, dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
+        s_in = s_out; a_in = a_out;
+    }
+    ZK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, a_in, (u32*)d_out);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(st));  // the pooled scratch above is released at scope exit
 }

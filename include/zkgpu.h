@@ -146,6 +146,9 @@ int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uin
  * set when the sum is the point at infinity.  `_dev` takes device pointers (d_out: 68 bytes).       */
 int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
 int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+/* synthetic CRS for benches and tests: d_bases[i] = [d_k[i]] G, G = (1, 2), k_i a non-zero 64-bit integer
+ * (what generate_random_parameters, groth16.rs:39,82, does with secret exponents).                     */
+int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
 
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,

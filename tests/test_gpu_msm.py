@@ -120,3 +120,30 @@ def test_msm_linearity(zk, orc):
     assert not (i1 or i2 or i12)
     both, inf = zk.msm_g1_bn254(np.concatenate([p1, p2]), np.concatenate([words(1), words(1)]))
     assert not inf and np.array_equal(both, p12)
+
+
+def test_generator_multiples_match_oracle(zk, orc):
+    rng = np.random.default_rng(3)
+    k = rng.integers(1, 2**64, size=200, dtype=np.uint64)
+    k[:4] = [1, 2, 2**64 - 1, 2**63]
+    bases = zk.g1_bn254_mul_generator(zk.DevArray.from_host(k)).to_host().reshape(-1, 8)
+    g = orc.bn254_generator()
+    for i in (0, 1, 2, 3, 57, 199):
+        exp, _ = orc.bn254_scalar_mul(g, words(int(k[i])))
+        assert np.array_equal(bases[i], exp)
+        assert orc.bn254_on_curve(bases[i])
+
+
+def test_msm_full_size_closed_form(zk, orc):
+    """BASELINE config 4: n = 2^22, bases [k_i]G generated on the device, uniform scalars below r."""
+    n = 1 << 22
+    rng = np.random.default_rng(22)
+    k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
+    scal = rand_scalars(rng, n)
+    d_bases = zk.g1_bn254_mul_generator(zk.DevArray.from_host(k))
+    out = zk.msm_g1_bn254_dev(d_bases, zk.DevArray.from_host(scal), n).to_host()
+    s4 = scal.reshape(-1, 4).astype(object)
+    sv = s4[:, 0] + (s4[:, 1] << 64) + (s4[:, 2] << 128) + (s4[:, 3] << 192)
+    kk = int((sv * k.astype(object)).sum() % R)
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(kk))
+    assert (int(out[8]) & 0xFFFFFFFF) == int(einf) and np.array_equal(out[:8], exp)
