@@ -25,6 +25,7 @@ import os
 import pathlib
 import sys
 import time
+import numpy as np
 
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "tests"))
@@ -32,6 +33,13 @@ sys.path.insert(0, str(ROOT / "tests"))
 NBITS = 24
 SEED = 0x9E3779B97F4A7C15
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+# HBM bytes per ntt_pass_kernel launch from the PMC counters (profiles/r01/pmc_hbm_traffic.txt:
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950
+# correction, calibrated on a 1 GiB copy in the same run): 2*65729 KiB read + 131072 KiB written at
+# 2^24 -- the pass moves exactly its compulsory 16 B/element, no re-reads.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {24: (2 * 65729.2 + 131072.0) * 1024}
 
 
 def shard_units(n_units, rank, world):
@@ -116,6 +124,7 @@ def msm_leg(zk, logn, cpu_baseline):
            "value": round(n / min(times) / 1e6, 2), "unit": "Mpts/s", "ms": round(min(times) * 1e3, 2)}
     if cpu_baseline:
         R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+        import oracle_lib
         orc = oracle_lib.load()
         w = lambda x: np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64)
         s4 = scal.astype(object)
@@ -128,8 +137,8 @@ def msm_leg(zk, logn, cpu_baseline):
         t0 = time.perf_counter()
         orc.bn254_msm(hb, scal[:m].reshape(-1), 14)
         cpu_s = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": 1, "kind": "port",
-                               "sample": "first 2^18 points of the same input, oracle/ec.c Pippenger c=14, %.2f s" % cpu_s}
+        res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": min(orc.threads(), 19), "kind": "port",
+                               "sample": "first 2^18 points of the same input, oracle/ec.c Pippenger c=14 (OpenMP over its 19 windows), %.2f s" % cpu_s}
     return res
 
 
@@ -222,7 +231,7 @@ def main():
                        "passes_per_transform": passes, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "launch_us": round(launch_us, 2),
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(nbits), "launch_us": round(launch_us, 2),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
         }
@@ -238,7 +247,7 @@ def main():
             cpu_s = time.perf_counter() - t0
             assert np.array_equal(yc, x_host)
             assert np.array_equal(Xc, X.cpu().numpy().view(np.uint64)), "GPU forward NTT != CPU oracle"
-            out["cpu_baseline"] = {"value": round(2.0 * n / cpu_s / 1e9, 5), "unit": "GElem/s", "cores": 1,
+            out["cpu_baseline"] = {"value": round(2.0 * n / cpu_s / 1e9, 5), "unit": "GElem/s", "cores": orc.threads(),
                                    "kind": "port", "sample": "1 step (fwd+inv) of the same 2^%d column, "
                                    "oracle/oracle.c orc_ntt, %.2f s" % (nbits, cpu_s)}
         print(json.dumps(out), flush=True)

@@ -4,12 +4,15 @@
 // Replaces starky/src/poseidon_opt.rs:80-200 (hash_inner), linearhash.rs:79-145 (hash/_hash),
 // merklehash.rs:293-346 (merkelize), :79-134 (merklize_level), :47-61 (get_n_nodes).
 //
-// Mapping: one lane = one permutation (12-word state in 24 VGPRs).  The kernel is integer-ALU
-// bound (2130 field multiplications per permutation, ~30 B of HBM traffic per permutation), so
-// the work goes into the multiplier: round constants sit in __constant__ memory and are fetched
-// with scalar loads (wave-uniform indices), and the dense MDS product exploits that M's entries
-// are < 2^6: 12 64x6-bit partial products are accumulated in 128 bits and reduced ONCE per
-// output word instead of 12 full modular multiplications.
+// Mapping: one lane = one permutation, the 12-word state lives in 24 VGPRs from the first load to
+// the digest store (the permutation is inlined once per kernel; a row's whole LinearHash is one
+// loop around that single site).  The kernel is integer-ALU bound (2130 field multiplications per
+// permutation, ~30 B of HBM traffic), so the work goes into the instruction count:
+//   * the dense MDS has entries < 2^6, known at compile time: they become instruction immediates,
+//     and each output word is two chains of 12 v_mad_u64_u32 over the 32-bit halves of the state
+//     (no carries: 12 * 2^6 * 2^32 < 2^42) and ONE reduction instead of 12 modular multiplications;
+//   * the 64-bit round constants, the pre-sparse matrix P and the sparse rows S sit in LDS (6.3 KB
+//     per block, broadcast reads) -- as scalar loads their 288+ SGPRs spilled into VGPR lanes.
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
 
@@ -17,156 +20,182 @@ namespace zk {
 
 namespace {
 
-__constant__ u64 cC[118];
-__constant__ u64 cM[144];
-__constant__ u64 cP[144];
-__constant__ u64 cS[506];
+// LDS image of the 64-bit tables (u64 offsets)
+constexpr int T_C0 = 0;            // C[0..12): added before round 0
+constexpr int T_FC = 12;           // [8][12]: constants added after the S-box of full round R (round 7: zeros)
+constexpr int T_PC = T_FC + 96;    // [22] partial-round constants (+2 pad)
+constexpr int T_P = T_PC + 24;     // [12][12] pre-sparse matrix
+constexpr int T_S = T_P + 144;     // [22][23] sparse rows
+constexpr int T_WORDS = T_S + 506; // 782
+__device__ u64 g_tab[T_WORDS];
+
+__device__ __forceinline__ void load_tables(u64* __restrict__ tab) {
+    for (int i = threadIdx.x; i < T_WORDS; i += blockDim.x) tab[i] = g_tab[i];
+    __syncthreads();
+}
 
 __device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74
     u64 x2 = gl::sqr(x), x3 = gl::mul(x2, x), x6 = gl::sqr(x3);
     return gl::mul(x6, x);
 }
 
-// out[i] = sum_j M[j][i] * st[j]  (poseidon_opt.rs:111-119), M[j][i] < 2^6
+// out[i] = sum_j M[j][i] * st[j]  (poseidon_opt.rs:111-119), M[j][i] < 2^6 folded to immediates
 __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
-    u64 t[12];
+    u32 lo32[12], hi32[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { lo32[j] = (u32)st[j]; hi32[j] = (u32)(st[j] >> 32); }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         u64 lo = 0, hi = 0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const u32 m = (u32)cM[j * 12 + i];
-            u64 pl = st[j] * m, ph = __umul64hi(st[j], (u64)m);
-            lo += pl;
-            hi += ph + (lo < pl);
+            const u32 m = (u32)ZK_POSEIDON_M[j * 12 + i];
+            lo += (u64)lo32[j] * m;
+            hi += (u64)hi32[j] * m;
         }
-        t[i] = gl::reduce128(lo, hi);
+        // value = lo + hi * 2^32, lo, hi < 2^42
+        const u64 l = lo + (hi << 32);
+        const u64 h = (hi >> 32) + (l < lo);          // < 2^11
+        // 2^64 = 2^32 - 1 (mod p)
+        const u64 t1 = (h << 32) - h;
+        u64 r = l + t1;
+        if (r < t1) r += GL_EPS;
+        st[i] = r >= GL_P ? r - GL_P : r;
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = t[i];
 }
 
-__device__ __forceinline__ void mat_full(const u64* __restrict__ Mx, u64 (&st)[12]) {
+// st <- P^T-style product with a dense 64-bit matrix in LDS.  One matrix row per (not unrolled) trip so
+// that only 12 constants are in flight; the state is rotated through st[0] instead of indexed.
+__device__ __forceinline__ void mat_full(const u64* __restrict__ Mx /* LDS */, u64 (&st)[12]) {
     u64 t[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        u64 acc = 0;
+    for (int i = 0; i < 12; ++i) t[i] = 0;
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+        const u64 x = st[0];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc = gl::add(acc, gl::mul(Mx[j * 12 + i], st[j]));
-        t[i] = acc;
+        for (int i = 0; i < 12; ++i) t[i] = gl::add(t[i], gl::mul(Mx[j * 12 + i], x));
+#pragma unroll
+        for (int k = 0; k < 11; ++k) st[k] = st[k + 1];
+        st[11] = x;
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) st[i] = t[i];
 }
 
-// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199)
-__device__ __noinline__ void poseidon_perm(u64 (&st)[12]) {
+// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables
+__device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], cC[i]);
+    for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], tab[T_C0 + i]);
 #pragma unroll 1
-    for (int r = 0; r < 3; ++r) {
+    for (int R = 0; R < 8; ++R) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), cC[(r + 1) * 12 + i]);
-        mds_small(st);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), cC[48 + i]);
-    mat_full(cP, st);
+        for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), tab[T_FC + R * 12 + i]);
+        if (R != 3) { mds_small(st); continue; }
+        mat_full(tab + T_P, st);
 #pragma unroll 1
-    for (int r = 0; r < 22; ++r) {
-        st[0] = gl::add(pow7(st[0]), cC[60 + r]);
-        u64 s0 = 0;
+        for (int r = 0; r < 22; ++r) {
+            const u64* __restrict__ S = tab + T_S + 23 * r;
+            st[0] = gl::add(pow7(st[0]), tab[T_PC + r]);
+            u64 s0 = 0;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) s0 = gl::add(s0, gl::mul(cS[23 * r + j], st[j]));
+            for (int j = 0; j < 12; ++j) s0 = gl::add(s0, gl::mul(S[j], st[j]));
 #pragma unroll
-        for (int k = 1; k < 12; ++k) st[k] = gl::add(st[k], gl::mul(cS[23 * r + 11 + k], st[0]));
-        st[0] = s0;
+            for (int k = 1; k < 12; ++k) st[k] = gl::add(st[k], gl::mul(S[11 + k], st[0]));
+            st[0] = s0;
+        }
     }
-#pragma unroll 1
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), cC[82 + 12 * r + i]);
-        mds_small(st);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = pow7(st[i]);
-    mds_small(st);
 }
 
-// linearhash.rs:119-145 _hash over a global-memory segment: rate 8, capacity carried, tail
-// zero-padded, <= 4 words -> identity padding.  Result in d[0..4).
-__device__ __forceinline__ void sponge_gmem(const u64* __restrict__ v, u32 n, u64 (&d)[4]) {
-    if (n <= 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = (u32)i < n ? v[i] : 0;
-        return;
-    }
-    u64 st[12];
-#pragma unroll
-    for (int i = 8; i < 12; ++i) st[i] = 0;
-    for (u32 off = 0; off < n; off += 8) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st[i] = (off + i < n) ? v[off + i] : 0;
-        poseidon_perm(st);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = st[i];
-}
-
-// linearhash.rs:79-110: bs = max(8, ceil(w/4)); <= 4 batch digests -> sponge over them
-__device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 w, u64 (&out)[4]) {
+// LinearHash of one row (linearhash.rs:79-145), one loop around the single inlined permutation.
+// hash(): bs = max(8, ceil(w/4)) words per batch; each batch is digested by _hash (rate-8 sponge,
+// capacity carried, tail zero-padded; a batch of <= 4 words is its own zero-padded digest -- only
+// the last batch can be that short); more than one batch digest -> _hash over the digests.
+// All control flow depends on w only, i.e. is wave-uniform.
+__device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 w, u64 (&out)[4], const u64* __restrict__ tab) {
     if (w <= 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[i] = (u32)i < w ? row[i] : 0;
         return;
     }
     u32 bs = (w + 3) / 4; if (bs < 8) bs = 8;
-    const u32 hsz = (w + bs - 1) / bs;  // 1..4
-    u64 h[4][4];
+    const u32 hsz = (w + bs - 1) / bs;  // 1..4 batch digests
+    u64 h[16];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        if ((u32)b < hsz) {
-            const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
-            sponge_gmem(row + (u64)b * bs, len, h[b]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) h[b][i] = 0;
-        }
-    }
-    if (hsz == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = h[0][i];
-        return;
-    }
-    // sponge over hsz*4 (8, 12 or 16) digest words
+    for (int i = 0; i < 16; ++i) h[i] = 0;
     u64 st[12];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { st[i] = h[0][i]; st[4 + i] = h[1][i]; st[8 + i] = 0; }
-    poseidon_perm(st);
-    if (hsz > 2) {
+    for (int i = 8; i < 12; ++i) st[i] = 0;
+    u32 b = 0, off = 0;
+    bool final_sponge = false, second = false;
+    for (;;) {
+        if (!final_sponge) {
+            const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
+            const u64* __restrict__ v = row + (u64)b * bs + off;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st[8 + i] = st[i]; }
+            for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[i] : 0;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st[i] = h[2][i]; st[4 + i] = h[3][i]; }  // h[3] is zero when hsz == 3
-        poseidon_perm(st);
+            for (int i = 0; i < 8; ++i) st[i] = second ? h[8 + i] : h[i];
+        }
+        poseidon_perm(st, tab);
+        if (!final_sponge) {
+            const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
+            off += 8;
+            if (off < len) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
+                continue;
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+                if ((u32)bb == b) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) h[4 * bb + i] = st[i];
+                }
+            ++b; off = 0;
+            if (b < hsz && w - b * bs <= 4) {  // short last batch: identity padding, no permutation
+                const u32 len2 = w - b * bs;
+                const u64* __restrict__ v = row + (u64)b * bs;
+#pragma unroll
+                for (int bb = 1; bb < 4; ++bb)
+                    if ((u32)bb == b) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) h[4 * bb + i] = (u32)i < len2 ? v[i] : 0;
+                    }
+                ++b;
+            }
+#pragma unroll
+            for (int i = 8; i < 12; ++i) st[i] = 0;
+            if (b < hsz) continue;
+            if (hsz == 1) break;      // st[0..4) is the digest
+            final_sponge = true;
+        } else {
+            if (second || hsz <= 2) break;
+            second = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = st[i];
 }
 
 __global__ __launch_bounds__(256) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= height) return;
     u64 d[4];
-    linearhash_row(rows + r * width, width, d);
+    linearhash_row(rows + r * width, width, d, tab);
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = d[i];
 }
 
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
 __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_ops) return;
     u64 st[12];
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
     for (int k = 0; k < 8; ++k) st[k] = in[8 * i + k];
 #pragma unroll
     for (int k = 8; k < 12; ++k) st[k] = 0;
-    poseidon_perm(st);
+    poseidon_perm(st, tab);
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
 }
@@ -182,14 +211,16 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
 // A tree over zero-width rows (tree2 / tree3 of a PIL without plookups or grand products,
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
-__global__ void zero_tree_chain_kernel(u32 levels, u64* __restrict__ h /* [levels + 1][4] */) {
+__global__ __launch_bounds__(64) void zero_tree_chain_kernel(u32 levels, u64* __restrict__ h /* [levels + 1][4] */) {
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
     u64 cur[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k) h[k] = 0;
     for (u32 l = 0; l < levels; ++l) {
         u64 st[12];
         for (int k = 0; k < 4; ++k) { st[k] = cur[k]; st[4 + k] = cur[k]; st[8 + k] = 0; }
-        poseidon_perm(st);
+        poseidon_perm(st, tab);
         for (int k = 0; k < 4; ++k) { cur[k] = st[k]; h[4 * (l + 1) + k] = st[k]; }
     }
 }
@@ -198,14 +229,16 @@ __global__ void fill_digest_kernel(u64* __restrict__ nodes, u64 n, const u64* __
     if (i < 4 * n) nodes[i] = h[i & 3];
 }
 
-__global__ void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, int n_out) {
+__global__ __launch_bounds__(64) void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, int n_out) {
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 st[12];
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = in8[k] >= GL_P ? in8[k] - GL_P : in8[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) st[8 + k] = cap4[k] >= GL_P ? cap4[k] - GL_P : cap4[k];
-    poseidon_perm(st);
+    poseidon_perm(st, tab);
 #pragma unroll
     for (int k = 0; k < 12; ++k) if (k < n_out) out[k] = st[k];
 }
@@ -217,47 +250,52 @@ __global__ void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, i
 // (a sponge is inherently serial); state layout = TranscriptState below.
 struct TranscriptState { u64 state[4]; u64 pending[8]; u64 out[12]; u32 n_pending, out_pos, n_out, _pad; };
 
-__device__ void tr_update(TranscriptState* t) {  // transcript.rs:15-24
+__device__ __forceinline__ void tr_update(TranscriptState* t, const u64* __restrict__ tab) {  // transcript.rs:15-24
     u64 st[12];
     for (int i = 0; i < 8; ++i) st[i] = (u32)i < t->n_pending ? t->pending[i] : 0;
     for (int i = 0; i < 4; ++i) st[8 + i] = t->state[i];
-    poseidon_perm(st);
+    poseidon_perm(st, tab);
     for (int i = 0; i < 12; ++i) t->out[i] = st[i];
     for (int i = 0; i < 4; ++i) t->state[i] = st[i];
     t->n_pending = 0; t->out_pos = 0; t->n_out = 12;
-}
-__device__ u64 tr_get1(TranscriptState* t) {     // transcript.rs:54-62
-    if (t->out_pos >= t->n_out) tr_update(t);
-    return t->out[t->out_pos++];
 }
 __global__ void tr_init_kernel(TranscriptState* t) {
     if (threadIdx.x | blockIdx.x) return;
     for (int i = 0; i < 4; ++i) t->state[i] = 0;
     t->n_pending = 0; t->out_pos = 0; t->n_out = 0;
 }
-__global__ void tr_put_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n) {  // transcript.rs:25-33,64-71
+__global__ __launch_bounds__(64) void tr_put_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n) {  // transcript.rs:25-33,64-71
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
     for (u64 i = 0; i < n; ++i) {
         t->n_out = 0; t->out_pos = 0;
         t->pending[t->n_pending++] = src[i];
-        if (t->n_pending == 8) tr_update(t);
+        if (t->n_pending == 8) tr_update(t, tab);
     }
 }
-__global__ void tr_get_kernel(TranscriptState* t, u64* __restrict__ dst, u32 n_words) {  // get_field = 3 words
+// squeeze n_words (transcript.rs:54-62 get_fields1, repeated); get_field = 3 words.  `bits` != 0
+// turns the squeezed words into n query indices of `bits` bits (get_permutations, :73-102).
+__global__ __launch_bounds__(64) void tr_get_kernel(TranscriptState* t, u64* __restrict__ dst, u32 n, u32 bits) {
+    __shared__ u64 tab[T_WORDS];
+    load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
-    for (u32 i = 0; i < n_words; ++i) dst[i] = tr_get1(t);
-}
-__global__ void tr_permutations_kernel(TranscriptState* t, u32 n, u32 nbits, u64* __restrict__ dst) {  // transcript.rs:73-102
-    if (threadIdx.x | blockIdx.x) return;
-    u64 field = 0; u32 cur_bit = 63;  // force a fetch on first use
-    for (u32 i = 0; i < n; ++i) {
-        u64 a = 0;
-        for (u32 j = 0; j < nbits; ++j) {
-            if (cur_bit == 63) { field = tr_get1(t); cur_bit = 0; }
-            if ((field >> cur_bit) & 1) a += 1ull << j;
-            ++cur_bit;
+    if (bits == 0) {
+        for (u32 i = 0; i < n; ++i) {
+            if (t->out_pos >= t->n_out) tr_update(t, tab);
+            dst[i] = t->out[t->out_pos++];
         }
-        dst[i] = a;
+        return;
+    }
+    u64 field = 0; u32 cur_bit = 63, i = 0, j = 0; u64 a = 0;  // cur_bit = 63 forces a fetch on first use
+    while (i < n) {
+        if (cur_bit == 63) {
+            if (t->out_pos >= t->n_out) tr_update(t, tab);
+            field = t->out[t->out_pos++]; cur_bit = 0;
+        }
+        if ((field >> cur_bit) & 1) a += 1ull << j;
+        ++cur_bit; ++j;
+        if (j == bits) { dst[i++] = a; a = 0; j = 0; }
     }
 }
 
@@ -267,10 +305,17 @@ void ensure_constants() {
     int dev; ZK_HIP(hipGetDevice(&dev));
     ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
     if (g_consts_loaded[dev]) return;
-    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cC), ZK_POSEIDON_C, sizeof(ZK_POSEIDON_C)));
-    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cM), ZK_POSEIDON_M, sizeof(ZK_POSEIDON_M)));
-    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cP), ZK_POSEIDON_P, sizeof(ZK_POSEIDON_P)));
-    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cS), ZK_POSEIDON_S, sizeof(ZK_POSEIDON_S)));
+    // regroup C[118] by use (poseidon_opt.rs:98-199): initial add, post-S-box constants of the 8 full
+    // rounds (C[12(R+1)+i] for R < 4, C[82+12(R-4)+i] for R = 4..6, none for the last), partial rounds
+    static u64 tab[T_WORDS];
+    for (int i = 0; i < T_WORDS; ++i) tab[i] = 0;
+    for (int i = 0; i < 12; ++i) tab[T_C0 + i] = ZK_POSEIDON_C[i];
+    for (int R = 0; R < 7; ++R)
+        for (int i = 0; i < 12; ++i) tab[T_FC + 12 * R + i] = ZK_POSEIDON_C[(R < 4 ? 12 * (R + 1) : 82 + 12 * (R - 4)) + i];
+    for (int r = 0; r < 22; ++r) tab[T_PC + r] = ZK_POSEIDON_C[60 + r];
+    for (int i = 0; i < 144; ++i) tab[T_P + i] = ZK_POSEIDON_P[i];
+    for (int i = 0; i < 506; ++i) tab[T_S + i] = ZK_POSEIDON_S[i];
+    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
     g_consts_loaded[dev] = true;
 }
 
@@ -288,12 +333,12 @@ void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st)
     ZK_HIP(hipGetLastError());
 }
 void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st) {
-    hipLaunchKernelGGL(tr_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_dst, n_words);
+    hipLaunchKernelGGL(tr_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_dst, n_words, 0u);
     ZK_HIP(hipGetLastError());
 }
 void transcript_permutations_dev(void* d_t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st) {
     ZK_REQUIRE(nbits >= 1 && nbits <= 63, "get_permutations: nbits out of range");
-    hipLaunchKernelGGL(tr_permutations_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, n, nbits, d_dst);
+    hipLaunchKernelGGL(tr_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_dst, n, nbits);
     ZK_HIP(hipGetLastError());
 }
 

@@ -9,6 +9,9 @@
 #include "poseidon_gl_constants.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------------------------- */
 /* Field helpers exported for the python tests                                                  */
@@ -34,6 +37,15 @@ void orc_f3_pow(const uint64_t a[3], uint64_t e, uint64_t out[3]) {
 
 /* ------------------------------------------------------------------------------------------- */
 /* fft_p.rs:14-32 BR(): bit reversal of the low `bits` bits                                       */
+/* worker threads the parallel loops of this library use (bench.py reports it as cpu_baseline.cores) */
+int orc_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 uint32_t orc_bitrev(uint32_t x, unsigned bits) {
     uint32_t r = 0; /* full 32-bit reversal, then >> (32 - bits): bits of x above `bits` spill in, as in the reference */
     for (unsigned i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);

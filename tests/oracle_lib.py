@@ -9,6 +9,9 @@ _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 
 class Oracle:
+    def threads(self):
+        return int(self.lib.orc_threads())
+
     def __init__(self, lib):
         self.lib = lib
         L = lib
@@ -18,6 +21,7 @@ class Oracle:
         L.orc_gl_inv.restype = C.c_uint64; L.orc_gl_inv.argtypes = [C.c_uint64]
         L.orc_gl_root.restype = C.c_uint64; L.orc_gl_root.argtypes = [C.c_uint]
         L.orc_bitrev.restype = C.c_uint32; L.orc_bitrev.argtypes = [C.c_uint32, C.c_uint]
+        L.orc_threads.restype = C.c_int; L.orc_threads.argtypes = []
         L.orc_f3_mul.argtypes = [_u64p, _u64p, _u64p]
         L.orc_f3_inv.argtypes = [_u64p, _u64p]
         L.orc_f3_pow.argtypes = [_u64p, C.c_uint64, _u64p]
