@@ -99,7 +99,37 @@ def prove_leg(zk, nbits):
     return {"workload": "wide-Fibonacci PIL, 20 committed + 1 constant column, nBits=%d, nBitsExt=%d, GL hash, "
                         "%d queries, FRI steps %s" % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]]),
             "ms": round(min(times), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
-            "poseidon_perms_per_proof": perms, "root1": proof["root1"], "includes": "H2D upload of the 2.7 GB trace"}
+            "poseidon_perms_per_proof": perms, "root1": proof["root1"], "includes": "H2D upload of the %.2f GB trace" % (cm.nbytes / 1e9)}
+
+
+def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
+    """BASELINE config 5, the sharded part of recursion/stark_aggregation.sh: independent sub-proofs, one
+    stream of them per GPU, no collective while proving; the one exchange is the all-gather of each
+    rank's root (32 B).  Every rank proves `n_proofs` witnesses of the same PIL with its own inputs."""
+    import importlib, torch
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth_pil
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
+    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
+    setup = stark.StarkSetup(synth_pil.const_trace(nbits), info, d["program"], ss)
+    traces = [synth_pil.wide_fib_trace(nbits, 10, seed=1000 * rank + i) for i in range(n_proofs)]
+    proof = stark.stark_gen(traces[0], setup)                            # warm-up (pool, JIT modules)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for t in traces:
+        proof = stark.stark_gen(t, setup)
+    zk.lib().zk_dev_sync()
+    dt = time.perf_counter() - t0
+    (dt,) = max_over_ranks(dist, [dt], device)
+    roots = gather_roots(dist, [v - (1 << 64) if v >= (1 << 63) else v for v in proof["root1"]], device)
+    return {"workload": "BASELINE config 5 (sharded part): %d sub-proofs per GPU, wide-Fibonacci PIL 20 columns, nBits=%d, "
+                        "own witness per rank, root all-gather only" % (n_proofs, nbits),
+            "proofs_per_s": round(world * n_proofs / dt, 3), "s": round(dt, 3), "n_gpus": world,
+            "distinct_roots": len({tuple(r) for r in roots})}
 
 
 def msm_leg(zk, logn, cpu_baseline):
@@ -151,6 +181,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the stark_prove leg")
     ap.add_argument("--prove-nbits", type=int, default=24)
+    ap.add_argument("--agg", action="store_true", help="run the aggregation leg even at N=1")
+    ap.add_argument("--agg-nbits", type=int, default=22, help="rows (log2) of each sub-proof of the N>1 aggregation leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the BN254 MSM leg")
     ap.add_argument("--msm-logn", type=int, default=22)
     args = ap.parse_args()
@@ -211,6 +243,10 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)                                     # HIP events on the launch stream
     wall, dev_ms = max_over_ranks(dist, [wall, dev_ms], dev)
 
+    agg = None
+    if (world > 1 or args.agg) and not args.no_prove:                  # every rank takes part
+        agg = aggregation_leg(zk, dist, rank, world, args.agg_nbits, dev)
+
     if rank == 0:
         passes = lib.zk_gl_ntt_passes(nbits)
         launches = 2 * passes * args.steps
@@ -239,6 +275,8 @@ def main():
             out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
         if not args.no_prove and world == 1:
             out["stark_prove"] = prove_leg(zk, args.prove_nbits)
+        if agg is not None:
+            out["aggregation"] = agg
         if not args.no_cpu_baseline and world >= 1:
             orc = oracle_lib.load()
             t0 = time.perf_counter()

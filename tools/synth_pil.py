@@ -63,10 +63,10 @@ def rescale(info, nbits):
     return info
 
 
-def wide_fib_trace(nbits, W):
+def wide_fib_trace(nbits, W, seed=0):
     import ctypes, pathlib
     import numpy as np
     lib = ctypes.CDLL(str(pathlib.Path(__file__).resolve().parent / "libtracegen.so"))
     out = np.zeros((1 << nbits) * 2 * W, np.uint64)
-    lib.widefib_trace(ctypes.c_uint(nbits), ctypes.c_uint(W), out.ctypes.data_as(ctypes.c_void_p))
+    lib.widefib_trace_seed(ctypes.c_uint(nbits), ctypes.c_uint(W), ctypes.c_uint64(seed), out.ctypes.data_as(ctypes.c_void_p))
     return out

@@ -5,9 +5,10 @@
 #include <stdint.h>
 #define P 0xFFFFFFFF00000001ULL
 static inline uint64_t addp(uint64_t a, uint64_t b) { unsigned __int128 s = (unsigned __int128)a + b; if (s >= P) s -= P; return (uint64_t)s; }
-void widefib_trace(unsigned nbits, unsigned W, uint64_t *out) {
+/* first row a_k = seed + k + 1, b_k = 2k + 3: every seed is a different valid witness (sub-proof input) */
+void widefib_trace_seed(unsigned nbits, unsigned W, uint64_t seed, uint64_t *out) {
     uint64_t N = (uint64_t)1 << nbits;
-    for (unsigned k = 0; k < W; ++k) { out[2 * k] = k + 1; out[2 * k + 1] = 2 * k + 3; }
+    for (unsigned k = 0; k < W; ++k) { out[2 * k] = (seed + k + 1) % P; out[2 * k + 1] = 2 * k + 3; }
     for (uint64_t i = 1; i < N; ++i)
         for (unsigned k = 0; k < W; ++k) {
             const uint64_t *p = out + (i - 1) * 2 * W + 2 * k;
@@ -15,3 +16,4 @@ void widefib_trace(unsigned nbits, unsigned W, uint64_t *out) {
             c[0] = p[1]; c[1] = addp(p[0], p[1]);
         }
 }
+void widefib_trace(unsigned nbits, unsigned W, uint64_t *out) { widefib_trace_seed(nbits, W, 0, out); }
