@@ -66,21 +66,8 @@ __host__ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi) {
 //   product : four v_mad_u64_u32 (the compiler's a*b + __umul64hi(a,b) spends seven multiplies)
 //   reduce  : x = lo + r2*2^64 + r3*2^96 = lo - r3 + r2*(2^32-1); the r2 term is ONE
 //             v_mad_u64_u32 whose carry-out (vcc) selects the +2^32-1 fix-up.
-__device__ __forceinline__ u64 mul(u64 a, u64 b) {
-    GL_OPAQUE(a); GL_OPAQUE(b);
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 p0 = (u64)a0 * b0;
-    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
-    const u64 p2 = (u64)a1 * b0 + (u32)p1;
-    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
-    const u32 r2 = (u32)p3, r3 = (u32)(p3 >> 32);
-    u32 bw0, bw1, e0, e1;
-    u32 t0 = __builtin_subc((u32)p0, r3, 0u, &bw0);      // t = lo - r3
-    u32 t1 = __builtin_subc((u32)p2, 0u, bw0, &bw1);
-    const u32 mb = 0u - bw1;                             // borrowed: t -= 2^32 - 1
-    t0 = __builtin_subc(t0, mb, 0u, &e0);
-    t1 = __builtin_subc(t1, 0u, e0, &e1);
-    const u64 t = mk64(t0, t1);
+// t + r2*(2^32-1) mod p, canonical: ONE v_mad_u64_u32 whose carry-out (vcc) selects the +2^32-1 fix-up
+__device__ __forceinline__ u64 mad_eps(u32 r2, u64 t) {
     u64 u; u32 m;
     asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
                  : "=&v"(u), "=v"(m) : "v"(r2), "v"(t) : "vcc");
@@ -89,6 +76,25 @@ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     const u32 v0 = __builtin_addc((u32)u, 0xFFFFFFFFu, 0u, &d0);
     const u32 v1 = __builtin_addc((u32)(u >> 32), 0u, d0, &d1);  // d1 <=> u >= p
     return mk64(d1 ? v0 : (u32)u, d1 ? v1 : (u32)(u >> 32));
+}
+// lo + r2*2^64 + r3*2^96 mod p = lo - r3 + r2*(2^32-1), canonical; any 32-bit words
+__device__ __forceinline__ u64 reduce_words(u32 w0, u32 w1, u32 r2, u32 r3) {
+    u32 bw0, bw1, e0, e1;
+    u32 t0 = __builtin_subc(w0, r3, 0u, &bw0);           // t = lo - r3
+    u32 t1 = __builtin_subc(w1, 0u, bw0, &bw1);
+    const u32 mb = 0u - bw1;                             // borrowed: t -= 2^32 - 1
+    t0 = __builtin_subc(t0, mb, 0u, &e0);
+    t1 = __builtin_subc(t1, 0u, e0, &e1);
+    return mad_eps(r2, mk64(t0, t1));
+}
+__device__ __forceinline__ u64 mul(u64 a, u64 b) {
+    GL_OPAQUE(a); GL_OPAQUE(b);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    return reduce_words((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
 }
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __device__ __forceinline__ u64 pow(u64 a, u64 e) {  // field_gl.rs:467-479
@@ -130,6 +136,30 @@ __device__ __forceinline__ f3 f3_inv(f3 x) {  // f3g.rs:207-235
 }
 
 // ZK-JIT-END
+
+// x * 2^E mod p for a compile-time 0 <= E < 96, canonical x -> canonical result.  2 has order 192
+// and 2^96 = -1, so every root of unity of order <= 64 is a power of two (MG.0[6] = 2^39,
+// constant.rs:54-68): the butterflies' small twiddles are shifts, not field multiplications.
+// Callers fold E >= 96 into a swapped subtraction.
+template <int E>
+__device__ __forceinline__ u64 mul_pow2(u64 x) {
+    static_assert(E >= 0 && E < 96, "fold 2^96 = -1 first");
+    GL_OPAQUE(x);
+    if constexpr (E == 0) {
+        return x;
+    } else if constexpr (E <= 32) {                       // lo + top*2^64, top < 2^32
+        return mad_eps((u32)(x >> (64 - E)), x << E);
+    } else if constexpr (E < 64) {                        // lo + hi*2^64, hi < 2^E
+        const u64 lo = x << E, hi = x >> (64 - E);
+        return reduce_words((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+    } else {                                              // E = 64 + r: t0*2^64 - (x*2^r >> 32), t0 = low word of x*2^r
+        constexpr int r = E - 64;
+        const u32 t0 = (u32)x << r;
+        u64 m = ((u64)t0 << 32) - t0;                     // t0*(2^32-1) < p
+        u64 s = r == 0 ? (x >> 32) : (x >> (32 - r));     // < p
+        return sub(m, s);
+    }
+}
 
 // host-side twins (used only to build twiddle tables at context creation)
 inline u64 hmul(u64 a, u64 b) {

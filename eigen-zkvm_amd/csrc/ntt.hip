@@ -30,6 +30,9 @@ namespace zk {
 
 namespace {
 
+#ifndef ZK_NTT_WAVES
+#define ZK_NTT_WAVES
+#endif
 constexpr int TW_LO_BITS = 12;
 constexpr int TW_LO = 1 << TW_LO_BITS;
 
@@ -39,6 +42,9 @@ struct PassParams {
     const u64* w256;   // w_256^e, e < 256 (direction-specific)
     const u64* tw_lo;  // w_N^i, i < 4096
     const u64* tw_hi;  // w_N^(4096 i)
+    const u64* tw_mid; // optional: w_N^(i << dshift), i < 2^16 -- direct inter-pass twiddles when L <= 2^16
+    u64 pre_scale;     // constant folded into sub-step A (w256 is then the pre-scaled table); 1 = none
+    u32 dshift;
     const u64* sc_lo;  // optional output scaling c * g^k (k = output row): g^i * c, i < 4096
     const u64* sc_hi;  // g^(4096 i)
     u64 sc_step;       // g^(RA * s)
@@ -55,8 +61,8 @@ __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __res
     return gl::mul(hi[e >> TW_LO_BITS], lo[e & (TW_LO - 1)]);
 }
 
-template <int LOGA, int LOGB, bool KMODE>
-__global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
+template <int LOGA, int LOGB, bool KMODE, bool INV>
+__global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassParams P) {
     constexpr int LOGR = LOGA + LOGB, R = 1 << LOGR, RA = 1 << LOGA, RB = 1 << LOGB;
     constexpr int C = 4096 / R;                // lanes per tile
     constexpr int GA = 16 / RA, GB = 16 / RB;  // independent sub-transforms per thread
@@ -64,7 +70,11 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
     constexpr int PAD = KMODE ? 512 / R : 0;   // words; spreads kappa_a rows over banks (KMODE reads)
     constexpr int ROW = RB * C + PAD;
     static_assert(LOGR >= 4 && LOGR <= 8 && LOGA <= 4 && LOGB <= 4, "tile shape");
+#ifdef ZK_NTT_LDSPAD
+    __shared__ u64 lds[RA * ROW + ZK_NTT_LDSPAD];
+#else
     __shared__ u64 lds[RA * ROW];
+#endif
 
     const int t = threadIdx.x;
     const u64 u0 = (u64)blockIdx.x * C;
@@ -82,15 +92,20 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
                 x[g][ja] = (live && idx < P.valid_in) ? P.in[idx] : 0;
             }
         }
+#ifndef ZK_NTT_NOMATH
 #pragma unroll
-        for (int g = 0; g < GA; ++g) ntt_reg<LOGA>(x[g], P.w256);
+        for (int g = 0; g < GA; ++g) ntt_reg<LOGA, INV>(x[g]);
+#endif
 #pragma unroll
         for (int g = 0; g < GA; ++g) {
             const int jb = ta * GA + g;
 #pragma unroll
             for (int ka = 0; ka < RA; ++ka) {
                 u64 v = x[g][bitrev_c(ka, LOGA)];
+#ifndef ZK_NTT_NOMATH
                 if (LOGB > 0 && ka > 0) v = gl::mul(v, P.w256[(jb * ka) << (8 - LOGR)]);
+                else if (P.pre_scale != 1) v = gl::mul(v, P.pre_scale);
+#endif
                 lds[ka * ROW + jb * C + c] = v;
             }
         }
@@ -107,15 +122,45 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
 #pragma unroll
             for (int jb = 0; jb < RB; ++jb) y[g][jb] = lds[ka * ROW + jb * C + c];
         }
+        const u64 uc = u < P.inner ? u : 0;
+        const u64 p = uc / P.s_np, rem = uc - p * P.s_np;
+        u64 tw[GB][RB];
+        if (P.tw_mid) {  // L <= 2^16: every twiddle w_L^(p*kappa) is one load from the 512 KB table (L2), no chain;
+                         // issued here so that the radix-2^LOGB butterflies below hide the latency
 #pragma unroll
-        for (int g = 0; g < GB; ++g) ntt_reg<LOGB>(y[g], P.w256);
+            for (int g = 0; g < GB; ++g) {
+                const int ka = tb + g * TG;
+#pragma unroll
+                for (int kb = 0; kb < RB; ++kb) tw[g][kb] = P.tw_mid[((p * (u64)(RA * kb + ka)) << P.log_s) >> P.dshift];
+            }
+        }
+        // (a uniform run-time branch on purpose: as `if constexpr` the compiler sinks these loads below the
+        // butterflies to save registers and the L2 latency lands on the critical path again)
+#ifndef ZK_NTT_NOMATH
+#pragma unroll
+        for (int g = 0; g < GB; ++g) ntt_reg<LOGB, INV>(y[g]);
+#endif
         if (u >= P.inner) return;
 
-        const u64 p = u / P.s_np, rem = u - p * P.s_np;
         u64* __restrict__ outp = P.out + p * R * P.s_np + rem;
+        const u64 row_q = P.sc_lo ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
+        if (P.tw_mid) {
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int ka = tb + g * TG;
+#pragma unroll
+                for (int kb = 0; kb < RB; ++kb) {
+                    u64 v = y[g][bitrev_c(kb, LOGB)];
+#ifndef ZK_NTT_NOMATH
+                    v = gl::mul(v, tw[g][kb]);
+#endif
+                    outp[(u64)(RA * kb + ka) * P.s_np] = v;
+                }
+            }
+            return;
+        }
         u64 tw_step = 1;
         if (P.has_tw) tw_step = tab2(P.tw_lo, P.tw_hi, (p * RA) << P.log_s);
-        const u64 row_q = P.sc_lo ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
 #pragma unroll
         for (int g = 0; g < GB; ++g) {
             const int ka = tb + g * TG;
@@ -127,7 +172,11 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(const PassParams P) {
 #pragma unroll
             for (int kb = 0; kb < RB; ++kb) {
                 u64 v = y[g][bitrev_c(kb, LOGB)];
+#ifdef ZK_NTT_NOMATH
+                if (false) {
+#else
                 if (scaled) {
+#endif
                     v = gl::mul(v, f);
                     if (kb + 1 < RB) f = gl::mul(f, fstep);
                 }
@@ -150,7 +199,7 @@ __global__ void ntt_small_kernel(const u64* in, u64* out, u32 np, u32 n_in, u32 
 }
 
 // ---- host side: tables + plan -------------------------------------------------------------
-struct Tables { u64 *w256 = nullptr, *lo = nullptr, *hi = nullptr; };
+struct Tables { u64 *w256 = nullptr, *w256s = nullptr, *lo = nullptr, *hi = nullptr, *mid = nullptr; u32 dshift = 0; };
 struct ScaleTables { u64 *lo = nullptr, *hi = nullptr; };
 
 std::mutex g_mu;
@@ -188,6 +237,21 @@ Tables get_tables(u32 nbits, bool inverse) {
     for (int i = 0; i < 256; ++i) { t256[i] = c; c = gl::hmul(c, w8); }
     two_level(w, 1, nbits, lo, hi);
     Tables T; T.w256 = upload(t256); T.lo = upload(lo); T.hi = upload(hi);
+    if (inverse) {  // w_256^-e / N: folds the inverse transform's 1/N into sub-step A of its last pass
+        const u64 ninv = gl::hinv((1ull << nbits) % GL_P);
+        std::vector<u64> t256s(256);
+        for (int i = 0; i < 256; ++i) t256s[i] = gl::hmul(t256[i], ninv);
+        T.w256s = upload(t256s);
+    }
+    {   // direct table for passes with L <= 2^16: w_N^(i << dshift)
+        T.dshift = nbits > 16 ? nbits - 16 : 0;
+        const size_t nm = (size_t)1 << (nbits - T.dshift);
+        std::vector<u64> mid(nm);
+        const u64 step = gl::hpow(w, 1ull << T.dshift);
+        c = 1;
+        for (size_t i = 0; i < nm; ++i) { mid[i] = c; c = gl::hmul(c, step); }
+        T.mid = upload(mid);
+    }
     g_tables[key] = T;
     return T;
 }
@@ -206,22 +270,28 @@ ScaleTables get_scale(u32 nbits, u64 g, u64 cst) {  // cst * g^k, k < 2^nbits
 }
 
 template <int LOGA, int LOGB>
-void launch_pass(const PassParams& P, bool kmode, hipStream_t st) {
+void launch_pass(const PassParams& P, bool kmode, bool inverse, hipStream_t st) {
     constexpr int C = 4096 >> (LOGA + LOGB);
     const u64 blocks = (P.inner + C - 1) / C;
     ZK_REQUIRE(blocks < (1ull << 31), "ntt: grid too large");
-    if (kmode) hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, true>), dim3((u32)blocks), dim3(256), 0, st, P);
-    else       hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, false>), dim3((u32)blocks), dim3(256), 0, st, P);
+    const dim3 g((u32)blocks), b(256);
+    const int variant = (kmode ? 2 : 0) | (inverse ? 1 : 0);
+#define ZK_PASS(K, I) hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, K, I>), g, b, 0, st, P)
+    switch (variant) {
+        case 0: ZK_PASS(false, false); break; case 1: ZK_PASS(false, true); break;
+        case 2: ZK_PASS(true, false); break;  default: ZK_PASS(true, true); break;
+    }
+#undef ZK_PASS
     ZK_HIP(hipGetLastError());
 }
 
-void launch_pass_logr(int logr, const PassParams& P, bool kmode, hipStream_t st) {
+void launch_pass_logr(int logr, const PassParams& P, bool kmode, bool inverse, hipStream_t st) {
     switch (logr) {
-        case 4: launch_pass<2, 2>(P, kmode, st); break;
-        case 5: launch_pass<3, 2>(P, kmode, st); break;
-        case 6: launch_pass<3, 3>(P, kmode, st); break;
-        case 7: launch_pass<4, 3>(P, kmode, st); break;
-        case 8: launch_pass<4, 4>(P, kmode, st); break;
+        case 4: launch_pass<2, 2>(P, kmode, inverse, st); break;
+        case 5: launch_pass<3, 2>(P, kmode, inverse, st); break;
+        case 6: launch_pass<3, 3>(P, kmode, inverse, st); break;
+        case 7: launch_pass<4, 3>(P, kmode, inverse, st); break;
+        case 8: launch_pass<4, 4>(P, kmode, inverse, st); break;
         default: throw Error("ntt: unsupported pass radix");
     }
 }
@@ -273,15 +343,22 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
         P.sc_hi = (last && sc.on) ? S.hi : nullptr;
         const int loga = (logr + 1) / 2;
         P.sc_step = (last && sc.on) ? gl::hpow(sc.g, (1ull << loga) << log_s) : 1;
-        P.out_scale = (last && !sc.on) ? out_scale : 1;
+        P.out_scale = 1; P.pre_scale = 1;
+        if (last && !sc.on && out_scale != 1) {
+            // the only constant scaling in use is the inverse transform's 1/N (ntt_dev)
+            ZK_REQUIRE(inverse && out_scale == gl::hinv(n % GL_P), "ntt: unsupported constant scaling");
+            P.w256 = T.w256s; P.pre_scale = out_scale;
+        }
         P.inner = (n >> logr) * n_pols;
         P.valid_in = (i == 0) ? valid_rows * n_pols : n * n_pols;
         P.s_np = ((u64)1 << log_s) * n_pols;
         P.np = n_pols;
         P.log_s = log_s;
         P.has_tw = last ? 0 : 1;
+        P.dshift = T.dshift;
+        P.tw_mid = (!last && log_s >= T.dshift) ? T.mid : nullptr;  // L = N >> log_s <= 2^16
         const bool kmode = P.s_np < 16;
-        launch_pass_logr(logr, P, kmode, st);
+        launch_pass_logr(logr, P, kmode, inverse, st);
         cur = dstbuf;
         log_s += logr;
     }

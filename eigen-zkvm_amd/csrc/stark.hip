@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const u64* __restrict__ p
         u64 x[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = pol[((u64)i * pol2_n + g) * 3 + l];
-        ntt_reg<LOGNX>(x, w256inv);  // coefficient k (times NX) sits in x[bitrev(k)]
+        ntt_reg<LOGNX, true>(x);  // coefficient k (times NX) sits in x[bitrev(k)]
         f3 acc{{x[bitrev_c(NX - 1, LOGNX)], 0, 0}};
 #pragma unroll
         for (int k = NX - 2; k >= 0; --k) {
