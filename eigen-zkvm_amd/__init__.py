@@ -33,6 +33,7 @@ EXPORTS = [
     "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
     "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
+    "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
 ]
 
 # include/zkgpu.h enums
@@ -122,6 +123,12 @@ def _load():
         "zk_stark_lev_dev": (C.c_int, [vp, C.c_uint32, C.c_int, vp, vp, vp, vp]),
         "zk_stark_evals_dev": (C.c_int, [C.POINTER(EvalDesc), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
         "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
+        "zk_stark_setup_new": (vp, [C.c_char_p, C.c_char_p, vp, C.c_uint64]),
+        "zk_stark_setup_const_root": (C.c_int, [vp, vp]),
+        "zk_stark_gen": (vp, [vp, vp, C.c_uint64]),
+        "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
+        "zk_string_free": (None, [vp]),
+        "zk_stark_setup_free": (C.c_int, [vp]),
         "zk_msm_g1_bn254": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "zk_msm_g1_bn254_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
         "zk_g1_bn254_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),

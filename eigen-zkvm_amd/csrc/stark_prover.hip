@@ -1,0 +1,599 @@
+// Host-side driver of the GL-hash eSTARK prover: StarkSetup::new (starky/src/stark_setup.rs:27-66),
+// StarkProof::stark_gen (stark_gen.rs:193-557), FRI::prove (fri.rs:84-184) and the zkin serialiser
+// (serializer.rs:140-264), in C++ behind two C entry points (zk_stark_setup_new / zk_stark_gen).
+//
+// The reference's driver is Rust; this is its counterpart for callers that bind the C ABI.  Every field
+// operation runs in the HIP kernels of this library (LDE, Merkle, transcript, run-time compiled
+// constraint programs, Z, Q split, evals, x/(x-xi), FRI folds); the host only sequences launches,
+// keeps the sections resident in HBM and formats the proof.  Inputs are the reference's own
+// serialised StarkInfo + Program (serde field names, starkinfo.rs:27-95) and StarkStruct
+// (types.rs): the reference's PIL front end and code generator stay in charge of them.
+// One host step remains, as in the reference: calculate_H1H2 (stark_gen.rs:624-651).
+#include "zk_internal.h"
+#include "../../include/zkgpu.h"
+#include "json_min.h"
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <unordered_map>
+#include <vector>
+
+using namespace zk;
+
+namespace {
+
+enum Slot { S_CM1_N, S_CM2_N, S_CM3_N, S_TMPEXP_N, S_CONST_N, S_CM1_2NS, S_CM2_2NS, S_CM3_2NS, S_CM4_2NS,
+            S_CONST_2NS, S_Q_2NS, S_F_2NS, S_SCRATCH, S_COUNT };
+const char* const SLOT_NAME[S_COUNT] = {"cm1_n", "cm2_n", "cm3_n", "tmpexp_n", "const_n", "cm1_2ns", "cm2_2ns",
+                                        "cm3_2ns", "cm4_2ns", "const_2ns", "q_2ns", "f_2ns", "scratch"};
+int slot_of(const std::string& s) {
+    for (int i = 0; i < S_COUNT; ++i) if (s == SLOT_NAME[i]) return i;
+    return -1;  // e.g. cm4_n: listed by the map, never materialised by the prover (an error only if used)
+}
+
+void ck(int rc) { if (rc != 0) throw Error(zk_last_error()); }
+// the C ABI speaks uint64_t (unsigned long), the kernels u64 (unsigned long long): same 8 bytes
+inline uint64_t* M(u64* p) { return reinterpret_cast<uint64_t*>(p); }
+inline const uint64_t* C(const u64* p) { return reinterpret_cast<const uint64_t*>(p); }
+inline const u64* K(const uint64_t* p) { return reinterpret_cast<const u64*>(p); }
+
+u64 parse_pil_number(const std::string& s) {  // types.rs:221-233: decimal or 0x hex, possibly negative, mod p
+    bool neg = !s.empty() && s[0] == '-';
+    size_t i = neg ? 1 : 0;
+    unsigned __int128 v = 0;
+    if (s.size() > i + 1 && s[i] == '0' && (s[i + 1] == 'x' || s[i + 1] == 'X')) {
+        for (i += 2; i < s.size(); ++i) {
+            const char c = s[i];
+            const int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+            if (d < 0) throw Error("bad PIL number " + s);
+            v = (v * 16 + d) % GL_P;
+        }
+    } else {
+        for (; i < s.size(); ++i) {
+            if (s[i] < '0' || s[i] > '9') throw Error("bad PIL number " + s);
+            v = (v * 10 + (s[i] - '0')) % GL_P;
+        }
+    }
+    u64 r = (u64)v;
+    return neg && r ? GL_P - r : r;
+}
+
+struct PolRef { int slot; u64 width; u64 pos; u32 dim; };
+
+struct ProgramDeleter { void operator()(zk_program_t* p) const { if (p) zk_program_free(p); } };
+using ProgramPtr = std::unique_ptr<zk_program_t, ProgramDeleter>;
+struct TreeDeleter { void operator()(zk_merkle_t* t) const { if (t) zk_merkle_free(t); } };
+using TreePtr = std::unique_ptr<zk_merkle_t, TreeDeleter>;
+struct TranscriptDeleter { void operator()(zk_transcript_t* t) const { if (t) zk_transcript_free(t); } };
+using TranscriptPtr = std::unique_ptr<zk_transcript_t, TranscriptDeleter>;
+
+struct GroupProof { std::vector<u64> row; std::vector<u64> path; u32 depth; };
+
+void zero(DevBuf& b, size_t words) { if (words) ZK_HIP(hipMemset(b.p, 0, words * 8)); }
+
+}  // namespace
+
+struct zk_stark_setup {
+    JVal info, prog, ss;
+    u32 nbits = 0, nbits_ext = 0, n_queries = 0, n_constants = 0, q_dim = 0, q_deg = 0, n_cm1 = 0, n_cm2 = 0;
+    std::vector<u32> steps;
+    u64 sN[S_COUNT] = {};                 // map_sectionsN (words per row)
+    std::vector<PolRef> var_pol_map;
+    std::vector<u64> cm_n, cm_2ns, tmpexp_n;
+    std::map<u64, u64> exp2pol;
+    DevBuf const_n, const_2ns;
+    TreePtr const_tree;
+    u64 const_root[4] = {};
+    ProgramPtr step2prev, step3prev, step3, step42ns, step52ns;
+    std::vector<ProgramPtr> public_programs;
+
+    PolRef pol(u64 pol_id) const {
+        ZK_REQUIRE(pol_id < var_pol_map.size(), "pol id out of range");
+        ZK_REQUIRE(var_pol_map[pol_id].slot >= 0, "polynomial lives in a section the prover does not hold");
+        return var_pol_map[pol_id];
+    }
+
+    // Node -> zk_operand, as interpreter.rs get_ref / set_ref / eval_map (:286-524) resolve addresses
+    zk_operand resolve(const JVal& node, bool ext) const {
+        zk_operand o; memset(&o, 0, sizeof o);
+        o.dim = 1;
+        const std::string& t = node.at("type_").str();
+        const u32 id = node.find("id") && !node.at("id").is_null() ? (u32)node.at("id").u64() : 0;
+        const bool prime = node.find("prime") && !node.at("prime").is_null() && node.at("prime").boolean();
+        if (t == "tmp") { o.kind = ZK_OPND_TMP; o.id = id; }
+        else if (t == "const") {
+            o.kind = ZK_OPND_MEM; o.id = id; o.dim = 1; o.prime = prime; o.buf = ext ? S_CONST_2NS : S_CONST_N; o.stride = n_constants;
+        } else if (t == "cm" || t == "tmpExp") {
+            const std::vector<u64>& m = t == "cm" ? (ext ? cm_2ns : cm_n) : tmpexp_n;
+            ZK_REQUIRE(id < m.size(), "cm id out of range");
+            const PolRef p = pol(m[id]);
+            o.kind = ZK_OPND_MEM; o.id = (u32)p.pos; o.dim = (uint8_t)p.dim; o.prime = prime; o.buf = (uint8_t)p.slot; o.stride = (u32)p.width;
+        } else if (t == "q") { o.kind = ZK_OPND_MEM; o.id = id; o.dim = (uint8_t)q_dim; o.buf = S_Q_2NS; o.stride = q_dim; }
+        else if (t == "f") { o.kind = ZK_OPND_MEM; o.id = id; o.dim = 3; o.buf = S_F_2NS; o.stride = 3; }
+        else if (t == "number") { o.kind = ZK_OPND_NUMBER; o.value = parse_pil_number(node.at("value").str()); }
+        else if (t == "public") { o.kind = ZK_OPND_PUBLIC; o.id = id; }
+        else if (t == "challenge") { o.kind = ZK_OPND_CHALLENGE; o.id = id; }
+        else if (t == "eval") { o.kind = ZK_OPND_EVAL; o.id = id; }
+        else if (t == "x") o.kind = ZK_OPND_X;
+        else if (t == "Zi") o.kind = ZK_OPND_ZI;
+        else if (t == "xDivXSubXi") o.kind = ZK_OPND_XDIVXSUBXI;
+        else if (t == "xDivXSubWXi") o.kind = ZK_OPND_XDIVXSUBWXI;
+        else throw Error("Invalid reference type " + t);
+        return o;
+    }
+
+    // compile_code (interpreter.rs:187-225): Segment.first -> one run-time compiled kernel
+    ProgramPtr compile_segment(const JVal& seg, bool ext, bool ret_to_scratch) const {
+        const JVal& first = seg.at("first");
+        std::vector<zk_instr> code;
+        for (const JVal& c : first.arr) {
+            zk_instr in; memset(&in, 0, sizeof in);
+            const std::string& op = c.at("op").str();
+            if (op == "add") in.op = ZK_OP_ADD; else if (op == "sub") in.op = ZK_OP_SUB;
+            else if (op == "mul") in.op = ZK_OP_MUL; else if (op == "copy") in.op = ZK_OP_COPY;
+            else throw Error("Invalid op " + op);  // the prover rejects muladd (interpreter.rs:208-216)
+            in.dest = resolve(c.at("dest"), ext);
+            const JVal& src = c.at("src");
+            ZK_REQUIRE(src.size() >= 1 && src.size() <= 2, "instruction needs 1 or 2 sources");
+            in.src[0] = resolve(src.at(0), ext);
+            if (src.size() > 1) in.src[1] = resolve(src.at(1), ext);
+            code.push_back(in);
+        }
+        if (ret_to_scratch && !code.empty()) {  // ret = true: the last destination is the result
+            zk_instr in; memset(&in, 0, sizeof in);
+            in.op = ZK_OP_COPY;
+            in.dest.kind = ZK_OPND_MEM; in.dest.dim = 3; in.dest.buf = S_SCRATCH; in.dest.stride = 3;
+            in.src[0] = resolve(first.arr.back().at("dest"), ext);
+            code.push_back(in);
+        }
+        if (code.empty()) return ProgramPtr();
+        zk_program_t* p = zk_program_compile(code.data(), (u32)code.size());
+        if (!p) throw Error(zk_last_error());
+        return ProgramPtr(p);
+    }
+};
+
+namespace {
+
+std::vector<u64> u64_list(const JVal& a) {
+    std::vector<u64> v;
+    for (const JVal& e : a.arr) v.push_back(e.u64());
+    return v;
+}
+
+std::string dec(u64 v) { return std::to_string(v); }
+void put_digest(std::ostringstream& o, const u64* d) {  // digest.rs:84-112
+    if (d[1] == 0 && d[2] == 0 && d[3] == 0) { o << '"' << dec(d[0]) << '"'; return; }
+    o << "[\"" << dec(d[0]) << "\",\"" << dec(d[1]) << "\",\"" << dec(d[2]) << "\",\"" << dec(d[3]) << "\"]";
+}
+void put_list(std::ostringstream& o, const u64* v, size_t n) {
+    o << '[';
+    for (size_t i = 0; i < n; ++i) { if (i) o << ','; o << '"' << dec(v[i]) << '"'; }
+    o << ']';
+}
+void put_path(std::ostringstream& o, const GroupProof& g) {
+    o << '[';
+    for (u32 l = 0; l < g.depth; ++l) { if (l) o << ','; put_list(o, g.path.data() + 4 * l, 4); }
+    o << ']';
+}
+
+GroupProof group_proof(zk_merkle_t* t, u32 width, u64 idx) {
+    GroupProof g; g.depth = zk_merkle_depth(t);
+    g.row.resize(width ? width : 1); g.path.resize(g.depth ? 4 * g.depth : 4);
+    ck(zk_merkle_group_proof(t, idx, M(g.row.data()), M(g.path.data())));
+    g.row.resize(width);
+    return g;
+}
+
+struct Key3 { u64 a, b, c; bool operator==(const Key3& o) const { return a == o.a && b == o.b && c == o.c; } };
+struct Key3Hash { size_t operator()(const Key3& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull) * 0xD1B54A32D192ED03ull ^ k.c * 0x2545F4914F6CDD1Dull); } };
+
+// calculate_H1H2 (stark_gen.rs:624-651): hash-map lookup + stable sort by table index; rows are [n][3]
+void calculate_h1h2(const std::vector<u64>& f, const std::vector<u64>& t, u64 n, std::vector<u64>& h1, std::vector<u64>& h2) {
+    std::unordered_map<Key3, u64, Key3Hash> idx_t;
+    idx_t.reserve(n * 2);
+    std::vector<std::pair<u64, Key3>> s; s.reserve(2 * n);
+    for (u64 i = 0; i < n; ++i) {
+        Key3 e{t[3 * i], t[3 * i + 1], t[3 * i + 2]};
+        idx_t[e] = i;
+        s.emplace_back(i, e);
+    }
+    for (u64 i = 0; i < n; ++i) {
+        Key3 e{f[3 * i], f[3 * i + 1], f[3 * i + 2]};
+        auto it = idx_t.find(e);
+        if (it == idx_t.end()) throw Error("Number not included: " + dec(e.a));
+        s.emplace_back(it->second, e);
+    }
+    std::stable_sort(s.begin(), s.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    h1.resize(3 * n); h2.resize(3 * n);
+    for (u64 i = 0; i < n; ++i) {
+        const Key3 &a = s[2 * i].second, &b = s[2 * i + 1].second;
+        h1[3 * i] = a.a; h1[3 * i + 1] = a.b; h1[3 * i + 2] = a.c;
+        h2[3 * i] = b.a; h2[3 * i + 1] = b.b; h2[3 * i + 2] = b.c;
+    }
+}
+
+const u64* tree_root_dev(zk_merkle_t* t, u64 height) {  // the root is the last node (merklehash.rs:455-457)
+    return K(zk_merkle_nodes_dev(t)) + 4 * (zk_merkle_n_nodes(height) - 1);
+}
+
+zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t* const_pols, uint64_t n_words) {
+    std::unique_ptr<zk_stark_setup> S(new zk_stark_setup);
+    JVal root = JParser::parse(json);
+    S->info = root.at("starkinfo"); S->prog = root.at("program");
+    S->ss = JParser::parse(ss_json);
+    const JVal& I = S->info;
+    S->nbits = (u32)S->ss.at("nBits").u64(); S->nbits_ext = (u32)S->ss.at("nBitsExt").u64();
+    S->n_queries = (u32)S->ss.at("nQueries").u64();
+    ZK_REQUIRE(S->ss.at("verificationHashType").str() == "GL", "only the GL hash is accelerated (SURVEY.md 8f-1)");
+    ZK_REQUIRE(S->nbits >= 1 && S->nbits <= S->nbits_ext && S->nbits_ext <= 32, "bad nBits / nBitsExt");
+    for (const JVal& st : S->ss.at("steps").arr) S->steps.push_back((u32)st.at("nBits").u64());
+    ZK_REQUIRE(!S->steps.empty(), "starkStruct without FRI steps");
+    S->n_constants = (u32)I.at("n_constants").u64();
+    S->q_dim = (u32)I.at("q_dim").u64(); S->q_deg = (u32)I.at("q_deg").u64();
+    S->n_cm1 = (u32)I.at("n_cm1").u64(); S->n_cm2 = (u32)I.at("n_cm2").u64();
+    const JVal& msn = I.at("map_sectionsN");
+    for (int i = 0; i < S_COUNT; ++i) if (const JVal* v = msn.find(SLOT_NAME[i])) S->sN[i] = v->u64();
+    S->sN[S_CONST_N] = S->sN[S_CONST_2NS] = S->n_constants;
+    S->sN[S_Q_2NS] = S->q_dim; S->sN[S_F_2NS] = 3; S->sN[S_SCRATCH] = 3;
+    for (const JVal& p : I.at("var_pol_map").arr) {
+        PolRef r; r.slot = slot_of(p.at("section").str()); r.width = r.slot >= 0 ? S->sN[r.slot] : 0;
+        r.pos = p.at("section_pos").u64(); r.dim = (u32)p.at("dim").u64();
+        S->var_pol_map.push_back(r);
+    }
+    S->cm_n = u64_list(I.at("cm_n")); S->cm_2ns = u64_list(I.at("cm_2ns")); S->tmpexp_n = u64_list(I.at("tmpexp_n"));
+    for (auto& kv : I.at("exp2pol").obj) S->exp2pol[strtoull(kv.first.c_str(), nullptr, 10)] = kv.second.u64();
+
+    const u64 N = 1ull << S->nbits, Next = 1ull << S->nbits_ext, nc = S->n_constants;
+    ZK_REQUIRE(n_words == nc * N, "const trace size mismatch");
+    S->const_n.reserve(std::max<u64>(1, nc * N) * 8); S->const_2ns.reserve(std::max<u64>(1, nc * Next) * 8);
+    if (nc) {
+        ZK_HIP(hipMemcpy(S->const_n.p, const_pols, nc * N * 8, hipMemcpyHostToDevice));
+        DevBuf tmp; tmp.reserve(nc * Next * 8);
+        lde_dev(S->const_n.u(), S->const_2ns.u(), tmp.u(), (u32)nc, S->nbits, S->nbits_ext, nullptr);
+        ZK_HIP(hipStreamSynchronize(nullptr));
+    }
+    S->const_tree.reset(zk_gl_merkelize_dev(C(S->const_2ns.u()), (u32)nc, Next, nullptr));
+    if (!S->const_tree) throw Error(zk_last_error());
+    ck(zk_merkle_root(S->const_tree.get(), M(S->const_root)));
+    const JVal& P = S->prog;
+    S->step2prev = S->compile_segment(P.at("step2prev"), false, false);
+    S->step3prev = S->compile_segment(P.at("step3prev"), false, false);
+    S->step3 = S->compile_segment(P.at("step3"), false, false);
+    S->step42ns = S->compile_segment(P.at("step42ns"), true, false);
+    S->step52ns = S->compile_segment(P.at("step52ns"), true, false);
+    for (const JVal& seg : P.at("publics_code").arr) S->public_programs.push_back(S->compile_segment(seg, false, true));
+    return S.release();
+}
+
+// cm_pols: host trace, or nullptr when d_cm (device-resident trace, borrowed) is given
+std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words) {
+    const JVal& I = S.info;
+    const u32 nbits = S.nbits, nbits_ext = S.nbits_ext, ext = nbits_ext - nbits;
+    const u64 N = 1ull << nbits, Next = 1ull << nbits_ext;
+    const u64* sN = S.sN;
+    ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
+    hipStream_t st = nullptr;
+
+    // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
+    DevBuf B[S_COUNT];
+    u64* ptr[S_COUNT] = {};
+    auto alloc = [&](int s, u64 words) { B[s].reserve(std::max<u64>(1, words) * 8); zero(B[s], words); ptr[s] = B[s].u(); };
+    if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
+    else {
+        B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
+        if (n_words) ZK_HIP(hipMemcpy(ptr[S_CM1_N], cm_pols, n_words * 8, hipMemcpyHostToDevice));
+    }
+    for (int s : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(s, sN[s] * N);
+    for (int s : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS, S_CM4_2NS}) alloc(s, sN[s] * Next);
+    alloc(S_Q_2NS, S.q_dim * Next); alloc(S_F_2NS, 3 * Next); alloc(S_SCRATCH, 3 * Next);
+    ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
+
+    DevBuf x_n, x_2ns, zi, d_chal, d_evals, d_pub, xdiv, xdivw;                     // stark_gen.rs:231-249
+    x_n.reserve(N * 8); x_2ns.reserve(Next * 8); zi.reserve((1ull << ext) * 8);
+    x_table_dev(nbits, 1, x_n.u(), st); x_table_dev(nbits_ext, 49, x_2ns.u(), st); zh_inv_dev(nbits, ext, zi.u(), st);
+    d_chal.reserve(24 * 8); zero(d_chal, 24);                                        // challenge[8] (constant.rs:39-50)
+    const u32 n_ev = (u32)I.at("ev_map").size();
+    const u32 n_pub = (u32)I.at("publics").size();
+    d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3);
+    d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub));
+
+    auto run = [&](const ProgramPtr& p, bool e) {
+        if (!p) return;
+        zk_eval_ctx c; memset(&c, 0, sizeof c);
+        for (int s = 0; s < S_COUNT; ++s) c.bufs[s] = M(ptr[s]);
+        c.publics = C(d_pub.u()); c.challenges = C(d_chal.u()); c.evals = C(d_evals.u());
+        c.x = C(e ? x_2ns.u() : x_n.u()); c.zi = C(zi.u()); c.zi_mask = (1ull << ext) - 1;
+        c.xdivxsubxi = C(xdiv.u()); c.xdivxsubwxi = C(xdivw.u());
+        ck(zk_program_run_dev(p.get(), &c, e ? nbits_ext : nbits, e ? (1ull << ext) : 1, st));
+    };
+    auto get_pol = [&](u64 pol_id, DevBuf& out) {                                  // stark_gen.rs:683-707
+        const PolRef p = S.pol(pol_id);
+        out.reserve(3 * N * 8);
+        pol_get_dev(ptr[p.slot], p.width, p.pos, p.dim, N, out.u(), st);
+    };
+    auto set_pol = [&](u64 pol_id, const u64* d_pol3) {                            // stark_gen.rs:594-622
+        const PolRef p = S.pol(pol_id);
+        pol_set_dev(ptr[p.slot], p.width, p.pos, p.dim, N, d_pol3, st);
+    };
+    auto e2p = [&](const JVal& v) {
+        auto it = S.exp2pol.find(v.u64());
+        if (it == S.exp2pol.end()) throw Error("exp2pol: unknown expression");
+        return it->second;
+    };
+
+    // publics (stark_gen.rs:256-270) and their absorption (:272-277)
+    std::vector<u64> publics;
+    for (u32 i = 0; i < n_pub; ++i) {
+        const JVal& pe = I.at("publics").at(i);
+        const std::string& ty = pe.at("polType").str();
+        const u64 idx = pe.at("idx").u64();
+        if (ty == "cmP") {
+            const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
+            ZK_REQUIRE(pos < n_words, "public out of range");
+            if (cm_pols) publics.push_back(cm_pols[pos]);
+            else { u64 v; ZK_HIP(hipMemcpy(&v, d_cm + pos, 8, hipMemcpyDeviceToHost)); publics.push_back(v); }
+        } else if (ty == "imP") {                                                  // calculate_exp_at_point :558-572
+            if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
+            ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
+            run(S.public_programs[i], false);
+            u64 v[3];
+            ZK_HIP(hipStreamSynchronize(st));
+            ZK_HIP(hipMemcpy(v, ptr[S_SCRATCH] + 3 * idx, 24, hipMemcpyDeviceToHost));
+            publics.push_back(v[0]);
+        } else throw Error("Invalid public type " + ty);
+    }
+    if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
+    TranscriptPtr tr(zk_transcript_new());
+    if (!tr) throw Error(zk_last_error());
+    if (!publics.empty()) ck(zk_transcript_put_dev(tr.get(), C(d_pub.u()), publics.size(), st));
+
+    std::vector<std::unique_ptr<DevBuf>> keep;                                     // workspaces alive until the end
+    auto extend_and_merkelize = [&](int sec_n, int sec_2ns) {                     // stark_gen.rs:709-732
+        const u64 width = sN[sec_n];
+        if (width) {
+            keep.emplace_back(new DevBuf); keep.back()->reserve(width * Next * 8);
+            lde_dev(ptr[sec_n], ptr[sec_2ns], keep.back()->u(), (u32)width, nbits, nbits_ext, st);
+        }
+        TreePtr t(zk_gl_merkelize_dev(C(ptr[sec_2ns]), (u32)width, Next, st));
+        if (!t) throw Error(zk_last_error());
+        return t;
+    };
+    auto challenge = [&](int i) { ck(zk_transcript_get_field_dev(tr.get(), M(d_chal.u() + 3 * i), st)); };
+    auto put_root = [&](const TreePtr& t, u64 height) { ck(zk_transcript_put_dev(tr.get(), C(tree_root_dev(t.get(), height)), 4, st)); };
+
+    TreePtr tree1 = extend_and_merkelize(S_CM1_N, S_CM1_2NS); put_root(tree1, Next);
+    challenge(0); challenge(1);                                                    // u, defVal
+    run(S.step2prev, false);
+    u64 n_cm = S.n_cm1;
+    for (const JVal& pu : I.at("pu_ctx").arr) {                                    // stark_gen.rs:300-308
+        DevBuf f, t;
+        get_pol(e2p(pu.at("f_exp_id")), f); get_pol(e2p(pu.at("t_exp_id")), t);
+        std::vector<u64> hf(3 * N), ht(3 * N), h1, h2;
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipMemcpy(hf.data(), f.p, 24 * N, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(ht.data(), t.p, 24 * N, hipMemcpyDeviceToHost));
+        calculate_h1h2(hf, ht, N, h1, h2);
+        ZK_HIP(hipMemcpy(f.p, h1.data(), 24 * N, hipMemcpyHostToDevice));
+        ZK_HIP(hipMemcpy(t.p, h2.data(), 24 * N, hipMemcpyHostToDevice));
+        set_pol(S.cm_n.at(n_cm++), f.u()); set_pol(S.cm_n.at(n_cm++), t.u());
+        ZK_HIP(hipStreamSynchronize(st));
+    }
+    TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
+    challenge(2); challenge(3);                                                    // gamma, beta
+    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N);             // an output-only section starts from zero (stark_gen.rs:944-951)
+    run(S.step3prev, false);
+    n_cm = S.n_cm1 + S.n_cm2;
+    for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {                       // stark_gen.rs:329-353
+        for (const JVal& o : I.at(ctx).arr) {
+            DevBuf num, den, z;
+            get_pol(e2p(o.at("num_id")), num); get_pol(e2p(o.at("den_id")), den);
+            z.reserve(3 * N * 8);
+            ck(zk_stark_calculate_z_dev(C(num.u()), C(den.u()), N, M(z.u()), st));
+            set_pol(S.cm_n.at(n_cm++), z.u());
+            ZK_HIP(hipStreamSynchronize(st));
+        }
+    }
+    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N);
+    run(S.step3, false);
+    TreePtr tree3 = extend_and_merkelize(S_CM3_N, S_CM3_2NS); put_root(tree3, Next);
+    challenge(4);                                                                  // vc
+    run(S.step42ns, true);
+    {   // Q split (stark_gen.rs:375-396)
+        const u32 q_dim = S.q_dim, q_deg = S.q_deg;
+        keep.emplace_back(new DevBuf); DevBuf& qq1 = *keep.back(); qq1.reserve(q_dim * Next * 8);
+        keep.emplace_back(new DevBuf); DevBuf& tmpq = *keep.back(); tmpq.reserve(q_dim * Next * 8);
+        ntt_dev(ptr[S_Q_2NS], qq1.u(), tmpq.u(), q_dim, nbits_ext, true, st);
+        if (q_deg > 0) {
+            keep.emplace_back(new DevBuf); DevBuf& qq2 = *keep.back(); qq2.reserve((u64)q_dim * q_deg * Next * 8);
+            ZK_HIP(hipMemsetAsync(qq2.p, 0, (u64)q_dim * q_deg * Next * 8, st));
+            qsplit_dev(qq1.u(), nbits, q_dim, q_deg, qq2.u(), st);
+            keep.emplace_back(new DevBuf); DevBuf& tmp4 = *keep.back(); tmp4.reserve((u64)q_dim * q_deg * Next * 8);
+            ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
+        }
+    }
+    TreePtr tree4(zk_gl_merkelize_dev(C(ptr[S_CM4_2NS]), (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
+    if (!tree4) throw Error(zk_last_error());
+    put_root(tree4, Next);
+    challenge(7);                                                                  // xi
+    const u64* d_xi = d_chal.u() + 3 * 7;
+    DevBuf LEv, LpEv, lt1, lt2;                                                     // stark_gen.rs:416-430
+    LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
+    lev_dev(d_xi, nbits, false, LEv.u(), lt1.u(), lt2.u(), st);
+    lev_dev(d_xi, nbits, true, LpEv.u(), lt1.u(), lt2.u(), st);
+    if (n_ev) {                                                                    // stark_gen.rs:432-466
+        std::vector<EvalDescHost> descs;
+        for (const JVal& ev : I.at("ev_map").arr) {
+            const std::string& ty = ev.at("type_").str();
+            EvalDescHost d;
+            d.prime = ev.at("prime").boolean() ? 1 : 0;
+            if (ty == "const") { d.buf = ptr[S_CONST_2NS]; d.width = S.n_constants; d.offset = ev.at("id").u64(); d.dim = 1; }
+            else if (ty == "cm") {
+                const PolRef p = S.pol(S.cm_2ns.at(ev.at("id").u64()));
+                d.buf = ptr[p.slot]; d.width = p.width; d.offset = p.pos; d.dim = p.dim;
+            } else throw Error("Invalid ev type: " + ty);
+            descs.push_back(d);
+        }
+        evals_dev(descs.data(), n_ev, nbits, ext, LEv.u(), LpEv.u(), d_evals.u(), st);
+        ck(zk_transcript_put_dev(tr.get(), C(d_evals.u()), 3 * (size_t)n_ev, st));     // stark_gen.rs:469-472
+    }
+    challenge(5); challenge(6);                                                    // v1, v2
+    xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);                        // stark_gen.rs:481-522
+    xdivxsub_dev(d_xi, 1, nbits_ext, xdiv.u(), st);
+    xdivxsub_dev(d_xi, gl::hroot(nbits), nbits_ext, xdivw.u(), st);
+    run(S.step52ns, true);
+
+    // ---- FRI::prove (fri.rs:84-184)
+    const std::vector<u32>& steps = S.steps;
+    const size_t n_steps = steps.size();
+    u32 pol_bits = nbits_ext;
+    u64 shift_inv = gl::hinv(49);
+    std::vector<TreePtr> fri_trees(n_steps);                                       // tree of step i+1's groups at [i]
+    std::vector<u32> fri_width(n_steps, 0);
+    std::vector<std::array<u64, 4>> fri_roots(n_steps);
+    DevBuf d_sx; d_sx.reserve(24);
+    const u64* d_pol = ptr[S_F_2NS];
+    for (size_t si = 0; si < n_steps; ++si) {
+        const u32 step_bits = steps[si];
+        ZK_REQUIRE(step_bits <= pol_bits, "FRI steps must not grow");
+        ck(zk_transcript_get_field_dev(tr.get(), M(d_sx.u()), st));                    // special_x
+        keep.emplace_back(new DevBuf); DevBuf& folded = *keep.back(); folded.reserve((3ull << step_bits) * 8);
+        fri_fold_dev(d_pol, pol_bits, step_bits, d_sx.u(), shift_inv, folded.u(), st);
+        d_pol = folded.u();
+        if (si + 1 < n_steps) {
+            const u32 nxt = steps[si + 1];
+            ZK_REQUIRE(nxt <= step_bits, "FRI steps must not grow");
+            const u64 n_groups = 1ull << nxt, group_size = (1ull << step_bits) >> nxt;
+            keep.emplace_back(new DevBuf); DevBuf& tb = *keep.back(); tb.reserve((3ull << step_bits) * 8);
+            fri_transpose_dev(d_pol, 1ull << step_bits, nxt, tb.u(), st);
+            fri_width[si] = (u32)(3 * group_size);
+            fri_trees[si].reset(zk_gl_merkelize_dev(C(tb.u()), fri_width[si], n_groups, st));
+            if (!fri_trees[si]) throw Error(zk_last_error());
+            ck(zk_merkle_root(fri_trees[si].get(), M(fri_roots[si].data())));
+            ck(zk_transcript_put_dev(tr.get(), C(tree_root_dev(fri_trees[si].get(), n_groups)), 4, st));
+        } else {
+            ck(zk_transcript_put_dev(tr.get(), C(d_pol), 3ull << step_bits, st));      // fri.rs:136-141
+        }
+        for (u32 k = 0; k < pol_bits - step_bits; ++k) shift_inv = gl::hmul(shift_inv, shift_inv);
+        pol_bits = step_bits;
+    }
+    std::vector<u64> ys(S.n_queries);
+    ck(zk_transcript_get_permutations(tr.get(), S.n_queries, steps[0], M(ys.data())));  // fri.rs:158
+
+    // ---- proof -> zkin JSON (serializer.rs:146-261)
+    u64 r1[4], r2[4], r3[4], r4[4];
+    ck(zk_merkle_root(tree1.get(), M(r1))); ck(zk_merkle_root(tree2.get(), M(r2)));
+    ck(zk_merkle_root(tree3.get(), M(r3))); ck(zk_merkle_root(tree4.get(), M(r4)));
+    std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev));
+    ZK_HIP(hipStreamSynchronize(st));
+    if (n_ev) ZK_HIP(hipMemcpy(ev_host.data(), d_evals.p, 24 * (size_t)n_ev, hipMemcpyDeviceToHost));
+    std::ostringstream o;
+    o << "{\"rootC\":"; put_digest(o, S.const_root);
+    o << ",\"root1\":"; put_digest(o, r1); o << ",\"root2\":"; put_digest(o, r2);
+    o << ",\"root3\":"; put_digest(o, r3); o << ",\"root4\":"; put_digest(o, r4);
+    o << ",\"evals\":[";
+    for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
+    o << ']';
+    // queries of the later steps: group proofs of the folded polynomials (fri.rs:160-181)
+    std::vector<u64> ysi = ys;
+    for (size_t si = 1; si < n_steps; ++si) {
+        for (u64& y : ysi) y %= (1ull << steps[si]);
+        std::vector<GroupProof> gp;
+        for (u64 y : ysi) gp.push_back(group_proof(fri_trees[si - 1].get(), fri_width[si - 1], y));
+        o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data());
+        o << ",\"s" << si << "_vals\":[";
+        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
+        o << "],\"s" << si << "_siblings\":[";
+        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_path(o, gp[q]); }
+        o << ']';
+    }
+    {   // step 0: openings of the five trees at the query indices
+        zk_merkle_t* trees0[5] = {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()};
+        const u32 widths[5] = {(u32)sN[S_CM1_2NS], (u32)sN[S_CM2_2NS], (u32)sN[S_CM3_2NS], (u32)sN[S_CM4_2NS], S.n_constants};
+        const char* names[5] = {"1", "2", "3", "4", "C"};
+        std::vector<std::vector<GroupProof>> gp(5);
+        for (int j = 0; j < 5; ++j)
+            for (u64 y : ys) gp[j].push_back(group_proof(trees0[j], widths[j], y));
+        for (int j = 0; j < 5; ++j) {
+            o << ",\"s0_vals" << names[j] << "\":[";
+            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
+            o << ']';
+        }
+        for (int j = 0; j < 5; ++j) {
+            o << ",\"s0_siblings" << names[j] << "\":[";
+            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_path(o, gp[j][q]); }
+            o << ']';
+        }
+    }
+    {
+        const u64 n_last = 1ull << steps.back();
+        std::vector<u64> last(3 * n_last);
+        ZK_HIP(hipMemcpy(last.data(), d_pol, 24 * n_last, hipMemcpyDeviceToHost));
+        o << ",\"finalPol\":[";
+        for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, last.data() + 3 * i, 3); }
+        o << ']';
+    }
+    o << ",\"publics\":"; put_list(o, publics.data(), publics.size());
+    o << '}';
+    return o.str();
+}
+
+template <class F>
+int guard(F&& f) {
+    try { f(); return 0; }
+    catch (const std::exception& e) { set_error(e.what()); return -1; }
+    catch (...) { set_error("unknown error"); return -1; }
+}
+
+}  // namespace
+
+extern "C" {
+
+zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const char* stark_struct_json,
+                                     const uint64_t* const_pols, uint64_t n_words) {
+    zk_stark_setup* s = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(starkinfo_program_json && stark_struct_json, "zk_stark_setup_new: null json");
+            ZK_REQUIRE(const_pols || n_words == 0, "zk_stark_setup_new: null constant trace");
+            s = setup_new(starkinfo_program_json, stark_struct_json, const_pols, n_words);
+        }) != 0) return nullptr;
+    return s;
+}
+
+int zk_stark_setup_const_root(const zk_stark_setup_t* s, uint64_t out[4]) {
+    return guard([&] { ZK_REQUIRE(s && out, "null argument"); memcpy(out, s->const_root, 32); });
+}
+
+char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_words) {
+    char* out = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(s, "zk_stark_gen: null setup");
+            ZK_REQUIRE(cm_pols || n_words == 0, "zk_stark_gen: null trace");
+            const std::string z = stark_gen(*s, cm_pols, nullptr, n_words);
+            out = (char*)malloc(z.size() + 1);
+            ZK_REQUIRE(out, "out of memory");
+            memcpy(out, z.c_str(), z.size() + 1);
+        }) != 0) return nullptr;
+    return out;
+}
+
+char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words) {
+    char* out = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(s && d_cm_pols, "zk_stark_gen_dev: null argument");
+            const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words);
+            out = (char*)malloc(z.size() + 1);
+            ZK_REQUIRE(out, "out of memory");
+            memcpy(out, z.c_str(), z.size() + 1);
+        }) != 0) return nullptr;
+    return out;
+}
+
+void zk_string_free(char* s) { free(s); }
+
+int zk_stark_setup_free(zk_stark_setup_t* s) { return guard([&] { delete s; }); }
+
+}  // extern "C"

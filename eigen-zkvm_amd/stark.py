@@ -352,6 +352,45 @@ def to_zkin(proof):
     return z
 
 
+class NativeStarkSetup:
+    """The C++ driver inside libzkgpu (csrc/stark_prover.hip): StarkSetup::new + stark_gen + FRI::prove
+    behind zk_stark_setup_new / zk_stark_gen.  `program_json` = '{"starkinfo": ..., "program": ...}' text."""
+
+    def __init__(self, const_n, program_json, stark_struct_json):
+        c = _np(const_n)
+        self._h = lib().zk_stark_setup_new(program_json.encode(), stark_struct_json.encode(), _ptr(c), c.size)
+        if not self._h:
+            raise ZkError(lib().zk_last_error().decode())
+
+    def const_root(self):
+        o = np.zeros(4, np.uint64); _check(lib().zk_stark_setup_const_root(self._h, _ptr(o))); return [int(v) for v in o]
+
+    def gen(self, cm_n):
+        """-> the proof as the zkin dict of serializer.rs:146-261; cm_n: host array or DevArray (HBM-resident trace)"""
+        import ctypes
+        if isinstance(cm_n, DevArray):
+            p = lib().zk_stark_gen_dev(self._h, cm_n.ptr, cm_n.n)
+        else:
+            c = _np(cm_n)
+            p = lib().zk_stark_gen(self._h, _ptr(c), c.size)
+        if not p:
+            raise ZkError(lib().zk_last_error().decode())
+        try:
+            return json.loads(ctypes.string_at(p).decode())
+        finally:
+            lib().zk_string_free(p)
+
+    def free(self):
+        if self._h:
+            lib().zk_stark_setup_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def load_program_json(path):
     """{"starkinfo": ..., "program": ...} as serialised by the reference (serde) or by a generator."""
     d = json.load(open(path))

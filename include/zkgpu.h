@@ -150,6 +150,28 @@ int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, 
  * (what generate_random_parameters, groth16.rs:39,82, does with secret exponents).                     */
 int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
 
+/* ---- whole prover (starky/src/prove.rs:95-160: StarkSetup::new + StarkProof::stark_gen + FRI::prove) ------
+ * zk_stark_setup_new stands behind StarkSetup::new (stark_setup.rs:27-66): it takes the reference's
+ * serialised code-generator output, {"starkinfo": StarkInfo, "program": Program} (serde field names,
+ * starkinfo.rs:27-95), the StarkStruct JSON (verificationHashType must be "GL") and the constant
+ * polynomials ([2^nBits][n_constants] words, the .const file, polsarray.rs:137-217); it extends and
+ * merkelizes the constants on the device and compiles the step programs for gfx950.
+ * zk_stark_gen stands behind StarkProof::stark_gen (stark_gen.rs:193-202) + FRI::prove (fri.rs:84-89):
+ * cm_pols = the committed trace ([2^nBits][n_cm1] words, the .cm file).  Returns the proof as the
+ * zkin JSON the reference's serialiser writes (serializer.rs:146-261), malloc'ed: release it with
+ * zk_string_free.  NULL on error (zk_last_error), e.g. "z does not close" (stark_gen.rs:663-664).
+ * A setup is bound to the device current at creation and is not re-entrant.                         */
+typedef struct zk_stark_setup zk_stark_setup_t;
+zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const char* stark_struct_json,
+                                     const uint64_t* const_pols, uint64_t n_words);
+int zk_stark_setup_const_root(const zk_stark_setup_t* s, uint64_t out[4]);   /* StarkSetup.const_root */
+char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_words);
+/* same with the trace already resident in HBM (borrowed, not modified), e.g. written there by a device-side
+ * witness generator or uploaded while the previous proof was running                                     */
+char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words);
+void zk_string_free(char* s);
+int zk_stark_setup_free(zk_stark_setup_t* s);
+
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
  * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as

@@ -49,3 +49,42 @@ def test_gpu_proof_equals_oracle_proof_and_verifies(zk, orc, tmp_path, name):
     assert got == exp
     assert stark.to_zkin(got) == SP.to_zkin(exp)                           # byte-identical zkin.json
     assert SP.stark_verify(got, got["rootC"], su["starkinfo"], su["program"], GL_STRUCT, orc)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_native_driver_zkin_equals_oracle_zkin(zk, orc, name):
+    """The C++ driver (zk_stark_setup_new / zk_stark_gen) writes the same zkin.json as the oracle prover."""
+    import importlib
+    import numpy as np
+    import stark_prover as SP
+    import starkinfo as SI
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    pil_f, const_f, cm_f = CASES[name]
+    pil = json.load(open(D / pil_f))
+    su = SP.setup(pil, D / const_f, GL_STRUCT, orc)
+    exp = SP.to_zkin(SP.stark_gen(D / cm_f, su, GL_STRUCT, orc))
+    ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"),
+                                json.dumps(SI.to_json(su["starkinfo"], su["program"])), json.dumps(GL_STRUCT))
+    got = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))
+    root_c = exp["rootC"] if isinstance(exp["rootC"], list) else [exp["rootC"], "0", "0", "0"]
+    assert [str(v) for v in ns.const_root()] == root_c
+    assert list(got.keys()) == list(exp.keys())                            # serializer.rs key order
+    assert got == exp
+    got2 = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))                       # a setup serves many proofs
+    assert got2 == exp
+
+
+def test_native_driver_rejects_bad_input(zk):
+    import importlib
+    import numpy as np
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    with pytest.raises(zk.ZkError):
+        stark.NativeStarkSetup(np.zeros(4, np.uint64), "{not json", json.dumps(GL_STRUCT))
+    bn = dict(GL_STRUCT, verificationHashType="BN128")
+    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    with pytest.raises(zk.ZkError):                                          # only the GL hash is on the device
+        stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bn))
+    with pytest.raises(zk.ZkError):                                          # const trace of the wrong size
+        stark.NativeStarkSetup(np.zeros(5, np.uint64), json.dumps(d), json.dumps(GL_STRUCT))

@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--nbits", type=int, nargs="+", default=[16])
     ap.add_argument("--w", type=int, default=10)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--python-driver", action="store_true", help="eigen-zkvm_amd/stark.py step-by-step driver instead of zk_stark_gen")
     ap.add_argument("--verify", action="store_true", help="check the proof with the oracle's restated verifier")
     args = ap.parse_args()
     assert args.w == 10, "only the committed W=10 program fixture is available"
@@ -27,17 +28,22 @@ def main():
         cm = synth_pil.wide_fib_trace(nbits, args.w)
         const = synth_pil.const_trace(nbits)
         t0 = time.perf_counter()
-        setup = stark.StarkSetup(const, info, d["program"], ss)
+        if args.python_driver:
+            setup = stark.StarkSetup(const, info, d["program"], ss)
+        else:                                                              # C++ driver inside libzkgpu
+            pj = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
+            setup = stark.NativeStarkSetup(const, pj, json.dumps(ss))
+            d_cm = zk.DevArray.from_host(cm)                               # trace resident in HBM
         zk.lib().zk_dev_sync()
         t_setup = time.perf_counter() - t0
         times = []
         for _ in range(args.reps):
             t0 = time.perf_counter()
-            proof = stark.stark_gen(cm, setup)
+            proof = stark.stark_gen(cm, setup) if args.python_driver else setup.gen(d_cm)
             times.append(time.perf_counter() - t0)
         out = {"workload": "wide-Fibonacci PIL W=%d (%d committed cols), nBits=%d, GL hash, %d queries" % (args.w, 2 * args.w, nbits, ss["nQueries"]),
                "setup_s": round(t_setup, 3), "stark_gen_ms": [round(t * 1e3, 1) for t in times], "root1": proof["root1"]}
-        if args.verify:
+        if args.verify and args.python_driver:
             sys.path.insert(0, str(ROOT / "oracle"))
             import stark_prover as SP, oracle_lib
             orc = oracle_lib.load()
