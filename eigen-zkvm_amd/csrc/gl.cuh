@@ -96,6 +96,16 @@ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
     return reduce_words((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
 }
+// a*b + c mod p, any u64 inputs, canonical output: c rides on the product's multiply-adds
+__device__ __forceinline__ u64 mul_add(u64 a, u64 b, u64 c) {
+    GL_OPAQUE(a); GL_OPAQUE(b); GL_OPAQUE(c);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0 + (u32)c;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32) + (c >> 32);   // <= (2^32-1)^2 + 2(2^32-1) = 2^64 - 1
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    return reduce_words((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
+}
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __device__ __forceinline__ u64 pow(u64 a, u64 e) {  // field_gl.rs:467-479
     u64 r = 1;

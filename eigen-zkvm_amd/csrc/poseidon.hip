@@ -20,18 +20,45 @@ namespace zk {
 
 namespace {
 
-// LDS image of the 64-bit tables (u64 offsets)
-constexpr int T_C0 = 0;            // C[0..12): added before round 0
-constexpr int T_FC = 12;           // [8][12]: constants added after the S-box of full round R (round 7: zeros)
-constexpr int T_PC = T_FC + 96;    // [22] partial-round constants (+2 pad)
-constexpr int T_P = T_PC + 24;     // [12][12] pre-sparse matrix
-constexpr int T_S = T_P + 144;     // [22][23] sparse rows
-constexpr int T_WORDS = T_S + 506; // 782
+// LDS image of the constant tables (u64 word offsets).  Constants that enter 12-term dot products (the
+// pre-sparse matrix P, transposed, and the first 12 entries of every sparse row S) are stored split in
+// three limbs of 22/22/20 bits, two words per constant: (l0 | l1 << 32, l2).
+constexpr int T_C0 = 0;              // C[0..12): added before round 0
+constexpr int T_FC = 12;             // [8][12]: constants added after the S-box of full round R (round 7: zeros)
+constexpr int T_PC = T_FC + 96;      // [22] partial-round constants (+2 pad)
+constexpr int T_SC = T_PC + 24;      // [22][11]: S[23r + 12 .. 23r + 22], the column applied to st[1..11]
+constexpr int T_PT = T_SC + 242;     // [12 i][12 j] split: P[j][i]
+constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
+constexpr int T_WORDS = T_SR + 528;  // 1190 words = 9.3 KB
+static_assert(T_PT % 2 == 0 && T_SR % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
+#define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
 
 __device__ __forceinline__ void load_tables(u64* __restrict__ tab) {
     for (int i = threadIdx.x; i < T_WORDS; i += blockDim.x) tab[i] = g_tab[i];
     __syncthreads();
+}
+
+// sum_j c_j * x_j mod p for 12 split constants (c points at 12 x 2 words in LDS) and 12 state words given
+// as 32-bit halves.  Six 64-bit accumulators take the 22x32-bit partial products straight from
+// v_mad_u64_u32 (12 * 2^54 < 2^58: no carries); one 128-bit recombination and ONE reduction per dot
+// product instead of twelve multiplications with a reduction each.
+__device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[12], const u32 (&x1)[12]) {
+    typedef unsigned __int128 u128;
+    u64 A00 = 0, A10 = 0, A20 = 0, A01 = 0, A11 = 0, A21 = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2*>(c)[j];
+        const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;
+        A00 += (u64)l0 * x0[j]; A10 += (u64)l1 * x0[j]; A20 += (u64)l2 * x0[j];
+        A01 += (u64)l0 * x1[j]; A11 += (u64)l1 * x1[j]; A21 += (u64)l2 * x1[j];
+    }
+    // V = X0 + X1 * 2^32, X = A0 + A1 * 2^22 + A2 * 2^44 < 2^103;  X1 * 2^32 = X1l * 2^32 + X1h * 2^96 = X1l * 2^32 - X1h
+    const u128 X0 = (u128)A00 + ((u128)A10 << 22) + ((u128)A20 << 44);
+    const u128 X1 = (u128)A01 + ((u128)A11 << 22) + ((u128)A21 << 44);
+    const u64 X1l = (u64)X1, X1h = (u64)(X1 >> 64);                       // X1h < 2^39
+    const u128 W = X0 + ((u128)X1l << 32) + (u128)(GL_P - X1h);            // < 2^104, congruent to V
+    return gl::reduce_words((u32)W, (u32)(W >> 32), (u32)(W >> 64), (u32)(W >> 96));
 }
 
 __device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74
@@ -64,23 +91,19 @@ __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
     }
 }
 
-// st <- P^T-style product with a dense 64-bit matrix in LDS.  One matrix row per (not unrolled) trip so
-// that only 12 constants are in flight; the state is rotated through st[0] instead of indexed.
-__device__ __forceinline__ void mat_full(const u64* __restrict__ Mx /* LDS */, u64 (&st)[12]) {
-    u64 t[12];
+// st <- sum_j P[j][i] * st[j]: twelve batched dot products against the transposed, split P in LDS
+__device__ __forceinline__ void mat_full(const u64* __restrict__ PT /* LDS */, u64 (&st)[12]) {
+    u32 x0[12], x1[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) t[i] = 0;
+    for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
+    // one output per (not unrolled) trip, shifted in at the top: only one dot product's constants are in flight
 #pragma unroll 1
-    for (int j = 0; j < 12; ++j) {
-        const u64 x = st[0];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) t[i] = gl::add(t[i], gl::mul(Mx[j * 12 + i], x));
+    for (int i = 0; i < 12; ++i) {
+        const u64 d = dot12(PT + 24 * i, x0, x1);
 #pragma unroll
         for (int k = 0; k < 11; ++k) st[k] = st[k + 1];
-        st[11] = x;
+        st[11] = d;
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = t[i];
 }
 
 // in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables
@@ -92,16 +115,17 @@ __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restri
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), tab[T_FC + R * 12 + i]);
         if (R != 3) { mds_small(st); continue; }
-        mat_full(tab + T_P, st);
+        mat_full(tab + T_PT, st);
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
-            const u64* __restrict__ S = tab + T_S + 23 * r;
+            const u64* __restrict__ SC = tab + T_SC + 11 * r;
             st[0] = gl::add(pow7(st[0]), tab[T_PC + r]);
-            u64 s0 = 0;
+            u32 x0[12], x1[12];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) s0 = gl::add(s0, gl::mul(S[j], st[j]));
+            for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
+            const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);
 #pragma unroll
-            for (int k = 1; k < 12; ++k) st[k] = gl::add(st[k], gl::mul(S[11 + k], st[0]));
+            for (int k = 1; k < 12; ++k) st[k] = gl::mul_add(SC[k - 1], st[0], st[k]);
             st[0] = s0;
         }
     }
@@ -181,8 +205,11 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
     for (int i = 0; i < 4; ++i) out[i] = st[i];
 }
 
-__global__ __launch_bounds__(256) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
-    __shared__ u64 tab[T_WORDS];
+#ifndef ZK_LH_WAVES
+#define ZK_LH_WAVES 4
+#endif
+__global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= height) return;
@@ -194,7 +221,7 @@ __global__ __launch_bounds__(256) void linearhash_rows_kernel(const u64* __restr
 
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
 __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
-    __shared__ u64 tab[T_WORDS];
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_ops) return;
@@ -212,7 +239,7 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
 __global__ __launch_bounds__(64) void zero_tree_chain_kernel(u32 levels, u64* __restrict__ h /* [levels + 1][4] */) {
-    __shared__ u64 tab[T_WORDS];
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
     u64 cur[4] = {0, 0, 0, 0};
@@ -230,7 +257,7 @@ __global__ void fill_digest_kernel(u64* __restrict__ nodes, u64 n, const u64* __
 }
 
 __global__ __launch_bounds__(64) void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, int n_out) {
-    __shared__ u64 tab[T_WORDS];
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 st[12];
@@ -265,7 +292,7 @@ __global__ void tr_init_kernel(TranscriptState* t) {
     t->n_pending = 0; t->out_pos = 0; t->n_out = 0;
 }
 __global__ __launch_bounds__(64) void tr_put_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n) {  // transcript.rs:25-33,64-71
-    __shared__ u64 tab[T_WORDS];
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
     for (u64 i = 0; i < n; ++i) {
@@ -277,7 +304,7 @@ __global__ __launch_bounds__(64) void tr_put_kernel(TranscriptState* t, const u6
 // squeeze n_words (transcript.rs:54-62 get_fields1, repeated); get_field = 3 words.  `bits` != 0
 // turns the squeezed words into n query indices of `bits` bits (get_permutations, :73-102).
 __global__ __launch_bounds__(64) void tr_get_kernel(TranscriptState* t, u64* __restrict__ dst, u32 n, u32 bits) {
-    __shared__ u64 tab[T_WORDS];
+    ZK_POSEIDON_LDS;
     load_tables(tab);
     if (threadIdx.x | blockIdx.x) return;
     if (bits == 0) {
@@ -313,8 +340,13 @@ void ensure_constants() {
     for (int R = 0; R < 7; ++R)
         for (int i = 0; i < 12; ++i) tab[T_FC + 12 * R + i] = ZK_POSEIDON_C[(R < 4 ? 12 * (R + 1) : 82 + 12 * (R - 4)) + i];
     for (int r = 0; r < 22; ++r) tab[T_PC + r] = ZK_POSEIDON_C[60 + r];
-    for (int i = 0; i < 144; ++i) tab[T_P + i] = ZK_POSEIDON_P[i];
-    for (int i = 0; i < 506; ++i) tab[T_S + i] = ZK_POSEIDON_S[i];
+    auto split = [&](int at, u64 c) { tab[at] = (c & 0x3FFFFF) | (((c >> 22) & 0x3FFFFF) << 32); tab[at + 1] = c >> 44; };
+    for (int i = 0; i < 12; ++i)
+        for (int j = 0; j < 12; ++j) split(T_PT + 2 * (12 * i + j), ZK_POSEIDON_P[12 * j + i]);
+    for (int r = 0; r < 22; ++r) {
+        for (int j = 0; j < 12; ++j) split(T_SR + 2 * (12 * r + j), ZK_POSEIDON_S[23 * r + j]);
+        for (int k = 1; k < 12; ++k) tab[T_SC + 11 * r + k - 1] = ZK_POSEIDON_S[23 * r + 11 + k];
+    }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
     g_consts_loaded[dev] = true;
 }
