@@ -142,7 +142,7 @@ def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
             "distinct_roots": len({tuple(r) for r in roots})}
 
 
-def msm_leg(zk, logn, cpu_baseline):
+def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
     """Second component of BASELINE's metric, "BN254 G1 MSM Mpts/s" (config 4): n = 2^22 uniform scalars
     below r, bases [k_i]G generated on the device, everything resident in HBM when the clock starts;
     the result is checked against the closed form [sum s_i k_i mod r]G by the CPU oracle."""
@@ -151,34 +151,36 @@ def msm_leg(zk, logn, cpu_baseline):
     k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
     scal = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
     scal[:, 3] &= np.uint64((1 << 60) - 1)                              # < 2^252 < r
-    d_bases = zk.g1_bn254_mul_generator(zk.DevArray.from_host(k))
+    nl = {"bn254": 4, "bls12_381": 6}[curve]
+    d_bases = zk.g1_mul_generator(zk.DevArray.from_host(k), curve)
     d_scal = zk.DevArray.from_host(scal.reshape(-1))
-    zk.msm_g1_bn254_dev(d_bases, d_scal, n)                             # warm the pool
+    zk.msm_g1_dev(d_bases, d_scal, n, curve)                            # warm the pool
     times = []
     for _ in range(5):
         t0 = time.perf_counter()
-        out = zk.msm_g1_bn254_dev(d_bases, d_scal, n)
+        out = zk.msm_g1_dev(d_bases, d_scal, n, curve)
         zk.lib().zk_dev_sync()
         times.append(time.perf_counter() - t0)
-    res = {"workload": "BASELINE config 4: BN254 G1 Pippenger MSM, n=2^%d, c=16, HBM-resident" % logn,
+    res = {"workload": "BASELINE config 4: %s G1 Pippenger MSM, n=2^%d, c=16, HBM-resident" % (curve, logn),
            "value": round(n / min(times) / 1e6, 2), "unit": "Mpts/s", "ms": round(min(times) * 1e3, 2)}
     if cpu_baseline:
-        R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
         import oracle_lib
         orc = oracle_lib.load()
+        cv = orc.curve(curve)
+        R = cv.r
         w = lambda x: np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64)
         s4 = scal.astype(object)
         sv = s4[:, 0] + (s4[:, 1] << 64) + (s4[:, 2] << 128) + (s4[:, 3] << 192)
-        exp, _ = orc.bn254_scalar_mul(orc.bn254_generator(), w(int((sv * k.astype(object)).sum() % R)))
-        assert np.array_equal(out.to_host()[:8], exp), "GPU MSM != closed form"
+        exp, _ = cv.scalar_mul(cv.generator(), w(int((sv * k.astype(object)).sum() % R)))
+        assert np.array_equal(out.to_host()[:2 * nl], exp), "GPU MSM != closed form"
         m = 1 << 18                                                     # bounded CPU sample of the same inputs
-        hb = np.empty(m * 8, np.uint64)
-        zk._check(zk.lib().zk_dev_download(zk._ptr(hb), d_bases.ptr, m * 64))
+        hb = np.empty(m * 2 * nl, np.uint64)
+        zk._check(zk.lib().zk_dev_download(zk._ptr(hb), d_bases.ptr, m * 16 * nl))
         t0 = time.perf_counter()
-        orc.bn254_msm(hb, scal[:m].reshape(-1), 14)
+        cv.msm(hb, scal[:m].reshape(-1), 14)
         cpu_s = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": min(orc.threads(), 19), "kind": "port",
-                               "sample": "first 2^18 points of the same input, oracle/ec.c Pippenger c=14 (OpenMP over its 19 windows), %.2f s" % cpu_s}
+                               "sample": "first 2^18 points of the same input, oracle/ec_impl.h Pippenger c=14 (OpenMP over its 19 windows), %.2f s" % cpu_s}
     return res
 
 
@@ -283,6 +285,7 @@ def main():
         }
         if not args.no_msm and world == 1:
             out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
+            out["msm_g1_bls12_381"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
         if not args.no_prove and world == 1:
             out["stark_prove"] = prove_leg(zk, args.prove_nbits)
         if agg is not None:

@@ -373,6 +373,30 @@ int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* ou
     });
 }
 
+int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {
+    return guard([&] { g1_bls12_381_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });
+}
+int zk_msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
+    return guard([&] { msm_g1_bls12_381_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });
+}
+int zk_msm_g1_bls12_381(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {
+    return guard([&] {
+        ZK_REQUIRE(out && is_infinity, "msm: null output");
+        ZK_REQUIRE(n == 0 || (bases && scalars), "msm: null input");
+        if (n == 0) { memset(out, 0, 96); *is_infinity = 1; return; }  // empty sum
+        DevBuf db, ds, dout;
+        db.reserve(n * 96); ds.reserve(n * 32); dout.reserve(100);
+        ZK_HIP(hipMemcpy(db.p, bases, n * 96, hipMemcpyHostToDevice));
+        ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+        msm_g1_bls12_381_dev(db.p, ds.p, n, dout.p, nullptr);
+        uint32_t h[25];
+        ZK_HIP(hipStreamSynchronize(nullptr));
+        ZK_HIP(hipMemcpy(h, dout.p, 100, hipMemcpyDeviceToHost));
+        memcpy(out, h, 96);
+        *is_infinity = (int)h[24];
+    });
+}
+
 int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, uint64_t* d_out3, void* stream) {
     return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, (hipStream_t)stream); });
 }

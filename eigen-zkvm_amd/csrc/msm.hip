@@ -19,11 +19,9 @@
 #include "zk_internal.h"
 
 namespace zk {
-namespace {
 
+namespace bn254 {
 constexpr int NL = 8;  // 32-bit limbs of Fq
-struct fq { u32 l[NL]; };
-
 // q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 (alt_bn128 base field), R = 2^256
 __host__ __device__ constexpr u32 FQ_Q(int i) {
     constexpr u32 q[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
@@ -34,330 +32,61 @@ __host__ __device__ constexpr u32 FQ_ONE(int i) {  // R mod q
     return r[i];
 }
 constexpr u32 FQ_INV = 0xe4866389u;  // -q^-1 mod 2^32
+__host__ __device__ constexpr u32 GEN_X(int i) { return FQ_ONE(i); }  // G = (1, 2)
+__host__ __device__ constexpr u32 GEN_Y(int i) {  // 2R mod q
+    constexpr u32 y[8] = {0x8b1e1b3au, 0xa6ba871bu, 0xeb8e167bu, 0x14f1d651u, 0xf0f28c58u, 0xccdd46deu, 0x340fbe5eu, 0x1c14ef83u};
+    return y[i];
+}
+namespace {
+#include "msm_impl.cuh"
+}
+}  // namespace bn254
 
-__device__ __forceinline__ bool fq_is_zero(const fq& a) {
-    u32 o = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) o |= a.l[i];
-    return o == 0;
+namespace bls12_381 {
+constexpr int NL = 12;
+// q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, R = 2^384
+__host__ __device__ constexpr u32 FQ_Q(int i) {
+    constexpr u32 q[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                           0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    return q[i];
 }
-__device__ __forceinline__ bool fq_eq(const fq& a, const fq& b) {
-    u32 o = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) o |= a.l[i] ^ b.l[i];
-    return o == 0;
+__host__ __device__ constexpr u32 FQ_ONE(int i) {  // R mod q
+    constexpr u32 r[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
+                           0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+    return r[i];
 }
-// r = a - q if a >= q (a < 2q, optional incoming carry bit)
-__device__ __forceinline__ fq fq_reduce_once(const fq& a, u32 carry) {
-    fq t; long long br = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { long long d = (long long)a.l[i] - FQ_Q(i) + br; t.l[i] = (u32)d; br = d >> 32; }
-    const bool ge = carry || br == 0;  // no final borrow <=> a >= q
-    fq r;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = ge ? t.l[i] : a.l[i];
-    return r;
+constexpr u32 FQ_INV = 0xfffcfffdu;  // -q^-1 mod 2^32
+// the G1 generator of the BLS12-381 specification, Montgomery form
+__host__ __device__ constexpr u32 GEN_X(int i) {
+    constexpr u32 x[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                           0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    return x[i];
 }
-__device__ __forceinline__ fq fq_add(const fq& a, const fq& b) {
-    fq s; u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { c += (u64)a.l[i] + b.l[i]; s.l[i] = (u32)c; c >>= 32; }
-    return fq_reduce_once(s, (u32)c);
+__host__ __device__ constexpr u32 GEN_Y(int i) {
+    constexpr u32 y[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                           0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    return y[i];
 }
-__device__ __forceinline__ fq fq_sub(const fq& a, const fq& b) {
-    fq d; long long br = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { long long x = (long long)a.l[i] - b.l[i] + br; d.l[i] = (u32)x; br = x >> 32; }
-    const bool neg = br != 0;
-    u64 c = 0; fq r;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { c += (u64)d.l[i] + (neg ? FQ_Q(i) : 0u); r.l[i] = (u32)c; c >>= 32; }
-    return r;
+// 12-limb products stay out of line: inlined, one point addition is > 128 KB of code, beyond the reach of
+// s_branch, and the relaxed long branches hipcc (ROCm 7.2) emits there hang the kernels
+#undef FQ_MUL_ATTR
+#define FQ_MUL_ATTR __noinline__
+namespace {
+#include "msm_impl.cuh"
 }
-__device__ __forceinline__ fq fq_dbl(const fq& a) { return fq_add(a, a); }
-// Montgomery product a*b*R^-1 mod q (CIOS, 32-bit limbs)
-#ifndef FQ_MUL_ATTR
-#define FQ_MUL_ATTR __forceinline__
-#endif
-__device__ FQ_MUL_ATTR fq fq_mul(const fq& a, const fq& b) {
-    u32 t[NL + 2];
-#pragma unroll
-    for (int i = 0; i < NL + 2; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) { c += (u64)a.l[j] * b.l[i] + t[j]; t[j] = (u32)c; c >>= 32; }
-        c += t[NL]; t[NL] = (u32)c; t[NL + 1] = (u32)(c >> 32);
-        const u32 m = t[0] * FQ_INV;
-        c = ((u64)m * FQ_Q(0) + t[0]) >> 32;
-#pragma unroll
-        for (int j = 1; j < NL; ++j) { c += (u64)m * FQ_Q(j) + t[j]; t[j - 1] = (u32)c; c >>= 32; }
-        c += t[NL]; t[NL - 1] = (u32)c; t[NL] = t[NL + 1] + (u32)(c >> 32);
-    }
-    fq r;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = t[i];
-    return fq_reduce_once(r, t[NL]);
-}
-__device__ __forceinline__ fq fq_sqr(const fq& a) { return fq_mul(a, a); }
-__device__ fq fq_inv(const fq& a) {  // a^(q-2)
-    fq r;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = FQ_ONE(i);
-    for (int bit = 255; bit >= 0; --bit) {
-        r = fq_sqr(r);
-        u32 w = FQ_Q(bit >> 5);  // exponent q - 2: only limb 0 differs
-        if ((bit >> 5) == 0) w -= 2;
-        // FQ_Q with a runtime index is a constant-array lookup; fine off the hot path
-        if ((w >> (bit & 31)) & 1) r = fq_mul(r, a);
-    }
-    return r;
-}
+}  // namespace bls12_381
 
-// XYZZ coordinates: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ == 0
-struct xyzz { fq X, Y, ZZ, ZZZ; };
-struct aff { fq x, y; };
-
-__device__ __forceinline__ xyzz pt_inf() {
-    xyzz p;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { p.X.l[i] = 0; p.Y.l[i] = 0; p.ZZ.l[i] = 0; p.ZZZ.l[i] = 0; }
-    return p;
-}
-__device__ __forceinline__ bool pt_is_inf(const xyzz& p) { return fq_is_zero(p.ZZ); }
-__device__ xyzz pt_dbl_aff(const aff& a) {  // mdbl-2008-s-1 (a = 0)
-    fq U = fq_dbl(a.y), V = fq_sqr(U), W = fq_mul(U, V), S = fq_mul(a.x, V);
-    fq xx = fq_sqr(a.x), M = fq_add(fq_dbl(xx), xx);
-    xyzz r;
-    r.X = fq_sub(fq_sqr(M), fq_dbl(S));
-    r.Y = fq_sub(fq_mul(M, fq_sub(S, r.X)), fq_mul(W, a.y));
-    r.ZZ = V; r.ZZZ = W;
-    return r;
-}
-__device__ xyzz pt_dbl(const xyzz& p) {  // dbl-2008-s-1 (a = 0)
-    if (pt_is_inf(p)) return p;
-    fq U = fq_dbl(p.Y), V = fq_sqr(U), W = fq_mul(U, V), S = fq_mul(p.X, V);
-    fq xx = fq_sqr(p.X), M = fq_add(fq_dbl(xx), xx);
-    xyzz r;
-    r.X = fq_sub(fq_sqr(M), fq_dbl(S));
-    r.Y = fq_sub(fq_mul(M, fq_sub(S, r.X)), fq_mul(W, p.Y));
-    r.ZZ = fq_mul(V, p.ZZ); r.ZZZ = fq_mul(W, p.ZZZ);
-    return r;
-}
-__device__ xyzz pt_madd(const xyzz& p, const aff& a) {  // madd-2008-s
-    if (pt_is_inf(p)) {
-        xyzz r; r.X = a.x; r.Y = a.y;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) { r.ZZ.l[i] = FQ_ONE(i); r.ZZZ.l[i] = FQ_ONE(i); }
-        return r;
-    }
-    fq U2 = fq_mul(a.x, p.ZZ), S2 = fq_mul(a.y, p.ZZZ);
-    fq Pd = fq_sub(U2, p.X), Rd = fq_sub(S2, p.Y);
-    if (fq_is_zero(Pd)) return fq_is_zero(Rd) ? pt_dbl_aff(a) : pt_inf();
-    fq PP = fq_sqr(Pd), PPP = fq_mul(Pd, PP), Qv = fq_mul(p.X, PP);
-    xyzz r;
-    r.X = fq_sub(fq_sub(fq_sqr(Rd), PPP), fq_dbl(Qv));
-    r.Y = fq_sub(fq_mul(Rd, fq_sub(Qv, r.X)), fq_mul(p.Y, PPP));
-    r.ZZ = fq_mul(p.ZZ, PP); r.ZZZ = fq_mul(p.ZZZ, PPP);
-    return r;
-}
-__device__ xyzz pt_add(const xyzz& p, const xyzz& q) {  // add-2008-s
-    if (pt_is_inf(p)) return q;
-    if (pt_is_inf(q)) return p;
-    fq U1 = fq_mul(p.X, q.ZZ), U2 = fq_mul(q.X, p.ZZ), S1 = fq_mul(p.Y, q.ZZZ), S2 = fq_mul(q.Y, p.ZZZ);
-    fq Pd = fq_sub(U2, U1), Rd = fq_sub(S2, S1);
-    if (fq_is_zero(Pd)) return fq_is_zero(Rd) ? pt_dbl(p) : pt_inf();
-    fq PP = fq_sqr(Pd), PPP = fq_mul(Pd, PP), Qv = fq_mul(U1, PP);
-    xyzz r;
-    r.X = fq_sub(fq_sub(fq_sqr(Rd), PPP), fq_dbl(Qv));
-    r.Y = fq_sub(fq_mul(Rd, fq_sub(Qv, r.X)), fq_mul(S1, PPP));
-    r.ZZ = fq_mul(fq_mul(p.ZZ, q.ZZ), PP); r.ZZZ = fq_mul(fq_mul(p.ZZZ, q.ZZZ), PPP);
-    return r;
-}
-__device__ __forceinline__ xyzz pt_neg(const xyzz& p) {
-    xyzz r = p;
-    fq z;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) z.l[i] = 0;
-    if (!fq_is_zero(p.Y)) r.Y = fq_sub(z, p.Y);
-    return r;
-}
-
-constexpr int C_BITS = 16, N_WIN = 16, N_BUCKET = 1 << C_BITS;  // 254-bit scalars: 16 windows of 16 bits
-
-__global__ void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __restrict__ counts) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // one lane per (point, window)
-    if (t >= n * N_WIN) return;
-    const u64 i = t / N_WIN; const u32 w = t % N_WIN;
-    const u32 word = scalars[i * 8 + (w >> 1)];
-    const u32 d = (w & 1) ? word >> 16 : word & 0xFFFF;
-    if (d) atomicAdd(&counts[w * N_BUCKET + d], 1u);
-}
-__global__ void msm_scatter_kernel(const u32* __restrict__ scalars, u64 n, const u32* __restrict__ offsets,
-                                   u32* __restrict__ cursors, u32* __restrict__ idx) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * N_WIN) return;
-    const u64 i = t / N_WIN; const u32 w = t % N_WIN;
-    const u32 word = scalars[i * 8 + (w >> 1)];
-    const u32 d = (w & 1) ? word >> 16 : word & 0xFFFF;
-    if (!d) return;
-    const u32 key = w * N_BUCKET + d;
-    idx[offsets[key] + atomicAdd(&cursors[key], 1u)] = (u32)i;
-}
-// exclusive scan of 2^20 counters, 1024 per block
-__global__ __launch_bounds__(256) void scan_block_kernel(const u32* __restrict__ in, u32* __restrict__ out, u32* __restrict__ block_sum) {
-    __shared__ u32 lds[256];
-    const u32 base = blockIdx.x * 1024 + threadIdx.x * 4;
-    u32 v[4], s = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = in[base + k]; s += v[k]; }
-    lds[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        u32 cur = lds[threadIdx.x], prev = threadIdx.x >= (u32)off ? lds[threadIdx.x - off] : 0;
-        __syncthreads();
-        lds[threadIdx.x] = cur + prev;
-        __syncthreads();
-    }
-    u32 ex = threadIdx.x ? lds[threadIdx.x - 1] : 0;
-    if (threadIdx.x == 255) block_sum[blockIdx.x] = lds[255];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { out[base + k] = ex; ex += v[k]; }
-}
-__global__ void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // nb <= 1024: one lane, serial
-    if (threadIdx.x | blockIdx.x) return;
-    u32 acc = 0;
-    for (u32 b = 0; b < nb; ++b) { u32 t = block_sum[b]; block_sum[b] = acc; acc += t; }
-}
-__global__ void scan_add_kernel(u32* __restrict__ out, const u32* __restrict__ block_sum) {
-    out[blockIdx.x * 1024 + threadIdx.x * 4 + 0] += block_sum[blockIdx.x];
-    out[blockIdx.x * 1024 + threadIdx.x * 4 + 1] += block_sum[blockIdx.x];
-    out[blockIdx.x * 1024 + threadIdx.x * 4 + 2] += block_sum[blockIdx.x];
-    out[blockIdx.x * 1024 + threadIdx.x * 4 + 3] += block_sum[blockIdx.x];
-}
-
-__device__ __forceinline__ aff load_aff(const u32* __restrict__ bases, u32 i) {
-    aff a;
-    const uint4* p = (const uint4*)(bases + (u64)i * 16);
-    uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-    a.x.l[0] = v0.x; a.x.l[1] = v0.y; a.x.l[2] = v0.z; a.x.l[3] = v0.w; a.x.l[4] = v1.x; a.x.l[5] = v1.y; a.x.l[6] = v1.z; a.x.l[7] = v1.w;
-    a.y.l[0] = v2.x; a.y.l[1] = v2.y; a.y.l[2] = v2.z; a.y.l[3] = v2.w; a.y.l[4] = v3.x; a.y.l[5] = v3.y; a.y.l[6] = v3.z; a.y.l[7] = v3.w;
-    return a;
-}
-__global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restrict__ bases, const u32* __restrict__ offsets,
-                                                            const u32* __restrict__ counts, const u32* __restrict__ idx,
-                                                            xyzz* __restrict__ buckets) {
-    const u32 key = blockIdx.x * blockDim.x + threadIdx.x;  // window * 2^16 + digit
-    xyzz acc = pt_inf();
-    const u32 n = counts[key], off = offsets[key];
-    for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(bases, idx[off + k]));
-    buckets[key] = acc;
-}
-// One level of the radix-16 hierarchy that computes sum_k k*B_k per window.  An item (S, A) stands
-// for a block of m = 16^level consecutive buckets: S = their sum, A = sum (local index) * bucket.
-// 16 neighbouring blocks combine as S' = sum_j S_j, A' = sum_j A_j + m * sum_j j*S_j (running-sum
-// trick for the last term).  Level 0 reads the buckets themselves (A = 0).  After 4 levels the one
-// item left per window holds A = sum_k k*B_k.  Every level keeps 1/16 of the lanes of the one
-// before: 2^16, 2^12, 2^8, 2^4 -- the serial chain per lane is 47 additions, not 65536.
-__global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __restrict__ S_in, const xyzz* __restrict__ A_in,
-                                                              xyzz* __restrict__ S_out, xyzz* __restrict__ A_out,
-                                                              u32 n_out, int level) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_out) return;
-    const xyzz* s = S_in + (u64)g * 16;
-    xyzz run = pt_inf(), acc = pt_inf();
-    for (int j = 15; j >= 1; --j) { run = pt_add(run, s[j]); acc = pt_add(acc, run); }
-    run = pt_add(run, s[0]);
-    if (level > 0) {
-        for (int k = 0; k < 4 * level; ++k) acc = pt_dbl(acc);
-        const xyzz* a = A_in + (u64)g * 16;
-        for (int j = 0; j < 16; ++j) acc = pt_add(acc, a[j]);
-    }
-    S_out[g] = run; A_out[g] = acc;
-}
-__global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 16 words + flag */) {
-    if (threadIdx.x | blockIdx.x) return;
-    xyzz acc = pt_inf();
-    for (int w = N_WIN - 1; w >= 0; --w) {
-        for (int k = 0; k < C_BITS; ++k) acc = pt_dbl(acc);
-        acc = pt_add(acc, win[w]);
-    }
-    if (pt_is_inf(acc)) { for (int i = 0; i < 16; ++i) out[i] = 0; out[16] = 1; return; }
-    // x = X/ZZ, y = Y/ZZZ ; 1/ZZ = (ZZ * 1/ZZZ)^2 because ZZ^3 = ZZZ^2
-    fq izzz = fq_inv(acc.ZZZ), t = fq_mul(acc.ZZ, izzz), izz = fq_sqr(t);
-    fq x = fq_mul(acc.X, izz), y = fq_mul(acc.Y, izzz);
-    for (int i = 0; i < 8; ++i) { out[i] = x.l[i]; out[8 + i] = y.l[i]; }
-    out[16] = 0;
-}
-
-// synthetic bases for benches/tests: P_i = [k_i]G, G = (1, 2); k_i 64-bit, non-zero
-__global__ __launch_bounds__(64) void g1_mul_generator_kernel(const u64* __restrict__ k, u64 n, u32* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    aff g;
-    for (int j = 0; j < NL; ++j) g.x.l[j] = FQ_ONE(j);
-    g.y = fq_dbl(g.x);
-    const u64 e = k[i];
-    xyzz acc = pt_inf();
-    for (int b = 63; b >= 0; --b) {
-        acc = pt_dbl(acc);
-        if ((e >> b) & 1) acc = pt_madd(acc, g);
-    }
-    u32* o = out + i * 16;
-    if (pt_is_inf(acc)) { for (int j = 0; j < 16; ++j) o[j] = 0; return; }
-    fq izzz = fq_inv(acc.ZZZ), t = fq_mul(acc.ZZ, izzz), izz = fq_sqr(t);
-    fq x = fq_mul(acc.X, izz), y = fq_mul(acc.Y, izzz);
-    for (int j = 0; j < 8; ++j) { o[j] = x.l[j]; o[8 + j] = y.l[j]; }
-}
-
-}  // namespace
-
-void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(g1_mul_generator_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_k, n, (u32*)d_bases);
-    ZK_HIP(hipGetLastError());
-}
-
-// d_out: 17 u32 words (x, y Montgomery, infinity flag)
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
-    ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
-    const size_t n_keys = (size_t)N_WIN * N_BUCKET;
-    DevBuf counts, offsets, cursors, tops, idx, buckets, S0, A0, S1, A1;
-    counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
-    idx.reserve((size_t)n * N_WIN * 4);
-    buckets.reserve(n_keys * sizeof(xyzz));
-    S0.reserve(n_keys / 16 * sizeof(xyzz)); A0.reserve(n_keys / 16 * sizeof(xyzz));
-    S1.reserve(n_keys / 256 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));
-    ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
-    ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
-    const u64 total = n * N_WIN;
-    const unsigned gb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(msm_count_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (u32*)counts.p);
-    ZK_HIP(hipGetLastError());
-    const unsigned nb = (unsigned)(n_keys / 1024);
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)counts.p, (u32*)offsets.p, (u32*)tops.p);
-    hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)offsets.p, (const u32*)tops.p);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (const u32*)offsets.p,
-                       (u32*)cursors.p, (u32*)idx.p);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, (const u32*)d_bases,
-                       (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (xyzz*)buckets.p);
-    ZK_HIP(hipGetLastError());
-    // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
-    const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
-    u32 n_out = (u32)(n_keys / 16);
-    for (int level = 0; level < C_BITS / 4; ++level, n_out /= 16) {
-        xyzz* s_out = (xyzz*)(level & 1 ? S1.p : S0.p); xyzz* a_out = (xyzz*)(level & 1 ? A1.p : A0.p);
-        hipLaunchKernelGGL(msm_reduce_level_kernel, dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
-        s_in = s_out; a_in = a_out;
-    }
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, a_in, (u32*)d_out);
-    ZK_HIP(hipGetLastError());
-    ZK_HIP(hipStreamSynchronize(st));  // the pooled scratch above is released at scope exit
+    bn254::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
+}
+void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
+    bn254::g1_mul_generator_dev(d_k, n, d_bases, st);
+}
+void msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
+    bls12_381::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
+}
+void g1_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
+    bls12_381::g1_mul_generator_dev(d_k, n, d_bases, st);
 }
 
 }  // namespace zk

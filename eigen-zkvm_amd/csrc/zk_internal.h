@@ -84,6 +84,9 @@ void calculate_z_dev(const u64* d_num, const u64* d_den, uint64_t n, u64* d_z, u
 // ---- MSM (msm.hip): bases n*64 B affine Montgomery, scalars n*32 B canonical; d_out 17 u32 (x, y, inf flag)
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
 void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);  // P_i = [k_i]G, k_i != 0
+// BLS12-381: bases n*96 B, scalars n*32 B; d_out 25 u32 (x, y, inf flag)
+void msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
+void g1_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
 
 }  // namespace zk

@@ -146,6 +146,11 @@ int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uin
  * set when the sum is the point at infinity.  `_dev` takes device pointers (d_out: 68 bytes).       */
 int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
 int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+/* the same on BLS12-381 G1 (zkit --curve BLS12381; pairing_ce bls12_381): Fq = 12 x 32-bit limbs, Montgomery
+ * R = 2^384, bases n x 96 B, scalars n x 32 B canonical (255 bits), out 96 B; d_out of `_dev`: 100 bytes.  */
+int zk_msm_g1_bls12_381(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
+int zk_msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
 /* synthetic CRS for benches and tests: d_bases[i] = [d_k[i]] G, G = (1, 2), k_i a non-zero 64-bit integer
  * (what generate_random_parameters, groth16.rs:39,82, does with secret exponents).                     */
 int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);

@@ -13,186 +13,18 @@
  * standard alt_bn128 constants.  Jacobian coordinates here, XYZZ on the GPU: different formulas,
  * same unique affine result.
  */
-#include <stdint.h>
-#include <stdlib.h>
-#include <string.h>
+#define EC_NL 4
+#define EC_Q {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}
+#define EC_R1 {0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL} /* 2^256 mod q */
+#define EC_R2 {0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL} /* 2^512 mod q */
+#define EC_QINV 0x87d20782e4866389ULL /* -q^-1 mod 2^64 */
+#define EC_B 3
+#define EC_GX {1, 0, 0, 0}
+#define EC_GY {2, 0, 0, 0}
+#define EC_X(name) orc_bn254_##name
+#include "ec_impl.h"
 
-typedef unsigned __int128 u128;
-typedef struct { uint64_t l[4]; } fq_t;
-typedef struct { fq_t x, y; int inf; } aff_t;
-typedef struct { fq_t x, y, z; } jac_t;   /* z == 0 <=> infinity */
-
-static const fq_t Q = {{0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}};
-static const fq_t R1 = {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}}; /* 2^256 mod q */
-static const fq_t R2 = {{0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}}; /* 2^512 mod q */
-#define QINV 0x87d20782e4866389ULL /* -q^-1 mod 2^64 */
-
-static int fq_geq(const fq_t *a, const fq_t *b) {
-    for (int i = 3; i >= 0; --i) { if (a->l[i] > b->l[i]) return 1; if (a->l[i] < b->l[i]) return 0; }
-    return 1;
-}
-static void fq_sub_nored(fq_t *r, const fq_t *a, const fq_t *b) {
-    u128 br = 0;
-    for (int i = 0; i < 4; ++i) { u128 d = (u128)a->l[i] - b->l[i] - br; r->l[i] = (uint64_t)d; br = (d >> 64) & 1; }
-}
-static fq_t fq_add(fq_t a, fq_t b) {
-    fq_t r; u128 c = 0;
-    for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
-    if (c || fq_geq(&r, &Q)) fq_sub_nored(&r, &r, &Q);
-    return r;
-}
-static fq_t fq_sub(fq_t a, fq_t b) {
-    fq_t r;
-    if (fq_geq(&a, &b)) fq_sub_nored(&r, &a, &b);
-    else { fq_t t; fq_sub_nored(&t, &Q, &b); u128 c = 0; for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + t.l[i]; r.l[i] = (uint64_t)c; c >>= 64; } }
-    return r;
-}
-static fq_t fq_mul(fq_t a, fq_t b) { /* Montgomery CIOS */
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-        uint64_t m = t[0] * QINV;
-        c = ((u128)m * Q.l[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; ++j) { c += (u128)m * Q.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
-    }
-    fq_t r = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || fq_geq(&r, &Q)) fq_sub_nored(&r, &r, &Q);
-    return r;
-}
-static fq_t fq_sqr(fq_t a) { return fq_mul(a, a); }
-static int fq_is_zero(fq_t a) { return !(a.l[0] | a.l[1] | a.l[2] | a.l[3]); }
-static int fq_eq(fq_t a, fq_t b) { return !memcmp(&a, &b, sizeof a); }
-static fq_t fq_inv(fq_t a) { /* a^(q-2) */
-    fq_t e = Q, r = R1; e.l[0] -= 2;
-    for (int i = 255; i >= 0; --i) { r = fq_sqr(r); if ((e.l[i / 64] >> (i % 64)) & 1) r = fq_mul(r, a); }
-    return r;
-}
-static fq_t fq_from_u64(uint64_t v) { fq_t a = {{v, 0, 0, 0}}; return fq_mul(a, R2); }
-
-static jac_t jac_inf(void) { jac_t p; memset(&p, 0, sizeof p); return p; }
-static jac_t jac_dbl(jac_t p) { /* dbl-2009-l, a = 0 */
-    if (fq_is_zero(p.z)) return p;
-    fq_t A = fq_sqr(p.x), B = fq_sqr(p.y), C = fq_sqr(B);
-    fq_t D = fq_sub(fq_sub(fq_sqr(fq_add(p.x, B)), A), C); D = fq_add(D, D);
-    fq_t E = fq_add(fq_add(A, A), A), F = fq_sqr(E);
-    jac_t r;
-    r.x = fq_sub(F, fq_add(D, D));
-    fq_t C8 = fq_add(C, C); C8 = fq_add(C8, C8); C8 = fq_add(C8, C8);
-    r.y = fq_sub(fq_mul(E, fq_sub(D, r.x)), C8);
-    r.z = fq_mul(p.y, p.z); r.z = fq_add(r.z, r.z);
-    return r;
-}
-static jac_t jac_add_aff(jac_t p, const aff_t *q) { /* madd-2007-bl */
-    if (q->inf) return p;
-    if (fq_is_zero(p.z)) { jac_t r; r.x = q->x; r.y = q->y; r.z = R1; return r; }
-    fq_t Z1Z1 = fq_sqr(p.z), U2 = fq_mul(q->x, Z1Z1), S2 = fq_mul(fq_mul(q->y, p.z), Z1Z1);
-    if (fq_eq(U2, p.x)) { if (fq_eq(S2, p.y)) return jac_dbl(p); return jac_inf(); }
-    fq_t H = fq_sub(U2, p.x), HH = fq_sqr(H), I = fq_add(HH, HH); I = fq_add(I, I);
-    fq_t J = fq_mul(H, I), r_ = fq_sub(S2, p.y); r_ = fq_add(r_, r_);
-    fq_t V = fq_mul(p.x, I);
-    jac_t r;
-    r.x = fq_sub(fq_sub(fq_sqr(r_), J), fq_add(V, V));
-    fq_t YJ = fq_mul(p.y, J);
-    r.y = fq_sub(fq_mul(r_, fq_sub(V, r.x)), fq_add(YJ, YJ));
-    r.z = fq_sub(fq_sub(fq_sqr(fq_add(p.z, H)), Z1Z1), HH);
-    return r;
-}
-static jac_t jac_add(jac_t p, jac_t q) { /* add-2007-bl */
-    if (fq_is_zero(p.z)) return q;
-    if (fq_is_zero(q.z)) return p;
-    fq_t Z1Z1 = fq_sqr(p.z), Z2Z2 = fq_sqr(q.z);
-    fq_t U1 = fq_mul(p.x, Z2Z2), U2 = fq_mul(q.x, Z1Z1);
-    fq_t S1 = fq_mul(fq_mul(p.y, q.z), Z2Z2), S2 = fq_mul(fq_mul(q.y, p.z), Z1Z1);
-    if (fq_eq(U1, U2)) { if (fq_eq(S1, S2)) return jac_dbl(p); return jac_inf(); }
-    fq_t H = fq_sub(U2, U1), I = fq_sqr(fq_add(H, H)), J = fq_mul(H, I);
-    fq_t r_ = fq_sub(S2, S1); r_ = fq_add(r_, r_);
-    fq_t V = fq_mul(U1, I);
-    jac_t r;
-    r.x = fq_sub(fq_sub(fq_sqr(r_), J), fq_add(V, V));
-    fq_t SJ = fq_mul(S1, J);
-    r.y = fq_sub(fq_mul(r_, fq_sub(V, r.x)), fq_add(SJ, SJ));
-    r.z = fq_mul(fq_sub(fq_sub(fq_sqr(fq_add(p.z, q.z)), Z1Z1), Z2Z2), H);
-    return r;
-}
-static aff_t jac_to_aff(jac_t p) {
-    aff_t a; memset(&a, 0, sizeof a);
-    if (fq_is_zero(p.z)) { a.inf = 1; return a; }
-    fq_t zi = fq_inv(p.z), zi2 = fq_sqr(zi);
-    a.x = fq_mul(p.x, zi2); a.y = fq_mul(p.y, fq_mul(zi2, zi));
-    return a;
-}
-
-/* ---- exported ------------------------------------------------------------------------------- */
-/* generator (1, 2) in Montgomery form */
-void orc_bn254_generator(uint64_t out[8]) { fq_t x = fq_from_u64(1), y = fq_from_u64(2); memcpy(out, &x, 32); memcpy(out + 4, &y, 32); }
-int orc_bn254_on_curve(const uint64_t p[8]) {
-    fq_t x, y; memcpy(&x, p, 32); memcpy(&y, p + 4, 32);
-    return fq_eq(fq_sqr(y), fq_add(fq_mul(fq_sqr(x), x), fq_from_u64(3)));
-}
-void orc_fq_mul(const uint64_t a[4], const uint64_t b[4], uint64_t r[4]) { fq_t x, y; memcpy(&x, a, 32); memcpy(&y, b, 32); x = fq_mul(x, y); memcpy(r, &x, 32); }
-void orc_fq_from_mont(const uint64_t a[4], uint64_t r[4]) { fq_t x, one = {{1, 0, 0, 0}}; memcpy(&x, a, 32); x = fq_mul(x, one); memcpy(r, &x, 32); }
-void orc_fq_to_mont(const uint64_t a[4], uint64_t r[4]) { fq_t x; memcpy(&x, a, 32); x = fq_mul(x, R2); memcpy(r, &x, 32); }
-
-/* [k]P, k = 256-bit little-endian; out: x || y (Montgomery), returns 1 if infinity */
-int orc_bn254_scalar_mul(const uint64_t p[8], const uint64_t k[4], uint64_t out[8]) {
-    aff_t a; memcpy(&a.x, p, 32); memcpy(&a.y, p + 4, 32); a.inf = 0;
-    jac_t acc = jac_inf();
-    for (int i = 255; i >= 0; --i) { acc = jac_dbl(acc); if ((k[i / 64] >> (i % 64)) & 1) acc = jac_add_aff(acc, &a); }
-    aff_t r = jac_to_aff(acc);
-    memcpy(out, &r.x, 32); memcpy(out + 4, &r.y, 32);
-    return r.inf;
-}
-
-/* bases[i] = [a + i*b]G for i < n (a, b 64-bit): one addition per base + batched affine conversion */
-void orc_bn254_make_bases(uint64_t n, uint64_t a, uint64_t b, uint64_t *out /* n*8 */) {
-    uint64_t g[8], tmp[8], ka[4] = {a, 0, 0, 0}, kb[4] = {b, 0, 0, 0};
-    orc_bn254_generator(g);
-    aff_t step; orc_bn254_scalar_mul(g, kb, tmp); memcpy(&step.x, tmp, 32); memcpy(&step.y, tmp + 4, 32); step.inf = 0;
-    aff_t first; orc_bn254_scalar_mul(g, ka, tmp); memcpy(&first.x, tmp, 32); memcpy(&first.y, tmp + 4, 32); first.inf = 0;
-    jac_t cur; cur.x = first.x; cur.y = first.y; cur.z = R1;
-    jac_t *pts = (jac_t *)malloc(n * sizeof(jac_t));
-    fq_t *pre = (fq_t *)malloc(n * sizeof(fq_t));
-    for (uint64_t i = 0; i < n; ++i) { pts[i] = cur; cur = jac_add_aff(cur, &step); }
-    fq_t acc = R1;                                           /* Montgomery batch inversion of all z */
-    for (uint64_t i = 0; i < n; ++i) { pre[i] = acc; acc = fq_mul(acc, pts[i].z); }
-    fq_t inv = fq_inv(acc);
-    for (uint64_t i = n; i-- > 0;) {
-        fq_t zi = fq_mul(inv, pre[i]); inv = fq_mul(inv, pts[i].z);
-        fq_t zi2 = fq_sqr(zi), x = fq_mul(pts[i].x, zi2), y = fq_mul(pts[i].y, fq_mul(zi2, zi));
-        memcpy(out + 8 * i, &x, 32); memcpy(out + 8 * i + 4, &y, 32);
-    }
-    free(pts); free(pre);
-}
-
-/* Pippenger bucket method, window c bits.  scalars: n*4 words canonical LE.  returns inf flag */
-int orc_bn254_msm(const uint64_t *bases, const uint64_t *scalars, uint64_t n, unsigned c, uint64_t out[8]) {
-    unsigned nw = (254 + c - 1) / c;
-    size_t nb = ((size_t)1 << c) - 1;
-    jac_t *wres = (jac_t *)malloc(nw * sizeof(jac_t));
-    #pragma omp parallel for schedule(dynamic, 1)
-    for (unsigned w = 0; w < nw; ++w) {
-        jac_t *bk = (jac_t *)calloc(nb, sizeof(jac_t));
-        for (uint64_t i = 0; i < n; ++i) {
-            unsigned bit = w * c; uint64_t limb = bit / 64, off = bit % 64;
-            uint64_t v = scalars[4 * i + limb] >> off;
-            if (off + c > 64 && limb < 3) v |= scalars[4 * i + limb + 1] << (64 - off);
-            v &= ((uint64_t)1 << c) - 1;
-            if (!v) continue;
-            aff_t a; memcpy(&a.x, bases + 8 * i, 32); memcpy(&a.y, bases + 8 * i + 4, 32); a.inf = 0;
-            bk[v - 1] = jac_add_aff(bk[v - 1], &a);
-        }
-        jac_t run = jac_inf(), sum = jac_inf();
-        for (size_t k = nb; k-- > 0;) { run = jac_add(run, bk[k]); sum = jac_add(sum, run); }
-        wres[w] = sum;
-        free(bk);
-    }
-    jac_t acc = jac_inf();
-    for (unsigned w = nw; w-- > 0;) { for (unsigned k = 0; k < c; ++k) acc = jac_dbl(acc); acc = jac_add(acc, wres[w]); }
-    free(wres);
-    aff_t r = jac_to_aff(acc);
-    memcpy(out, &r.x, 32); memcpy(out + 4, &r.y, 32);
-    return r.inf;
-}
+/* historical names used by the tests */
+void orc_fq_mul(const uint64_t a[4], const uint64_t b[4], uint64_t r[4]) { orc_bn254_fq_mul(a, b, r); }
+void orc_fq_from_mont(const uint64_t a[4], uint64_t r[4]) { orc_bn254_fq_from_mont(a, r); }
+void orc_fq_to_mont(const uint64_t a[4], uint64_t r[4]) { orc_bn254_fq_to_mont(a, r); }

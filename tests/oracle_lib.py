@@ -121,6 +121,10 @@ class Oracle:
         self._ec_setup(); bases = _a(bases); o = np.zeros(8, np.uint64)
         inf = self.lib.orc_bn254_msm(bases, _a(scalars), bases.size // 8, c, o); return o, bool(inf)
 
+    def curve(self, name):
+        """G1 arithmetic of `name` in ("bn254", "bls12_381") (oracle/ec.c, ec_bls12_381.c over ec_impl.h)."""
+        return Curve(self.lib, name)
+
     # -- prover glue (oracle/stark_steps.c)
     def f3_ntt(self, v, bits, inverse=False):
         v = _a(v).copy(); self.lib.orc_f3_ntt(v, bits, int(inverse)); return v
@@ -169,6 +173,42 @@ def build():
 
 
 _cached = None
+class Curve:
+    """points = 2*nl u64 words x||y (Montgomery), scalars = 4 words canonical little-endian"""
+    PARAMS = {"bn254": (4, 21888242871839275222246405745257275088548364400416034343698204186575808495617),
+              "bls12_381": (6, 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001)}
+
+    def __init__(self, lib, name):
+        self.nl, self.r = self.PARAMS[name]
+        self.name = name
+        f = lambda n: getattr(lib, "orc_%s_%s" % (name, n))
+        self._gen, self._on, self._mul, self._bases, self._msm, self._from_mont = (
+            f("generator"), f("on_curve"), f("scalar_mul"), f("make_bases"), f("msm"), f("fq_from_mont"))
+        self._gen.argtypes = [_u64p]; self._gen.restype = None
+        self._on.argtypes = [_u64p]; self._on.restype = C.c_int
+        self._mul.argtypes = [_u64p, _u64p, _u64p]; self._mul.restype = C.c_int
+        self._bases.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]; self._bases.restype = None
+        self._msm.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint, _u64p]; self._msm.restype = C.c_int
+        self._from_mont.argtypes = [_u64p, _u64p]; self._from_mont.restype = None
+
+    def generator(self):
+        o = np.zeros(2 * self.nl, np.uint64); self._gen(o); return o
+    def on_curve(self, p):
+        return bool(self._on(_a(p)))
+    def fq_from_mont(self, a):
+        o = np.zeros(self.nl, np.uint64); self._from_mont(_a(a), o); return o
+    def scalar_mul(self, p, k):
+        o = np.zeros(2 * self.nl, np.uint64); inf = self._mul(_a(p), _a(k), o); return o, bool(inf)
+    def make_bases(self, n, a, b):
+        o = np.zeros(2 * self.nl * n, np.uint64); self._bases(n, a, b, o); return o
+    def msm(self, bases, scalars, c=8):
+        bases = _a(bases); o = np.zeros(2 * self.nl, np.uint64)
+        inf = self._msm(bases, _a(scalars), bases.size // (2 * self.nl), c, o); return o, bool(inf)
+    def affine_ints(self, p):
+        to_int = lambda w: sum(int(v) << (64 * i) for i, v in enumerate(w))
+        return to_int(self.fq_from_mont(p[:self.nl])), to_int(self.fq_from_mont(p[self.nl:]))
+
+
 def load():
     global _cached
     if _cached is None:

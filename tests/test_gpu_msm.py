@@ -147,3 +147,73 @@ def test_msm_full_size_closed_form(zk, orc):
     kk = int((sv * k.astype(object)).sum() % R)
     exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(kk))
     assert (int(out[8]) & 0xFFFFFFFF) == int(einf) and np.array_equal(out[:8], exp)
+
+
+# ---- BLS12-381 G1 (zk_msm_g1_bls12_381) ---------------------------------------------------------------
+R_BLS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def rand_scalars_255(rng, n):
+    raw = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 62) - 1)          # < 2^254 < r : canonical by construction
+    return raw.reshape(-1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 33, 65, 1000, 4097])
+def test_bls_msm_matches_oracle_small(zk, orc, n):
+    cv = orc.curve("bls12_381")
+    rng = np.random.default_rng(381 + n)
+    bases = cv.make_bases(n, 3, 5)
+    scal = rand_scalars_255(rng, n)
+    got, inf = zk.msm_g1(bases, scal, "bls12_381")
+    exp, einf = cv.msm(bases, scal, 8)
+    assert inf == einf and np.array_equal(got, exp)
+
+
+def test_bls_msm_edge_scalars_and_cancellation(zk, orc):
+    cv = orc.curve("bls12_381")
+    vals = [0, 1, R_BLS - 1, R_BLS - 2, 2**16 - 1, 2**16, (1 << 254) % R_BLS, (1 << 240) - 1, 0xFFFF << 48, 0xFFFF << 239]
+    vals = [v % R_BLS for v in vals]
+    bases = cv.make_bases(len(vals), 7, 11)
+    got, inf = zk.msm_g1(bases, np.concatenate([words(v) for v in vals]), "bls12_381")
+    k = sum(v * (7 + 11 * i) for i, v in enumerate(vals)) % R_BLS
+    exp, einf = cv.scalar_mul(cv.generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+    one = cv.make_bases(1, 5, 1)
+    assert zk.msm_g1(np.concatenate([one, one]), np.concatenate([words(9), words(R_BLS - 9)]), "bls12_381")[1]
+    assert zk.msm_g1(cv.make_bases(50, 1, 1), np.zeros(200, np.uint64), "bls12_381")[1]
+    assert zk.msm_g1(np.zeros(0, np.uint64), np.zeros(0, np.uint64), "bls12_381")[1]
+    n = 300                                                     # the same base 300 times: doublings inside buckets
+    got, inf = zk.msm_g1(np.tile(one, n), np.tile(words(0x0123456789abcdef0123456789abcdef), n), "bls12_381")
+    exp, einf = cv.scalar_mul(cv.generator(), words(5 * n * 0x0123456789abcdef0123456789abcdef % R_BLS))
+    assert inf == einf and np.array_equal(got, exp)
+
+
+def test_bls_generator_multiples_match_oracle(zk, orc):
+    cv = orc.curve("bls12_381")
+    rng = np.random.default_rng(4)
+    k = rng.integers(1, 2**64, size=100, dtype=np.uint64)
+    k[:4] = [1, 2, 2**64 - 1, 2**63]
+    bases = zk.g1_mul_generator(zk.DevArray.from_host(k), "bls12_381").to_host().reshape(-1, 12)
+    for i in (0, 1, 2, 3, 57, 99):
+        exp, _ = cv.scalar_mul(cv.generator(), words(int(k[i])))
+        assert np.array_equal(bases[i], exp) and cv.on_curve(bases[i])
+
+
+@pytest.mark.parametrize("logn", [16, 20])
+def test_bls_msm_large_closed_form(zk, orc, logn):
+    cv = orc.curve("bls12_381")
+    n = 1 << logn
+    rng = np.random.default_rng(1000 + logn)
+    k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
+    scal = rand_scalars_255(rng, n)
+    d_bases = zk.g1_mul_generator(zk.DevArray.from_host(k), "bls12_381")
+    out = zk.msm_g1_dev(d_bases, zk.DevArray.from_host(scal), n, "bls12_381").to_host()
+    s4 = scal.reshape(-1, 4).astype(object)
+    sv = s4[:, 0] + (s4[:, 1] << 64) + (s4[:, 2] << 128) + (s4[:, 3] << 192)
+    kk = int((sv * k.astype(object)).sum() % R_BLS)
+    exp, einf = cv.scalar_mul(cv.generator(), words(kk))
+    assert (int(out[12]) & 0xFFFFFFFF) == int(einf) and np.array_equal(out[:12], exp)
+    if logn == 16:                                              # and the oracle's own Pippenger on the same bases
+        exp2, _ = cv.msm(d_bases.to_host(), scal, 13)
+        assert np.array_equal(out[:12], exp2)

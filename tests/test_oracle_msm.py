@@ -73,3 +73,59 @@ def test_msm_cancellation_gives_infinity(orc):
     bases = np.concatenate([one, one])                            # the same point twice
     scal = np.concatenate([words(9), words(R - 9)])
     assert orc.bn254_msm(bases, scal, 6)[1]
+
+
+# ---- BLS12-381 G1 (oracle/ec_bls12_381.c) -----------------------------------------------------------------
+BLS_Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+BLS_GX = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+BLS_GY = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+
+
+def _py_affine_mul(k, P, q):
+    """textbook affine double-and-add over Python integers: an implementation independent of the C oracle"""
+    def add(A, B):
+        if A is None: return B
+        if B is None: return A
+        (x1, y1), (x2, y2) = A, B
+        if x1 == x2:
+            if (y1 + y2) % q == 0: return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, q) % q
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, q) % q
+        x3 = (lam * lam - x1 - x2) % q
+        return x3, (lam * (x1 - x3) - y1) % q
+    acc = None
+    while k:
+        if k & 1: acc = add(acc, P)
+        P = add(P, P); k >>= 1
+    return acc
+
+
+def test_bls12_381_generator_and_group_law(orc):
+    cv = orc.curve("bls12_381")
+    g = cv.generator()
+    assert cv.affine_ints(g) == (BLS_GX, BLS_GY) and cv.on_curve(g)
+    assert (BLS_GY * BLS_GY - BLS_GX ** 3 - 4) % BLS_Q == 0                # y^2 = x^3 + 4
+    assert cv.scalar_mul(g, words(cv.r))[1]                                # [r]G = infinity
+    for k in (2, 3, 0xdeadbeefcafebabe1234567, cv.r - 1):
+        got, inf = cv.scalar_mul(g, words(k))
+        assert not inf and cv.affine_ints(got) == _py_affine_mul(k, (BLS_GX, BLS_GY), BLS_Q)
+
+
+def test_bls12_381_msm_matches_closed_form(orc):
+    cv = orc.curve("bls12_381")
+    rng = np.random.default_rng(381)
+    g = cv.generator()
+    for n, c in ((1, 4), (2, 8), (33, 5), (500, 8), (2000, 11)):
+        a, b = 3, 5
+        bases = cv.make_bases(n, a, b)
+        s = [int.from_bytes(rng.bytes(32), "little") % cv.r for _ in range(n)]
+        if n >= 33:
+            s[0] = 0; s[1] = cv.r - 1; s[2] = 1
+        scal = np.concatenate([words(v) for v in s])
+        got, inf = cv.msm(bases, scal, c)
+        k = sum(si * (a + b * i) for i, si in enumerate(s)) % cv.r
+        exp, einf = cv.scalar_mul(g, words(k))
+        assert inf == einf and (inf or np.array_equal(got, exp)), (n, c)
+    one = cv.make_bases(1, 5, 1)
+    assert cv.msm(np.concatenate([one, one]), np.concatenate([words(9), words(cv.r - 9)]), 6)[1]
