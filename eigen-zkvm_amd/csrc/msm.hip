@@ -1,4 +1,4 @@
-// G1 multi-scalar multiplication (Pippenger bucket method) for BN254 on gfx950.
+// G1 multi-scalar multiplication (Pippenger bucket method) for BN254 and BLS12-381 on gfx950.
 //
 // Stands behind groth16/src/groth16.rs:88-96 (Groth16::prove -> bellman_ce::create_random_proof ->
 // multiexp; the arithmetic itself is third-party).  Data layout = bellman's:
@@ -6,6 +6,7 @@
 // n x 32 B canonical little-endian; result 64 B affine + infinity flag.
 //
 // Pipeline (all on the device, one stream):
+//   0. bases: external 32-bit-limb Montgomery form -> internal 29-bit limbs (one product per coordinate)
 //   1. digits: 16-bit windows (c = 16, 16 windows); histogram of (window, digit) keys with atomics
 //   2. exclusive scan of the 2^20 counters -> bucket offsets
 //   3. scatter point indices into bucket order (atomic cursors)
@@ -14,7 +15,7 @@
 //   5. per-window reduction sum_k k*B_k: radix-16 hierarchy of (S, A) block summaries, 4 levels,
 //      2^16 .. 2^4 lanes; the serial chain per lane is 47 point additions
 //   6. Horner over the windows + conversion to affine (one lane)
-// Field: 8 x 32-bit limbs, CIOS Montgomery multiplication on v_mad_u64_u32 (128 per product).
+// Field: 29-bit limbs with 64-bit column accumulators, lazily reduced (msm_impl.cuh).
 // Integer-ALU bound (about 10 Fq products per point and window); HBM traffic is 96 B per point.
 #include "zk_internal.h"
 
@@ -22,17 +23,41 @@ namespace zk {
 
 namespace bn254 {
 constexpr int NL = 8;  // 32-bit limbs of Fq
-// q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 (alt_bn128 base field), R = 2^256
-__host__ __device__ constexpr u32 FQ_Q(int i) {
-    constexpr u32 q[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    return q[i];
+// q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 (alt_bn128 base field); external R = 2^256
+constexpr int NR = 9;  // 29-bit limbs of the internal representation, R' = 2^261
+constexpr u32 QINV29 = 0x04866389u;  // -q^-1 mod 2^29
+__host__ __device__ constexpr u32 Q29(int i) {
+    constexpr u32 v[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    return v[i];
 }
-__host__ __device__ constexpr u32 FQ_ONE(int i) {  // R mod q
+__host__ __device__ constexpr u32 ONE29(int i) {
+    constexpr u32 v[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 CIN29(int i) {
+    constexpr u32 v[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 COUT29(int i) {
+    constexpr u32 v[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q2_29(int i) {
+    constexpr u32 v[9] = {0x10f9fa8eu, 0x0208c16du, 0x18e5469eu, 0x05aa45a1u, 0x0b0bb2f0u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q4_29(int i) {
+    constexpr u32 v[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q8_29(int i) {
+    constexpr u32 v[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 GEN_X(int i) {  // G = (1, 2), external Montgomery form: R mod q
     constexpr u32 r[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     return r[i];
 }
-constexpr u32 FQ_INV = 0xe4866389u;  // -q^-1 mod 2^32
-__host__ __device__ constexpr u32 GEN_X(int i) { return FQ_ONE(i); }  // G = (1, 2)
 __host__ __device__ constexpr u32 GEN_Y(int i) {  // 2R mod q
     constexpr u32 y[8] = {0x8b1e1b3au, 0xa6ba871bu, 0xeb8e167bu, 0x14f1d651u, 0xf0f28c58u, 0xccdd46deu, 0x340fbe5eu, 0x1c14ef83u};
     return y[i];
@@ -44,19 +69,38 @@ namespace {
 
 namespace bls12_381 {
 constexpr int NL = 12;
-// q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab, R = 2^384
-__host__ __device__ constexpr u32 FQ_Q(int i) {
-    constexpr u32 q[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
-                           0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
-    return q[i];
+// q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab; external R = 2^384
+constexpr int NR = 14;  // 29-bit limbs of the internal representation, R' = 2^406
+constexpr u32 QINV29 = 0x1ffcfffdu;  // -q^-1 mod 2^29
+__host__ __device__ constexpr u32 Q29(int i) {
+    constexpr u32 v[14] = {0x1fffaaabu, 0x0ff7ffffu, 0x14ffffeeu, 0x17fffd62u, 0x0f6241eau, 0x09507b58u, 0x0afd9cc3u, 0x109e70a2u, 0x1764774bu, 0x121a5d66u, 0x12c6e9edu, 0x12ffcd34u, 0x00111ea3u, 0x0000000du};
+    return v[i];
 }
-__host__ __device__ constexpr u32 FQ_ONE(int i) {  // R mod q
-    constexpr u32 r[12] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u,
-                           0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
-    return r[i];
+__host__ __device__ constexpr u32 ONE29(int i) {
+    constexpr u32 v[14] = {0x03a9fb84u, 0x0ba00690u, 0x071288f1u, 0x0f59bcc5u, 0x126cb614u, 0x0585bf36u, 0x1b85ac3du, 0x1cf856fau, 0x1891ecbdu, 0x1a7eec05u, 0x155a88f0u, 0x0741ac6du, 0x1317c30fu, 0x00000009u};
+    return v[i];
 }
-constexpr u32 FQ_INV = 0xfffcfffdu;  // -q^-1 mod 2^32
-// the G1 generator of the BLS12-381 specification, Montgomery form
+__host__ __device__ constexpr u32 CIN29(int i) {
+    constexpr u32 v[14] = {0x1fddebbdu, 0x1a4f5474u, 0x0291f399u, 0x14d03b3cu, 0x0f6cad2cu, 0x1b4cabcau, 0x1592827cu, 0x021c6ac7u, 0x1ec52a84u, 0x16fd5ec4u, 0x0c960da6u, 0x0fd2af6bu, 0x13263591u, 0x0000000bu};
+    return v[i];
+}
+__host__ __device__ constexpr u32 COUT29(int i) {
+    constexpr u32 v[14] = {0x0002fffdu, 0x10480000u, 0x0300009du, 0x08001788u, 0x158baebfu, 0x0c2ba9e3u, 0x1d157d22u, 0x0a6e0a4au, 0x0d77ce58u, 0x1d12b763u, 0x1701c6a5u, 0x1501c926u, 0x1f65ec3fu, 0x0000000au};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q2_29(int i) {
+    constexpr u32 v[14] = {0x1fff5556u, 0x1fefffffu, 0x09ffffdcu, 0x0ffffac5u, 0x1ec483d5u, 0x12a0f6b0u, 0x15fb3986u, 0x013ce144u, 0x0ec8ee97u, 0x0434bacdu, 0x058dd3dbu, 0x05ff9a69u, 0x00223d47u, 0x0000001au};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q4_29(int i) {
+    constexpr u32 v[14] = {0x1ffeaaacu, 0x1fdfffffu, 0x13ffffb9u, 0x1ffff58au, 0x1d8907aau, 0x0541ed61u, 0x0bf6730du, 0x0279c289u, 0x1d91dd2eu, 0x0869759au, 0x0b1ba7b6u, 0x0bff34d2u, 0x00447a8eu, 0x00000034u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 Q8_29(int i) {
+    constexpr u32 v[14] = {0x1ffd5558u, 0x1fbfffffu, 0x07ffff73u, 0x1fffeb15u, 0x1b120f55u, 0x0a83dac3u, 0x17ece61au, 0x04f38512u, 0x1b23ba5cu, 0x10d2eb35u, 0x16374f6cu, 0x17fe69a4u, 0x0088f51cu, 0x00000068u};
+    return v[i];
+}
+// the G1 generator of the BLS12-381 specification, external Montgomery form (R = 2^384)
 __host__ __device__ constexpr u32 GEN_X(int i) {
     constexpr u32 x[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
                            0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
@@ -67,10 +111,6 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
                            0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
     return y[i];
 }
-// 12-limb products stay out of line: inlined, one point addition is > 128 KB of code, beyond the reach of
-// s_branch, and the relaxed long branches hipcc (ROCm 7.2) emits there hang the kernels
-#undef FQ_MUL_ATTR
-#define FQ_MUL_ATTR __noinline__
 namespace {
 #include "msm_impl.cuh"
 }

@@ -71,6 +71,28 @@ static void ntt_column(uint64_t *buf, size_t n, unsigned bits, const uint64_t *r
     }
 }
 
+/* the same transform with every stage's n/2 butterflies spread over the OpenMP team: used when the matrix has
+ * fewer columns than threads (the reference parallelises inside a transform too, fft_p.rs:214-239), so that
+ * the timed CPU baseline of a single-column NTT is not a one-core number */
+static void ntt_column_par(uint64_t *buf, size_t n, unsigned bits, const uint64_t *roots) {
+    #pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        size_t r = orc_bitrev((uint32_t)i, bits);
+        if (r > i) { uint64_t t = buf[i]; buf[i] = buf[r]; buf[r] = t; }
+    }
+    for (unsigned s = 1; s <= bits; ++s) {
+        size_t m = (size_t)1 << s, md2 = m >> 1, step = n >> s;
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n / 2; ++i) {
+            size_t k = (i >> (s - 1)) << s, j = i & (md2 - 1);
+            uint64_t t = gl_mul(roots[j * step], buf[k + j + md2]);
+            uint64_t u = buf[k + j];
+            buf[k + j] = gl_add(u, t);
+            buf[k + j + md2] = gl_sub(u, t);
+        }
+    }
+}
+
 static uint64_t *make_roots(unsigned bits) {
     size_t half = bits ? ((size_t)1 << (bits - 1)) : 1;
     uint64_t *r = (uint64_t *)malloc(half * sizeof(uint64_t));
@@ -86,6 +108,24 @@ int orc_ntt(const uint64_t *src, uint64_t *dst, uint32_t n_pols, uint32_t nbits,
     size_t n = (size_t)1 << nbits;
     uint64_t *roots = make_roots(nbits);
     uint64_t n_inv = gl_inv(gl_red((uint64_t)n));
+    if ((int)n_pols < orc_threads() && nbits >= 14) {            /* few columns: parallelism inside each transform */
+        uint64_t *col = (uint64_t *)malloc(n * sizeof(uint64_t));
+        for (uint32_t c = 0; c < n_pols; ++c) {
+            #pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < n; ++i) col[i] = src[i * n_pols + c];
+            ntt_column_par(col, n, nbits, roots);
+            if (!inverse) {
+                #pragma omp parallel for schedule(static)
+                for (size_t i = 0; i < n; ++i) dst[i * n_pols + c] = col[i];
+            } else {
+                dst[c] = gl_mul(col[0], n_inv);
+                #pragma omp parallel for schedule(static)
+                for (size_t i = 1; i < n; ++i) dst[i * n_pols + c] = gl_mul(col[n - i], n_inv);
+            }
+        }
+        free(col); free(roots);
+        return 0;
+    }
     #pragma omp parallel
     {
         uint64_t *col = (uint64_t *)malloc(n * sizeof(uint64_t));
