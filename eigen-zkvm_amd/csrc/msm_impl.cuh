@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void scan_block_kernel(const u32* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) { out[base + k] = ex; ex += v[k]; }
 }
-__global__ void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // nb <= 1024: one lane, serial
+__global__ void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // a few thousand entries: one lane, serial
     if (threadIdx.x | blockIdx.x) return;
     u32 acc = 0;
     for (u32 b = 0; b < nb; ++b) { u32 t = block_sum[b]; block_sum[b] = acc; acc += t; }
@@ -266,6 +266,74 @@ __global__ void scan_add_kernel(u32* __restrict__ out, const u32* __restrict__ b
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 1] += block_sum[blockIdx.x];
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 2] += block_sum[blockIdx.x];
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 3] += block_sum[blockIdx.x];
+}
+
+
+// ---- bucket sort without global atomics (n < 2^24) ------------------------------------------------------
+// key(i, w) = w * 2^16 + digit.  Two LDS-histogram partition passes replace 2 x 16 n device-scope atomics
+// on 2^20 counters (2.6 + 3.4 ms at n = 2^22): pass 1 splits the (point, window) pairs into the 4096 coarse
+// bins key >> 8 (block histograms [bin][block], one exclusive scan, LDS cursors), pass 2 lets one block per
+// coarse bin split its ~16 n / 4096 entries into the 256 fine buckets and emits counts / offsets / idx in
+// the layout the accumulation kernel reads.
+constexpr int SORT_PTS = 8192;        // points per block in pass 1
+constexpr int N_COARSE = N_WIN * 256;  // 4096
+__device__ __forceinline__ u32 digit_of(const u32* __restrict__ scalars, u64 i, u32 w) {
+    const u32 word = scalars[i * 8 + (w >> 1)];
+    return (w & 1) ? word >> 16 : word & 0xFFFF;
+}
+__global__ __launch_bounds__(256) void sort_hist_kernel(const u32* __restrict__ scalars, u64 n, u32 n_blocks, u32* __restrict__ hist /* [N_COARSE][n_blocks] */) {
+    __shared__ u32 h[N_COARSE];
+    for (int k = threadIdx.x; k < N_COARSE; k += 256) h[k] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * SORT_PTS;
+    for (u32 t = threadIdx.x; t < SORT_PTS * N_WIN; t += 256) {
+        const u64 i = base + t / N_WIN; const u32 w = t % N_WIN;
+        if (i >= n) break;
+        const u32 d = digit_of(scalars, i, w);
+        if (d) atomicAdd(&h[w * 256 + (d >> 8)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N_COARSE; k += 256) hist[(u64)k * n_blocks + blockIdx.x] = h[k];
+}
+__global__ __launch_bounds__(256) void sort_coarse_kernel(const u32* __restrict__ scalars, u64 n, u32 n_blocks, const u32* __restrict__ hist_scanned,
+                                                          u32* __restrict__ coarse /* (i << 8) | low digit byte */) {
+    __shared__ u32 cur[N_COARSE];
+    for (int k = threadIdx.x; k < N_COARSE; k += 256) cur[k] = hist_scanned[(u64)k * n_blocks + blockIdx.x];
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * SORT_PTS;
+    for (u32 t = threadIdx.x; t < SORT_PTS * N_WIN; t += 256) {
+        const u64 i = base + t / N_WIN; const u32 w = t % N_WIN;
+        if (i >= n) break;
+        const u32 d = digit_of(scalars, i, w);
+        if (d) coarse[atomicAdd(&cur[w * 256 + (d >> 8)], 1u)] = ((u32)i << 8) | (d & 0xFF);
+    }
+}
+// grand total of non-zero (point, window) pairs = last scanned entry + last count
+__global__ void sort_total_kernel(const u32* __restrict__ hist, const u32* __restrict__ hist_scanned, u32 last, u32* __restrict__ total) {
+    if ((threadIdx.x | blockIdx.x) == 0) total[0] = hist_scanned[last] + hist[last];
+}
+__global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__ coarse, const u32* __restrict__ hist_scanned, u32 n_blocks, const u32* __restrict__ total,
+                                                         u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ idx) {
+    __shared__ u32 h[256], cur[256];
+    const u32 bin = blockIdx.x;
+    const u32 start = hist_scanned[(u64)bin * n_blocks];
+    const u32 end = bin + 1 < (u32)N_COARSE ? hist_scanned[(u64)(bin + 1) * n_blocks] : total[0];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 k = start + threadIdx.x; k < end; k += 256) atomicAdd(&h[coarse[k] & 0xFF], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // 256-entry exclusive scan
+        u32 acc = start;
+        for (int k = 0; k < 256; ++k) { cur[k] = acc; acc += h[k]; }
+    }
+    __syncthreads();
+    counts[bin * 256 + threadIdx.x] = h[threadIdx.x];
+    offsets[bin * 256 + threadIdx.x] = cur[threadIdx.x];
+    __syncthreads();
+    for (u32 k = start + threadIdx.x; k < end; k += 256) {
+        const u32 e = coarse[k];
+        idx[atomicAdd(&cur[e & 0xFF], 1u)] = e >> 8;
+    }
 }
 
 // ---- bases: external 2*NL words per point -> internal 2*NR limbs, padded to PTW words for 16-byte loads
@@ -380,20 +448,42 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
     buckets.reserve(n_keys * sizeof(xyzz));
     S0.reserve(n_keys / 16 * sizeof(xyzz)); A0.reserve(n_keys / 16 * sizeof(xyzz));
     S1.reserve(n_keys / 256 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));
-    ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
-    ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
     const u64 total = n * N_WIN;
-    const unsigned gb = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(msm_count_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (u32*)counts.p);
-    ZK_HIP(hipGetLastError());
-    const unsigned nb = (unsigned)(n_keys / 1024);
-    hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)counts.p, (u32*)offsets.p, (u32*)tops.p);
-    hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)offsets.p, (const u32*)tops.p);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (const u32*)offsets.p,
-                       (u32*)cursors.p, (u32*)idx.p);
-    ZK_HIP(hipGetLastError());
+    if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
+        const u32 n_blocks = (u32)((n + SORT_PTS - 1) / SORT_PTS);
+        const size_t n_hist = ((size_t)N_COARSE * n_blocks + 1023) / 1024 * 1024;   // scan granularity
+        DevBuf hist, hist_scanned, coarse;
+        hist.reserve(n_hist * 4); hist_scanned.reserve(n_hist * 4); coarse.reserve(total * 4);
+        tops.reserve(n_hist / 1024 * 4 + 4);
+        ZK_HIP(hipMemsetAsync(hist.p, 0, n_hist * 4, st));
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(256), 0, st, (const u32*)d_scalars, n, n_blocks, (u32*)hist.p);
+        const unsigned nb = (unsigned)(n_hist / 1024);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)hist.p, (u32*)hist_scanned.p, (u32*)tops.p);
+        hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)hist_scanned.p, (const u32*)tops.p);
+        ZK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(sort_coarse_kernel, dim3(n_blocks), dim3(256), 0, st, (const u32*)d_scalars, n, n_blocks, (const u32*)hist_scanned.p, (u32*)coarse.p);
+        // the last coarse bin ends at the number of non-zero pairs: last scanned entry + last count, kept on the device
+        hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(64), 0, st, (const u32*)hist.p, (const u32*)hist_scanned.p, (u32)(n_hist - 1), (u32*)tops.p);
+        hipLaunchKernelGGL(sort_fine_kernel2, dim3(N_COARSE), dim3(256), 0, st, (const u32*)coarse.p, (const u32*)hist_scanned.p, n_blocks, (const u32*)tops.p,
+                           (u32*)counts.p, (u32*)offsets.p, (u32*)idx.p);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));  // hist/coarse go back to the pool at scope exit
+    } else {
+        ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
+        ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
+        const unsigned gb = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(msm_count_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (u32*)counts.p);
+        ZK_HIP(hipGetLastError());
+        const unsigned nb = (unsigned)(n_keys / 1024);
+        hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)counts.p, (u32*)offsets.p, (u32*)tops.p);
+        hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)offsets.p, (const u32*)tops.p);
+        ZK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (const u32*)offsets.p,
+                           (u32*)cursors.p, (u32*)idx.p);
+        ZK_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, (const u32*)conv.p,
                        (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (xyzz*)buckets.p);
     ZK_HIP(hipGetLastError());
