@@ -131,6 +131,77 @@ __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restri
     }
 }
 
+
+// ---- cooperative permutation: 16 lanes per permutation, lane l < 12 owns state word l ---------------------
+// A single-lane permutation is a 33 k-instruction dependent chain (~100 us).  The small levels of a Merkle
+// tree, the transcript and every other place where fewer than a few thousand permutations are in flight are
+// bound by that latency, not by throughput; spreading one state over 12 lanes cuts the chain to ~1/5.
+// Words travel by ds_bpermute (__shfl, width 16); constants as in the one-lane version.
+static_assert(ZK_POSEIDON_M[0] == ZK_POSEIDON_M[13] + 8, "MDS = circulant + 8 * E00");
+__host__ __device__ constexpr bool mds_is_circulant() {
+    for (int j = 0; j < 12; ++j)
+        for (int i = 0; i < 12; ++i) {
+            const u64 want = ZK_POSEIDON_M[((j - i + 12) % 12) * 12] - ((j - i + 12) % 12 == 0 ? 8 : 0) + (i == 0 && j == 0 ? 8 : 0);
+            if (ZK_POSEIDON_M[j * 12 + i] != want) return false;
+        }
+    return true;
+}
+static_assert(mds_is_circulant(), "out[i] = sum_k circ[k] * st[(i + k) % 12] (+ 8 st[0] for i = 0)");
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const u32 lo = (u32)__shfl((int)(u32)v, src, 16), hi = (u32)__shfl((int)(u32)(v >> 32), src, 16);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 coop_mds(u64 x, int l) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    const u32 c0 = (u32)ZK_POSEIDON_M[13] + (l == 0 ? 8u : 0u);
+    u64 alo = (u64)lo * c0, ahi = (u64)hi * c0;
+#pragma unroll
+    for (int k = 1; k < 12; ++k) {
+        const int src = l + k >= 12 ? l + k - 12 : l + k;
+        const u32 m = (u32)ZK_POSEIDON_M[k * 12];                    // circ[k], an immediate
+        alo += (u64)(u32)__shfl((int)lo, src, 16) * m;
+        ahi += (u64)(u32)__shfl((int)hi, src, 16) * m;
+    }
+    const u64 lw = alo + (ahi << 32);
+    const u64 hw = (ahi >> 32) + (lw < alo);
+    const u64 t1 = (hw << 32) - hw;
+    u64 r = lw + t1;
+    if (r < t1) r += GL_EPS;
+    return r >= GL_P ? r - GL_P : r;
+}
+__device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12]) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        x0[j] = (u32)__shfl((int)(u32)x, j, 16);
+        x1[j] = (u32)__shfl((int)(u32)(x >> 32), j, 16);
+    }
+}
+// x = this lane's state word (lanes 12..15 of a group carry garbage and only serve the shuffles)
+__device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
+    const int l = threadIdx.x & 15, lc = l < 12 ? l : 11;
+    x = gl::add(x, tab[T_C0 + lc]);
+#pragma unroll 1
+    for (int R = 0; R < 8; ++R) {
+        x = gl::add(pow7(x), tab[T_FC + R * 12 + lc]);
+        if (R != 3) { x = coop_mds(x, l); continue; }
+        {
+            u32 x0[12], x1[12];
+            coop_gather(x, x0, x1);
+            x = dot12(tab + T_PT + 24 * lc, x0, x1);
+        }
+#pragma unroll 1
+        for (int r = 0; r < 22; ++r) {
+            const u64 st0 = shfl64(gl::add(pow7(x), tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
+            u32 x0[12], x1[12];
+            coop_gather(l == 0 ? st0 : x, x0, x1);
+            const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);           // every lane computes the same s0
+            const u64 rest = gl::mul_add(tab[T_SC + 11 * r + (lc > 0 ? lc - 1 : 0)], st0, x);
+            x = l == 0 ? s0 : rest;
+        }
+    }
+    return x;
+}
+
 // LinearHash of one row (linearhash.rs:79-145), one loop around the single inlined permutation.
 // hash(): bs = max(8, ceil(w/4)) words per batch; each batch is digested by _hash (rate-8 sponge,
 // capacity carried, tail zero-padded; a batch of <= 4 words is its own zero-padded digest -- only
@@ -235,6 +306,18 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
 }
 
+// the same for small levels: 16 lanes per parent (coop_perm), 16 parents per block
+__global__ __launch_bounds__(256) void merkle_level_coop_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    ZK_POSEIDON_LDS;
+    load_tables(tab);
+    const int l = threadIdx.x & 15;
+    const u64 i = (u64)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const u64 ic = i < n_ops ? i : n_ops - 1;                  // idle groups shadow the last parent (no divergence)
+    u64 x = l < 8 ? in[8 * ic + l] : 0;
+    x = coop_perm(x, tab);
+    if (i < n_ops && l < 4) out[4 * i + l] = x;
+}
+
 // A tree over zero-width rows (tree2 / tree3 of a PIL without plookups or grand products,
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
@@ -277,14 +360,30 @@ __global__ __launch_bounds__(64) void poseidon_one_kernel(const u64* in8, const 
 // (a sponge is inherently serial); state layout = TranscriptState below.
 struct TranscriptState { u64 state[4]; u64 pending[8]; u64 out[12]; u32 n_pending, out_pos, n_out, _pad; };
 
-__device__ __forceinline__ void tr_update(TranscriptState* t, const u64* __restrict__ tab) {  // transcript.rs:15-24
-    u64 st[12];
-    for (int i = 0; i < 8; ++i) st[i] = (u32)i < t->n_pending ? t->pending[i] : 0;
-    for (int i = 0; i < 4; ++i) st[8 + i] = t->state[i];
-    poseidon_perm(st, tab);
-    for (int i = 0; i < 12; ++i) t->out[i] = st[i];
-    for (int i = 0; i < 4; ++i) t->state[i] = st[i];
-    t->n_pending = 0; t->out_pos = 0; t->n_out = 12;
+// One wave runs the sponge: lanes 0..15 carry the permutation (coop_perm), lane 0 keeps the counters.  The
+// state is staged in LDS for the duration of a kernel so that all lanes see lane 0's bookkeeping.
+__device__ __forceinline__ void tr_load(TranscriptState* ts, const TranscriptState* t) {
+    const u32* g = reinterpret_cast<const u32*>(t); u32* s = reinterpret_cast<u32*>(ts);
+    for (u32 k = threadIdx.x; k < sizeof(TranscriptState) / 4; k += blockDim.x) s[k] = g[k];
+    __syncthreads();
+}
+__device__ __forceinline__ void tr_store(TranscriptState* t, const TranscriptState* ts) {
+    __syncthreads();
+    u32* g = reinterpret_cast<u32*>(t); const u32* s = reinterpret_cast<const u32*>(ts);
+    for (u32 k = threadIdx.x; k < sizeof(TranscriptState) / 4; k += blockDim.x) g[k] = s[k];
+}
+// transcript.rs:15-24; called by every lane of the wave (uniform control flow)
+__device__ __forceinline__ void tr_update(TranscriptState* ts, const u64* __restrict__ tab) {
+    const int l = threadIdx.x & 15;
+    u64 x = 0;
+    if (l < 8) x = (u32)l < ts->n_pending ? ts->pending[l] : 0;
+    else if (l < 12) x = ts->state[l - 8];
+    x = coop_perm(x, tab);
+    __syncthreads();
+    if (threadIdx.x < 12) ts->out[threadIdx.x] = x;
+    if (threadIdx.x < 4) ts->state[threadIdx.x] = x;
+    if (threadIdx.x == 0) { ts->n_pending = 0; ts->out_pos = 0; ts->n_out = 12; }
+    __syncthreads();
 }
 __global__ void tr_init_kernel(TranscriptState* t) {
     if (threadIdx.x | blockIdx.x) return;
@@ -293,37 +392,47 @@ __global__ void tr_init_kernel(TranscriptState* t) {
 }
 __global__ __launch_bounds__(64) void tr_put_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n) {  // transcript.rs:25-33,64-71
     ZK_POSEIDON_LDS;
+    __shared__ TranscriptState ts;
     load_tables(tab);
-    if (threadIdx.x | blockIdx.x) return;
+    tr_load(&ts, t);
     for (u64 i = 0; i < n; ++i) {
-        t->n_out = 0; t->out_pos = 0;
-        t->pending[t->n_pending++] = src[i];
-        if (t->n_pending == 8) tr_update(t, tab);
+        if (threadIdx.x == 0) { ts.n_out = 0; ts.out_pos = 0; ts.pending[ts.n_pending++] = src[i]; }
+        __syncthreads();
+        if (ts.n_pending == 8) tr_update(&ts, tab);
     }
+    tr_store(t, &ts);
 }
 // squeeze n_words (transcript.rs:54-62 get_fields1, repeated); get_field = 3 words.  `bits` != 0
 // turns the squeezed words into n query indices of `bits` bits (get_permutations, :73-102).
 __global__ __launch_bounds__(64) void tr_get_kernel(TranscriptState* t, u64* __restrict__ dst, u32 n, u32 bits) {
     ZK_POSEIDON_LDS;
+    __shared__ TranscriptState ts;
     load_tables(tab);
-    if (threadIdx.x | blockIdx.x) return;
+    tr_load(&ts, t);
     if (bits == 0) {
         for (u32 i = 0; i < n; ++i) {
-            if (t->out_pos >= t->n_out) tr_update(t, tab);
-            dst[i] = t->out[t->out_pos++];
+            if (ts.out_pos >= ts.n_out) tr_update(&ts, tab);
+            if (threadIdx.x == 0) dst[i] = ts.out[ts.out_pos++];
+            __syncthreads();
         }
+        tr_store(t, &ts);
         return;
     }
     u64 field = 0; u32 cur_bit = 63, i = 0, j = 0; u64 a = 0;  // cur_bit = 63 forces a fetch on first use
-    while (i < n) {
+    while (i < n) {                                            // every lane runs the same bookkeeping
         if (cur_bit == 63) {
-            if (t->out_pos >= t->n_out) tr_update(t, tab);
-            field = t->out[t->out_pos++]; cur_bit = 0;
+            if (ts.out_pos >= ts.n_out) tr_update(&ts, tab);
+            field = ts.out[ts.out_pos];
+            __syncthreads();
+            if (threadIdx.x == 0) ts.out_pos++;
+            __syncthreads();
+            cur_bit = 0;
         }
         if ((field >> cur_bit) & 1) a += 1ull << j;
         ++cur_bit; ++j;
-        if (j == bits) { dst[i++] = a; a = 0; j = 0; }
+        if (j == bits) { if (threadIdx.x == 0) dst[i] = a; ++i; a = 0; j = 0; }
     }
+    tr_store(t, &ts);
 }
 
 bool g_consts_loaded[64] = {};
@@ -406,11 +515,19 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
     if (width == 0 && (height & (height - 1)) == 0 && height > 1) {  // all-zero leaves, full binary tree
         uint32_t levels = 0;
         while ((1ull << levels) < height) ++levels;
-        DevBuf hbuf;  // pooled; returned at scope exit, reuse is stream ordered
-        hbuf.reserve((levels + 1) * 32);
-        u64* d_h = hbuf.u();
-        hipLaunchKernelGGL(zero_tree_chain_kernel, dim3(1), dim3(64), 0, st, levels, d_h);
-        ZK_HIP(hipGetLastError());
+        // digest of an all-zero subtree of every height up to 2^32: a property of the hash, not of the proof --
+        // computed once per device (33 serial permutations, 3 ms) and kept
+        static u64* g_zero_chain[64] = {};
+        int dev; ZK_HIP(hipGetDevice(&dev));
+        ZK_REQUIRE(levels <= 32, "merkelize: tree too tall");
+        if (!g_zero_chain[dev]) {
+            u64* d = nullptr;
+            ZK_HIP(hipMalloc((void**)&d, 33 * 32));
+            hipLaunchKernelGGL(zero_tree_chain_kernel, dim3(1), dim3(64), 0, st, 32u, d);
+            ZK_HIP(hipGetLastError());
+            g_zero_chain[dev] = d;
+        }
+        const u64* d_h = g_zero_chain[dev];
         uint64_t n = height, off = 0;
         for (uint32_t l = 1; l <= levels; ++l) {  // level l has height >> l nodes, starting after level l-1
             off += n; n >>= 1;
@@ -422,8 +539,12 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
     linearhash_rows_dev(d_rows, width, height, d_nodes, st);
     uint64_t n64 = height, next = (n64 - 1) / 2 + 1, p_in = 0, p_out = next * 2;
     while (n64 > 1) {  // merklehash.rs:331-343
-        const u64 blocks = (next + 255) / 256;
-        hipLaunchKernelGGL(merkle_level_kernel, dim3((u32)blocks), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        if (next <= 32768) {  // few parents: latency-bound, 16 lanes per permutation
+            hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((u32)((next + 15) / 16)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        } else {
+            const u64 blocks = (next + 255) / 256;
+            hipLaunchKernelGGL(merkle_level_kernel, dim3((u32)blocks), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        }
         ZK_HIP(hipGetLastError());
         n64 = next; next = (n64 - 1) / 2 + 1; p_in = p_out; p_out = p_in + next * 2;
     }
