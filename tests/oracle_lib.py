@@ -1,6 +1,7 @@
 """ctypes wrapper around oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (the checker, never the
 product).  Builds the oracle on first use if the .so is missing (gcc only, seconds)."""
-import ctypes as C, pathlib, subprocess
+import ctypes as C
+import pathlib, subprocess
 import numpy as np
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
@@ -121,6 +122,10 @@ class Oracle:
         self._ec_setup(); bases = _a(bases); o = np.zeros(8, np.uint64)
         inf = self.lib.orc_bn254_msm(bases, _a(scalars), bases.size // 8, c, o); return o, bool(inf)
 
+    def bn128(self):
+        """BN128-field Poseidon / LinearHash / Merkle / transcript (oracle/bn128_hash.c)"""
+        return BN128Hash(self.lib)
+
     def curve(self, name):
         """G1 arithmetic of `name` in ("bn254", "bls12_381") (oracle/ec.c, ec_bls12_381.c over ec_impl.h)."""
         return Curve(self.lib, name)
@@ -173,6 +178,93 @@ def build():
 
 
 _cached = None
+class BN128Hash:
+    """digests and field elements travel as 4 u64 raw (Montgomery) limbs, like ElementDigest<4, Fr>"""
+    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+    def __init__(self, lib):
+        self.lib = L = lib
+        L.orc_bn128_load_constants.argtypes = [C.c_char_p]; L.orc_bn128_load_constants.restype = C.c_int
+        path = str(pathlib.Path(__file__).resolve().parent.parent / "oracle" / "poseidon_bn128_constants.bin")
+        assert L.orc_bn128_load_constants(path.encode()) == 0, "cannot load " + path
+        L.orc_bn128_fr_to_mont.argtypes = [_u64p, _u64p]; L.orc_bn128_fr_from_mont.argtypes = [_u64p, _u64p]
+        L.orc_bn128_poseidon.argtypes = [_u64p, C.c_uint32, _u64p, C.c_uint32, _u64p]; L.orc_bn128_poseidon.restype = C.c_int
+        L.orc_bn128_hash_element_array.argtypes = [_u64p, C.c_uint64, _u64p]; L.orc_bn128_hash_element_array.restype = C.c_int
+        L.orc_bn128_hash_element_matrix.argtypes = [_u64p, C.c_uint64, _u64p]; L.orc_bn128_hash_element_matrix.restype = C.c_int
+        L.orc_bn128_merkle_n_nodes.argtypes = [C.c_uint64]; L.orc_bn128_merkle_n_nodes.restype = C.c_uint64
+        L.orc_bn128_merkle_depth.argtypes = [C.c_uint64]; L.orc_bn128_merkle_depth.restype = C.c_uint32
+        L.orc_bn128_merkelize.argtypes = [_u64p, C.c_uint32, C.c_uint64, _u64p]; L.orc_bn128_merkelize.restype = C.c_int
+        L.orc_bn128_merkle_proof.argtypes = [_u64p, C.c_uint64, C.c_uint64, _u64p]; L.orc_bn128_merkle_proof.restype = None
+        L.orc_bn128_merkle_root_from_proof.argtypes = [_u64p, C.c_uint32, _u64p, _u64p]; L.orc_bn128_merkle_root_from_proof.restype = C.c_int
+        L.orc_bn128_tr_new.restype = C.c_void_p; L.orc_bn128_tr_free.argtypes = [C.c_void_p]
+        L.orc_bn128_tr_put1.argtypes = [C.c_void_p, C.c_uint64]; L.orc_bn128_tr_put4.argtypes = [C.c_void_p, _u64p]
+        L.orc_bn128_tr_get_fields1.argtypes = [C.c_void_p, _u64p]
+        L.orc_bn128_tr_get_permutations.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, _u64p]
+
+    @staticmethod
+    def words(x):
+        return np.array([(x >> (64 * i)) & (2**64 - 1) for i in range(4)], np.uint64)
+    @staticmethod
+    def to_int(w):
+        return sum(int(v) << (64 * i) for i, v in enumerate(w))
+    def to_mont(self, x):
+        """canonical integer -> raw limbs"""
+        o = np.zeros(4, np.uint64); self.lib.orc_bn128_fr_to_mont(self.words(x % self.R), o); return o
+    def from_mont(self, raw):
+        """raw limbs -> canonical integer"""
+        o = np.zeros(4, np.uint64); self.lib.orc_bn128_fr_from_mont(_a(raw), o); return self.to_int(o)
+    def poseidon(self, inp_raw, init_raw=None, n_out=1):
+        inp = _a(np.asarray(inp_raw, np.uint64).reshape(-1)); n = inp.size // 4
+        init = _a(init_raw) if init_raw is not None else np.zeros(4, np.uint64)
+        o = np.zeros(4 * n_out, np.uint64)
+        assert self.lib.orc_bn128_poseidon(inp, n, init, n_out, o) == 0
+        return o.reshape(n_out, 4)
+    def hash_ints(self, vals, init=0, n_out=1):
+        """Poseidon::hash over canonical integers -> canonical integers (the form of poseidon_bn128_opt.rs's tests)"""
+        raw = np.concatenate([self.to_mont(v) for v in vals])
+        return [self.from_mont(r) for r in self.poseidon(raw, self.to_mont(init), n_out)]
+    def hash_element_array(self, vals):
+        v = _a(vals); o = np.zeros(4, np.uint64); assert self.lib.orc_bn128_hash_element_array(v, v.size, o) == 0; return o
+    def hash_element_matrix(self, vals):
+        v = _a(vals); o = np.zeros(4, np.uint64); assert self.lib.orc_bn128_hash_element_matrix(v, v.size, o) == 0; return o
+    def n_nodes(self, height):
+        return int(self.lib.orc_bn128_merkle_n_nodes(height))
+    def depth(self, height):
+        return int(self.lib.orc_bn128_merkle_depth(height))
+    def merkelize(self, rows, width, height):
+        r = _a(rows); nodes = np.zeros(4 * self.n_nodes(height), np.uint64)
+        assert self.lib.orc_bn128_merkelize(r, width, height, nodes) == 0
+        return nodes.reshape(-1, 4)
+    def merkle_proof(self, nodes, height, idx):
+        path = np.zeros(self.depth(height) * 64, np.uint64)
+        self.lib.orc_bn128_merkle_proof(_a(nodes.reshape(-1)), height, idx, path); return path.reshape(-1, 16, 4)
+    def root_from_proof(self, path, leaf):
+        o = np.zeros(4, np.uint64)
+        assert self.lib.orc_bn128_merkle_root_from_proof(_a(path.reshape(-1)), path.shape[0], _a(leaf), o) == 0; return o
+    def transcript(self):
+        return BN128Transcript(self)
+
+
+class BN128Transcript:
+    def __init__(self, h):
+        self.h, self.p = h, h.lib.orc_bn128_tr_new()
+    def put1(self, v):
+        assert self.h.lib.orc_bn128_tr_put1(self.p, int(v)) == 0
+    def put4(self, d):
+        assert self.h.lib.orc_bn128_tr_put4(self.p, _a(d)) == 0
+    def get_fields1(self):
+        o = np.zeros(1, np.uint64); assert self.h.lib.orc_bn128_tr_get_fields1(self.p, o) == 0; return int(o[0])
+    def get_field(self):
+        return [self.get_fields1() for _ in range(3)]
+    def get_permutations(self, n, nbits):
+        o = np.zeros(n, np.uint64); assert self.h.lib.orc_bn128_tr_get_permutations(self.p, n, nbits, o) == 0; return o
+    def __del__(self):
+        try:
+            self.h.lib.orc_bn128_tr_free(self.p)
+        except Exception:
+            pass
+
+
 class Curve:
     """points = 2*nl u64 words x||y (Montgomery), scalars = 4 words canonical little-endian"""
     PARAMS = {"bn254": (4, 21888242871839275222246405745257275088548364400416034343698204186575808495617),
