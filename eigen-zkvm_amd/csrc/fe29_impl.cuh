@@ -1,0 +1,146 @@
+// Prime-field arithmetic in 29-bit limbs for gfx950, shared by the G1 MSM (msm_impl.cuh: Fq of BN254 and
+// BLS12-381) and the BN128-field Poseidon (poseidon_bn128.hip: Fr of BN254).  Included inside a namespace that
+// provides NL (32-bit limbs of the external Montgomery form, R = 2^(32 NL)), NR (29-bit limbs, R' = 2^(29 NR)),
+// Q29, QINV29, ONE29 (R' mod q), CIN29 (R'^2/R mod q), COUT29 (R mod q), Q2_29 / Q4_29 / Q8_29.
+// No include guard on purpose.
+//
+// gfx950 has no cheap carry chain (every v_addc costs two wait states), but v_mad_u64_u32 adds a full 64-bit
+// accumulator for free.  The 2 NR^2 partial products of a Montgomery multiplication (product + reduction)
+// accumulate in 64-bit column registers with no carry handling at all (NR * 2^58 * 2 < 2^63), one
+// shift-and-add per column at the end.  tools/ubench_fq.hip: 156 G products/s against 80 G for the 8 x 32-bit
+// CIOS form.  Values are kept lazily reduced: products are < 2q, sums and differences carry explicit bounds,
+// every pair of multiplicands a < Aq, b < Bq must satisfy A*B <= 168 (BN254; far looser for BLS12-381) so that
+// ab/R' + q stays < 2q.
+constexpr int LB = 29;
+constexpr u32 LMASK = (1u << LB) - 1;
+struct fe { u32 l[NR]; };
+
+__device__ __forceinline__ fe fe_zero() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ fe fe_one() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = ONE29(i);
+    return r;
+}
+// carry propagation: limbs back below 2^29 (the top limb keeps the excess); _s for signed limbs
+__device__ __forceinline__ void fe_norm_u(fe& a) {
+#pragma unroll
+    for (int i = 0; i + 1 < NR; ++i) { a.l[i + 1] += a.l[i] >> LB; a.l[i] &= LMASK; }
+}
+__device__ __forceinline__ void fe_norm_s(fe& a) {
+#pragma unroll
+    for (int i = 0; i + 1 < NR; ++i) { a.l[i + 1] += (u32)((int)a.l[i] >> LB); a.l[i] &= LMASK; }
+}
+__device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = a.l[i] + b.l[i];
+    fe_norm_u(r);
+    return r;
+}
+__device__ __forceinline__ fe fe_dbl(const fe& a) { return fe_add(a, a); }
+// a - b + M q for M in {2, 4, 8}; requires b <= M q so that the value stays non-negative
+template <int M>
+__device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {
+    static_assert(M == 2 || M == 4 || M == 8, "bias");
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = a.l[i] + (M == 2 ? Q2_29(i) : M == 4 ? Q4_29(i) : Q8_29(i)) - b.l[i];
+    fe_norm_s(r);
+    return r;
+}
+// Montgomery product a*b/R' mod q: operands with limbs <= 2^29 and values < 11q, result < 2q, limbs normalised
+#ifndef FQ_MUL_ATTR
+#define FQ_MUL_ATTR __forceinline__
+#endif
+__device__ FQ_MUL_ATTR fe fe_mul(const fe& a, const fe& b) {
+    u64 t[2 * NR];
+#pragma unroll
+    for (int i = 0; i < 2 * NR; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t[i + j] += (u64)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const u32 m = ((u32)t[i] * QINV29) & LMASK;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t[i + j] += (u64)m * Q29(j);
+        t[i + 1] += t[i] >> LB;                       // the low 29 bits of t[i] are zero now
+    }
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (k + 1 < NR) { r.l[k] = (u32)t[NR + k] & LMASK; t[NR + k + 1] += t[NR + k] >> LB; }
+        else r.l[k] = (u32)t[NR + k];
+    }
+    return r;
+}
+__device__ __forceinline__ fe fe_sqr(const fe& a) { return fe_mul(a, a); }
+// x == 0 (mod q) for a product x (< 2q, normalised): x is 0 or q
+__device__ __forceinline__ bool fe_is_zero_m(const fe& a) {
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { z |= a.l[i]; e |= a.l[i] ^ Q29(i); }
+    return z == 0 || e == 0;
+}
+// canonical representative of a value < 2q
+__device__ __forceinline__ fe fe_canon(const fe& a) {
+    fe t;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) t.l[i] = a.l[i] - Q29(i);
+    fe_norm_s(t);
+    const bool neg = (int)t.l[NR - 1] < 0;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
+    return r;
+}
+__device__ fe fe_inv(const fe& a) {  // a^(q-2); q - 2 differs from q in limb 0 only
+    fe r = fe_one();
+    for (int i = NR - 1; i >= 0; --i) {
+        u32 w = Q29(i);
+        if (i == 0) w -= 2;
+        for (int b = LB - 1; b >= 0; --b) {
+            r = fe_sqr(r);
+            if ((w >> b) & 1) r = fe_mul(r, a);
+        }
+    }
+    return r;
+}
+// external layout (NL x 32-bit words, Montgomery R) <-> internal (NR x 29-bit limbs, Montgomery R')
+__device__ __forceinline__ fe fe_from_std(const u32 (&w)[NL]) {
+    fe x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int bit = LB * k, wi = bit >> 5, s = bit & 31;
+        u32 v = wi < NL ? w[wi] >> s : 0;
+        if (s > 32 - LB && wi + 1 < NL) v |= w[wi + 1] << (32 - s);
+        x.l[k] = v & LMASK;
+    }
+    fe c;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.l[i] = CIN29(i);
+    return fe_mul(x, c);                                // x R * (R'^2/R) / R' = x R'
+}
+__device__ __forceinline__ void fe_to_std(const fe& a, u32 (&w)[NL]) {
+    fe c;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.l[i] = COUT29(i);
+    const fe x = fe_canon(fe_mul(a, c));                 // x R' * R / R' = x R, canonical
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int bit = 32 * j, k = bit / LB, s = bit % LB;
+        u32 v = x.l[k] >> s;
+        if (k + 1 < NR) v |= x.l[k + 1] << (LB - s);
+        if (k + 2 < NR && 2 * LB - s < 32) v |= x.l[k + 2] << (2 * LB - s);
+        w[j] = v;
+    }
+}
+

@@ -1,0 +1,272 @@
+// BN128-field hashing for verificationHashType == "BN128" (the final STARK of every aggregation,
+// test/stark_aggregation.sh:199-210) on gfx950:
+//   Poseidon over the BN254 scalar field, t = 2..17      starky/src/poseidon_bn128_opt.rs:98-224
+//   LinearHashBN128::hash_element_array                   starky/src/linearhash_bn128.rs:105-131
+//   MerkleTreeBN128 (arity 16)                            starky/src/merklehash_bn128.rs:26-39, 196-239, 86-106
+// A digest (ElementDigest<4, Fr>) holds the RAW limbs of an Fr, i.e. its Montgomery form a*2^256 mod r
+// (digest.rs:45-53); that is the format of every node buffer here.
+//
+// Mapping: one lane = one permutation; the state (t <= 17 elements of 9 x 29-bit limbs) lives in the lane's
+// private segment, the parameter tables (24 060 constants, converted once per device to the internal
+// Montgomery form) in global memory behind wave-uniform addresses.  Integer-ALU bound: 5 457 Fr products per
+// t = 17 permutation, 225 instructions each (fe29_impl.cuh).  Value bounds: round-boundary state < 2r; a
+// column of the dense products sums 17 products (< 34r) and is brought back below 2r by one product with
+// R' mod r; the sparse rounds' running columns are renormalised every 16 rounds (< 34r in between).
+#include "zk_internal.h"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace zk {
+namespace bn128fr {
+
+constexpr int NL = 8;   // external Montgomery form: R = 2^256
+constexpr int NR = 9;   // internal: R' = 2^261
+constexpr u32 QINV29 = 0x0fffffffu;
+#define ZK_FR_CONST(NAME, ...)                                                      \
+    __host__ __device__ constexpr u32 NAME(int i) { constexpr u32 v[9] = {__VA_ARGS__}; return v[i]; }
+// r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+ZK_FR_CONST(Q29, 0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu)
+ZK_FR_CONST(ONE29, 0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u)
+ZK_FR_CONST(CIN29, 0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u)
+ZK_FR_CONST(COUT29, 0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u)
+ZK_FR_CONST(RRP29, 0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au)  // R'^2 mod r
+ZK_FR_CONST(Q2_29, 0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu)
+ZK_FR_CONST(Q4_29, 0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u)
+ZK_FR_CONST(Q8_29, 0x00000008u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u)
+#undef ZK_FR_CONST
+#define FQ_MUL_ATTR __noinline__   // called from run-time loops over t: one copy keeps the kernels small
+
+namespace {
+#include "fe29_impl.cuh"
+
+// canonical 256-bit integer (8 words, may exceed r) -> internal Montgomery form: x * R'^2 / R' = x R'
+__device__ __forceinline__ fe fe_from_int(const u32 (&w)[NL]) {
+    fe x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int bit = LB * k, wi = bit >> 5, s = bit & 31;
+        u32 v = wi < NL ? w[wi] >> s : 0;
+        if (s > 32 - LB && wi + 1 < NL) v |= w[wi + 1] << (32 - s);
+        x.l[k] = v & LMASK;
+    }
+    fe c;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c.l[i] = RRP29(i);
+    return fe_mul(x, c);
+}
+__device__ __forceinline__ fe fe_renorm(const fe& a) { return fe_mul(a, fe_one()); }   // value < 168r -> < 2r, same residue
+
+// ---- parameter tables: per t (index t-2) offsets into one array of fe --------------------------------
+struct Params { u32 t, n_rp; const fe* c; const fe* m; const fe* p; const fe* s; };
+__device__ Params g_prm[16];
+
+__device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
+
+// st <- (sum_j MAT[j][i] st[j])_i, st[j] < 3r in, < 2r out
+__device__ void matmul(const fe* __restrict__ mat, fe* st, fe* tmp, u32 t) {
+    for (u32 i = 0; i < t; ++i) {
+        fe acc = fe_mul(mat[i], st[0]);
+        for (u32 j = 1; j < t; ++j) acc = fe_add(acc, fe_mul(mat[j * t + i], st[j]));   // < 34r
+        tmp[i] = fe_renorm(acc);
+    }
+    for (u32 i = 0; i < t; ++i) st[i] = tmp[i];
+}
+
+// poseidon_bn128_opt.rs:98-224 hash_inner on st[0..t) (st[0] = init state, st[1..] = inputs), all < 2r
+__device__ void poseidon_fr(fe* st, fe* tmp, u32 t) {
+    const Params P = g_prm[t - 2];
+    for (u32 i = 0; i < t; ++i) st[i] = fe_add(st[i], P.c[i]);
+    for (u32 r = 0; r < 3; ++r) {
+        for (u32 i = 0; i < t; ++i) { pow5(st[i]); st[i] = fe_add(st[i], P.c[(r + 1) * t + i]); }
+        matmul(P.m, st, tmp, t);
+    }
+    for (u32 i = 0; i < t; ++i) { pow5(st[i]); st[i] = fe_add(st[i], P.c[4 * t + i]); }
+    matmul(P.p, st, tmp, t);
+    for (u32 r = 0; r < P.n_rp; ++r) {
+        pow5(st[0]);
+        st[0] = fe_add(st[0], P.c[5 * t + r]);
+        const fe* __restrict__ S = P.s + (size_t)(2 * t - 1) * r;
+        fe s0 = fe_mul(S[0], st[0]);
+        for (u32 j = 1; j < t; ++j) s0 = fe_add(s0, fe_mul(S[j], st[j]));               // < 34r
+        for (u32 k = 1; k < t; ++k) st[k] = fe_add(st[k], fe_mul(S[t + k - 1], st[0])); // grows by < 2r per round
+        st[0] = fe_renorm(s0);
+        if ((r & 15) == 15) for (u32 k = 1; k < t; ++k) st[k] = fe_renorm(st[k]);        // < 2r + 16*2r in between
+    }
+    for (u32 k = 1; k < t; ++k) st[k] = fe_renorm(st[k]);
+    for (u32 r = 0; r < 3; ++r) {
+        for (u32 i = 0; i < t; ++i) { pow5(st[i]); st[i] = fe_add(st[i], P.c[5 * t + P.n_rp + r * t + i]); }
+        matmul(P.m, st, tmp, t);
+    }
+    for (u32 i = 0; i < t; ++i) pow5(st[i]);
+    matmul(P.m, st, tmp, t);
+}
+
+__device__ __forceinline__ fe load_raw(const u64* __restrict__ p) {   // 4 raw limbs -> internal
+    u32 w[NL];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u64 v = p[k]; w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
+    return fe_from_std(w);
+}
+__device__ __forceinline__ void store_raw(const fe& a, u64* __restrict__ p) {
+    u32 w[NL];
+    fe_to_std(a, w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = ((u64)w[2 * k + 1] << 32) | w[2 * k];
+}
+// digest.rs:162-175 to_bn128 / linearhash_bn128.rs:70-91 to_bn128_mont: e0 + e1 2^64 + ... as a field element
+__device__ __forceinline__ fe words_to_fe(const u64* __restrict__ e, u32 n) {
+    u32 w[NL];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const u64 v = (u32)k < n ? e[k] : 0; w[2 * k] = (u32)v; w[2 * k + 1] = (u32)(v >> 32); }
+    return fe_from_int(w);
+}
+
+// table conversion: canonical 32-byte integers -> internal form, in place layout change (8 -> NR words)
+__global__ void bn128_convert_kernel(const u32* __restrict__ canon, u64 n, fe* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[NL];
+    for (int k = 0; k < NL; ++k) w[k] = canon[i * NL + k];
+    out[i] = fe_from_int(w);
+}
+// Poseidon::hash_ex on a batch: inp [n][n_in][4] raw, init [4] raw (shared), out [n][n_out][4] raw
+__global__ __launch_bounds__(64) void bn128_poseidon_kernel(const u64* __restrict__ inp, u64 n, u32 n_in, const u64* __restrict__ init,
+                                                            u32 n_out, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe st[17], tmp[17];
+    st[0] = load_raw(init);
+    for (u32 k = 0; k < n_in; ++k) st[k + 1] = load_raw(inp + (i * n_in + k) * 4);
+    poseidon_fr(st, tmp, n_in + 1);
+    for (u32 k = 0; k < n_out; ++k) store_raw(st[k], out + (i * n_out + k) * 4);
+}
+// LinearHashBN128::hash_element_array per row (linearhash_bn128.rs:105-131)
+__global__ __launch_bounds__(64) void bn128_leaf_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= height) return;
+    const u64* __restrict__ v = rows + i * width;
+    if (width <= 4) { store_raw(words_to_fe(v, width), digests + 4 * i); return; }
+    fe st[17], tmp[17];
+    const u32 nb = (width - 1) / 3 + 1;
+    fe digest = fe_zero();
+    for (u32 b = 0; b < nb; b += 16) {
+        const u32 sz = nb - b < 16 ? nb - b : 16;
+        st[0] = digest;
+        for (u32 k = 0; k < sz; ++k) {
+            const u32 at = 3 * (b + k), len = width - at < 3 ? width - at : 3;
+            st[k + 1] = words_to_fe(v + at, len);
+        }
+        poseidon_fr(st, tmp, sz + 1);
+        digest = st[0];
+    }
+    store_raw(digest, digests + 4 * i);
+}
+// hash_node (linearhash_bn128.rs:93-103): parent i = Poseidon(16 digests, init 0)
+__global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ops) return;
+    fe st[17], tmp[17];
+    st[0] = fe_zero();
+    for (u32 k = 0; k < 16; ++k) st[k + 1] = load_raw(in + (i * 16 + k) * 4);
+    poseidon_fr(st, tmp, 17);
+    store_raw(st[0], out + 4 * i);
+}
+
+struct DeviceTables { fe* all = nullptr; bool ready = false; };
+DeviceTables g_tables[64];
+const u32 NRP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};  // poseidon_bn128_opt.rs:62
+
+void require_tables() {
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    ZK_REQUIRE(dev >= 0 && dev < 64 && g_tables[dev].ready, "BN128 Poseidon constants not loaded (zk_bn128_load_constants)");
+}
+
+}  // namespace
+}  // namespace bn128fr
+
+using namespace bn128fr;
+
+// file format: tools/gen_poseidon_bn128_constants.py
+void bn128_load_constants(const char* path) {
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    if (g_tables[dev].ready) return;
+    FILE* f = fopen(path, "rb");
+    if (!f) throw Error(std::string("cannot open ") + path);
+    std::vector<unsigned char> buf;
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    buf.resize(sz > 0 ? (size_t)sz : 0);
+    const size_t got = fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    ZK_REQUIRE(got == buf.size() && buf.size() >= 8 && !memcmp(buf.data(), "PBN1", 4), "bad BN128 constants file");
+    uint32_t nt; memcpy(&nt, buf.data() + 4, 4);
+    ZK_REQUIRE(nt == 16, "bad BN128 constants file (t range)");
+    std::vector<unsigned char> canon;   // all 32-byte values back to back
+    struct Off { size_t c, m, p, s; u32 t; } off[16];
+    size_t pos = 8, count = 0;
+    for (int k = 0; k < 16; ++k) {
+        ZK_REQUIRE(pos + 12 <= buf.size(), "truncated BN128 constants file");
+        uint32_t h[3]; memcpy(h, buf.data() + pos, 12); pos += 12;
+        const u32 t = h[0], n_c = h[1], n_s = h[2];
+        ZK_REQUIRE(t == (u32)k + 2 && n_c == 5 * t + NRP[k] + 3 * t && n_s == (2 * t - 1) * NRP[k], "unexpected BN128 table shape");
+        const size_t n = n_c + 2 * (size_t)t * t + n_s;
+        ZK_REQUIRE(pos + 32 * n <= buf.size(), "truncated BN128 constants file");
+        off[k] = {count, count + n_c, count + n_c + (size_t)t * t, count + n_c + 2 * (size_t)t * t, t};
+        canon.insert(canon.end(), buf.begin() + pos, buf.begin() + pos + 32 * n);
+        pos += 32 * n; count += n;
+    }
+    DevBuf d_canon; d_canon.reserve(canon.size());
+    ZK_HIP(hipMemcpy(d_canon.p, canon.data(), canon.size(), hipMemcpyHostToDevice));
+    fe* d_all = nullptr;
+    ZK_HIP(hipMalloc((void**)&d_all, count * sizeof(fe)));
+    hipLaunchKernelGGL(bn128_convert_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, (const u32*)d_canon.p, (u64)count, d_all);
+    ZK_HIP(hipGetLastError());
+    Params prm[16];
+    for (int k = 0; k < 16; ++k) prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s};
+    ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prm), prm, sizeof(prm)));
+    ZK_HIP(hipDeviceSynchronize());
+    g_tables[dev].all = d_all; g_tables[dev].ready = true;
+}
+
+void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st) {
+    require_tables();
+    ZK_REQUIRE(n_in >= 1 && n_in <= 16, "Wrong inputs length");            // poseidon_bn128_opt.rs:99-105
+    ZK_REQUIRE(n_out >= 1 && n_out <= n_in + 1, "Wrong output length");
+    if (n == 0) return;
+    hipLaunchKernelGGL(bn128_poseidon_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
+    ZK_HIP(hipGetLastError());
+}
+
+uint64_t bn128_merkle_n_nodes(uint64_t n_) {  // merklehash_bn128.rs:26-39
+    uint64_t n = n_, next_n = (n - 1) / 16 + 1, acc = next_n * 16;
+    while (n > 1) {
+        n = next_n; next_n = (n - 1) / 16 + 1;
+        if (n > 1) acc += next_n * 16; else acc += 1;
+    }
+    return acc;
+}
+
+void bn128_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
+    require_tables();
+    if (height == 0) return;
+    hipLaunchKernelGGL(bn128_leaf_kernel, dim3((unsigned)((height + 63) / 64)), dim3(64), 0, st, d_rows, width, height, d_digests);
+    ZK_HIP(hipGetLastError());
+}
+
+// nodes: bn128_merkle_n_nodes(height) * 4 words, zero-filled by this call (merklehash_bn128.rs:196-239)
+void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st) {
+    require_tables();
+    ZK_REQUIRE(height >= 1, "merkelize: height must be >= 1");
+    const uint64_t nn = bn128_merkle_n_nodes(height);
+    ZK_HIP(hipMemsetAsync(d_nodes, 0, nn * 32, st));
+    if (width) bn128_linearhash_rows_dev(d_rows, width, height, d_nodes, st);
+    uint64_t n = height, next = (n - 1) / 16 + 1, p_in = 0, p_out = next * 16;
+    while (n > 1) {
+        hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        ZK_HIP(hipGetLastError());
+        n = next; next = (n - 1) / 16 + 1; p_in = p_out; p_out = p_in + next * 16;
+    }
+}
+
+}  // namespace zk

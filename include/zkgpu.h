@@ -155,6 +155,41 @@ int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_b
  * (what generate_random_parameters, groth16.rs:39,82, does with secret exponents).                     */
 int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
 
+/* ---- BN128-field hashing: verificationHashType "BN128", the final STARK of every aggregation --------------
+ * (test/stark_aggregation.sh:199-210).  A digest is an ElementDigest<4, Fr> (starky/src/digest.rs:45-65): the
+ * four RAW limbs of an Fr of BN254's scalar field, i.e. its Montgomery form a*2^256 mod r -- every uint64_t[4]
+ * below carries that format, exactly what MTNodeType::from_scalar / as_scalar exchange.
+ * zk_bn128_load_constants reads the Poseidon parameter tables (t = 2..17; data/poseidon_bn128_constants.bin,
+ * written by tools/gen_poseidon_bn128_constants.py from poseidon_bn128_constants_opt.rs) once per device.      */
+int zk_bn128_load_constants(const char* path);
+/* Poseidon::hash_ex(inp, init_state, out) (poseidon_bn128_opt.rs:80-86, 98-224): n_in = 1..16 inputs, t = n_in + 1,
+ * first n_out (<= t) state words.  Wrong lengths are errors, as the reference bails (:99-105).                   */
+int zk_bn128_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out);
+/* batch form on device memory: inp [n][n_in][4], one shared init_state, out [n][n_out][4]                        */
+int zk_bn128_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out,
+                          uint64_t* d_out, void* stream);
+/* LinearHashBN128::hash_element_array (linearhash_bn128.rs:105-131): n Goldilocks words -> digest               */
+int zk_bn128_linearhash(const uint64_t* v, size_t n, uint64_t out[4]);
+/* MerkleTreeBN128 (merklehash_bn128.rs): arity 16; same ownership rules as zk_gl_merkelize(_dev)                */
+typedef struct zk_bn128_merkle zk_bn128_merkle_t;
+uint64_t zk_bn128_merkle_n_nodes(uint64_t height);                        /* :26-39                     */
+zk_bn128_merkle_t* zk_bn128_merkelize(const uint64_t* buff, uint32_t width, uint64_t height);           /* :196-239 */
+zk_bn128_merkle_t* zk_bn128_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream);
+int zk_bn128_merkle_root(const zk_bn128_merkle_t* t, uint64_t out[4]);   /* :275-277                    */
+int zk_bn128_merkle_nodes(const zk_bn128_merkle_t* t, uint64_t* out);    /* all n_nodes*4 words         */
+uint32_t zk_bn128_merkle_depth(const zk_bn128_merkle_t* t);
+/* get_group_proof (:246-254): row_out[width], path_out[depth][16][4]; idx >= height is an error          */
+int zk_bn128_merkle_group_proof(const zk_bn128_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out);
+int zk_bn128_merkle_free(zk_bn128_merkle_t* t);
+/* TranscriptBN128 (transcript_bn128.rs:14-132): put takes one Goldilocks word (n = 1) or one digest (n = 4)       */
+typedef struct zk_bn128_transcript zk_bn128_transcript_t;
+zk_bn128_transcript_t* zk_bn128_transcript_new(void);
+int zk_bn128_transcript_put(zk_bn128_transcript_t* t, const uint64_t* e, size_t n);
+int zk_bn128_transcript_get_fields1(zk_bn128_transcript_t* t, uint64_t* out);
+int zk_bn128_transcript_get_field(zk_bn128_transcript_t* t, uint64_t out[3]);
+int zk_bn128_transcript_get_permutations(zk_bn128_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out);
+int zk_bn128_transcript_free(zk_bn128_transcript_t* t);
+
 /* ---- whole prover (starky/src/prove.rs:95-160: StarkSetup::new + StarkProof::stark_gen + FRI::prove) ------
  * zk_stark_setup_new stands behind StarkSetup::new (stark_setup.rs:27-66): it takes the reference's
  * serialised code-generator output, {"starkinfo": StarkInfo, "program": Program} (serde field names,
