@@ -142,6 +142,42 @@ def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
             "distinct_roots": len({tuple(r) for r in roots})}
 
 
+def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
+    """SURVEY 8f-1 (first widening row): MerkleTreeBN128 over an HBM-resident [2^log_height][width] matrix -- the
+    tree the final STARK of an aggregation commits to (c12a-sized: 12 columns); checked node for node against the
+    CPU oracle on a bounded sample, which is also the timed CPU baseline."""
+    h = 1 << log_height
+    zk.bn128_init()
+    rng = np.random.default_rng(0xB128)
+    rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
+    d = zk.DevArray.from_host(rows)
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        tr = zk.MerkleTreeBN128(); tr.merkelize_dev(d.ptr, width, h); zk.lib().zk_dev_sync()
+        times.append(time.perf_counter() - t0)
+        root = tr.root(); tr.free()
+    nb = (width - 1) // 3 + 1 if width > 4 else 0
+    n, nodes = h, 0
+    while n > 1:
+        n = (n - 1) // 16 + 1; nodes += n
+    res = {"workload": "MerkleTreeBN128, 2^%d rows x %d Goldilocks columns, HBM-resident" % (log_height, width),
+           "ms": round(min(times[1:]) * 1e3, 2), "rows_per_s": round(h / min(times[1:]), 1),
+           "permutations": {"leaf_t%d" % (nb + 1): h * ((nb + 15) // 16), "node_t17": nodes}}
+    if cpu_baseline:
+        import oracle_lib
+        ob = oracle_lib.load().bn128()
+        m = 1 << 19                                                      # bounded CPU sample: the first 2^19 rows
+        t0 = time.perf_counter()
+        exp = ob.merkelize(rows[:m * width], width, m)
+        cpu_s = time.perf_counter() - t0
+        ts = zk.MerkleTreeBN128(); ts.merkelize(rows[:m * width], width, m)
+        assert np.array_equal(ts.nodes(), exp), "GPU BN128 tree != CPU oracle"
+        res["cpu_baseline"] = {"value": round(m / cpu_s, 1), "unit": "rows/s", "cores": oracle_lib.load().threads(), "kind": "port",
+                               "sample": "2^19-row tree of the same matrix, oracle/bn128_hash.c (OpenMP), %.2f s" % cpu_s}
+    return res
+
+
 def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
     """Second component of BASELINE's metric, "BN254 G1 MSM Mpts/s" (config 4): n = 2^22 uniform scalars
     below r, bases [k_i]G generated on the device, everything resident in HBM when the clock starts;
@@ -195,6 +231,7 @@ def main():
     ap.add_argument("--prove-nbits", type=int, default=24)
     ap.add_argument("--agg", action="store_true", help="run the aggregation leg even at N=1")
     ap.add_argument("--agg-nbits", type=int, default=22, help="rows (log2) of each sub-proof of the N>1 aggregation leg")
+    ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 Merkle leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the BN254 MSM leg")
     ap.add_argument("--msm-logn", type=int, default=22)
     args = ap.parse_args()
@@ -286,6 +323,8 @@ def main():
         if not args.no_msm and world == 1:
             out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
             out["msm_g1_bls12_381"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
+        if not args.no_bn128 and world == 1:
+            out["merkle_bn128"] = bn128_merkle_leg(zk, 20, 12, not args.no_cpu_baseline)
         if not args.no_prove and world == 1:
             out["stark_prove"] = prove_leg(zk, args.prove_nbits)
         if agg is not None:

@@ -173,6 +173,86 @@ __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__
     store_raw(st[0], out + 4 * i);
 }
 
+
+// ---- cooperative permutation for the small levels of a tree: 32 lanes per permutation, lane l < t owns st[l].
+// A one-lane t = 17 permutation is a 1.2 M-instruction dependent chain (4.6 ms): the last three levels of every
+// tree (1 + 16 + 256 parents) would cost 14 ms.  Here the 17 columns of a dense product, the 17 S-boxes and the
+// 16 column updates of a sparse round run side by side; words are exchanged through LDS (`xs`: 17 x 9 words per
+// group).  Same bounds as poseidon_fr.  Called by all 64 threads of a block (two groups), uniform control flow.
+__device__ __forceinline__ void coop_put(u32* xs, int l, u32 t, const fe& v) {
+    if ((u32)l < t) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) xs[l * NR + k] = v.l[k];
+    }
+}
+__device__ __forceinline__ fe coop_get(const u32* xs, u32 j) {
+    fe v;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v.l[k] = xs[j * NR + k];
+    return v;
+}
+__device__ fe coop_matmul(const fe* __restrict__ mat, const fe& x, u32* xs, int l, u32 t) {
+    __syncthreads();
+    coop_put(xs, l, t, x);
+    __syncthreads();
+    const u32 lc = (u32)l < t ? l : 0;
+    fe acc = fe_mul(mat[lc], coop_get(xs, 0));
+    for (u32 j = 1; j < t; ++j) acc = fe_add(acc, fe_mul(mat[j * t + lc], coop_get(xs, j)));
+    return fe_renorm(acc);
+}
+__device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
+    const int l = threadIdx.x & 31;
+    const u32 lc = (u32)l < t ? l : 0;
+    const Params P = g_prm[t - 2];
+    x = fe_add(x, P.c[lc]);
+    for (u32 r = 0; r < 3; ++r) {
+        pow5(x); x = fe_add(x, P.c[(r + 1) * t + lc]);
+        x = coop_matmul(P.m, x, xs, l, t);
+    }
+    pow5(x); x = fe_add(x, P.c[4 * t + lc]);
+    x = coop_matmul(P.p, x, xs, l, t);
+    for (u32 r = 0; r < P.n_rp; ++r) {
+        const fe* __restrict__ S = P.s + (size_t)(2 * t - 1) * r;
+        fe y = x;
+        pow5(y); y = fe_add(y, P.c[5 * t + r]);                 // only lane 0's result is used
+        if (l == 0) x = y;
+        __syncthreads();
+        if (l == 0) coop_put(xs, 0, t, x);                      // broadcast the new st[0]
+        __syncthreads();
+        const fe st0 = coop_get(xs, 0);
+        const fe prod = fe_mul(S[lc], x);                       // S[j] * st[j]
+        __syncthreads();
+        coop_put(xs, l, t, prod);
+        __syncthreads();
+        if (l == 0) {
+            fe s0 = coop_get(xs, 0);
+            for (u32 j = 1; j < t; ++j) s0 = fe_add(s0, coop_get(xs, j));   // < 34r
+            x = fe_renorm(s0);
+        } else {
+            x = fe_add(x, fe_mul(S[t + (lc > 0 ? lc : 1) - 1], st0));
+            if ((r & 15) == 15) x = fe_renorm(x);
+        }
+    }
+    if (l != 0) x = fe_renorm(x);
+    for (u32 r = 0; r < 3; ++r) {
+        pow5(x); x = fe_add(x, P.c[5 * t + P.n_rp + r * t + lc]);
+        x = coop_matmul(P.m, x, xs, l, t);
+    }
+    pow5(x);
+    return coop_matmul(P.m, x, xs, l, t);
+}
+__global__ __launch_bounds__(64) void bn128_level_coop_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    __shared__ u32 xs_all[2][17 * NR];
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    u32* xs = xs_all[g];
+    const u64 i = (u64)blockIdx.x * 2 + g;
+    const u64 ic = i < n_ops ? i : n_ops - 1;                   // an idle group shadows the last parent
+    fe x = fe_zero();
+    if (l >= 1 && l <= 16) x = load_raw(in + (ic * 16 + (l - 1)) * 4);
+    x = coop_poseidon_fr(x, xs, 17);
+    if (i < n_ops && l == 0) store_raw(x, out + 4 * i);
+}
+
 struct DeviceTables { fe* all = nullptr; bool ready = false; };
 DeviceTables g_tables[64];
 const u32 NRP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};  // poseidon_bn128_opt.rs:62
@@ -263,7 +343,10 @@ void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
     if (width) bn128_linearhash_rows_dev(d_rows, width, height, d_nodes, st);
     uint64_t n = height, next = (n - 1) / 16 + 1, p_in = 0, p_out = next * 16;
     while (n > 1) {
-        hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        if (next <= 4096)  // latency-bound: 32 lanes per parent
+            hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)((next + 1) / 2)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        else
+            hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         ZK_HIP(hipGetLastError());
         n = next; next = (n - 1) / 16 + 1; p_in = p_out; p_out = p_in + next * 16;
     }
