@@ -39,7 +39,7 @@ EXPORTS = [
     "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_free",
     "zk_bn128_transcript_new", "zk_bn128_transcript_put", "zk_bn128_transcript_get_fields1", "zk_bn128_transcript_get_field",
     "zk_bn128_transcript_get_permutations", "zk_bn128_transcript_free",
-    "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
+    "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
 ]
 
 # include/zkgpu.h enums
@@ -149,6 +149,7 @@ def _load():
         "zk_bn128_transcript_free": (C.c_int, [vp]),
         "zk_stark_setup_new": (vp, [C.c_char_p, C.c_char_p, vp, C.c_uint64]),
         "zk_stark_setup_const_root": (C.c_int, [vp, vp]),
+        "zk_stark_setup_set_prover_addr": (C.c_int, [vp, C.c_char_p]),
         "zk_stark_gen": (vp, [vp, vp, C.c_uint64]),
         "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
         "zk_string_free": (None, [vp]),

@@ -65,10 +65,54 @@ struct PolRef { int slot; u64 width; u64 pos; u32 dim; };
 
 struct ProgramDeleter { void operator()(zk_program_t* p) const { if (p) zk_program_free(p); } };
 using ProgramPtr = std::unique_ptr<zk_program_t, ProgramDeleter>;
-struct TreeDeleter { void operator()(zk_merkle_t* t) const { if (t) zk_merkle_free(t); } };
-using TreePtr = std::unique_ptr<zk_merkle_t, TreeDeleter>;
-struct TranscriptDeleter { void operator()(zk_transcript_t* t) const { if (t) zk_transcript_free(t); } };
-using TranscriptPtr = std::unique_ptr<zk_transcript_t, TranscriptDeleter>;
+// The two instantiations of the reference's generics: StarkProof<MerkleTreeGL>::stark_gen::<TranscriptGL> and
+// StarkProof<MerkleTreeBN128>::stark_gen::<TranscriptBN128> (prove.rs:47-91), chosen by verificationHashType.
+struct AnyTree {
+    zk_merkle_t* gl = nullptr; zk_bn128_merkle_t* bn = nullptr;
+    u32 width = 0; u64 height = 0;
+    AnyTree(bool bn128, const u64* d_rows, u32 w, u64 h, hipStream_t st) : width(w), height(h) {
+        if (bn128) bn = zk_bn128_merkelize_dev(C(d_rows), w, h, st); else gl = zk_gl_merkelize_dev(C(d_rows), w, h, st);
+        if (!gl && !bn) throw Error(zk_last_error());
+    }
+    AnyTree(const AnyTree&) = delete; AnyTree& operator=(const AnyTree&) = delete;
+    ~AnyTree() { if (gl) zk_merkle_free(gl); if (bn) zk_bn128_merkle_free(bn); }
+    void root(u64* out) const { ck(gl ? zk_merkle_root(gl, M(out)) : zk_bn128_merkle_root(bn, M(out))); }
+    u32 depth() const { return gl ? zk_merkle_depth(gl) : zk_bn128_merkle_depth(bn); }
+    u32 level_words() const { return gl ? 4 : 64; }   // one sibling digest, or the 16 digests of the group
+};
+using TreePtr = std::unique_ptr<AnyTree>;
+struct AnyTranscript {
+    zk_transcript_t* gl = nullptr; zk_bn128_transcript_t* bn = nullptr;
+    explicit AnyTranscript(bool bn128) {
+        if (bn128) bn = zk_bn128_transcript_new(); else gl = zk_transcript_new();
+        if (!gl && !bn) throw Error(zk_last_error());
+    }
+    AnyTranscript(const AnyTranscript&) = delete; AnyTranscript& operator=(const AnyTranscript&) = delete;
+    ~AnyTranscript() { if (gl) zk_transcript_free(gl); if (bn) zk_bn128_transcript_free(bn); }
+    // n Goldilocks words, one transcript element each (publics, evals, the last FRI polynomial)
+    void put_words_dev(const u64* d, size_t n, hipStream_t st) {
+        if (!n) return;
+        if (gl) { ck(zk_transcript_put_dev(gl, C(d), n, st)); return; }
+        std::vector<u64> h(n);
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipMemcpy(h.data(), d, 8 * n, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) ck(zk_bn128_transcript_put(bn, M(&h[i]), 1));
+    }
+    void put_root(const AnyTree& t, hipStream_t st) {   // a digest is ONE element of the BN128 transcript
+        if (gl) { ck(zk_transcript_put_dev(gl, zk_merkle_nodes_dev(t.gl) + 4 * (zk_merkle_n_nodes(t.height) - 1), 4, st)); return; }
+        u64 r[4]; t.root(r);
+        ck(zk_bn128_transcript_put(bn, M(r), 4));
+    }
+    void get_field_dev(u64* d_out3, hipStream_t st) {
+        if (gl) { ck(zk_transcript_get_field_dev(gl, M(d_out3), st)); return; }
+        u64 f[3];
+        ck(zk_bn128_transcript_get_field(bn, M(f)));
+        ZK_HIP(hipMemcpy(d_out3, f, 24, hipMemcpyHostToDevice));
+    }
+    void get_permutations(u32 n, u32 nbits, u64* out) {
+        ck(gl ? zk_transcript_get_permutations(gl, n, nbits, M(out)) : zk_bn128_transcript_get_permutations(bn, n, nbits, M(out)));
+    }
+};
 
 struct GroupProof { std::vector<u64> row; std::vector<u64> path; u32 depth; };
 
@@ -85,6 +129,8 @@ struct zk_stark_setup {
     std::vector<u64> cm_n, cm_2ns, tmpexp_n;
     std::map<u64, u64> exp2pol;
     DevBuf const_n, const_2ns;
+    bool bn128 = false;                    // verificationHashType == "BN128"
+    std::string prover_addr;               // StarkProof.prover_addr (serializer.rs:255-262), non-GL proofs only
     TreePtr const_tree;
     u64 const_root[4] = {};
     ProgramPtr step2prev, step3prev, step3, step42ns, step52ns;
@@ -165,7 +211,43 @@ std::vector<u64> u64_list(const JVal& a) {
 }
 
 std::string dec(u64 v) { return std::to_string(v); }
-void put_digest(std::ostringstream& o, const u64* d) {  // digest.rs:84-112
+// a BN128 digest holds the raw Montgomery limbs of an Fr; JSON carries its canonical value in decimal
+// (digest.rs:91-94 -> helper::fr_to_biguint)
+std::string fr_raw_to_dec(const u64* raw) {
+    typedef unsigned __int128 u128;
+    static const u64 RM[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+    const u64 INV = 0xc2e1f593efffffffULL;
+    u64 t[5] = {raw[0], raw[1], raw[2], raw[3], 0};     // Montgomery reduction: raw / 2^256 mod r (into_repr)
+    for (int i = 0; i < 4; ++i) {
+        const u64 m = t[0] * INV;
+        u128 c = ((u128)m * RM[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * RM[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+        c += t[4]; t[3] = (u64)c; t[4] = (u64)(c >> 64);
+    }
+    for (;;) {                                           // canonical: < r
+        bool ge = t[4] != 0;
+        if (!ge) { ge = true; for (int i = 3; i >= 0; --i) { if (t[i] > RM[i]) break; if (t[i] < RM[i]) { ge = false; break; } } }
+        if (!ge) break;
+        u128 br = 0;
+        for (int i = 0; i < 4; ++i) { u128 d = (u128)t[i] - RM[i] - br; t[i] = (u64)d; br = (d >> 64) & 1; }
+        t[4] -= (u64)br;
+    }
+    u64 v[4] = {t[0], t[1], t[2], t[3]};
+    std::string out;
+    for (;;) {                                           // repeated division by 10^18
+        bool zero = !(v[0] | v[1] | v[2] | v[3]);
+        if (zero) break;
+        u128 rem = 0;
+        for (int i = 3; i >= 0; --i) { u128 cur = (rem << 64) | v[i]; v[i] = (u64)(cur / 1000000000000000000ULL); rem = cur % 1000000000000000000ULL; }
+        std::string chunk = std::to_string((u64)rem);
+        const bool last = !(v[0] | v[1] | v[2] | v[3]);
+        if (!last) chunk = std::string(18 - chunk.size(), '0') + chunk;
+        out = chunk + out;
+    }
+    return out.empty() ? "0" : out;
+}
+void put_digest(std::ostringstream& o, const u64* d, bool bn128) {  // digest.rs:84-112
+    if (bn128) { o << '"' << fr_raw_to_dec(d) << '"'; return; }
     if (d[1] == 0 && d[2] == 0 && d[3] == 0) { o << '"' << dec(d[0]) << '"'; return; }
     o << "[\"" << dec(d[0]) << "\",\"" << dec(d[1]) << "\",\"" << dec(d[2]) << "\",\"" << dec(d[3]) << "\"]";
 }
@@ -174,17 +256,25 @@ void put_list(std::ostringstream& o, const u64* v, size_t n) {
     for (size_t i = 0; i < n; ++i) { if (i) o << ','; o << '"' << dec(v[i]) << '"'; }
     o << ']';
 }
-void put_path(std::ostringstream& o, const GroupProof& g) {
+void put_path(std::ostringstream& o, const GroupProof& g, bool bn128) {
     o << '[';
-    for (u32 l = 0; l < g.depth; ++l) { if (l) o << ','; put_list(o, g.path.data() + 4 * l, 4); }
+    for (u32 l = 0; l < g.depth; ++l) {
+        if (l) o << ',';
+        if (!bn128) { put_list(o, g.path.data() + 4 * l, 4); continue; }
+        o << '[';                                        // the 16 nodes of the group, each an Fr (merklehash_bn128.rs:86-106)
+        for (int k = 0; k < 16; ++k) { if (k) o << ','; o << '"' << fr_raw_to_dec(g.path.data() + 64 * l + 4 * k) << '"'; }
+        o << ']';
+    }
     o << ']';
 }
 
-GroupProof group_proof(zk_merkle_t* t, u32 width, u64 idx) {
-    GroupProof g; g.depth = zk_merkle_depth(t);
-    g.row.resize(width ? width : 1); g.path.resize(g.depth ? 4 * g.depth : 4);
-    ck(zk_merkle_group_proof(t, idx, M(g.row.data()), M(g.path.data())));
-    g.row.resize(width);
+GroupProof group_proof(const AnyTree& t, u64 idx) {
+    GroupProof g; g.depth = t.depth();
+    const u32 lw = t.level_words();
+    g.row.resize(t.width ? t.width : 1); g.path.resize(g.depth ? (size_t)lw * g.depth : lw);
+    ck(t.gl ? zk_merkle_group_proof(t.gl, idx, M(g.row.data()), M(g.path.data()))
+            : zk_bn128_merkle_group_proof(t.bn, idx, M(g.row.data()), M(g.path.data())));
+    g.row.resize(t.width);
     return g;
 }
 
@@ -216,9 +306,6 @@ void calculate_h1h2(const std::vector<u64>& f, const std::vector<u64>& t, u64 n,
     }
 }
 
-const u64* tree_root_dev(zk_merkle_t* t, u64 height) {  // the root is the last node (merklehash.rs:455-457)
-    return K(zk_merkle_nodes_dev(t)) + 4 * (zk_merkle_n_nodes(height) - 1);
-}
 
 zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t* const_pols, uint64_t n_words) {
     std::unique_ptr<zk_stark_setup> S(new zk_stark_setup);
@@ -228,7 +315,9 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     const JVal& I = S->info;
     S->nbits = (u32)S->ss.at("nBits").u64(); S->nbits_ext = (u32)S->ss.at("nBitsExt").u64();
     S->n_queries = (u32)S->ss.at("nQueries").u64();
-    ZK_REQUIRE(S->ss.at("verificationHashType").str() == "GL", "only the GL hash is accelerated (SURVEY.md 8f-1)");
+    const std::string& hash_type = S->ss.at("verificationHashType").str();
+    ZK_REQUIRE(hash_type == "GL" || hash_type == "BN128", "verificationHashType must be GL or BN128 (BLS12381 is not on the device yet)");
+    S->bn128 = hash_type == "BN128";
     ZK_REQUIRE(S->nbits >= 1 && S->nbits <= S->nbits_ext && S->nbits_ext <= 32, "bad nBits / nBitsExt");
     for (const JVal& st : S->ss.at("steps").arr) S->steps.push_back((u32)st.at("nBits").u64());
     ZK_REQUIRE(!S->steps.empty(), "starkStruct without FRI steps");
@@ -256,9 +345,8 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         lde_dev(S->const_n.u(), S->const_2ns.u(), tmp.u(), (u32)nc, S->nbits, S->nbits_ext, nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
     }
-    S->const_tree.reset(zk_gl_merkelize_dev(C(S->const_2ns.u()), (u32)nc, Next, nullptr));
-    if (!S->const_tree) throw Error(zk_last_error());
-    ck(zk_merkle_root(S->const_tree.get(), M(S->const_root)));
+    S->const_tree.reset(new AnyTree(S->bn128, S->const_2ns.u(), (u32)nc, Next, nullptr));
+    S->const_tree->root(S->const_root);
     const JVal& P = S->prog;
     S->step2prev = S->compile_segment(P.at("step2prev"), false, false);
     S->step3prev = S->compile_segment(P.at("step3prev"), false, false);
@@ -347,9 +435,9 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         } else throw Error("Invalid public type " + ty);
     }
     if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
-    TranscriptPtr tr(zk_transcript_new());
-    if (!tr) throw Error(zk_last_error());
-    if (!publics.empty()) ck(zk_transcript_put_dev(tr.get(), C(d_pub.u()), publics.size(), st));
+    const bool bn128 = S.bn128;
+    AnyTranscript tr(bn128);
+    tr.put_words_dev(d_pub.u(), publics.size(), st);
 
     std::vector<std::unique_ptr<DevBuf>> keep;                                     // workspaces alive until the end
     auto extend_and_merkelize = [&](int sec_n, int sec_2ns) {                     // stark_gen.rs:709-732
@@ -358,12 +446,10 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             keep.emplace_back(new DevBuf); keep.back()->reserve(width * Next * 8);
             lde_dev(ptr[sec_n], ptr[sec_2ns], keep.back()->u(), (u32)width, nbits, nbits_ext, st);
         }
-        TreePtr t(zk_gl_merkelize_dev(C(ptr[sec_2ns]), (u32)width, Next, st));
-        if (!t) throw Error(zk_last_error());
-        return t;
+        return TreePtr(new AnyTree(bn128, ptr[sec_2ns], (u32)width, Next, st));
     };
-    auto challenge = [&](int i) { ck(zk_transcript_get_field_dev(tr.get(), M(d_chal.u() + 3 * i), st)); };
-    auto put_root = [&](const TreePtr& t, u64 height) { ck(zk_transcript_put_dev(tr.get(), C(tree_root_dev(t.get(), height)), 4, st)); };
+    auto challenge = [&](int i) { tr.get_field_dev(d_chal.u() + 3 * i, st); };
+    auto put_root = [&](const TreePtr& t, u64) { tr.put_root(*t, st); };
 
     TreePtr tree1 = extend_and_merkelize(S_CM1_N, S_CM1_2NS); put_root(tree1, Next);
     challenge(0); challenge(1);                                                    // u, defVal
@@ -415,8 +501,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
         }
     }
-    TreePtr tree4(zk_gl_merkelize_dev(C(ptr[S_CM4_2NS]), (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
-    if (!tree4) throw Error(zk_last_error());
+    TreePtr tree4(new AnyTree(bn128, ptr[S_CM4_2NS], (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
     put_root(tree4, Next);
     challenge(7);                                                                  // xi
     const u64* d_xi = d_chal.u() + 3 * 7;
@@ -438,7 +523,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             descs.push_back(d);
         }
         evals_dev(descs.data(), n_ev, nbits, ext, LEv.u(), LpEv.u(), d_evals.u(), st);
-        ck(zk_transcript_put_dev(tr.get(), C(d_evals.u()), 3 * (size_t)n_ev, st));     // stark_gen.rs:469-472
+        tr.put_words_dev(d_evals.u(), 3 * (size_t)n_ev, st);                          // stark_gen.rs:469-472
     }
     challenge(5); challenge(6);                                                    // v1, v2
     xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);                        // stark_gen.rs:481-522
@@ -459,7 +544,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     for (size_t si = 0; si < n_steps; ++si) {
         const u32 step_bits = steps[si];
         ZK_REQUIRE(step_bits <= pol_bits, "FRI steps must not grow");
-        ck(zk_transcript_get_field_dev(tr.get(), M(d_sx.u()), st));                    // special_x
+        tr.get_field_dev(d_sx.u(), st);                                                // special_x
         keep.emplace_back(new DevBuf); DevBuf& folded = *keep.back(); folded.reserve((3ull << step_bits) * 8);
         fri_fold_dev(d_pol, pol_bits, step_bits, d_sx.u(), shift_inv, folded.u(), st);
         d_pol = folded.u();
@@ -470,30 +555,28 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             keep.emplace_back(new DevBuf); DevBuf& tb = *keep.back(); tb.reserve((3ull << step_bits) * 8);
             fri_transpose_dev(d_pol, 1ull << step_bits, nxt, tb.u(), st);
             fri_width[si] = (u32)(3 * group_size);
-            fri_trees[si].reset(zk_gl_merkelize_dev(C(tb.u()), fri_width[si], n_groups, st));
-            if (!fri_trees[si]) throw Error(zk_last_error());
-            ck(zk_merkle_root(fri_trees[si].get(), M(fri_roots[si].data())));
-            ck(zk_transcript_put_dev(tr.get(), C(tree_root_dev(fri_trees[si].get(), n_groups)), 4, st));
+            fri_trees[si].reset(new AnyTree(bn128, tb.u(), fri_width[si], n_groups, st));
+            fri_trees[si]->root(fri_roots[si].data());
+            tr.put_root(*fri_trees[si], st);
         } else {
-            ck(zk_transcript_put_dev(tr.get(), C(d_pol), 3ull << step_bits, st));      // fri.rs:136-141
+            tr.put_words_dev(d_pol, 3ull << step_bits, st);                             // fri.rs:136-141
         }
         for (u32 k = 0; k < pol_bits - step_bits; ++k) shift_inv = gl::hmul(shift_inv, shift_inv);
         pol_bits = step_bits;
     }
     std::vector<u64> ys(S.n_queries);
-    ck(zk_transcript_get_permutations(tr.get(), S.n_queries, steps[0], M(ys.data())));  // fri.rs:158
+    tr.get_permutations(S.n_queries, steps[0], ys.data());                             // fri.rs:158
 
     // ---- proof -> zkin JSON (serializer.rs:146-261)
     u64 r1[4], r2[4], r3[4], r4[4];
-    ck(zk_merkle_root(tree1.get(), M(r1))); ck(zk_merkle_root(tree2.get(), M(r2)));
-    ck(zk_merkle_root(tree3.get(), M(r3))); ck(zk_merkle_root(tree4.get(), M(r4)));
+    tree1->root(r1); tree2->root(r2); tree3->root(r3); tree4->root(r4);
     std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev));
     ZK_HIP(hipStreamSynchronize(st));
     if (n_ev) ZK_HIP(hipMemcpy(ev_host.data(), d_evals.p, 24 * (size_t)n_ev, hipMemcpyDeviceToHost));
     std::ostringstream o;
-    o << "{\"rootC\":"; put_digest(o, S.const_root);
-    o << ",\"root1\":"; put_digest(o, r1); o << ",\"root2\":"; put_digest(o, r2);
-    o << ",\"root3\":"; put_digest(o, r3); o << ",\"root4\":"; put_digest(o, r4);
+    o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
+    o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
+    o << ",\"root3\":"; put_digest(o, r3, bn128); o << ",\"root4\":"; put_digest(o, r4, bn128);
     o << ",\"evals\":[";
     for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
     o << ']';
@@ -502,21 +585,20 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     for (size_t si = 1; si < n_steps; ++si) {
         for (u64& y : ysi) y %= (1ull << steps[si]);
         std::vector<GroupProof> gp;
-        for (u64 y : ysi) gp.push_back(group_proof(fri_trees[si - 1].get(), fri_width[si - 1], y));
-        o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data());
+        for (u64 y : ysi) gp.push_back(group_proof(*fri_trees[si - 1], y));
+        o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);
         o << ",\"s" << si << "_vals\":[";
         for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
         o << "],\"s" << si << "_siblings\":[";
-        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_path(o, gp[q]); }
+        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_path(o, gp[q], bn128); }
         o << ']';
     }
     {   // step 0: openings of the five trees at the query indices
-        zk_merkle_t* trees0[5] = {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()};
-        const u32 widths[5] = {(u32)sN[S_CM1_2NS], (u32)sN[S_CM2_2NS], (u32)sN[S_CM3_2NS], (u32)sN[S_CM4_2NS], S.n_constants};
+        const AnyTree* trees0[5] = {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()};
         const char* names[5] = {"1", "2", "3", "4", "C"};
         std::vector<std::vector<GroupProof>> gp(5);
         for (int j = 0; j < 5; ++j)
-            for (u64 y : ys) gp[j].push_back(group_proof(trees0[j], widths[j], y));
+            for (u64 y : ys) gp[j].push_back(group_proof(*trees0[j], y));
         for (int j = 0; j < 5; ++j) {
             o << ",\"s0_vals" << names[j] << "\":[";
             for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
@@ -524,7 +606,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         }
         for (int j = 0; j < 5; ++j) {
             o << ",\"s0_siblings" << names[j] << "\":[";
-            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_path(o, gp[j][q]); }
+            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_path(o, gp[j][q], bn128); }
             o << ']';
         }
     }
@@ -537,6 +619,11 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         o << ']';
     }
     o << ",\"publics\":"; put_list(o, publics.data(), publics.size());
+    if (bn128) {                                          // serializer.rs:255-262: non-GL proofs carry the prover address
+        o << ",\"proverAddr\":\"";
+        for (char c : S.prover_addr) { if (c == '"' || c == '\\') o << '\\'; o << c; }
+        o << '"';
+    }
     o << '}';
     return o.str();
 }
@@ -590,6 +677,10 @@ char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t 
             memcpy(out, z.c_str(), z.size() + 1);
         }) != 0) return nullptr;
     return out;
+}
+
+int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr) {
+    return guard([&] { ZK_REQUIRE(s && prover_addr, "null argument"); s->prover_addr = prover_addr; });
 }
 
 void zk_string_free(char* s) { free(s); }

@@ -356,11 +356,16 @@ class NativeStarkSetup:
     """The C++ driver inside libzkgpu (csrc/stark_prover.hip): StarkSetup::new + stark_gen + FRI::prove
     behind zk_stark_setup_new / zk_stark_gen.  `program_json` = '{"starkinfo": ..., "program": ...}' text."""
 
-    def __init__(self, const_n, program_json, stark_struct_json):
+    def __init__(self, const_n, program_json, stark_struct_json, prover_addr=None):
         c = _np(const_n)
+        if json.loads(stark_struct_json).get("verificationHashType") == "BN128":
+            from . import bn128_init
+            bn128_init()
         self._h = lib().zk_stark_setup_new(program_json.encode(), stark_struct_json.encode(), _ptr(c), c.size)
         if not self._h:
             raise ZkError(lib().zk_last_error().decode())
+        if prover_addr is not None:
+            _check(lib().zk_stark_setup_set_prover_addr(self._h, prover_addr.encode()))
 
     def const_root(self):
         o = np.zeros(4, np.uint64); _check(lib().zk_stark_setup_const_root(self._h, _ptr(o))); return [int(v) for v in o]

@@ -193,7 +193,8 @@ int zk_bn128_transcript_free(zk_bn128_transcript_t* t);
 /* ---- whole prover (starky/src/prove.rs:95-160: StarkSetup::new + StarkProof::stark_gen + FRI::prove) ------
  * zk_stark_setup_new stands behind StarkSetup::new (stark_setup.rs:27-66): it takes the reference's
  * serialised code-generator output, {"starkinfo": StarkInfo, "program": Program} (serde field names,
- * starkinfo.rs:27-95), the StarkStruct JSON (verificationHashType must be "GL") and the constant
+ * starkinfo.rs:27-95), the StarkStruct JSON (verificationHashType "GL", or "BN128" after
+ * zk_bn128_load_constants: MerkleTreeBN128 + TranscriptBN128, prove.rs:47-61) and the constant
  * polynomials ([2^nBits][n_constants] words, the .const file, polsarray.rs:137-217); it extends and
  * merkelizes the constants on the device and compiles the step programs for gfx950.
  * zk_stark_gen stands behind StarkProof::stark_gen (stark_gen.rs:193-202) + FRI::prove (fri.rs:84-89):
@@ -205,6 +206,8 @@ typedef struct zk_stark_setup zk_stark_setup_t;
 zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const char* stark_struct_json,
                                      const uint64_t* const_pols, uint64_t n_words);
 int zk_stark_setup_const_root(const zk_stark_setup_t* s, uint64_t out[4]);   /* StarkSetup.const_root */
+/* stark_gen's `prover_addr` argument (stark_gen.rs:201): echoed as "proverAddr" by non-GL proofs (serializer.rs:255-262) */
+int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr);
 char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_words);
 /* same with the trace already resident in HBM (borrowed, not modified), e.g. written there by a device-side
  * witness generator or uploaded while the previous proof was running                                     */

@@ -85,6 +85,58 @@ def setup(pil_json, const_path, stark_struct, orc):
     return {"const_n": const_n, "const_2ns": const_2ns, "const_tree": const_tree, "starkinfo": info, "program": prog}
 
 
+class BN128Backend:
+    """Stands in for the oracle handle when verificationHashType == "BN128": the reference's
+    StarkProof<MerkleTreeBN128>::stark_gen::<TranscriptBN128> (prove.rs:47-61) differs from the GL instantiation
+    only through the MerkleTree and Transcript traits; everything else is delegated to the GL oracle.
+    Digests are 4 raw (Montgomery) limbs; a group-proof path is [depth][16] digests (merklehash_bn128.rs:86-106)."""
+
+    def __init__(self, orc):
+        self._orc, self._h = orc, orc.bn128()
+
+    def __getattr__(self, name):
+        return getattr(self._orc, name)
+
+    def merkelize(self, rows, width, height):
+        return self._h.merkelize(np.asarray(rows, np.uint64), width, height).reshape(-1)
+
+    def merkle_proof(self, nodes, height, idx):
+        return self._h.merkle_proof(np.asarray(nodes, np.uint64).reshape(-1, 4), height, idx).reshape(-1)
+
+    def root_from_proof(self, row, path, idx):
+        """verify_group_proof (merklehash_bn128.rs:130-138, 260-269): leaf = hash_element_matrix(row)"""
+        leaf = self._h.hash_element_matrix(np.asarray(row, np.uint64))
+        return self._h.root_from_proof(np.asarray(path, np.uint64).reshape(-1, 16, 4), leaf)
+
+    def transcript(self):
+        return _BN128Transcript(self._h)
+
+    def digest_str(self, d):
+        return str(self._h.from_mont(np.asarray(d, np.uint64)))
+
+
+class _BN128Transcript:
+    """TranscriptBN128::put (transcript_bn128.rs:90-101): 4 words = one digest, anything else one element per word
+    (stark_gen.rs absorbs publics, evals and the last polynomial word by word, roots as digests)"""
+
+    def __init__(self, h):
+        self.t = h.transcript()
+
+    def put(self, v):
+        v = np.asarray(v, np.uint64).reshape(-1)
+        if v.size == 4:
+            self.t.put4(v)
+        else:
+            for w in v:
+                self.t.put1(int(w))
+
+    def get_field(self):
+        return np.array(self.t.get_field(), np.uint64)
+
+    def get_permutations(self, n, nbits):
+        return self.t.get_permutations(n, nbits)
+
+
 def group_proof(orc, nodes, elements, width, height, idx):
     row = [int(v) for v in elements[idx * width:(idx + 1) * width]]
     path = orc.merkle_proof(nodes, height, idx).reshape(-1, 4)
@@ -273,6 +325,31 @@ def fri_prove(orc, tr, pol, stark_struct, query_pol):                         # 
 # ---- serializer.rs:140-264 ---------------------------------------------------------------------------
 def _digest(d):                                                               # digest.rs:84-112
     return str(d[0]) if d[1] == 0 and d[2] == 0 and d[3] == 0 else [str(v) for v in d]
+
+
+def to_zkin_bn128(proof, backend, prover_addr=""):
+    """serializer.rs:146-262 for MerkleTreeBN128: digests and siblings are decimal Fr, 16 siblings per level"""
+    dg = backend.digest_str
+    z = {"rootC": dg(proof["rootC"])}
+    for k in ("root1", "root2", "root3", "root4"):
+        z[k] = dg(proof[k])
+    z["evals"] = [[str(v) for v in e] for e in proof["evals"]]
+    qs = proof["fri_proof"]["queries"]
+    def sib(path):                                                            # path: depth*16 rows of 4 raw limbs
+        return [[dg(path[16 * l + k]) for k in range(16)] for l in range(len(path) // 16)]
+    for i in range(1, len(qs)):
+        z["s%d_root" % i] = dg(qs[i]["root"])
+        z["s%d_vals" % i] = [[str(v) for v in q[0][0]] for q in qs[i]["pol_queries"]]
+        z["s%d_siblings" % i] = [sib(q[0][1]) for q in qs[i]["pol_queries"]]
+    names = ["1", "2", "3", "4", "C"]
+    for j, nm in enumerate(names):
+        z["s0_vals" + nm] = [[str(v) for v in q[j][0]] for q in qs[0]["pol_queries"]]
+    for j, nm in enumerate(names):
+        z["s0_siblings" + nm] = [sib(q[j][1]) for q in qs[0]["pol_queries"]]
+    z["finalPol"] = [[str(v) for v in e] for e in proof["fri_proof"]["last"]]
+    z["publics"] = [str(p) for p in proof["publics"]]
+    z["proverAddr"] = prover_addr
+    return z
 
 
 def to_zkin(proof):

@@ -82,9 +82,42 @@ def test_native_driver_rejects_bad_input(zk):
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     with pytest.raises(zk.ZkError):
         stark.NativeStarkSetup(np.zeros(4, np.uint64), "{not json", json.dumps(GL_STRUCT))
-    bn = dict(GL_STRUCT, verificationHashType="BN128")
+    bls = dict(GL_STRUCT, verificationHashType="BLS12381")
     d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    with pytest.raises(zk.ZkError):                                          # only the GL hash is on the device
-        stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bn))
+    with pytest.raises(zk.ZkError):                                          # GL and BN128 are on the device, BLS12381 is not
+        stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bls))
     with pytest.raises(zk.ZkError):                                          # const trace of the wrong size
         stark.NativeStarkSetup(np.zeros(5, np.uint64), json.dumps(d), json.dumps(GL_STRUCT))
+
+
+BN128_STRUCT = dict(GL_STRUCT, verificationHashType="BN128")                 # starky/data/starkStruct.json
+BN128_CASES = {"fibonacci": CASES["fibonacci_imP"], "permutation": CASES["permutation"],
+               "plookup": ("plookup.pil.json", "plookup.const", "plookup.cm"), "connection": CASES["connection"]}
+PROVER_ADDR = "273030697313060285579891744179749754319274977764"               # stark_gen.rs:1012
+
+
+@pytest.mark.parametrize("name", list(BN128_CASES))
+def test_native_driver_bn128_zkin_equals_oracle_zkin(zk, orc, name):
+    """verificationHashType BN128 (StarkProof<MerkleTreeBN128>::stark_gen::<TranscriptBN128>, the instantiation the
+    reference's own tests prove, stark_gen.rs:981-1146): GPU proof == oracle proof, and the restated verifier accepts."""
+    import importlib
+    import numpy as np
+    import stark_prover as SP
+    import starkinfo as SI
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    pil_f, const_f, cm_f = BN128_CASES[name]
+    pil = json.load(open(D / pil_f))
+    b = SP.BN128Backend(orc)
+    su = SP.setup(pil, D / const_f, BN128_STRUCT, b)
+    proof = SP.stark_gen(D / cm_f, su, BN128_STRUCT, b)
+    assert SP.stark_verify(proof, proof["rootC"], su["starkinfo"], su["program"], BN128_STRUCT, b)
+    exp = SP.to_zkin_bn128(proof, b, PROVER_ADDR)
+    if name == "fibonacci":                                                  # stark_setup.rs:83-97
+        assert exp["rootC"] == "4658128321472362347225942316135505030498162093259225938328465623672244875764"
+    ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"), json.dumps(SI.to_json(su["starkinfo"], su["program"])),
+                                json.dumps(BN128_STRUCT), prover_addr=PROVER_ADDR)
+    got = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))
+    assert list(got.keys()) == list(exp.keys())
+    for k in exp:
+        assert got[k] == exp[k], k

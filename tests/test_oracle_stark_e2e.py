@@ -62,3 +62,33 @@ def test_fib_gl_const_root_is_the_reference_kat(orc, golden):
     import stark_prover as SP
     su = SP.setup(json.load(open(D / "fib.pil.json.gl")), D / "fib.const.gl", GL_STRUCT, orc)
     assert [int(v) for v in su["const_tree"][-4:]] == golden["const_root_fib_gl"]["root"]   # stark_setup.rs:100-116
+
+
+# ---- verificationHashType "BN128": the instantiation the reference's own tests prove (stark_gen.rs:981-1146) ----
+BN128_STRUCT = dict(GL_STRUCT, verificationHashType="BN128")                 # starky/data/starkStruct.json
+
+
+def test_bn128_const_root_known_answer(orc):
+    """stark_setup.rs:83-97: LDE + MerkleTreeBN128 of data/fib.const"""
+    import stark_prover as SP
+    b = SP.BN128Backend(orc)
+    su = SP.setup(json.load(open(D / "fib.pil.json")), D / "fib.const", BN128_STRUCT, b)
+    assert b.digest_str(su["const_tree"][-4:]) == "4658128321472362347225942316135505030498162093259225938328465623672244875764"
+
+
+@pytest.mark.parametrize("pil_f,const_f,cm_f", [("fib.pil.json", "fib.const", "fib.cm"), ("plookup.pil.json", "plookup.const", "plookup.cm")])
+def test_bn128_prove_then_verify_and_tamper(orc, pil_f, const_f, cm_f):
+    import stark_prover as SP
+    b = SP.BN128Backend(orc)
+    su = SP.setup(json.load(open(D / pil_f)), D / const_f, BN128_STRUCT, b)
+    proof = SP.stark_gen(D / cm_f, su, BN128_STRUCT, b)
+    assert SP.stark_verify(proof, proof["rootC"], su["starkinfo"], su["program"], BN128_STRUCT, b)
+    bad = copy.deepcopy(proof)
+    bad["evals"][0][0] = (bad["evals"][0][0] + 1) % 0xFFFFFFFF00000001
+    try:
+        ok = SP.stark_verify(bad, bad["rootC"], su["starkinfo"], su["program"], BN128_STRUCT, b)
+    except ValueError:
+        ok = False
+    assert not ok
+    z = SP.to_zkin_bn128(proof, b, "addr")
+    assert list(z)[-1] == "proverAddr" and len(z["s0_siblings1"][0][0]) == 16
