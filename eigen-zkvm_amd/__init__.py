@@ -39,6 +39,11 @@ EXPORTS = [
     "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_free",
     "zk_bn128_transcript_new", "zk_bn128_transcript_put", "zk_bn128_transcript_get_fields1", "zk_bn128_transcript_get_field",
     "zk_bn128_transcript_get_permutations", "zk_bn128_transcript_free",
+    "zk_bls12381_load_constants", "zk_bls12381_poseidon", "zk_bls12381_poseidon_dev", "zk_bls12381_linearhash",
+    "zk_bls12381_merkle_n_nodes", "zk_bls12381_merkelize", "zk_bls12381_merkelize_dev", "zk_bls12381_merkle_root", "zk_bls12381_merkle_nodes",
+    "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_free",
+    "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
+    "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
     "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
 ]
 
@@ -147,6 +152,24 @@ def _load():
         "zk_bn128_transcript_get_field": (C.c_int, [vp, vp]),
         "zk_bn128_transcript_get_permutations": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "zk_bn128_transcript_free": (C.c_int, [vp]),
+        "zk_bls12381_load_constants": (C.c_int, [C.c_char_p]),
+        "zk_bls12381_poseidon": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
+        "zk_bls12381_poseidon_dev": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp]),
+        "zk_bls12381_linearhash": (C.c_int, [vp, C.c_size_t, vp]),
+        "zk_bls12381_merkle_n_nodes": (C.c_uint64, [C.c_uint64]),
+        "zk_bls12381_merkelize": (vp, [vp, C.c_uint32, C.c_uint64]),
+        "zk_bls12381_merkelize_dev": (vp, [vp, C.c_uint32, C.c_uint64, vp]),
+        "zk_bls12381_merkle_root": (C.c_int, [vp, vp]),
+        "zk_bls12381_merkle_nodes": (C.c_int, [vp, vp]),
+        "zk_bls12381_merkle_depth": (C.c_uint32, [vp]),
+        "zk_bls12381_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_bls12381_merkle_free": (C.c_int, [vp]),
+        "zk_bls12381_transcript_new": (vp, []),
+        "zk_bls12381_transcript_put": (C.c_int, [vp, vp, C.c_size_t]),
+        "zk_bls12381_transcript_get_fields1": (C.c_int, [vp, vp]),
+        "zk_bls12381_transcript_get_field": (C.c_int, [vp, vp]),
+        "zk_bls12381_transcript_get_permutations": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
+        "zk_bls12381_transcript_free": (C.c_int, [vp]),
         "zk_stark_setup_new": (vp, [C.c_char_p, C.c_char_p, vp, C.c_uint64]),
         "zk_stark_setup_const_root": (C.c_int, [vp, vp]),
         "zk_stark_setup_set_prover_addr": (C.c_int, [vp, C.c_char_p]),
@@ -453,63 +476,70 @@ class Program:
 
 # ---- BN128-field hashing (verificationHashType "BN128"): poseidon_bn128_opt.rs, linearhash_bn128.rs, ------
 # ---- merklehash_bn128.rs, transcript_bn128.rs.  Digests / field elements = 4 u64 raw (Montgomery) limbs.
-def bn128_init(path=None):
-    """loads the Poseidon-BN128 parameter tables on the current device (once)"""
+def _fr(name, field):
+    """the C entry point zk_<field>_<name>; field in ("bn128", "bls12381")"""
+    if field not in ("bn128", "bls12381"):
+        raise ZkError("unknown scalar field " + str(field))
+    return getattr(lib(), "zk_%s_%s" % (field, name))
+
+
+def bn128_init(path=None, field="bn128"):
+    """loads the Poseidon parameter tables of `field` on the current device (once)"""
     import pathlib
-    p = path or str(pathlib.Path(__file__).resolve().parent / "data" / "poseidon_bn128_constants.bin")
-    _check(lib().zk_bn128_load_constants(str(p).encode()))
+    p = path or str(pathlib.Path(__file__).resolve().parent / "data" / ("poseidon_%s_constants.bin" % field))
+    _check(_fr("load_constants", field)(str(p).encode()))
 
 
-def bn128_poseidon(inp, init_state=None, n_out=1):
+def bn128_poseidon(inp, init_state=None, n_out=1, field="bn128"):
     """Poseidon::hash_ex: inp [n_in][4] raw limbs -> [n_out][4]"""
     a = _np(inp).reshape(-1); n_in = a.size // 4
     init = _np(init_state) if init_state is not None else np.zeros(4, np.uint64)
     out = np.zeros(4 * max(1, n_out), np.uint64)
-    _check(lib().zk_bn128_poseidon(_ptr(a), n_in, _ptr(init), n_out, _ptr(out)))
+    _check(_fr("poseidon", field)(_ptr(a), n_in, _ptr(init), n_out, _ptr(out)))
     return out.reshape(-1, 4)[:n_out]
 
 
-def bn128_linearhash(vals):
+def bn128_linearhash(vals, field="bn128"):
     """LinearHashBN128::hash_element_array"""
     v = _np(vals); out = np.zeros(4, np.uint64)
-    _check(lib().zk_bn128_linearhash(_ptr(v), v.size, _ptr(out))); return out
+    _check(_fr("linearhash", field)(_ptr(v), v.size, _ptr(out))); return out
 
 
 class MerkleTreeBN128:
     """trait MerkleTree for MerkleTreeBN128 (merklehash_bn128.rs:139-278)"""
 
-    def __init__(self):
-        self._h, self.width, self.height = None, 0, 0
+    def __init__(self, field="bn128"):
+        self._h, self.width, self.height, self.field = None, 0, 0, field
 
     def merkelize(self, buff, width, height):
         b = _np(buff)
-        self._h = lib().zk_bn128_merkelize(_ptr(b), width, height)
+        self._h = _fr("merkelize", self.field)(_ptr(b), width, height)
         if not self._h:
             raise ZkError(lib().zk_last_error().decode())
         self.width, self.height = width, height
 
     def merkelize_dev(self, d_ptr, width, height, stream=0):
-        self._h = lib().zk_bn128_merkelize_dev(d_ptr, width, height, stream)
+        self._h = _fr("merkelize_dev", self.field)(d_ptr, width, height, stream)
         if not self._h:
             raise ZkError(lib().zk_last_error().decode())
         self.width, self.height = width, height
 
     def root(self):
-        o = np.zeros(4, np.uint64); _check(lib().zk_bn128_merkle_root(self._h, _ptr(o))); return o
+        o = np.zeros(4, np.uint64); _check(_fr("merkle_root", self.field)(self._h, _ptr(o))); return o
 
     def nodes(self):
-        o = np.zeros(4 * lib().zk_bn128_merkle_n_nodes(self.height), np.uint64)
-        _check(lib().zk_bn128_merkle_nodes(self._h, _ptr(o))); return o.reshape(-1, 4)
+        o = np.zeros(4 * _fr("merkle_n_nodes", self.field)(self.height), np.uint64)
+        _check(_fr("merkle_nodes", self.field)(self._h, _ptr(o))); return o.reshape(-1, 4)
 
     def get_group_proof(self, idx):
-        depth = lib().zk_bn128_merkle_depth(self._h)
+        depth = _fr("merkle_depth", self.field)(self._h)
         row, path = np.zeros(max(1, self.width), np.uint64), np.zeros(max(1, depth) * 64, np.uint64)
-        _check(lib().zk_bn128_merkle_group_proof(self._h, idx, _ptr(row), _ptr(path)))
+        _check(_fr("merkle_group_proof", self.field)(self._h, idx, _ptr(row), _ptr(path)))
         return row[:self.width], path[:depth * 64].reshape(depth, 16, 4)
 
     def free(self):
         if self._h:
-            lib().zk_bn128_merkle_free(self._h); self._h = None
+            _fr("merkle_free", self.field)(self._h); self._h = None
 
     def __del__(self):
         try:
@@ -521,29 +551,30 @@ class MerkleTreeBN128:
 class TranscriptBN128:
     """trait Transcript for TranscriptBN128 (transcript_bn128.rs:51-132)"""
 
-    def __init__(self):
-        self._h = lib().zk_bn128_transcript_new()
+    def __init__(self, field="bn128"):
+        self.field = field
+        self._h = _fr("transcript_new", field)()
 
     def put(self, es):
         """es: list of 1-word (Goldilocks value) or 4-word (digest) entries"""
         for e in es:
             v = _np(e)
-            _check(lib().zk_bn128_transcript_put(self._h, _ptr(v), v.size))
+            _check(_fr("transcript_put", self.field)(self._h, _ptr(v), v.size))
 
     def get_fields1(self):
-        o = np.zeros(1, np.uint64); _check(lib().zk_bn128_transcript_get_fields1(self._h, _ptr(o))); return int(o[0])
+        o = np.zeros(1, np.uint64); _check(_fr("transcript_get_fields1", self.field)(self._h, _ptr(o))); return int(o[0])
 
     def get_field(self):
-        o = np.zeros(3, np.uint64); _check(lib().zk_bn128_transcript_get_field(self._h, _ptr(o))); return [int(v) for v in o]
+        o = np.zeros(3, np.uint64); _check(_fr("transcript_get_field", self.field)(self._h, _ptr(o))); return [int(v) for v in o]
 
     def get_permutations(self, n, nbits):
         o = np.zeros(n, np.uint64)
-        _check(lib().zk_bn128_transcript_get_permutations(self._h, n, nbits, _ptr(o))); return o
+        _check(_fr("transcript_get_permutations", self.field)(self._h, n, nbits, _ptr(o))); return o
 
     def __del__(self):
         try:
             if self._h:
-                lib().zk_bn128_transcript_free(self._h); self._h = None
+                _fr("transcript_free", self.field)(self._h); self._h = None
         except Exception:
             pass
 

@@ -397,14 +397,37 @@ int zk_msm_g1_bls12_381(const void* bases, const void* scalars, uint64_t n, void
     });
 }
 
-// ---- BN128-field hashing (verificationHashType "BN128") ------------------------------------------------
-struct zk_bn128_merkle {
+// ---- scalar-field hashing (verificationHashType "BN128" / "BLS12381") -----------------------------------
+}  // extern "C" (reopened below): the two fields share one implementation, instantiated per field
+
+namespace {
+struct FrOps {   // one scalar field: device entry points (frhash.hip) + the host-side modulus for the sponge bookkeeping
+    const char* name;
+    uint64_t R[4], R2[4], INV;     // modulus, 2^512 mod r, -r^-1 mod 2^64
+    void (*load)(const char*);
+    void (*poseidon_dev)(const u64*, uint64_t, uint32_t, const u64*, uint32_t, u64*, hipStream_t);
+    uint64_t (*n_nodes)(uint64_t);
+    void (*linearhash_rows_dev)(const u64*, uint32_t, uint64_t, u64*, hipStream_t);
+    void (*merkelize_dev)(const u64*, uint32_t, uint64_t, u64*, hipStream_t);
+};
+const FrOps FR_BN128 = {"bn128",
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    {1997599621687373223ULL, 6052339484930628067ULL, 10108755138030829701ULL, 150537098327114917ULL}, 0xc2e1f593efffffffULL,
+    bn128_load_constants, bn128_poseidon_dev, bn128_merkle_n_nodes, bn128_linearhash_rows_dev, bn128_merkelize_dev};
+const FrOps FR_BLS12381 = {"bls12381",
+    {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL},
+    {14526898881837571181ULL, 3129137299524312099ULL, 419701826671360399ULL, 524908885293268753ULL}, 0xfffffffeffffffffULL,
+    bls12381_load_constants, bls12381_poseidon_dev, bls12381_merkle_n_nodes, bls12381_linearhash_rows_dev, bls12381_merkelize_dev};
+
+struct FrMerkle {
+    const FrOps* F = nullptr;
     const u64* d_elements = nullptr;
-    DevBuf owned_elements, nodes, proof;
+    DevBuf owned_elements, nodes;
     uint32_t width = 0, depth = 0;
     uint64_t height = 0, n_nodes = 0;
 };
-struct zk_bn128_transcript {   // transcript_bn128.rs:14-20, sponge bookkeeping on the host, permutations on the device
+struct FrTranscript {   // transcript_bn128.rs:14-20: sponge bookkeeping on the host, permutations on the device
+    const FrOps* F = nullptr;
     uint64_t state[4] = {0, 0, 0, 0};
     std::vector<uint64_t> pending;          // raw limbs, 4 per element
     std::vector<uint64_t> out;              // 17 x 4 raw limbs
@@ -412,133 +435,111 @@ struct zk_bn128_transcript {   // transcript_bn128.rs:14-20, sponge bookkeeping 
     uint64_t out3[3] = {0, 0, 0}; size_t out3_pos = 0, n_out3 = 0;
     DevBuf d_in, d_init, d_out;
 };
-namespace {
-const uint64_t BN128_R[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-uint32_t bn128_depth(uint64_t height) { uint32_t d = 0; uint64_t n = height; while (n > 1) { n = (n - 1) / 16 + 1; ++d; } return d; }
-// raw (Montgomery) limbs -> canonical integer and back, through one 1-input Poseidon-free device round trip is overkill:
-// a*2^256 mod r and its inverse are plain 256-bit modular products, done here with 128-bit arithmetic.
-void mont_mul_host(const uint64_t a[4], const uint64_t b[4], uint64_t r[4]) {   // a*b/2^256 mod r (CIOS)
+uint32_t fr_depth(uint64_t height) { uint32_t d = 0; uint64_t n = height; while (n > 1) { n = (n - 1) / 16 + 1; ++d; } return d; }
+void fr_mont_mul_host(const FrOps& F, const uint64_t a[4], const uint64_t b[4], uint64_t r[4]) {   // a*b/2^256 mod r (CIOS)
     typedef unsigned __int128 u128;
-    const uint64_t INV = 0xc2e1f593efffffffULL;
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
         u128 c = 0;
         for (int j = 0; j < 4; ++j) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
         c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-        const uint64_t m = t[0] * INV;
-        c = ((u128)m * BN128_R[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; ++j) { c += (u128)m * BN128_R[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        const uint64_t m = t[0] * F.INV;
+        c = ((u128)m * F.R[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; ++j) { c += (u128)m * F.R[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
         c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
     }
     for (;;) {
         bool ge = t[4] != 0;
-        if (!ge) { ge = true; for (int i = 3; i >= 0; --i) { if (t[i] > BN128_R[i]) break; if (t[i] < BN128_R[i]) { ge = false; break; } } }
+        if (!ge) { ge = true; for (int i = 3; i >= 0; --i) { if (t[i] > F.R[i]) break; if (t[i] < F.R[i]) { ge = false; break; } } }
         if (!ge) break;
         u128 br = 0;
-        for (int i = 0; i < 4; ++i) { u128 d = (u128)t[i] - BN128_R[i] - br; t[i] = (uint64_t)d; br = (d >> 64) & 1; }
+        for (int i = 0; i < 4; ++i) { u128 d = (u128)t[i] - F.R[i] - br; t[i] = (uint64_t)d; br = (d >> 64) & 1; }
         t[4] -= (uint64_t)br;
     }
     memcpy(r, t, 32);
 }
-const uint64_t BN128_R2[4] = {1997599621687373223ULL, 6052339484930628067ULL, 10108755138030829701ULL, 150537098327114917ULL};
-void bn128_tr_update(zk_bn128_transcript* t) {   // transcript_bn128.rs:22-31
+void fr_tr_update(FrTranscript* t) {   // transcript_bn128.rs:22-31
     t->pending.resize(64, 0);
     t->d_in.reserve(64 * 8); t->d_init.reserve(32); t->d_out.reserve(17 * 32);
     ZK_HIP(hipMemcpy(t->d_in.p, t->pending.data(), 64 * 8, hipMemcpyHostToDevice));
     ZK_HIP(hipMemcpy(t->d_init.p, t->state, 32, hipMemcpyHostToDevice));
-    bn128_poseidon_dev(t->d_in.u(), 1, 16, t->d_init.u(), 17, t->d_out.u(), nullptr);
+    t->F->poseidon_dev(t->d_in.u(), 1, 16, t->d_init.u(), 17, t->d_out.u(), nullptr);
     t->out.resize(68);
     ZK_HIP(hipStreamSynchronize(nullptr));
     ZK_HIP(hipMemcpy(t->out.data(), t->d_out.p, 17 * 32, hipMemcpyDeviceToHost));
     t->out_pos = 0; t->n_out = 17; t->n_out3 = 0; t->out3_pos = 0; t->pending.clear();
     memcpy(t->state, t->out.data(), 32);
 }
-void bn128_tr_add1(zk_bn128_transcript* t, const uint64_t raw[4]) {   // :32-40
+void fr_tr_add1(FrTranscript* t, const uint64_t raw[4]) {   // :32-40
     t->n_out = 0; t->out_pos = 0;
     t->pending.insert(t->pending.end(), raw, raw + 4);
-    if (t->pending.size() == 64) bn128_tr_update(t);
+    if (t->pending.size() == 64) fr_tr_update(t);
 }
-void bn128_tr_get253(zk_bn128_transcript* t, uint64_t canon[4]) {   // :42-48, canonical value of the popped element
-    if (t->out_pos >= t->n_out) bn128_tr_update(t);
+void fr_tr_get253(FrTranscript* t, uint64_t canon[4]) {   // :42-48, canonical value of the popped element
+    if (t->out_pos >= t->n_out) fr_tr_update(t);
     const uint64_t one[4] = {1, 0, 0, 0};
-    mont_mul_host(t->out.data() + 4 * t->out_pos, one, canon);
+    fr_mont_mul_host(*t->F, t->out.data() + 4 * t->out_pos, one, canon);
     ++t->out_pos;
 }
-}  // namespace
 
-int zk_bn128_load_constants(const char* path) {
-    return guard([&] { ZK_REQUIRE(path, "null path"); bn128_load_constants(path); });
-}
-int zk_bn128_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out) {
+int fr_poseidon(const FrOps& F, const uint64_t* inp, uint32_t n_in, const uint64_t* init_state, uint32_t n_out, uint64_t* out) {
     return guard([&] {
-        ZK_REQUIRE(inp && init_state && out, "zk_bn128_poseidon: null buffer");
+        ZK_REQUIRE(inp && init_state && out, "poseidon: null buffer");
         ZK_REQUIRE(n_in >= 1 && n_in <= 16, "Wrong inputs length");
         DevBuf d_in, d_init, d_out;
         d_in.reserve(n_in * 32); d_init.reserve(32); d_out.reserve(17 * 32);
         ZK_HIP(hipMemcpy(d_in.p, inp, n_in * 32, hipMemcpyHostToDevice));
         ZK_HIP(hipMemcpy(d_init.p, init_state, 32, hipMemcpyHostToDevice));
-        bn128_poseidon_dev(d_in.u(), 1, n_in, d_init.u(), n_out, d_out.u(), nullptr);
+        F.poseidon_dev(d_in.u(), 1, n_in, d_init.u(), n_out, d_out.u(), nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
         ZK_HIP(hipMemcpy(out, d_out.p, n_out * 32, hipMemcpyDeviceToHost));
     });
 }
-int zk_bn128_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out,
-                          uint64_t* d_out, void* stream) {
-    return guard([&] { bn128_poseidon_dev((const u64*)d_inp, n, n_in, (const u64*)d_init_state, n_out, (u64*)d_out, (hipStream_t)stream); });
-}
-int zk_bn128_linearhash(const uint64_t* v, size_t n, uint64_t out[4]) {
+int fr_linearhash(const FrOps& F, const uint64_t* v, size_t n, uint64_t* out) {
     return guard([&] {
-        ZK_REQUIRE(out && (v || n == 0), "zk_bn128_linearhash: null buffer");
+        ZK_REQUIRE(out && (v || n == 0), "linearhash: null buffer");
         DevBuf d_v, d_o; d_v.reserve(n * 8 + 8); d_o.reserve(32);
         if (n) ZK_HIP(hipMemcpy(d_v.p, v, n * 8, hipMemcpyHostToDevice));
         ZK_HIP(hipMemset(d_o.p, 0, 32));
-        bn128_linearhash_rows_dev(d_v.u(), (uint32_t)n, 1, d_o.u(), nullptr);
+        F.linearhash_rows_dev(d_v.u(), (uint32_t)n, 1, d_o.u(), nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
         ZK_HIP(hipMemcpy(out, d_o.p, 32, hipMemcpyDeviceToHost));
     });
 }
-uint64_t zk_bn128_merkle_n_nodes(uint64_t height) { return height ? bn128_merkle_n_nodes(height) : 0; }
-zk_bn128_merkle_t* zk_bn128_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream) {
-    zk_bn128_merkle* t = nullptr;
-    if (guard([&] {
-            ZK_REQUIRE(height >= 1, "merkelize: height must be >= 1");
-            t = new zk_bn128_merkle;
-            t->d_elements = (const u64*)d_buff; t->width = width; t->height = height;
-            t->n_nodes = bn128_merkle_n_nodes(height); t->depth = bn128_depth(height);
-            t->nodes.reserve(t->n_nodes * 32);
-            bn128_merkelize_dev(t->d_elements, width, height, t->nodes.u(), (hipStream_t)stream);
-        }) != 0) { delete t; return nullptr; }
-    return t;
-}
-zk_bn128_merkle_t* zk_bn128_merkelize(const uint64_t* buff, uint32_t width, uint64_t height) {
-    zk_bn128_merkle* t = nullptr;
+template <class T>
+T* fr_merkelize(const FrOps& F, const uint64_t* buff, bool on_device, uint32_t width, uint64_t height, void* stream) {
+    T* t = nullptr;
     if (guard([&] {
             ZK_REQUIRE(height >= 1, "merkelize: height must be >= 1");
             ZK_REQUIRE(buff || width == 0, "merkelize: null buffer");
-            t = new zk_bn128_merkle;
-            t->owned_elements.reserve((size_t)width * height * 8 + 8);
-            if (width) ZK_HIP(hipMemcpy(t->owned_elements.p, buff, (size_t)width * height * 8, hipMemcpyHostToDevice));
-            t->d_elements = t->owned_elements.u(); t->width = width; t->height = height;
-            t->n_nodes = bn128_merkle_n_nodes(height); t->depth = bn128_depth(height);
+            t = new T;
+            t->F = &F;
+            if (on_device) t->d_elements = (const u64*)buff;
+            else {
+                t->owned_elements.reserve((size_t)width * height * 8 + 8);
+                if (width) ZK_HIP(hipMemcpy(t->owned_elements.p, buff, (size_t)width * height * 8, hipMemcpyHostToDevice));
+                t->d_elements = t->owned_elements.u();
+            }
+            t->width = width; t->height = height;
+            t->n_nodes = F.n_nodes(height); t->depth = fr_depth(height);
             t->nodes.reserve(t->n_nodes * 32);
-            bn128_merkelize_dev(t->d_elements, width, height, t->nodes.u(), nullptr);
-            ZK_HIP(hipStreamSynchronize(nullptr));
+            F.merkelize_dev(t->d_elements, width, height, t->nodes.u(), on_device ? (hipStream_t)stream : nullptr);
+            if (!on_device) ZK_HIP(hipStreamSynchronize(nullptr));
         }) != 0) { delete t; return nullptr; }
     return t;
 }
-int zk_bn128_merkle_root(const zk_bn128_merkle_t* t, uint64_t out[4]) {
+int fr_merkle_root(const FrMerkle* t, uint64_t* out) {
     return guard([&] {
         ZK_REQUIRE(t && out, "null argument");
         ZK_HIP(hipDeviceSynchronize());
         ZK_HIP(hipMemcpy(out, t->nodes.u() + 4 * (t->n_nodes - 1), 32, hipMemcpyDeviceToHost));
     });
 }
-int zk_bn128_merkle_nodes(const zk_bn128_merkle_t* t, uint64_t* out) {
+int fr_merkle_nodes(const FrMerkle* t, uint64_t* out) {
     return guard([&] { ZK_REQUIRE(t && out, "null argument"); ZK_HIP(hipDeviceSynchronize()); ZK_HIP(hipMemcpy(out, t->nodes.p, t->n_nodes * 32, hipMemcpyDeviceToHost)); });
 }
-uint32_t zk_bn128_merkle_depth(const zk_bn128_merkle_t* t) { return t ? t->depth : 0; }
 // get_group_proof (merklehash_bn128.rs:246-254): row_out[width], path_out[depth][16][4]
-int zk_bn128_merkle_group_proof(const zk_bn128_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {
+int fr_merkle_group_proof(const FrMerkle* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {
     return guard([&] {
         ZK_REQUIRE(t && row_out && path_out, "null argument");
         ZK_REQUIRE(idx < t->height, "MerkleTreeError: access invalid node");
@@ -553,51 +554,40 @@ int zk_bn128_merkle_group_proof(const zk_bn128_merkle_t* t, uint64_t idx, uint64
         }
     });
 }
-int zk_bn128_merkle_free(zk_bn128_merkle_t* t) { return guard([&] { delete t; }); }
-
-zk_bn128_transcript_t* zk_bn128_transcript_new(void) {
-    zk_bn128_transcript* t = nullptr;
-    if (guard([&] { t = new zk_bn128_transcript; }) != 0) return nullptr;
-    return t;
-}
 // put (transcript_bn128.rs:90-101): n == 1 -> a Goldilocks value, n == 4 -> a digest (raw limbs); anything else is an error
-int zk_bn128_transcript_put(zk_bn128_transcript_t* t, const uint64_t* e, size_t n) {
+int fr_transcript_put(FrTranscript* t, const uint64_t* e, size_t n) {
     return guard([&] {
         ZK_REQUIRE(t && e, "null argument");
         if (n == 1) {
             const uint64_t x[4] = {e[0], 0, 0, 0}; uint64_t m[4];
-            mont_mul_host(x, BN128_R2, m);
-            bn128_tr_add1(t, m);
-        } else if (n == 4) bn128_tr_add1(t, e);
+            fr_mont_mul_host(*t->F, x, t->F->R2, m);
+            fr_tr_add1(t, m);
+        } else if (n == 4) fr_tr_add1(t, e);
         else throw Error("Invalid elements as inputs to transcript");
     });
 }
-int zk_bn128_transcript_get_fields1(zk_bn128_transcript_t* t, uint64_t* out) {   // :71-88
+int fr_transcript_get_fields1(FrTranscript* t, uint64_t* out) {   // :71-88
     return guard([&] {
         ZK_REQUIRE(t && out, "null argument");
         for (;;) {
             if (t->out3_pos < t->n_out3) { *out = t->out3[t->out3_pos++]; return; }
             if (t->out_pos < t->n_out) {
                 uint64_t c[4];
-                bn128_tr_get253(t, c);
+                fr_tr_get253(t, c);
                 for (int i = 0; i < 3; ++i) t->out3[i] = c[i] % GL_P;   // biguint_to_be (helper.rs:61-65)
                 t->out3_pos = 0; t->n_out3 = 3;
                 continue;
             }
-            bn128_tr_update(t);
+            fr_tr_update(t);
         }
     });
 }
-int zk_bn128_transcript_get_field(zk_bn128_transcript_t* t, uint64_t out[3]) {
-    for (int i = 0; i < 3; ++i) { const int rc = zk_bn128_transcript_get_fields1(t, out + i); if (rc) return rc; }
-    return 0;
-}
-int zk_bn128_transcript_get_permutations(zk_bn128_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out) {   // :103-131
+int fr_transcript_get_permutations(FrTranscript* t, uint32_t n, uint32_t nbits, uint64_t* out) {   // :103-131
     return guard([&] {
         ZK_REQUIRE(t && out && n >= 1 && nbits >= 1 && nbits <= 63, "bad argument");
         const uint32_t total = n * nbits, nf = (total - 1) / 253 + 1;
         std::vector<uint64_t> f(4 * (size_t)nf);
-        for (uint32_t i = 0; i < nf; ++i) bn128_tr_get253(t, f.data() + 4 * i);
+        for (uint32_t i = 0; i < nf; ++i) fr_tr_get253(t, f.data() + 4 * i);
         uint32_t cf = 0, cb = 0;
         for (uint32_t i = 0; i < n; ++i) {
             uint64_t a = 0;
@@ -609,7 +599,56 @@ int zk_bn128_transcript_get_permutations(zk_bn128_transcript_t* t, uint32_t n, u
         }
     });
 }
-int zk_bn128_transcript_free(zk_bn128_transcript_t* t) { return guard([&] { delete t; }); }
+}  // namespace
+
+struct zk_bn128_merkle : FrMerkle {};
+struct zk_bn128_transcript : FrTranscript {};
+struct zk_bls12381_merkle : FrMerkle {};
+struct zk_bls12381_transcript : FrTranscript {};
+
+extern "C" {
+#define ZK_FRHASH_CAPI(P, OPS)                                                                                          \
+    int zk_##P##_load_constants(const char* path) { return guard([&] { ZK_REQUIRE(path, "null path"); OPS.load(path); }); } \
+    int zk_##P##_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out) { \
+        return fr_poseidon(OPS, inp, n_in, init_state, n_out, out);                                                     \
+    }                                                                                                                   \
+    int zk_##P##_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out, \
+                              uint64_t* d_out, void* stream) {                                                          \
+        return guard([&] { OPS.poseidon_dev((const u64*)d_inp, n, n_in, (const u64*)d_init_state, n_out, (u64*)d_out, (hipStream_t)stream); }); \
+    }                                                                                                                   \
+    int zk_##P##_linearhash(const uint64_t* v, size_t n, uint64_t out[4]) { return fr_linearhash(OPS, v, n, out); }       \
+    uint64_t zk_##P##_merkle_n_nodes(uint64_t height) { return height ? OPS.n_nodes(height) : 0; }                        \
+    zk_##P##_merkle_t* zk_##P##_merkelize(const uint64_t* buff, uint32_t width, uint64_t height) {                        \
+        return fr_merkelize<zk_##P##_merkle>(OPS, buff, false, width, height, nullptr);                                  \
+    }                                                                                                                   \
+    zk_##P##_merkle_t* zk_##P##_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream) {    \
+        return fr_merkelize<zk_##P##_merkle>(OPS, d_buff, true, width, height, stream);                                  \
+    }                                                                                                                   \
+    int zk_##P##_merkle_root(const zk_##P##_merkle_t* t, uint64_t out[4]) { return fr_merkle_root(t, out); }              \
+    int zk_##P##_merkle_nodes(const zk_##P##_merkle_t* t, uint64_t* out) { return fr_merkle_nodes(t, out); }              \
+    uint32_t zk_##P##_merkle_depth(const zk_##P##_merkle_t* t) { return t ? t->depth : 0; }                               \
+    int zk_##P##_merkle_group_proof(const zk_##P##_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {    \
+        return fr_merkle_group_proof(t, idx, row_out, path_out);                                                         \
+    }                                                                                                                   \
+    int zk_##P##_merkle_free(zk_##P##_merkle_t* t) { return guard([&] { delete t; }); }                                   \
+    zk_##P##_transcript_t* zk_##P##_transcript_new(void) {                                                               \
+        zk_##P##_transcript* t = nullptr;                                                                               \
+        if (guard([&] { t = new zk_##P##_transcript; t->F = &OPS; }) != 0) return nullptr;                               \
+        return t;                                                                                                       \
+    }                                                                                                                   \
+    int zk_##P##_transcript_put(zk_##P##_transcript_t* t, const uint64_t* e, size_t n) { return fr_transcript_put(t, e, n); } \
+    int zk_##P##_transcript_get_fields1(zk_##P##_transcript_t* t, uint64_t* out) { return fr_transcript_get_fields1(t, out); } \
+    int zk_##P##_transcript_get_field(zk_##P##_transcript_t* t, uint64_t out[3]) {                                        \
+        for (int i = 0; i < 3; ++i) { const int rc = fr_transcript_get_fields1(t, out + i); if (rc) return rc; }         \
+        return 0;                                                                                                       \
+    }                                                                                                                   \
+    int zk_##P##_transcript_get_permutations(zk_##P##_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out) {       \
+        return fr_transcript_get_permutations(t, n, nbits, out);                                                         \
+    }                                                                                                                   \
+    int zk_##P##_transcript_free(zk_##P##_transcript_t* t) { return guard([&] { delete t; }); }
+ZK_FRHASH_CAPI(bn128, FR_BN128)
+ZK_FRHASH_CAPI(bls12381, FR_BLS12381)
+#undef ZK_FRHASH_CAPI
 
 int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, uint64_t* d_out3, void* stream) {
     return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, (hipStream_t)stream); });

@@ -1,40 +1,7 @@
-// BN128-field hashing for verificationHashType == "BN128" (the final STARK of every aggregation,
-// test/stark_aggregation.sh:199-210) on gfx950:
-//   Poseidon over the BN254 scalar field, t = 2..17      starky/src/poseidon_bn128_opt.rs:98-224
-//   LinearHashBN128::hash_element_array                   starky/src/linearhash_bn128.rs:105-131
-//   MerkleTreeBN128 (arity 16)                            starky/src/merklehash_bn128.rs:26-39, 196-239, 86-106
-// A digest (ElementDigest<4, Fr>) holds the RAW limbs of an Fr, i.e. its Montgomery form a*2^256 mod r
-// (digest.rs:45-53); that is the format of every node buffer here.
-//
-// Mapping: one lane = one permutation; the state (t <= 17 elements of 9 x 29-bit limbs) lives in the lane's
-// private segment, the parameter tables (24 060 constants, converted once per device to the internal
-// Montgomery form) in global memory behind wave-uniform addresses.  Integer-ALU bound: 5 457 Fr products per
-// t = 17 permutation, 225 instructions each (fe29_impl.cuh).  Value bounds: round-boundary state < 2r; a
-// column of the dense products sums 17 products (< 34r) and is brought back below 2r by one product with
-// R' mod r; the sparse rounds' running columns are renormalised every 16 rounds (< 34r in between).
-#include "zk_internal.h"
-#include <cstdio>
-#include <cstring>
-#include <vector>
-
-namespace zk {
-namespace bn128fr {
-
-constexpr int NL = 8;   // external Montgomery form: R = 2^256
-constexpr int NR = 9;   // internal: R' = 2^261
-constexpr u32 QINV29 = 0x0fffffffu;
-#define ZK_FR_CONST(NAME, ...)                                                      \
-    __host__ __device__ constexpr u32 NAME(int i) { constexpr u32 v[9] = {__VA_ARGS__}; return v[i]; }
-// r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-ZK_FR_CONST(Q29, 0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu)
-ZK_FR_CONST(ONE29, 0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u)
-ZK_FR_CONST(CIN29, 0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u)
-ZK_FR_CONST(COUT29, 0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u)
-ZK_FR_CONST(RRP29, 0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au)  // R'^2 mod r
-ZK_FR_CONST(Q2_29, 0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u, 0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu)
-ZK_FR_CONST(Q4_29, 0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u)
-ZK_FR_CONST(Q8_29, 0x00000008u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u)
-#undef ZK_FR_CONST
+// Field-generic body of the scalar-field hashing (see frhash.hip): included once per field inside that field's
+// namespace, which provides the fe29 constants (NL, NR, Q29, ...), RRP29 (R'^2 mod r), FH_NRP (partial rounds of
+// t = 2..17), FH_OUT_IDX (the state word Poseidon::hash returns: 0 for BN128, 1 for BLS12-381), FH_NAME and
+// FH_FN(name) (host entry points).  No include guard on purpose.
 #define FQ_MUL_ATTR __noinline__   // called from run-time loops over t: one copy keeps the kernels small
 
 namespace {
@@ -158,7 +125,7 @@ __global__ __launch_bounds__(64) void bn128_leaf_kernel(const u64* __restrict__ 
             st[k + 1] = words_to_fe(v + at, len);
         }
         poseidon_fr(st, tmp, sz + 1);
-        digest = st[0];
+        digest = st[FH_OUT_IDX];                          // Poseidon::hash
     }
     store_raw(digest, digests + 4 * i);
 }
@@ -170,7 +137,7 @@ __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__
     st[0] = fe_zero();
     for (u32 k = 0; k < 16; ++k) st[k + 1] = load_raw(in + (i * 16 + k) * 4);
     poseidon_fr(st, tmp, 17);
-    store_raw(st[0], out + 4 * i);
+    store_raw(st[FH_OUT_IDX], out + 4 * i);
 }
 
 
@@ -250,25 +217,36 @@ __global__ __launch_bounds__(64) void bn128_level_coop_kernel(const u64* __restr
     fe x = fe_zero();
     if (l >= 1 && l <= 16) x = load_raw(in + (ic * 16 + (l - 1)) * 4);
     x = coop_poseidon_fr(x, xs, 17);
-    if (i < n_ops && l == 0) store_raw(x, out + 4 * i);
+    if (i < n_ops && l == FH_OUT_IDX) store_raw(x, out + 4 * i);
+}
+// Poseidon::hash_ex for a handful of permutations (the transcript: one sponge step at a time): 32 lanes each
+__global__ __launch_bounds__(64) void bn128_poseidon_coop_kernel(const u64* __restrict__ inp, u64 n, u32 n_in, const u64* __restrict__ init,
+                                                                 u32 n_out, u64* __restrict__ out) {
+    __shared__ u32 xs_all[2][17 * NR];
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    u32* xs = xs_all[g];
+    const u64 i = (u64)blockIdx.x * 2 + g;
+    const u64 ic = i < n ? i : n - 1;
+    fe x = fe_zero();
+    if (l == 0) x = load_raw(init);
+    else if ((u32)l <= n_in) x = load_raw(inp + (ic * n_in + (l - 1)) * 4);
+    x = coop_poseidon_fr(x, xs, n_in + 1);
+    if (i < n && (u32)l < n_out) store_raw(x, out + (i * n_out + l) * 4);
 }
 
 struct DeviceTables { fe* all = nullptr; bool ready = false; };
 DeviceTables g_tables[64];
-const u32 NRP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};  // poseidon_bn128_opt.rs:62
+const u32 NRP[16] = {FH_NRP};
 
 void require_tables() {
     int dev; ZK_HIP(hipGetDevice(&dev));
-    ZK_REQUIRE(dev >= 0 && dev < 64 && g_tables[dev].ready, "BN128 Poseidon constants not loaded (zk_bn128_load_constants)");
+    ZK_REQUIRE(dev >= 0 && dev < 64 && g_tables[dev].ready, FH_NAME " Poseidon constants not loaded (zk_" FH_NAME "_load_constants)");
 }
 
 }  // namespace
-}  // namespace bn128fr
-
-using namespace bn128fr;
 
 // file format: tools/gen_poseidon_bn128_constants.py
-void bn128_load_constants(const char* path) {
+void FH_FN(load_constants)(const char* path) {
     int dev; ZK_HIP(hipGetDevice(&dev));
     ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
     if (g_tables[dev].ready) return;
@@ -279,19 +257,19 @@ void bn128_load_constants(const char* path) {
     buf.resize(sz > 0 ? (size_t)sz : 0);
     const size_t got = fread(buf.data(), 1, buf.size(), f);
     fclose(f);
-    ZK_REQUIRE(got == buf.size() && buf.size() >= 8 && !memcmp(buf.data(), "PBN1", 4), "bad BN128 constants file");
+    ZK_REQUIRE(got == buf.size() && buf.size() >= 8 && !memcmp(buf.data(), "PBN1", 4), "bad Poseidon constants file");
     uint32_t nt; memcpy(&nt, buf.data() + 4, 4);
-    ZK_REQUIRE(nt == 16, "bad BN128 constants file (t range)");
+    ZK_REQUIRE(nt == 16, "bad Poseidon constants file (t range)");
     std::vector<unsigned char> canon;   // all 32-byte values back to back
     struct Off { size_t c, m, p, s; u32 t; } off[16];
     size_t pos = 8, count = 0;
     for (int k = 0; k < 16; ++k) {
-        ZK_REQUIRE(pos + 12 <= buf.size(), "truncated BN128 constants file");
+        ZK_REQUIRE(pos + 12 <= buf.size(), "truncated Poseidon constants file");
         uint32_t h[3]; memcpy(h, buf.data() + pos, 12); pos += 12;
         const u32 t = h[0], n_c = h[1], n_s = h[2];
-        ZK_REQUIRE(t == (u32)k + 2 && n_c == 5 * t + NRP[k] + 3 * t && n_s == (2 * t - 1) * NRP[k], "unexpected BN128 table shape");
+        ZK_REQUIRE(t == (u32)k + 2 && n_c == 5 * t + NRP[k] + 3 * t && n_s == (2 * t - 1) * NRP[k], "unexpected Poseidon table shape");
         const size_t n = n_c + 2 * (size_t)t * t + n_s;
-        ZK_REQUIRE(pos + 32 * n <= buf.size(), "truncated BN128 constants file");
+        ZK_REQUIRE(pos + 32 * n <= buf.size(), "truncated Poseidon constants file");
         off[k] = {count, count + n_c, count + n_c + (size_t)t * t, count + n_c + 2 * (size_t)t * t, t};
         canon.insert(canon.end(), buf.begin() + pos, buf.begin() + pos + 32 * n);
         pos += 32 * n; count += n;
@@ -309,16 +287,19 @@ void bn128_load_constants(const char* path) {
     g_tables[dev].all = d_all; g_tables[dev].ready = true;
 }
 
-void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st) {
+void FH_FN(poseidon_dev)(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st) {
     require_tables();
     ZK_REQUIRE(n_in >= 1 && n_in <= 16, "Wrong inputs length");            // poseidon_bn128_opt.rs:99-105
     ZK_REQUIRE(n_out >= 1 && n_out <= n_in + 1, "Wrong output length");
     if (n == 0) return;
-    hipLaunchKernelGGL(bn128_poseidon_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
+    if (n <= 4096)  // latency-bound
+        hipLaunchKernelGGL(bn128_poseidon_coop_kernel, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
+    else
+        hipLaunchKernelGGL(bn128_poseidon_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
     ZK_HIP(hipGetLastError());
 }
 
-uint64_t bn128_merkle_n_nodes(uint64_t n_) {  // merklehash_bn128.rs:26-39
+uint64_t FH_FN(merkle_n_nodes)(uint64_t n_) {  // merklehash_bn128.rs:26-39
     uint64_t n = n_, next_n = (n - 1) / 16 + 1, acc = next_n * 16;
     while (n > 1) {
         n = next_n; next_n = (n - 1) / 16 + 1;
@@ -327,20 +308,20 @@ uint64_t bn128_merkle_n_nodes(uint64_t n_) {  // merklehash_bn128.rs:26-39
     return acc;
 }
 
-void bn128_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
+void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     require_tables();
     if (height == 0) return;
     hipLaunchKernelGGL(bn128_leaf_kernel, dim3((unsigned)((height + 63) / 64)), dim3(64), 0, st, d_rows, width, height, d_digests);
     ZK_HIP(hipGetLastError());
 }
 
-// nodes: bn128_merkle_n_nodes(height) * 4 words, zero-filled by this call (merklehash_bn128.rs:196-239)
-void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st) {
+// nodes: FH_FN(merkle_n_nodes)(height) * 4 words, zero-filled by this call (merklehash_bn128.rs:196-239)
+void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st) {
     require_tables();
     ZK_REQUIRE(height >= 1, "merkelize: height must be >= 1");
-    const uint64_t nn = bn128_merkle_n_nodes(height);
+    const uint64_t nn = FH_FN(merkle_n_nodes)(height);
     ZK_HIP(hipMemsetAsync(d_nodes, 0, nn * 32, st));
-    if (width) bn128_linearhash_rows_dev(d_rows, width, height, d_nodes, st);
+    if (width) FH_FN(linearhash_rows_dev)(d_rows, width, height, d_nodes, st);
     uint64_t n = height, next = (n - 1) / 16 + 1, p_in = 0, p_out = next * 16;
     while (n > 1) {
         if (next <= 4096)  // latency-bound: 32 lanes per parent
@@ -352,4 +333,3 @@ void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
     }
 }
 
-}  // namespace zk

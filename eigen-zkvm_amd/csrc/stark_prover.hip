@@ -67,28 +67,59 @@ struct ProgramDeleter { void operator()(zk_program_t* p) const { if (p) zk_progr
 using ProgramPtr = std::unique_ptr<zk_program_t, ProgramDeleter>;
 // The two instantiations of the reference's generics: StarkProof<MerkleTreeGL>::stark_gen::<TranscriptGL> and
 // StarkProof<MerkleTreeBN128>::stark_gen::<TranscriptBN128> (prove.rs:47-91), chosen by verificationHashType.
+// the scalar-field variants through their (twin) C entry points
+struct FrApi {
+    const char* name;
+    u64 R[4], INV;                                   // modulus and -r^-1 mod 2^64: digests print as canonical decimals
+    void* (*merkelize_dev)(const uint64_t*, uint32_t, uint64_t, void*);
+    int (*root)(const void*, uint64_t*);
+    uint32_t (*depth)(const void*);
+    int (*group_proof)(const void*, uint64_t, uint64_t*, uint64_t*);
+    int (*tree_free)(void*);
+    void* (*tr_new)(void);
+    int (*tr_put)(void*, const uint64_t*, size_t);
+    int (*tr_get_field)(void*, uint64_t*);
+    int (*tr_get_permutations)(void*, uint32_t, uint32_t, uint64_t*);
+    int (*tr_free)(void*);
+};
+#define ZK_FR_API(P, R0, R1, R2, R3, INV)                                                                                     \
+    {#P, {R0, R1, R2, R3}, INV,                                                                                               \
+     [](const uint64_t* d, uint32_t w, uint64_t h, void* st) -> void* { return zk_##P##_merkelize_dev(d, w, h, st); },          \
+     [](const void* t, uint64_t* o) { return zk_##P##_merkle_root((const zk_##P##_merkle_t*)t, o); },                           \
+     [](const void* t) { return zk_##P##_merkle_depth((const zk_##P##_merkle_t*)t); },                                          \
+     [](const void* t, uint64_t i, uint64_t* r, uint64_t* p) { return zk_##P##_merkle_group_proof((const zk_##P##_merkle_t*)t, i, r, p); }, \
+     [](void* t) { return zk_##P##_merkle_free((zk_##P##_merkle_t*)t); },                                                       \
+     []() -> void* { return zk_##P##_transcript_new(); },                                                                       \
+     [](void* t, const uint64_t* e, size_t n) { return zk_##P##_transcript_put((zk_##P##_transcript_t*)t, e, n); },             \
+     [](void* t, uint64_t* o) { return zk_##P##_transcript_get_field((zk_##P##_transcript_t*)t, o); },                          \
+     [](void* t, uint32_t n, uint32_t b, uint64_t* o) { return zk_##P##_transcript_get_permutations((zk_##P##_transcript_t*)t, n, b, o); }, \
+     [](void* t) { return zk_##P##_transcript_free((zk_##P##_transcript_t*)t); }}
+const FrApi FR_BN128 = ZK_FR_API(bn128, 0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL, 0xc2e1f593efffffffULL);
+const FrApi FR_BLS12381 = ZK_FR_API(bls12381, 0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL, 0xfffffffeffffffffULL);
+#undef ZK_FR_API
+
 struct AnyTree {
-    zk_merkle_t* gl = nullptr; zk_bn128_merkle_t* bn = nullptr;
+    zk_merkle_t* gl = nullptr; const FrApi* F = nullptr; void* fr = nullptr;
     u32 width = 0; u64 height = 0;
-    AnyTree(bool bn128, const u64* d_rows, u32 w, u64 h, hipStream_t st) : width(w), height(h) {
-        if (bn128) bn = zk_bn128_merkelize_dev(C(d_rows), w, h, st); else gl = zk_gl_merkelize_dev(C(d_rows), w, h, st);
-        if (!gl && !bn) throw Error(zk_last_error());
+    AnyTree(const FrApi* f, const u64* d_rows, u32 w, u64 h, hipStream_t st) : F(f), width(w), height(h) {
+        if (F) fr = F->merkelize_dev(C(d_rows), w, h, st); else gl = zk_gl_merkelize_dev(C(d_rows), w, h, st);
+        if (!gl && !fr) throw Error(zk_last_error());
     }
     AnyTree(const AnyTree&) = delete; AnyTree& operator=(const AnyTree&) = delete;
-    ~AnyTree() { if (gl) zk_merkle_free(gl); if (bn) zk_bn128_merkle_free(bn); }
-    void root(u64* out) const { ck(gl ? zk_merkle_root(gl, M(out)) : zk_bn128_merkle_root(bn, M(out))); }
-    u32 depth() const { return gl ? zk_merkle_depth(gl) : zk_bn128_merkle_depth(bn); }
+    ~AnyTree() { if (gl) zk_merkle_free(gl); if (fr) F->tree_free(fr); }
+    void root(u64* out) const { ck(gl ? zk_merkle_root(gl, M(out)) : F->root(fr, M(out))); }
+    u32 depth() const { return gl ? zk_merkle_depth(gl) : F->depth(fr); }
     u32 level_words() const { return gl ? 4 : 64; }   // one sibling digest, or the 16 digests of the group
 };
 using TreePtr = std::unique_ptr<AnyTree>;
 struct AnyTranscript {
-    zk_transcript_t* gl = nullptr; zk_bn128_transcript_t* bn = nullptr;
-    explicit AnyTranscript(bool bn128) {
-        if (bn128) bn = zk_bn128_transcript_new(); else gl = zk_transcript_new();
-        if (!gl && !bn) throw Error(zk_last_error());
+    zk_transcript_t* gl = nullptr; const FrApi* F = nullptr; void* fr = nullptr;
+    explicit AnyTranscript(const FrApi* f) : F(f) {
+        if (F) fr = F->tr_new(); else gl = zk_transcript_new();
+        if (!gl && !fr) throw Error(zk_last_error());
     }
     AnyTranscript(const AnyTranscript&) = delete; AnyTranscript& operator=(const AnyTranscript&) = delete;
-    ~AnyTranscript() { if (gl) zk_transcript_free(gl); if (bn) zk_bn128_transcript_free(bn); }
+    ~AnyTranscript() { if (gl) zk_transcript_free(gl); if (fr) F->tr_free(fr); }
     // n Goldilocks words, one transcript element each (publics, evals, the last FRI polynomial)
     void put_words_dev(const u64* d, size_t n, hipStream_t st) {
         if (!n) return;
@@ -96,21 +127,21 @@ struct AnyTranscript {
         std::vector<u64> h(n);
         ZK_HIP(hipStreamSynchronize(st));
         ZK_HIP(hipMemcpy(h.data(), d, 8 * n, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; ++i) ck(zk_bn128_transcript_put(bn, M(&h[i]), 1));
+        for (size_t i = 0; i < n; ++i) ck(F->tr_put(fr, M(&h[i]), 1));
     }
-    void put_root(const AnyTree& t, hipStream_t st) {   // a digest is ONE element of the BN128 transcript
+    void put_root(const AnyTree& t, hipStream_t st) {   // a digest is ONE element of the scalar-field transcripts
         if (gl) { ck(zk_transcript_put_dev(gl, zk_merkle_nodes_dev(t.gl) + 4 * (zk_merkle_n_nodes(t.height) - 1), 4, st)); return; }
         u64 r[4]; t.root(r);
-        ck(zk_bn128_transcript_put(bn, M(r), 4));
+        ck(F->tr_put(fr, M(r), 4));
     }
     void get_field_dev(u64* d_out3, hipStream_t st) {
         if (gl) { ck(zk_transcript_get_field_dev(gl, M(d_out3), st)); return; }
         u64 f[3];
-        ck(zk_bn128_transcript_get_field(bn, M(f)));
+        ck(F->tr_get_field(fr, M(f)));
         ZK_HIP(hipMemcpy(d_out3, f, 24, hipMemcpyHostToDevice));
     }
     void get_permutations(u32 n, u32 nbits, u64* out) {
-        ck(gl ? zk_transcript_get_permutations(gl, n, nbits, M(out)) : zk_bn128_transcript_get_permutations(bn, n, nbits, M(out)));
+        ck(gl ? zk_transcript_get_permutations(gl, n, nbits, M(out)) : F->tr_get_permutations(fr, n, nbits, M(out)));
     }
 };
 
@@ -129,7 +160,7 @@ struct zk_stark_setup {
     std::vector<u64> cm_n, cm_2ns, tmpexp_n;
     std::map<u64, u64> exp2pol;
     DevBuf const_n, const_2ns;
-    bool bn128 = false;                    // verificationHashType == "BN128"
+    const FrApi* fr = nullptr;             // verificationHashType "BN128" / "BLS12381"; nullptr = "GL"
     std::string prover_addr;               // StarkProof.prover_addr (serializer.rs:255-262), non-GL proofs only
     TreePtr const_tree;
     u64 const_root[4] = {};
@@ -213,10 +244,10 @@ std::vector<u64> u64_list(const JVal& a) {
 std::string dec(u64 v) { return std::to_string(v); }
 // a BN128 digest holds the raw Montgomery limbs of an Fr; JSON carries its canonical value in decimal
 // (digest.rs:91-94 -> helper::fr_to_biguint)
-std::string fr_raw_to_dec(const u64* raw) {
+std::string fr_raw_to_dec(const FrApi& F, const u64* raw) {
     typedef unsigned __int128 u128;
-    static const u64 RM[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-    const u64 INV = 0xc2e1f593efffffffULL;
+    const u64* RM = F.R;
+    const u64 INV = F.INV;
     u64 t[5] = {raw[0], raw[1], raw[2], raw[3], 0};     // Montgomery reduction: raw / 2^256 mod r (into_repr)
     for (int i = 0; i < 4; ++i) {
         const u64 m = t[0] * INV;
@@ -246,8 +277,8 @@ std::string fr_raw_to_dec(const u64* raw) {
     }
     return out.empty() ? "0" : out;
 }
-void put_digest(std::ostringstream& o, const u64* d, bool bn128) {  // digest.rs:84-112
-    if (bn128) { o << '"' << fr_raw_to_dec(d) << '"'; return; }
+void put_digest(std::ostringstream& o, const u64* d, const FrApi* fr) {  // digest.rs:84-112
+    if (fr) { o << '"' << fr_raw_to_dec(*fr, d) << '"'; return; }
     if (d[1] == 0 && d[2] == 0 && d[3] == 0) { o << '"' << dec(d[0]) << '"'; return; }
     o << "[\"" << dec(d[0]) << "\",\"" << dec(d[1]) << "\",\"" << dec(d[2]) << "\",\"" << dec(d[3]) << "\"]";
 }
@@ -256,13 +287,13 @@ void put_list(std::ostringstream& o, const u64* v, size_t n) {
     for (size_t i = 0; i < n; ++i) { if (i) o << ','; o << '"' << dec(v[i]) << '"'; }
     o << ']';
 }
-void put_path(std::ostringstream& o, const GroupProof& g, bool bn128) {
+void put_path(std::ostringstream& o, const GroupProof& g, const FrApi* fr) {
     o << '[';
     for (u32 l = 0; l < g.depth; ++l) {
         if (l) o << ',';
-        if (!bn128) { put_list(o, g.path.data() + 4 * l, 4); continue; }
+        if (!fr) { put_list(o, g.path.data() + 4 * l, 4); continue; }
         o << '[';                                        // the 16 nodes of the group, each an Fr (merklehash_bn128.rs:86-106)
-        for (int k = 0; k < 16; ++k) { if (k) o << ','; o << '"' << fr_raw_to_dec(g.path.data() + 64 * l + 4 * k) << '"'; }
+        for (int k = 0; k < 16; ++k) { if (k) o << ','; o << '"' << fr_raw_to_dec(*fr, g.path.data() + 64 * l + 4 * k) << '"'; }
         o << ']';
     }
     o << ']';
@@ -273,7 +304,7 @@ GroupProof group_proof(const AnyTree& t, u64 idx) {
     const u32 lw = t.level_words();
     g.row.resize(t.width ? t.width : 1); g.path.resize(g.depth ? (size_t)lw * g.depth : lw);
     ck(t.gl ? zk_merkle_group_proof(t.gl, idx, M(g.row.data()), M(g.path.data()))
-            : zk_bn128_merkle_group_proof(t.bn, idx, M(g.row.data()), M(g.path.data())));
+            : t.F->group_proof(t.fr, idx, M(g.row.data()), M(g.path.data())));
     g.row.resize(t.width);
     return g;
 }
@@ -316,8 +347,8 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     S->nbits = (u32)S->ss.at("nBits").u64(); S->nbits_ext = (u32)S->ss.at("nBitsExt").u64();
     S->n_queries = (u32)S->ss.at("nQueries").u64();
     const std::string& hash_type = S->ss.at("verificationHashType").str();
-    ZK_REQUIRE(hash_type == "GL" || hash_type == "BN128", "verificationHashType must be GL or BN128 (BLS12381 is not on the device yet)");
-    S->bn128 = hash_type == "BN128";
+    ZK_REQUIRE(hash_type == "GL" || hash_type == "BN128" || hash_type == "BLS12381", "verificationHashType must be GL, BN128 or BLS12381");
+    S->fr = hash_type == "BN128" ? &FR_BN128 : hash_type == "BLS12381" ? &FR_BLS12381 : nullptr;
     ZK_REQUIRE(S->nbits >= 1 && S->nbits <= S->nbits_ext && S->nbits_ext <= 32, "bad nBits / nBitsExt");
     for (const JVal& st : S->ss.at("steps").arr) S->steps.push_back((u32)st.at("nBits").u64());
     ZK_REQUIRE(!S->steps.empty(), "starkStruct without FRI steps");
@@ -345,7 +376,7 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         lde_dev(S->const_n.u(), S->const_2ns.u(), tmp.u(), (u32)nc, S->nbits, S->nbits_ext, nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
     }
-    S->const_tree.reset(new AnyTree(S->bn128, S->const_2ns.u(), (u32)nc, Next, nullptr));
+    S->const_tree.reset(new AnyTree(S->fr, S->const_2ns.u(), (u32)nc, Next, nullptr));
     S->const_tree->root(S->const_root);
     const JVal& P = S->prog;
     S->step2prev = S->compile_segment(P.at("step2prev"), false, false);
@@ -435,7 +466,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         } else throw Error("Invalid public type " + ty);
     }
     if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
-    const bool bn128 = S.bn128;
+    const FrApi* bn128 = S.fr;                            // non-null: a scalar-field hash type
     AnyTranscript tr(bn128);
     tr.put_words_dev(d_pub.u(), publics.size(), st);
 

@@ -93,6 +93,12 @@ void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* 
 uint64_t bn128_merkle_n_nodes(uint64_t height);
 void bn128_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
 void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
+// the same over the BLS12-381 scalar field (verificationHashType "BLS12381")
+void bls12381_load_constants(const char* path);
+void bls12381_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st);
+uint64_t bls12381_merkle_n_nodes(uint64_t height);
+void bls12381_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
+void bls12381_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
 
 }  // namespace zk

@@ -358,9 +358,10 @@ class NativeStarkSetup:
 
     def __init__(self, const_n, program_json, stark_struct_json, prover_addr=None):
         c = _np(const_n)
-        if json.loads(stark_struct_json).get("verificationHashType") == "BN128":
+        hash_type = json.loads(stark_struct_json).get("verificationHashType")
+        if hash_type in ("BN128", "BLS12381"):
             from . import bn128_init
-            bn128_init()
+            bn128_init(field=hash_type.lower())
         self._h = lib().zk_stark_setup_new(program_json.encode(), stark_struct_json.encode(), _ptr(c), c.size)
         if not self._h:
             raise ZkError(lib().zk_last_error().decode())

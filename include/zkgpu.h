@@ -190,6 +190,32 @@ int zk_bn128_transcript_get_field(zk_bn128_transcript_t* t, uint64_t out[3]);
 int zk_bn128_transcript_get_permutations(zk_bn128_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out);
 int zk_bn128_transcript_free(zk_bn128_transcript_t* t);
 
+/* ---- the same over the BLS12-381 scalar field: verificationHashType "BLS12381" (`--curve BLS12381`).  Twins of the
+ * BN128 entry points above, behind poseidon_bls12381_opt.rs (hash() returns state[1], :94-103), linearhash_bls12381.rs,
+ * merklehash_bls12381.rs, transcript_bls12381.rs; tables in data/poseidon_bls12381_constants.bin.                     */
+typedef struct zk_bls12381_merkle zk_bls12381_merkle_t;
+typedef struct zk_bls12381_transcript zk_bls12381_transcript_t;
+int zk_bls12381_load_constants(const char* path);
+int zk_bls12381_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out);
+int zk_bls12381_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out,
+                          uint64_t* d_out, void* stream);
+int zk_bls12381_linearhash(const uint64_t* v, size_t n, uint64_t out[4]);
+uint64_t zk_bls12381_merkle_n_nodes(uint64_t height);
+zk_bls12381_merkle_t* zk_bls12381_merkelize(const uint64_t* buff, uint32_t width, uint64_t height);
+zk_bls12381_merkle_t* zk_bls12381_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream);
+int zk_bls12381_merkle_root(const zk_bls12381_merkle_t* t, uint64_t out[4]);
+int zk_bls12381_merkle_nodes(const zk_bls12381_merkle_t* t, uint64_t* out);
+uint32_t zk_bls12381_merkle_depth(const zk_bls12381_merkle_t* t);
+int zk_bls12381_merkle_group_proof(const zk_bls12381_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out);
+int zk_bls12381_merkle_free(zk_bls12381_merkle_t* t);
+zk_bls12381_transcript_t* zk_bls12381_transcript_new(void);
+int zk_bls12381_transcript_put(zk_bls12381_transcript_t* t, const uint64_t* e, size_t n);
+int zk_bls12381_transcript_get_fields1(zk_bls12381_transcript_t* t, uint64_t* out);
+int zk_bls12381_transcript_get_field(zk_bls12381_transcript_t* t, uint64_t out[3]);
+int zk_bls12381_transcript_get_permutations(zk_bls12381_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out);
+int zk_bls12381_transcript_free(zk_bls12381_transcript_t* t);
+
+
 /* ---- whole prover (starky/src/prove.rs:95-160: StarkSetup::new + StarkProof::stark_gen + FRI::prove) ------
  * zk_stark_setup_new stands behind StarkSetup::new (stark_setup.rs:27-66): it takes the reference's
  * serialised code-generator output, {"starkinfo": StarkInfo, "program": Program} (serde field names,

@@ -91,8 +91,9 @@ class BN128Backend:
     only through the MerkleTree and Transcript traits; everything else is delegated to the GL oracle.
     Digests are 4 raw (Montgomery) limbs; a group-proof path is [depth][16] digests (merklehash_bn128.rs:86-106)."""
 
-    def __init__(self, orc):
-        self._orc, self._h = orc, orc.bn128()
+    def __init__(self, orc, field="bn128"):
+        """field: "bn128" (MerkleTreeBN128 / TranscriptBN128) or "bls12381" (their BLS12-381 twins)"""
+        self._orc, self._h = orc, (orc.bn128() if field == "bn128" else orc.bls12381())
 
     def __getattr__(self, name):
         return getattr(self._orc, name)

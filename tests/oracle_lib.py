@@ -124,7 +124,11 @@ class Oracle:
 
     def bn128(self):
         """BN128-field Poseidon / LinearHash / Merkle / transcript (oracle/bn128_hash.c)"""
-        return BN128Hash(self.lib)
+        return BN128Hash(self.lib, "bn128")
+
+    def bls12381(self):
+        """the same over the BLS12-381 scalar field (oracle/bls12381_hash.c)"""
+        return BN128Hash(self.lib, "bls12381")
 
     def curve(self, name):
         """G1 arithmetic of `name` in ("bn254", "bls12_381") (oracle/ec.c, ec_bls12_381.c over ec_impl.h)."""
@@ -180,13 +184,23 @@ def build():
 _cached = None
 class BN128Hash:
     """digests and field elements travel as 4 u64 raw (Montgomery) limbs, like ElementDigest<4, Fr>"""
-    R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    MODULI = {"bn128": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+              "bls12381": 52435875175126190479447740508185965837690552500527637822603658699938581184513}
 
-    def __init__(self, lib):
-        self.lib = L = lib
+    class _Lib:
+        """view of liboracle.so that maps orc_bn128_x to orc_<field>_x"""
+        def __init__(self, lib, field):
+            self._lib, self._field = lib, field
+        def __getattr__(self, name):
+            return getattr(self._lib, name.replace("orc_bn128_", "orc_%s_" % self._field))
+
+    def __init__(self, lib, field="bn128"):
+        self.field, self.R = field, self.MODULI[field]
+        self.lib = L = self._Lib(lib, field)
         L.orc_bn128_load_constants.argtypes = [C.c_char_p]; L.orc_bn128_load_constants.restype = C.c_int
-        path = str(pathlib.Path(__file__).resolve().parent.parent / "oracle" / "poseidon_bn128_constants.bin")
+        path = str(pathlib.Path(__file__).resolve().parent.parent / "oracle" / ("poseidon_%s_constants.bin" % field))
         assert L.orc_bn128_load_constants(path.encode()) == 0, "cannot load " + path
+        L.orc_bn128_hash.argtypes = [_u64p, C.c_uint32, _u64p, _u64p]; L.orc_bn128_hash.restype = C.c_int
         L.orc_bn128_fr_to_mont.argtypes = [_u64p, _u64p]; L.orc_bn128_fr_from_mont.argtypes = [_u64p, _u64p]
         L.orc_bn128_poseidon.argtypes = [_u64p, C.c_uint32, _u64p, C.c_uint32, _u64p]; L.orc_bn128_poseidon.restype = C.c_int
         L.orc_bn128_hash_element_array.argtypes = [_u64p, C.c_uint64, _u64p]; L.orc_bn128_hash_element_array.restype = C.c_int
@@ -220,9 +234,14 @@ class BN128Hash:
         assert self.lib.orc_bn128_poseidon(inp, n, init, n_out, o) == 0
         return o.reshape(n_out, 4)
     def hash_ints(self, vals, init=0, n_out=1):
-        """Poseidon::hash over canonical integers -> canonical integers (the form of poseidon_bn128_opt.rs's tests)"""
+        """Poseidon::hash_ex over canonical integers -> canonical integers"""
         raw = np.concatenate([self.to_mont(v) for v in vals])
         return [self.from_mont(r) for r in self.poseidon(raw, self.to_mont(init), n_out)]
+    def hash1_ints(self, vals, init=0):
+        """Poseidon::hash (one element: state[0] for BN128, state[1] for BLS12-381), the form of the reference's tests"""
+        raw = np.concatenate([self.to_mont(v) for v in vals]); o = np.zeros(4, np.uint64)
+        assert self.lib.orc_bn128_hash(raw, len(vals), self.to_mont(init), o) == 0
+        return self.from_mont(o)
     def hash_element_array(self, vals):
         v = _a(vals); o = np.zeros(4, np.uint64); assert self.lib.orc_bn128_hash_element_array(v, v.size, o) == 0; return o
     def hash_element_matrix(self, vals):

@@ -113,3 +113,75 @@ def test_transcript_matches_oracle_sequence(zk, orc):
     assert t.get_field() == o.get_field()
     with pytest.raises(zk.ZkError):
         t.put([np.zeros(3, np.uint64)])                                 # "Invalid elements as inputs to transcript"
+
+
+# ---- BLS12-381 scalar field: the twin entry points zk_bls12381_* ----------------------------------------
+@pytest.fixture(scope="module")
+def bls(zk):
+    zk.bn128_init(field="bls12381")
+    return "bls12381"
+
+
+def test_bls12381_poseidon_known_answers_on_gpu(zk, orc, bls):
+    """poseidon_bls12381_opt.rs:236-311: Poseidon::hash = state[1]"""
+    h = orc.bls12381()
+    kat = [([1], 0x164efff6c8a32ef98836c868f8c8dedcbe3068d16ba6098f282a6d185edb551f),
+           ([1, 2, 0, 0, 0], 0x385acd94e53a8c6f981809c2201582beceaec12250200f1e75ba93e6cf5ec736),
+           ([1, 2, 3, 4], 0x6f5f297b0ab0d1e7400501b9bdd4c3be2fe676b6a05deb845143b87355167a8d),
+           (list(range(16)), 0x12d374bbdb8d3c1c0230b20b8fe1572f1e652a616d16e834718a982574106405)]
+    for inp, exp in kat:
+        raw = np.concatenate([h.to_mont(v) for v in inp])
+        assert h.from_mont(zk.bn128_poseidon(raw, None, 2, field=bls)[1]) == exp, inp
+
+
+@pytest.mark.parametrize("n_in", [1, 2, 5, 8, 15, 16])
+def test_bls12381_poseidon_matches_oracle(zk, orc, bls, n_in):
+    h = orc.bls12381()
+    rng = np.random.default_rng(500 + n_in)
+    vals = [int.from_bytes(rng.bytes(32), "little") % h.R for _ in range(n_in + 1)]
+    raw = np.concatenate([h.to_mont(v) for v in vals[1:]])
+    init = h.to_mont(vals[0])
+    assert np.array_equal(zk.bn128_poseidon(raw, init, n_in + 1, field=bls), h.poseidon(raw, init, n_in + 1))
+
+
+def test_bls12381_linearhash_and_corner_cases(zk, orc, bls):
+    h = orc.bls12381()
+    rng = np.random.default_rng(77)
+    for n in (0, 1, 3, 4, 5, 47, 48, 49, 97):
+        v = rng.integers(0, P, size=n, dtype=np.uint64)
+        if n >= 4:
+            v[:4] = [P - 1, P - 1, P - 1, P - 1]
+        assert np.array_equal(zk.bn128_linearhash(v, field=bls), h.hash_element_array(v)), n
+    d = zk.bn128_linearhash(np.array([6188675464075253840, 2608530331018891925], np.uint64), field=bls)   # linearhash_bls12381.rs:171-181
+    assert [int(x) for x in d] == [664572115127318441, 16413352647427919515, 17253685441004911215, 6212100569330953807]
+
+
+def test_bls12381_merkle_known_answer_and_oracle(zk, orc, bls):
+    h = orc.bls12381()
+    i, j = np.meshgrid(np.arange(4, dtype=np.uint64), np.arange(3, dtype=np.uint64), indexing="ij")
+    t = zk.MerkleTreeBN128(field=bls); t.merkelize((i + j * np.uint64(10) + np.uint64(1)).reshape(-1), 3, 4)
+    assert h.from_mont(t.root()) == 32227206116237215740162377531481191838063909532381497804787245624658969614932   # merklehash_bls12381.rs:274-300
+    for height, width in ((33, 6), (257, 12), (4096, 20), (5000, 1)):
+        rng = np.random.default_rng(height + width)
+        rows = rng.integers(0, P, size=height * width, dtype=np.uint64)
+        t = zk.MerkleTreeBN128(field=bls); t.merkelize(rows, width, height)
+        exp = h.merkelize(rows, width, height)
+        assert np.array_equal(t.nodes(), exp)
+        row, path = t.get_group_proof(height - 1)
+        assert np.array_equal(path, h.merkle_proof(exp, height, height - 1))
+
+
+def test_bls12381_transcript_matches_oracle(zk, orc, bls):
+    h = orc.bls12381()
+    rng = np.random.default_rng(6)
+    t, o = zk.TranscriptBN128(field=bls), h.transcript()
+    for step in range(30):
+        if step % 3 == 2:
+            d = h.to_mont(int.from_bytes(rng.bytes(32), "little"))
+            t.put([d]); o.put4(d)
+        else:
+            v = int(rng.integers(0, P, dtype=np.uint64))
+            t.put([np.array([v], np.uint64)]); o.put1(v)
+        if step % 5 == 0:
+            assert t.get_field() == o.get_field()
+    assert list(t.get_permutations(64, 23)) == list(o.get_permutations(64, 23))

@@ -82,10 +82,10 @@ def test_native_driver_rejects_bad_input(zk):
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     with pytest.raises(zk.ZkError):
         stark.NativeStarkSetup(np.zeros(4, np.uint64), "{not json", json.dumps(GL_STRUCT))
-    bls = dict(GL_STRUCT, verificationHashType="BLS12381")
+    bad = dict(GL_STRUCT, verificationHashType="SHA256")
     d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    with pytest.raises(zk.ZkError):                                          # GL and BN128 are on the device, BLS12381 is not
-        stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bls))
+    with pytest.raises(zk.ZkError):                                          # GL, BN128 and BLS12381 only
+        stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bad))
     with pytest.raises(zk.ZkError):                                          # const trace of the wrong size
         stark.NativeStarkSetup(np.zeros(5, np.uint64), json.dumps(d), json.dumps(GL_STRUCT))
 
@@ -117,6 +117,31 @@ def test_native_driver_bn128_zkin_equals_oracle_zkin(zk, orc, name):
         assert exp["rootC"] == "4658128321472362347225942316135505030498162093259225938328465623672244875764"
     ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"), json.dumps(SI.to_json(su["starkinfo"], su["program"])),
                                 json.dumps(BN128_STRUCT), prover_addr=PROVER_ADDR)
+    got = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))
+    assert list(got.keys()) == list(exp.keys())
+    for k in exp:
+        assert got[k] == exp[k], k
+
+
+@pytest.mark.parametrize("name", ["fibonacci", "plookup"])
+def test_native_driver_bls12381_zkin_equals_oracle_zkin(zk, orc, name):
+    """verificationHashType BLS12381 (MerkleTreeBLS12381 + TranscriptBLS128, prove.rs:62-76)"""
+    import importlib
+    import numpy as np
+    import stark_prover as SP
+    import starkinfo as SI
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    struct = dict(GL_STRUCT, verificationHashType="BLS12381")
+    pil_f, const_f, cm_f = BN128_CASES[name]
+    pil = json.load(open(D / pil_f))
+    b = SP.BN128Backend(orc, "bls12381")
+    su = SP.setup(pil, D / const_f, struct, b)
+    proof = SP.stark_gen(D / cm_f, su, struct, b)
+    assert SP.stark_verify(proof, proof["rootC"], su["starkinfo"], su["program"], struct, b)
+    exp = SP.to_zkin_bn128(proof, b, PROVER_ADDR)
+    ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"), json.dumps(SI.to_json(su["starkinfo"], su["program"])),
+                                json.dumps(struct), prover_addr=PROVER_ADDR)
     got = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))
     assert list(got.keys()) == list(exp.keys())
     for k in exp:

@@ -79,3 +79,45 @@ def test_transcript_is_deterministic_and_sensitive(orc):
     st = h.poseidon(np.concatenate([h.to_mont(7)] + [np.zeros(4, np.uint64)] * 15), np.zeros(4, np.uint64), 17)
     v = h.from_mont(st[0])
     assert f == [((v >> (64 * i)) & (2**64 - 1)) % 0xFFFFFFFF00000001 for i in range(3)]
+
+
+# ---- BLS12-381 scalar field (oracle/bls12381_hash.c) ------------------------------------------------------
+def test_bls12381_poseidon_known_answers(orc):
+    """poseidon_bls12381_opt.rs:236-311"""
+    h = orc.bls12381()
+    kat = [([1], 0x164efff6c8a32ef98836c868f8c8dedcbe3068d16ba6098f282a6d185edb551f),
+           ([1, 0], 0x59220c0fc5748e83c141c7bb8dae0a2bd5bbb227c778ede87296ba07960ec3d8),
+           ([1, 0, 0], 0x73584296b068384db6028b55d995108518d4483ab177197274effe979b91526e),
+           ([1, 2, 0, 0, 0], 0x385acd94e53a8c6f981809c2201582beceaec12250200f1e75ba93e6cf5ec736),
+           ([1, 2, 0, 0, 0, 0], 0x023dd8aecc0967c0588754eebd39af39bdae2bbf4195fee1208613c909aaa29b),
+           ([3, 4, 0, 0, 0], 0x19c96d726da9e3df4e5d0da19f324f7bf376dc7bf97efbf37082473f7fa24af8),
+           ([3, 4, 0, 0, 0, 0], 0x0cb7b1761b9abe661847a10701c6eae7c631ff580c5b7f3ac2f8be1088d22bba),
+           ([1, 2, 3, 4], 0x6f5f297b0ab0d1e7400501b9bdd4c3be2fe676b6a05deb845143b87355167a8d),
+           (list(range(16)), 0x12d374bbdb8d3c1c0230b20b8fe1572f1e652a616d16e834718a982574106405)]
+    for inp, exp in kat:
+        assert h.hash1_ints(inp) == exp, inp
+
+
+def test_bls12381_linearhash_known_answers(orc):
+    """linearhash_bls12381.rs:141-193"""
+    h = orc.bls12381()
+    cols = np.array([[e, e * 1000, e * 1000000] for e in range(100)], np.uint64).reshape(-1)
+    assert h.from_mont(h.hash_element_matrix(cols)) == 0x1aea10165e8c452045633835341291832bf7d46ace4bd6e8b1a2ddb9f257c2be
+    cols = np.array([[e, e, e] for e in range(9)], np.uint64).reshape(-1)
+    assert h.from_mont(h.hash_element_matrix(cols)) == 0x683f0b0c6f1a15d7715cbac061ca80f1f30a28920d32993c2f9cd307aee7bcbb
+    d = h.hash_element_array(np.array([6188675464075253840, 2608530331018891925], np.uint64))
+    assert [int(v) for v in d] == [664572115127318441, 16413352647427919515, 17253685441004911215, 6212100569330953807]
+    d = h.hash_element_array(np.array([18440682777423237490, 1156220815552880681], np.uint64))
+    assert int(d[0]) == 13796980492452026086
+
+
+def test_bls12381_merkle_root_known_answer(orc):
+    """merklehash_bls12381.rs:274-300"""
+    h = orc.bls12381()
+    n, w = 4, 3
+    i, j = np.meshgrid(np.arange(n, dtype=np.uint64), np.arange(w, dtype=np.uint64), indexing="ij")
+    rows = (i + j * np.uint64(10) + np.uint64(1)).reshape(-1)
+    nodes = h.merkelize(rows, w, n)
+    assert h.from_mont(nodes[-1]) == 32227206116237215740162377531481191838063909532381497804787245624658969614932
+    path = h.merkle_proof(nodes, n, 1)
+    assert np.array_equal(h.root_from_proof(path, h.hash_element_matrix(rows[3:6])), nodes[-1])
