@@ -41,7 +41,7 @@ __device__ void matmul(const fe* __restrict__ mat, fe* st, fe* tmp, u32 t) {
 }
 
 // poseidon_bn128_opt.rs:98-224 hash_inner on st[0..t) (st[0] = init state, st[1..] = inputs), all < 2r
-__device__ void poseidon_fr(fe* st, fe* tmp, u32 t) {
+__device__ __noinline__ void poseidon_fr(fe* st, fe* tmp, u32 t) {   // one generic copy: specialised for t = 17 it takes 256 VGPRs
     const Params P = g_prm[t - 2];
     for (u32 i = 0; i < t; ++i) st[i] = fe_add(st[i], P.c[i]);
     for (u32 r = 0; r < 3; ++r) {

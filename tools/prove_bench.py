@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--nbits", type=int, nargs="+", default=[16])
     ap.add_argument("--w", type=int, default=10)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--hash", default="GL", choices=["GL", "BN128", "BLS12381"], help="verificationHashType")
     ap.add_argument("--python-driver", action="store_true", help="eigen-zkvm_amd/stark.py step-by-step driver instead of zk_stark_gen")
     ap.add_argument("--verify", action="store_true", help="check the proof with the oracle's restated verifier")
     args = ap.parse_args()
@@ -25,6 +26,7 @@ def main():
     for nbits in args.nbits:
         info = synth_pil.rescale(d["starkinfo"], nbits)
         ss = synth_pil.stark_struct(nbits)
+        ss["verificationHashType"] = args.hash
         cm = synth_pil.wide_fib_trace(nbits, args.w)
         const = synth_pil.const_trace(nbits)
         t0 = time.perf_counter()
@@ -41,7 +43,7 @@ def main():
             t0 = time.perf_counter()
             proof = stark.stark_gen(cm, setup) if args.python_driver else setup.gen(d_cm)
             times.append(time.perf_counter() - t0)
-        out = {"workload": "wide-Fibonacci PIL W=%d (%d committed cols), nBits=%d, GL hash, %d queries" % (args.w, 2 * args.w, nbits, ss["nQueries"]),
+        out = {"workload": "wide-Fibonacci PIL W=%d (%d committed cols), nBits=%d, %s hash, %d queries" % (args.w, 2 * args.w, nbits, args.hash, ss["nQueries"]),
                "setup_s": round(t_setup, 3), "stark_gen_ms": [round(t * 1e3, 1) for t in times], "root1": proof["root1"]}
         if args.verify and args.python_driver:
             sys.path.insert(0, str(ROOT / "oracle"))
