@@ -149,11 +149,16 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const u32* __restrict__ 
     for (int k = threadIdx.x; k < N_COARSE; k += 256) h[k] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * SORT_PTS;
-    for (u32 t = threadIdx.x; t < SORT_PTS * N_WIN; t += 256) {
-        const u64 i = base + t / N_WIN; const u32 w = t % N_WIN;
+    for (u32 t = threadIdx.x; t < SORT_PTS; t += 256) {   // one point per trip: its 16 digits are independent work
+        const u64 i = base + t;
         if (i >= n) break;
-        const u32 d = digit_of(scalars, i, w);
-        if (d) atomicAdd(&h[w * 256 + (d >> 8)], 1u);
+        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[2 * i], hi = reinterpret_cast<const uint4*>(scalars)[2 * i + 1];
+        const u32 wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int w = 0; w < N_WIN; ++w) {
+            const u32 d = (w & 1) ? wd[w >> 1] >> 16 : wd[w >> 1] & 0xFFFF;
+            if (d) atomicAdd(&h[w * 256 + (d >> 8)], 1u);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < N_COARSE; k += 256) hist[(u64)k * n_blocks + blockIdx.x] = h[k];
@@ -164,11 +169,22 @@ __global__ __launch_bounds__(256) void sort_coarse_kernel(const u32* __restrict_
     for (int k = threadIdx.x; k < N_COARSE; k += 256) cur[k] = hist_scanned[(u64)k * n_blocks + blockIdx.x];
     __syncthreads();
     const u64 base = (u64)blockIdx.x * SORT_PTS;
-    for (u32 t = threadIdx.x; t < SORT_PTS * N_WIN; t += 256) {
-        const u64 i = base + t / N_WIN; const u32 w = t % N_WIN;
+    for (u32 t = threadIdx.x; t < SORT_PTS; t += 256) {
+        const u64 i = base + t;
         if (i >= n) break;
-        const u32 d = digit_of(scalars, i, w);
-        if (d) coarse[atomicAdd(&cur[w * 256 + (d >> 8)], 1u)] = ((u32)i << 8) | (d & 0xFF);
+        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[2 * i], hi = reinterpret_cast<const uint4*>(scalars)[2 * i + 1];
+        const u32 wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        u32 pos[N_WIN];
+#pragma unroll
+        for (int w = 0; w < N_WIN; ++w) {
+            const u32 d = (w & 1) ? wd[w >> 1] >> 16 : wd[w >> 1] & 0xFFFF;
+            pos[w] = d ? atomicAdd(&cur[w * 256 + (d >> 8)], 1u) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int w = 0; w < N_WIN; ++w) {
+            const u32 d = (w & 1) ? wd[w >> 1] >> 16 : wd[w >> 1] & 0xFFFF;
+            if (d) coarse[pos[w]] = ((u32)i << 8) | (d & 0xFF);
+        }
     }
 }
 // grand total of non-zero (point, window) pairs = last scanned entry + last count
@@ -227,10 +243,41 @@ __device__ __forceinline__ aff load_aff(const u32* __restrict__ conv, u32 i) {
     for (int k = 0; k < NR; ++k) { a.x.l[k] = w[k]; a.y.l[k] = w[NR + k]; }
     return a;
 }
+// Load balance: a wave runs as long as its fullest bucket, and bucket sizes are Poisson(n / 2^16).  Buckets are
+// therefore handed to lanes in order of decreasing size (a counting sort of the 2^20 bucket ids by size, sizes
+// clamped to 1023): the 64 buckets of a wave then differ by at most one point, and the heaviest waves start first.
+constexpr int BAL_BINS = 1024;
+__global__ __launch_bounds__(256) void balance_hist_kernel(const u32* __restrict__ counts, u32* __restrict__ hist) {
+    __shared__ u32 h[BAL_BINS];
+    for (int k = threadIdx.x; k < BAL_BINS; k += 256) h[k] = 0;
+    __syncthreads();
+    const u32 key = blockIdx.x * 256 + threadIdx.x;
+    const u32 c = counts[key] < BAL_BINS ? counts[key] : BAL_BINS - 1;
+    atomicAdd(&h[c], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < BAL_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
+}
+__global__ void balance_scan_kernel(u32* __restrict__ hist) {   // descending exclusive scan of 1024 counters, one lane
+    if (threadIdx.x | blockIdx.x) return;
+    u32 acc = 0;
+    for (int k = BAL_BINS - 1; k >= 0; --k) { const u32 v = hist[k]; hist[k] = acc; acc += v; }
+}
+__global__ __launch_bounds__(256) void balance_scatter_kernel(const u32* __restrict__ counts, u32* __restrict__ cursor, u32* __restrict__ order) {
+    __shared__ u32 h[BAL_BINS];   // block-local ranks first: one device-scope atomic per (block, non-empty size), not per bucket
+    for (int k = threadIdx.x; k < BAL_BINS; k += 256) h[k] = 0;
+    __syncthreads();
+    const u32 key = blockIdx.x * 256 + threadIdx.x;
+    const u32 c = counts[key] < BAL_BINS ? counts[key] : BAL_BINS - 1;
+    const u32 rank = atomicAdd(&h[c], 1u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < BAL_BINS; k += 256) if (h[k]) h[k] = atomicAdd(&cursor[k], h[k]);
+    __syncthreads();
+    order[h[c] + rank] = key;
+}
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restrict__ conv, const u32* __restrict__ offsets,
                                                             const u32* __restrict__ counts, const u32* __restrict__ idx,
-                                                            xyzz* __restrict__ buckets) {
-    const u32 key = blockIdx.x * blockDim.x + threadIdx.x;  // window * 2^16 + digit
+                                                            const u32* __restrict__ order, xyzz* __restrict__ buckets) {
+    const u32 key = order[blockIdx.x * blockDim.x + threadIdx.x];  // window * 2^16 + digit, heaviest first
     xyzz acc = pt_inf();
     const u32 n = counts[key], off = offsets[key];
     for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(conv, idx[off + k]));
@@ -347,8 +394,15 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
                            (u32*)cursors.p, (u32*)idx.p);
         ZK_HIP(hipGetLastError());
     }
+    DevBuf bal, order;
+    bal.reserve(BAL_BINS * 4); order.reserve(n_keys * 4);
+    ZK_HIP(hipMemsetAsync(bal.p, 0, BAL_BINS * 4, st));
+    hipLaunchKernelGGL(balance_hist_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, st, (const u32*)counts.p, (u32*)bal.p);
+    hipLaunchKernelGGL(balance_scan_kernel, dim3(1), dim3(64), 0, st, (u32*)bal.p);
+    hipLaunchKernelGGL(balance_scatter_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, st, (const u32*)counts.p, (u32*)bal.p, (u32*)order.p);
+    ZK_HIP(hipGetLastError());
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, (const u32*)conv.p,
-                       (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (xyzz*)buckets.p);
+                       (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (const u32*)order.p, (xyzz*)buckets.p);
     ZK_HIP(hipGetLastError());
     // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
     const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
