@@ -34,3 +34,30 @@ def test_no_cpu_fallback_in_product():
     for f in (ROOT / "eigen-zkvm_amd").rglob("*"):
         if f.is_file() and f.suffix in (".py", ".hip", ".h", ".cuh", ".cpp"):
             assert "oracle" not in f.read_text().replace("no CPU fallback", ""), f
+
+
+def test_host_side_argument_errors_without_gpu(zk):
+    """Errors the host code raises before any device work: malformed inputs of the prover entry point, hash types,
+    tree sizes -- int status / NULL + zk_last_error(), never an exception across the C ABI."""
+    import json
+    import numpy as np
+    lib = zk.lib()
+    err = lambda: lib.zk_last_error().decode()
+    c = np.zeros(4, np.uint64)
+    struct = {"nBits": 2, "nBitsExt": 3, "nQueries": 1, "verificationHashType": "GL", "steps": [{"nBits": 3}]}
+    assert not lib.zk_stark_setup_new(b"{not json", json.dumps(struct).encode(), zk._ptr(c), 4) and "json" in err()
+    assert not lib.zk_stark_setup_new(b'{"starkinfo": {}}', json.dumps(struct).encode(), zk._ptr(c), 4) and "program" in err()
+    bad = dict(struct, verificationHashType="SHA256")
+    assert not lib.zk_stark_setup_new(b'{"starkinfo": {}, "program": {}}', json.dumps(bad).encode(), zk._ptr(c), 4)
+    assert "verificationHashType" in err()
+    assert not lib.zk_stark_setup_new(None, None, None, 0) and "null" in err()
+    assert lib.zk_bn128_merkle_n_nodes(256) == 256 + 16 + 1 and lib.zk_bn128_merkle_n_nodes(33) == 48 + 16 + 1
+    assert lib.zk_bls12381_merkle_n_nodes(17) == 32 + 16 + 1
+    assert lib.zk_bn128_load_constants(b"/nonexistent/file") != 0 and err()
+
+
+def test_program_compiles_without_gpu(zk):
+    """zk_program_compile needs hipRTC, not a device: the generated source is inspectable on any host"""
+    p = zk.Program([zk.instr(zk.OP_MUL, zk.opnd(zk.OPND_TMP, id=0, dim=1), zk.opnd(zk.OPND_NUMBER, value=3), zk.opnd(zk.OPND_NUMBER, value=5))])
+    src = zk.lib().zk_program_source(p._h)
+    assert src and b"zk_eval_kernel" in src
