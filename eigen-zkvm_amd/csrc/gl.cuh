@@ -147,6 +147,54 @@ __device__ __forceinline__ f3 f3_inv(f3 x) {  // f3g.rs:207-235
 
 // ZK-JIT-END
 
+// ---- non-canonical ("nc") variants: results are SOME u64 congruent to the value, not necessarily < p.  Every
+// operation here accepts such operands wherever it says "any u64"; chains of them (the Poseidon permutation)
+// canonicalise once at the end instead of after every step (4-5 instructions per operation).
+__device__ __forceinline__ u64 mad_eps_nc(u32 r2, u64 t) {          // t + r2*(2^32-1), any u64 representative
+    u64 u; u32 m;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
+                 : "=&v"(u), "=v"(m) : "v"(r2), "v"(t) : "vcc");
+    return u + m;                                                    // carried: += 2^32 - 1 (cannot carry again)
+}
+__device__ __forceinline__ u64 reduce_words_nc(u32 w0, u32 w1, u32 r2, u32 r3) {
+    u32 bw0, bw1, e0, e1;
+    u32 t0 = __builtin_subc(w0, r3, 0u, &bw0);
+    u32 t1 = __builtin_subc(w1, 0u, bw0, &bw1);
+    const u32 mb = 0u - bw1;
+    t0 = __builtin_subc(t0, mb, 0u, &e0);
+    t1 = __builtin_subc(t1, 0u, e0, &e1);
+    return mad_eps_nc(r2, mk64(t0, t1));
+}
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {                // any u64 in, nc out
+    GL_OPAQUE(a); GL_OPAQUE(b);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
+}
+__device__ __forceinline__ u64 mul_add_nc(u64 a, u64 b, u64 c) {     // a*b + c, any u64 in, nc out
+    GL_OPAQUE(a); GL_OPAQUE(b); GL_OPAQUE(c);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0 + (u32)c;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32) + (c >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
+}
+// a + b for any u64 a and CANONICAL b (< p): a + b - 2^64 <= p - 2, so the 2^32 - 1 fix-up cannot carry again
+__device__ __forceinline__ u64 add_nc(u64 a, u64 b) {
+    GL_OPAQUE(a); GL_OPAQUE(b);
+    u32 c0, c1, d0, d1;
+    const u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
+    const u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+    const u32 m = 0u - c1;
+    const u32 r0 = __builtin_addc(s0, m, 0u, &d0);
+    const u32 r1 = __builtin_addc(s1, 0u, d0, &d1);
+    return mk64(r0, r1);
+}
+
 // x * 2^E mod p for a compile-time 0 <= E < 96, canonical x -> canonical result.  2 has order 192
 // and 2^96 = -1, so every root of unity of order <= 64 is a power of two (MG.0[6] = 2^39,
 // constant.rs:54-68): the butterflies' small twiddles are shifts, not field multiplications.

@@ -58,12 +58,14 @@ __device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[
     const u128 X1 = (u128)A01 + ((u128)A11 << 22) + ((u128)A21 << 44);
     const u64 X1l = (u64)X1, X1h = (u64)(X1 >> 64);                       // X1h < 2^39
     const u128 W = X0 + ((u128)X1l << 32) + (u128)(GL_P - X1h);            // < 2^104, congruent to V
-    return gl::reduce_words((u32)W, (u32)(W >> 32), (u32)(W >> 64), (u32)(W >> 96));
+    return gl::reduce_words_nc((u32)W, (u32)(W >> 32), (u32)(W >> 64), (u32)(W >> 96));
 }
 
-__device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74
-    u64 x2 = gl::sqr(x), x3 = gl::mul(x2, x), x6 = gl::sqr(x3);
-    return gl::mul(x6, x);
+// Inside a permutation every word is "nc" (gl.cuh: some u64 congruent to the value); the dense MDS product and the
+// batched dot products accept that and the last MDS of the permutation emits canonical words.
+__device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74; any u64 in, nc out
+    u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);
+    return gl::mul_nc(x6, x);
 }
 
 // out[i] = sum_j M[j][i] * st[j]  (poseidon_opt.rs:111-119), M[j][i] < 2^6 folded to immediates
@@ -109,23 +111,23 @@ __device__ __forceinline__ void mat_full(const u64* __restrict__ PT /* LDS */, u
 // in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables
 __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = gl::add(st[i], tab[T_C0 + i]);
+    for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], tab[T_C0 + i]);
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) st[i] = gl::add(pow7(st[i]), tab[T_FC + R * 12 + i]);
+        for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(pow7(st[i]), tab[T_FC + R * 12 + i]);
         if (R != 3) { mds_small(st); continue; }
         mat_full(tab + T_PT, st);
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
             const u64* __restrict__ SC = tab + T_SC + 11 * r;
-            st[0] = gl::add(pow7(st[0]), tab[T_PC + r]);
+            st[0] = gl::add_nc(pow7(st[0]), tab[T_PC + r]);
             u32 x0[12], x1[12];
 #pragma unroll
             for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
             const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);
 #pragma unroll
-            for (int k = 1; k < 12; ++k) st[k] = gl::mul_add(SC[k - 1], st[0], st[k]);
+            for (int k = 1; k < 12; ++k) st[k] = gl::mul_add_nc(SC[k - 1], st[0], st[k]);
             st[0] = s0;
         }
     }
@@ -179,10 +181,10 @@ __device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12])
 // x = this lane's state word (lanes 12..15 of a group carry garbage and only serve the shuffles)
 __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
     const int l = threadIdx.x & 15, lc = l < 12 ? l : 11;
-    x = gl::add(x, tab[T_C0 + lc]);
+    x = gl::add_nc(x, tab[T_C0 + lc]);
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
-        x = gl::add(pow7(x), tab[T_FC + R * 12 + lc]);
+        x = gl::add_nc(pow7(x), tab[T_FC + R * 12 + lc]);
         if (R != 3) { x = coop_mds(x, l); continue; }
         {
             u32 x0[12], x1[12];
@@ -191,11 +193,11 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
         }
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
-            const u64 st0 = shfl64(gl::add(pow7(x), tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
+            const u64 st0 = shfl64(gl::add_nc(pow7(x), tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
             u32 x0[12], x1[12];
             coop_gather(l == 0 ? st0 : x, x0, x1);
             const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);           // every lane computes the same s0
-            const u64 rest = gl::mul_add(tab[T_SC + 11 * r + (lc > 0 ? lc - 1 : 0)], st0, x);
+            const u64 rest = gl::mul_add_nc(tab[T_SC + 11 * r + (lc > 0 ? lc - 1 : 0)], st0, x);
             x = l == 0 ? s0 : rest;
         }
     }
