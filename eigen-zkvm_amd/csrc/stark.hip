@@ -99,28 +99,36 @@ __global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi
 
 // ---- evals (stark_gen.rs:432-466) ----------------------------------------------------------
 struct EvalDesc { const u64* buf; u64 width; u64 offset; u32 dim; u32 prime; };
-constexpr int EV_BLOCKS = 64;
+constexpr int EV_BLOCKS = 512;   // blocks along the row axis
+constexpr int EV_LANES = 32;     // evaluations per block: consecutive descriptors sit in consecutive lanes
 
-__global__ __launch_bounds__(256) void evals_partial_kernel(const EvalDesc* __restrict__ descs, u32 nbits, u32 ext,
+// One block = 8 rows x 32 evaluations per trip: the 32 lanes of a row read neighbouring columns of the same
+// section row (ev_map lists a section's columns one after the other), so a trip reads whole row segments
+// instead of one word per 128-byte line; L[k] is shared by the lanes of a row.
+__global__ __launch_bounds__(256) void evals_partial_kernel(const EvalDesc* __restrict__ descs, u32 n_ev, u32 nbits, u32 ext,
                                                             const u64* __restrict__ LEv, const u64* __restrict__ LpEv,
                                                             u64* __restrict__ partial /* [n_ev][EV_BLOCKS][3] */) {
-    const EvalDesc d = descs[blockIdx.y];
+    const u32 lane = threadIdx.x % EV_LANES, rowl = threadIdx.x / EV_LANES;   // 8 rows per trip
+    const u32 e = blockIdx.y * EV_LANES + lane;
+    const bool live = e < n_ev;
+    EvalDesc d = descs[live ? e : 0];
     const u64 N = 1ull << nbits;
     const u64* __restrict__ L = d.prime ? LpEv : LEv;
     f3 acc{{0, 0, 0}};
-    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (u64)gridDim.x * blockDim.x) {
-        const u64* c = d.buf + (k << ext) * d.width + d.offset;
-        const f3 l = ld3(L + 3 * k);
-        acc = gl::f3_add(acc, d.dim == 1 ? gl::f3_muls(l, c[0]) : gl::f3_mul(ld3(c), l));
-    }
+    if (live)
+        for (u64 k = (u64)blockIdx.x * 8 + rowl; k < N; k += (u64)gridDim.x * 8) {
+            const u64* c = d.buf + (k << ext) * d.width + d.offset;
+            const f3 l = ld3(L + 3 * k);
+            acc = gl::f3_add(acc, d.dim == 1 ? gl::f3_muls(l, c[0]) : gl::f3_mul(ld3(c), l));
+        }
     __shared__ u64 red[256 * 3];
-    red[threadIdx.x * 3] = acc.v[0]; red[threadIdx.x * 3 + 1] = acc.v[1]; red[threadIdx.x * 3 + 2] = acc.v[2];
+    st3(red + threadIdx.x * 3, acc);
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s) * 3)));
+    for (int s = 4; s > 0; s >>= 1) {   // over the 8 rows of the block
+        if ((int)rowl < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s * EV_LANES) * 3)));
         __syncthreads();
     }
-    if (threadIdx.x == 0) st3(partial + ((u64)blockIdx.y * gridDim.x + blockIdx.x) * 3, ld3(red));
+    if (rowl == 0 && live) st3(partial + ((u64)e * gridDim.x + blockIdx.x) * 3, ld3(red + lane * 3));
 }
 __global__ void evals_final_kernel(const u64* __restrict__ partial, u32 n_ev, u32 nblk, u64* __restrict__ out) {
     const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,7 +323,8 @@ void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_
     partial.reserve((size_t)n_ev * EV_BLOCKS * 24);
     ZK_HIP(hipMemcpyAsync(desc.p, descs, n_ev * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
     ZK_HIP(hipStreamSynchronize(st));  // `descs` is caller-owned pageable memory
-    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, n_ev), dim3(256), 0, st, (const EvalDesc*)desc.p, nbits, ext, d_LEv, d_LpEv, partial.u());
+    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, (n_ev + EV_LANES - 1) / EV_LANES), dim3(256), 0, st, (const EvalDesc*)desc.p, n_ev, nbits, ext,
+                       d_LEv, d_LpEv, partial.u());
     ZK_HIP(hipGetLastError());
     hipLaunchKernelGGL(evals_final_kernel, grid1(n_ev, 64), dim3(64), 0, st, partial.u(), n_ev, (u32)EV_BLOCKS, d_out);
     ZK_HIP(hipGetLastError());
