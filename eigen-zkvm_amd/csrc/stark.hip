@@ -82,19 +82,41 @@ __global__ void zh_inv_kernel(u64 sn, u64 we, u32 n, u64* __restrict__ out) {   
     if (j < n) out[j] = gl::inv(gl::sub(gl::mul(sn, gl::pow(we, j)), 1));
 }
 // x/(x - xi*mulw) for x = 49*w_ext^k                                            stark_gen.rs:481-522
+// Eight consecutive points per lane: one exponentiation for the first x, one extension-field inversion for all
+// eight denominators (Montgomery's trick: prefix products, invert the last, walk back).
+constexpr int XD_PER = 8;
 __global__ __launch_bounds__(256) void xdivxsub_kernel(const u64* __restrict__ xi, u64 mulw, u64 w_ext, u64 n, u64* __restrict__ out) {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const u64 k0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * XD_PER;
+    if (k0 >= n) return;
     const f3 z = gl::f3_muls(ld3(xi), mulw);
-    const u64 x = gl::mul(49, gl::pow(w_ext, k));
-    const f3 den{{gl::sub(x, z.v[0]), gl::neg(z.v[1]), gl::neg(z.v[2])}};
-    st3(out + 3 * k, gl::f3_muls(gl::f3_inv(den), x));
+    u64 x[XD_PER]; f3 den[XD_PER], pre[XD_PER];
+    x[0] = gl::mul(49, gl::pow(w_ext, k0));
+#pragma unroll
+    for (int j = 1; j < XD_PER; ++j) x[j] = gl::mul(x[j - 1], w_ext);
+#pragma unroll
+    for (int j = 0; j < XD_PER; ++j) {
+        den[j] = f3{{gl::sub(x[j], z.v[0]), gl::neg(z.v[1]), gl::neg(z.v[2])}};
+        pre[j] = j ? gl::f3_mul(pre[j - 1], den[j]) : den[0];
+    }
+    f3 inv = gl::f3_inv(pre[XD_PER - 1]);
+#pragma unroll
+    for (int j = XD_PER - 1; j >= 0; --j) {
+        const f3 dj = j ? gl::f3_mul(inv, pre[j - 1]) : inv;      // 1/den[j]
+        if (j) inv = gl::f3_mul(inv, den[j]);
+        if (k0 + j < n) st3(out + 3 * (k0 + j), gl::f3_muls(dj, x[j]));
+    }
 }
 // LEv[i] = (xi * mulw / 49)^i                                                   stark_gen.rs:416-427
 __global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi, u64 mul_c, u64 n, u64* __restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    st3(out + 3 * i, f3_pow(gl::f3_muls(ld3(xi), mul_c), i));
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * XD_PER;   // eight consecutive powers per lane
+    if (i0 >= n) return;
+    const f3 b = gl::f3_muls(ld3(xi), mul_c);
+    f3 p = f3_pow(b, i0);
+#pragma unroll
+    for (int j = 0; j < XD_PER; ++j) {
+        if (i0 + j < n) st3(out + 3 * (i0 + j), p);
+        p = gl::f3_mul(p, b);
+    }
 }
 
 // ---- evals (stark_gen.rs:432-466) ----------------------------------------------------------
@@ -301,7 +323,7 @@ void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st
 
 void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st) {
     const u64 n = 1ull << nbits_ext;
-    hipLaunchKernelGGL(xdivxsub_kernel, grid1(n), dim3(256), 0, st, d_xi, mulw, gl::hroot(nbits_ext), n, d_out);
+    hipLaunchKernelGGL(xdivxsub_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, mulw, gl::hroot(nbits_ext), n, d_out);
     ZK_HIP(hipGetLastError());
 }
 
@@ -309,7 +331,7 @@ void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp
     const u64 n = 1ull << nbits;
     u64 c = gl::hinv(49);
     if (prime) c = gl::hmul(c, gl::hroot(nbits));
-    hipLaunchKernelGGL(lev_pow_kernel, grid1(n), dim3(256), 0, st, d_xi, c, n, d_tmp);
+    hipLaunchKernelGGL(lev_pow_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, c, n, d_tmp);
     ZK_HIP(hipGetLastError());
     ntt_dev(d_tmp, d_out, d_tmp2, 3, nbits, true, st);  // FFT::ifft over F3G == per-limb iNTT (base-field roots)
 }
