@@ -400,15 +400,20 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
     DevBuf B[S_COUNT];
     u64* ptr[S_COUNT] = {};
-    auto alloc = [&](int s, u64 words) { B[s].reserve(std::max<u64>(1, words) * 8); zero(B[s], words); ptr[s] = B[s].u(); };
+    auto alloc = [&](int s, u64 words, bool zeroed = true) {
+        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words); ptr[s] = B[s].u();
+    };
     if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
     else {
         B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
         if (n_words) ZK_HIP(hipMemcpy(ptr[S_CM1_N], cm_pols, n_words * 8, hipMemcpyHostToDevice));
     }
     for (int s : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(s, sN[s] * N);
-    for (int s : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS, S_CM4_2NS}) alloc(s, sN[s] * Next);
-    alloc(S_Q_2NS, S.q_dim * Next); alloc(S_F_2NS, 3 * Next); alloc(S_SCRATCH, 3 * Next);
+    // sections that a kernel writes in full before anything reads them are not cleared: the extended sections (LDE
+    // output), cm4 (the forward NTT of the split quotient), q and f (every row written by step42ns / step52ns)
+    for (int s : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS}) alloc(s, sN[s] * Next, false);
+    alloc(S_CM4_2NS, sN[S_CM4_2NS] * Next, S.q_deg == 0);
+    alloc(S_Q_2NS, S.q_dim * Next, false); alloc(S_F_2NS, 3 * Next, false); alloc(S_SCRATCH, 3 * Next);
     ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
 
     DevBuf x_n, x_2ns, zi, d_chal, d_evals, d_pub, xdiv, xdivw;                     // stark_gen.rs:231-249
