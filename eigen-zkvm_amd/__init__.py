@@ -34,6 +34,8 @@ EXPORTS = [
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
     "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
     "zk_msm_g1_bls12_381", "zk_msm_g1_bls12_381_dev", "zk_g1_bls12_381_mul_generator_dev",
+    "zk_msm_g2_bn254", "zk_msm_g2_bn254_dev", "zk_g2_bn254_mul_generator_dev",
+    "zk_msm_g2_bls12_381", "zk_msm_g2_bls12_381_dev", "zk_g2_bls12_381_mul_generator_dev",
     "zk_bn128_load_constants", "zk_bn128_poseidon", "zk_bn128_poseidon_dev", "zk_bn128_linearhash",
     "zk_bn128_merkle_n_nodes", "zk_bn128_merkelize", "zk_bn128_merkelize_dev", "zk_bn128_merkle_root", "zk_bn128_merkle_nodes",
     "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_free",
@@ -183,6 +185,12 @@ def _load():
         "zk_msm_g1_bls12_381": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "zk_msm_g1_bls12_381_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
         "zk_g1_bls12_381_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bn254": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
+        "zk_msm_g2_bn254_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+        "zk_g2_bn254_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bls12_381": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
+        "zk_msm_g2_bls12_381_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
+        "zk_g2_bls12_381_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
@@ -583,16 +591,17 @@ class TranscriptBN128:
 _CURVES = {"bn254": 4, "bls12_381": 6}     # 64-bit words per Fq element
 
 
-def msm_g1(bases, scalars, curve="bn254"):
-    """sum_i scalars[i] * bases[i] on G1 of `curve`.  bases: n x 2*nl u64 (affine x||y, Montgomery limbs),
-    scalars: n x 4 u64 canonical.  Returns (point[2*nl] u64 Montgomery affine, is_infinity)."""
-    nl = _CURVES[curve]
+def msm_g1(bases, scalars, curve="bn254", group="g1"):
+    """sum_i scalars[i] * bases[i] on G1 (or group="g2": the twist, Fq2 coordinates c0 || c1) of `curve`.
+    bases: n x pw u64 (affine x||y, Montgomery limbs; pw = 2*nl for G1, 4*nl for G2), scalars: n x 4 u64 canonical.
+    Returns (point[pw] u64 Montgomery affine, is_infinity)."""
+    pw = _CURVES[curve] * (4 if group == "g2" else 2)
     b, s = _np(bases).reshape(-1), _np(scalars).reshape(-1)
     n = s.size // 4
-    if b.size != n * 2 * nl or s.size != n * 4:
+    if b.size != n * pw or s.size != n * 4:
         raise ZkError("msm: bases/scalars length mismatch")
-    out, inf = np.zeros(2 * nl, np.uint64), C.c_int(0)
-    _check(getattr(lib(), "zk_msm_g1_" + curve)(_ptr(b), _ptr(s), n, _ptr(out), C.byref(inf)))
+    out, inf = np.zeros(pw, np.uint64), C.c_int(0)
+    _check(getattr(lib(), "zk_msm_%s_%s" % (group, curve))(_ptr(b), _ptr(s), n, _ptr(out), C.byref(inf)))
     return out, bool(inf.value)
 
 
@@ -600,20 +609,20 @@ def msm_g1_bn254(bases, scalars):
     return msm_g1(bases, scalars, "bn254")
 
 
-def g1_mul_generator(d_k, curve="bn254", stream=0):
-    """bases[i] = [k_i]G for the n non-zero u64 in d_k; returns a DevArray of n * 2*nl words."""
-    out = DevArray(d_k.n * 2 * _CURVES[curve])
-    _check(getattr(lib(), "zk_g1_%s_mul_generator_dev" % curve)(d_k.ptr, d_k.n, out.ptr, stream)); return out
+def g1_mul_generator(d_k, curve="bn254", stream=0, group="g1"):
+    """bases[i] = [k_i]G for the n non-zero u64 in d_k; returns a DevArray of n * pw words."""
+    out = DevArray(d_k.n * _CURVES[curve] * (4 if group == "g2" else 2))
+    _check(getattr(lib(), "zk_%s_%s_mul_generator_dev" % (group, curve))(d_k.ptr, d_k.n, out.ptr, stream)); return out
 
 
 def g1_bn254_mul_generator(d_k, stream=0):
     return g1_mul_generator(d_k, "bn254", stream)
 
 
-def msm_g1_dev(d_bases, d_scalars, n, curve="bn254", stream=0):
-    """device-resident variant; returns a DevArray of 2*nl + 1 words (x, y, flag in the low 32 bits of the last)."""
-    out = DevArray(2 * _CURVES[curve] + 1, zero=True)
-    _check(getattr(lib(), "zk_msm_g1_%s_dev" % curve)(d_bases.ptr, d_scalars.ptr, n, out.ptr, stream)); return out
+def msm_g1_dev(d_bases, d_scalars, n, curve="bn254", stream=0, group="g1"):
+    """device-resident variant; returns a DevArray of pw + 1 words (the point, flag in the low 32 bits of the last)."""
+    out = DevArray(_CURVES[curve] * (4 if group == "g2" else 2) + 1, zero=True)
+    _check(getattr(lib(), "zk_msm_%s_%s_dev" % (group, curve))(d_bases.ptr, d_scalars.ptr, n, out.ptr, stream)); return out
 
 
 def msm_g1_bn254_dev(d_bases, d_scalars, n, stream=0):

@@ -373,6 +373,35 @@ int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* ou
     });
 }
 
+// G2 variants: same contract, points of PB bytes
+#define ZK_MSM_G2(NAME, PB)                                                                                               \
+    int zk_g2_##NAME##_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {                 \
+        return guard([&] { g2_##NAME##_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });          \
+    }                                                                                                                   \
+    int zk_msm_g2_##NAME##_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {       \
+        return guard([&] { msm_g2_##NAME##_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });                   \
+    }                                                                                                                   \
+    int zk_msm_g2_##NAME(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {               \
+        return guard([&] {                                                                                              \
+            ZK_REQUIRE(out && is_infinity, "msm: null output");                                                        \
+            ZK_REQUIRE(n == 0 || (bases && scalars), "msm: null input");                                               \
+            if (n == 0) { memset(out, 0, PB); *is_infinity = 1; return; }                                               \
+            DevBuf db, ds, dout;                                                                                        \
+            db.reserve(n * PB); ds.reserve(n * 32); dout.reserve(PB + 4);                                               \
+            ZK_HIP(hipMemcpy(db.p, bases, n * PB, hipMemcpyHostToDevice));                                              \
+            ZK_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));                                            \
+            msm_g2_##NAME##_dev(db.p, ds.p, n, dout.p, nullptr);                                                        \
+            uint32_t h[PB / 4 + 1];                                                                                     \
+            ZK_HIP(hipStreamSynchronize(nullptr));                                                                      \
+            ZK_HIP(hipMemcpy(h, dout.p, PB + 4, hipMemcpyDeviceToHost));                                                \
+            memcpy(out, h, PB);                                                                                         \
+            *is_infinity = (int)h[PB / 4];                                                                              \
+        });                                                                                                             \
+    }
+ZK_MSM_G2(bn254, 128)
+ZK_MSM_G2(bls12_381, 192)
+#undef ZK_MSM_G2
+
 int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {
     return guard([&] { g1_bls12_381_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });
 }

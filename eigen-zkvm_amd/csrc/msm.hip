@@ -54,6 +54,7 @@ __host__ __device__ constexpr u32 Q8_29(int i) {
     constexpr u32 v[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
     return v[i];
 }
+namespace g1 {
 __host__ __device__ constexpr u32 GEN_X(int i) {  // G = (1, 2), external Montgomery form: R mod q
     constexpr u32 r[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     return r[i];
@@ -65,6 +66,30 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {  // 2R mod q
 namespace {
 #include "msm_impl.cuh"
 }
+}  // namespace g1
+namespace g2 {   // the twist y^2 = x^3 + 3/(9 + u) over Fq2 = Fq[u]/(u^2 + 1); generator of EIP-197, x = c0 + c1 u
+__host__ __device__ constexpr u32 GEN_X(int i) {
+    constexpr u32 v[16] = {0x02bc2026u, 0x8e83b5d1u, 0x497b0172u, 0xdceb1935u, 0x97811adfu, 0xfbb82647u, 0xaf96503bu, 0x19573841u,
+                           0xa84c6140u, 0xafb4737du, 0x5802d8c4u, 0x6043dd5au, 0x52a02f86u, 0x09e950fcu, 0x3aea7b6bu, 0x14fef083u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 GEN_Y(int i) {
+    constexpr u32 v[16] = {0x886be9f6u, 0x619dfa9du, 0xf59e9b78u, 0xfe7fd297u, 0x231b7dfeu, 0xff9e1a62u, 0xae9e4206u, 0x28fd7eebu,
+                           0xc71856eeu, 0x64095b56u, 0x327d3cbbu, 0xdc57f922u, 0x33351076u, 0x55f935beu, 0x93fd6482u, 0x0da4a0e6u};
+    return v[i];
+}
+// Fq products stay out of line here: inlined (as for G1) a G2 point addition is > 128 KB of code, beyond the reach of
+// s_branch, and kernels of that size built by hipcc (ROCm 7.2) did not terminate on the device (seen twice: 12 x 32-bit
+// limbs inlined for BLS12-381 G1, and this)
+#undef FQ_MUL_ATTR
+#define FQ_MUL_ATTR __noinline__
+#define MSM_G2
+namespace {
+#include "msm_impl.cuh"
+}
+#undef MSM_G2
+#undef FQ_MUL_ATTR
+}  // namespace g2
 }  // namespace bn254
 
 namespace bls12_381 {
@@ -100,6 +125,7 @@ __host__ __device__ constexpr u32 Q8_29(int i) {
     constexpr u32 v[14] = {0x1ffd5558u, 0x1fbfffffu, 0x07ffff73u, 0x1fffeb15u, 0x1b120f55u, 0x0a83dac3u, 0x17ece61au, 0x04f38512u, 0x1b23ba5cu, 0x10d2eb35u, 0x16374f6cu, 0x17fe69a4u, 0x0088f51cu, 0x00000068u};
     return v[i];
 }
+namespace g1 {
 // the G1 generator of the BLS12-381 specification, external Montgomery form (R = 2^384)
 __host__ __device__ constexpr u32 GEN_X(int i) {
     constexpr u32 x[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
@@ -114,19 +140,49 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 namespace {
 #include "msm_impl.cuh"
 }
+}  // namespace g1
+namespace g2 {   // the twist y^2 = x^3 + 4(1 + u) over Fq2 = Fq[u]/(u^2 + 1); G2 generator of the BLS12-381 specification
+__host__ __device__ constexpr u32 GEN_X(int i) {
+    constexpr u32 v[24] = {0x02940a10u, 0xf5f28fa2u, 0x87b4961au, 0xb3f5fb26u, 0x3e2ae580u, 0xa1a893b5u, 0x1a3caee9u, 0x9894999du, 0x1863366bu, 0x6f67b763u, 0x4350bcd7u, 0x05819192u,
+                           0x9e23f606u, 0xa5a9c075u, 0xbccd60c3u, 0xaaa0c59du, 0xe2867806u, 0x3bb17e18u, 0x8541b367u, 0x1b1ab6ccu, 0xf2158547u, 0xc2b6ed0eu, 0x7360edf3u, 0x11922a09u};
+    return v[i];
+}
+__host__ __device__ constexpr u32 GEN_Y(int i) {
+    constexpr u32 v[24] = {0x60494c4au, 0x4c730af8u, 0x5e369c5au, 0x597cfa1fu, 0xaa0a635au, 0xe7e6856cu, 0x6e0d495fu, 0xbbefb5e9u, 0xf0ef25a2u, 0x07d3a975u, 0x7e80dae5u, 0x0083fd8eu,
+                           0xdf64b05du, 0xadc0fc92u, 0x2b1461dcu, 0x18aa270au, 0x3be4eba0u, 0x86adac6au, 0xc93da33au, 0x79495c4eu, 0xa43ccaedu, 0xe7175850u, 0x63de1bf2u, 0x0b2bc2a1u};
+    return v[i];
+}
+// Fq products stay out of line here: inlined (as for G1) a G2 point addition is > 128 KB of code, beyond the reach of
+// s_branch, and kernels of that size built by hipcc (ROCm 7.2) did not terminate on the device (seen twice: 12 x 32-bit
+// limbs inlined for BLS12-381 G1, and this)
+#undef FQ_MUL_ATTR
+#define FQ_MUL_ATTR __noinline__
+#define MSM_G2
+namespace {
+#include "msm_impl.cuh"
+}
+#undef MSM_G2
+#undef FQ_MUL_ATTR
+}  // namespace g2
 }  // namespace bls12_381
 
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
-    bn254::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
+    bn254::g1::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
 }
 void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
-    bn254::g1_mul_generator_dev(d_k, n, d_bases, st);
+    bn254::g1::g1_mul_generator_dev(d_k, n, d_bases, st);
 }
 void msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
-    bls12_381::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
+    bls12_381::g1::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
 }
 void g1_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
-    bls12_381::g1_mul_generator_dev(d_k, n, d_bases, st);
+    bls12_381::g1::g1_mul_generator_dev(d_k, n, d_bases, st);
 }
+
+// G2: points n x 4 coordinates-words (x.c0, x.c1, y.c0, y.c1), i.e. 128 B (BN254) / 192 B (BLS12-381) each
+void msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { bn254::g2::msm_g1_dev(d_bases, d_scalars, n, d_out, st); }
+void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) { bn254::g2::g1_mul_generator_dev(d_k, n, d_bases, st); }
+void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { bls12_381::g2::msm_g1_dev(d_bases, d_scalars, n, d_out, st); }
+void g2_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) { bls12_381::g2::g1_mul_generator_dev(d_k, n, d_bases, st); }
 
 }  // namespace zk

@@ -9,73 +9,162 @@
 // Field arithmetic: fe29_impl.cuh (29-bit limbs, 64-bit column accumulators, lazily reduced values).
 #include "fe29_impl.cuh"
 
+// ---- coordinate field `cf`: Fq for G1; Fq2 = Fq[u]/(u^2 + 1) for G2 (MSM_G2), built from the Fq operations
+// with every component brought back below 2q after a product (one extra product with R' mod q), so that the
+// bounds of the point formulas below hold for both.
+#ifndef MSM_G2
+typedef fe cf;
+constexpr int CW_STD = NL, CW_INT = NR;   // words per coordinate: external layout / internal limbs
+__device__ __forceinline__ cf cf_zero() { return fe_zero(); }
+__device__ __forceinline__ cf cf_one() { return fe_one(); }
+__device__ __forceinline__ cf cf_add(const cf& a, const cf& b) { return fe_add(a, b); }
+__device__ __forceinline__ cf cf_dbl(const cf& a) { return fe_dbl(a); }
+template <int M> __device__ __forceinline__ cf cf_sub(const cf& a, const cf& b) { return fe_sub<M>(a, b); }
+__device__ __forceinline__ cf cf_mul(const cf& a, const cf& b) { return fe_mul(a, b); }
+__device__ __forceinline__ cf cf_sqr(const cf& a) { return fe_sqr(a); }
+__device__ __forceinline__ bool cf_is_zero_m(const cf& a) { return fe_is_zero_m(a); }
+__device__ __forceinline__ cf cf_inv(const cf& a) { return fe_inv(a); }
+__device__ __forceinline__ cf cf_from_std(const u32* w) {
+    u32 t[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) t[i] = w[i];
+    return fe_from_std(t);
+}
+__device__ __forceinline__ void cf_to_std(const cf& a, u32* w) {
+    u32 t[NL];
+    fe_to_std(a, t);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) w[i] = t[i];
+}
+__device__ __forceinline__ cf cf_load_int(const u32* p) {
+    cf a;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) a.l[k] = p[k];
+    return a;
+}
+__device__ __forceinline__ void cf_store_int(const cf& a, u32* p) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) p[k] = a.l[k];
+}
+#else
+struct cf { fe c0, c1; };                 // c0 + c1 u, u^2 = -1 (both BN254 and BLS12-381 build Fq2 this way)
+constexpr int CW_STD = 2 * NL, CW_INT = 2 * NR;
+__device__ __forceinline__ fe fe_renorm(const fe& a) { return fe_mul(a, fe_one()); }   // < 168q -> < 2q, same residue
+__device__ __forceinline__ cf cf_zero() { cf r; r.c0 = fe_zero(); r.c1 = fe_zero(); return r; }
+__device__ __forceinline__ cf cf_one() { cf r; r.c0 = fe_one(); r.c1 = fe_zero(); return r; }
+__device__ __forceinline__ cf cf_add(const cf& a, const cf& b) { cf r; r.c0 = fe_add(a.c0, b.c0); r.c1 = fe_add(a.c1, b.c1); return r; }
+__device__ __forceinline__ cf cf_dbl(const cf& a) { return cf_add(a, a); }
+template <int M> __device__ __forceinline__ cf cf_sub(const cf& a, const cf& b) { cf r; r.c0 = fe_sub<M>(a.c0, b.c0); r.c1 = fe_sub<M>(a.c1, b.c1); return r; }
+__device__ __noinline__ cf cf_mul(const cf& a, const cf& b) {   // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, components < 2q
+    cf r;
+    r.c0 = fe_renorm(fe_sub<2>(fe_mul(a.c0, b.c0), fe_mul(a.c1, b.c1)));
+    r.c1 = fe_renorm(fe_add(fe_mul(a.c0, b.c1), fe_mul(a.c1, b.c0)));
+    return r;
+}
+__device__ __noinline__ cf cf_sqr(const cf& a) {
+    cf r;
+    r.c0 = fe_renorm(fe_sub<2>(fe_sqr(a.c0), fe_sqr(a.c1)));
+    r.c1 = fe_renorm(fe_dbl(fe_mul(a.c0, a.c1)));
+    return r;
+}
+__device__ __forceinline__ bool cf_is_zero_m(const cf& a) { return fe_is_zero_m(a.c0) && fe_is_zero_m(a.c1); }
+__device__ cf cf_inv(const cf& a) {       // (a0 - a1 u) / (a0^2 + a1^2), a < 2q
+    const fe n = fe_inv(fe_renorm(fe_add(fe_sqr(a.c0), fe_sqr(a.c1))));
+    cf r; r.c0 = fe_mul(a.c0, n); r.c1 = fe_mul(fe_sub<2>(fe_zero(), a.c1), n);
+    return r;
+}
+__device__ __forceinline__ cf cf_from_std(const u32* w) {
+    u32 t0[NL], t1[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { t0[i] = w[i]; t1[i] = w[NL + i]; }
+    cf r; r.c0 = fe_from_std(t0); r.c1 = fe_from_std(t1);
+    return r;
+}
+__device__ __forceinline__ void cf_to_std(const cf& a, u32* w) {
+    u32 t0[NL], t1[NL];
+    fe_to_std(a.c0, t0); fe_to_std(a.c1, t1);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { w[i] = t0[i]; w[NL + i] = t1[i]; }
+}
+__device__ __forceinline__ cf cf_load_int(const u32* p) {
+    cf a;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { a.c0.l[k] = p[k]; a.c1.l[k] = p[NR + k]; }
+    return a;
+}
+__device__ __forceinline__ void cf_store_int(const cf& a, u32* p) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) { p[k] = a.c0.l[k]; p[NR + k] = a.c1.l[k]; }
+}
+#endif
+
 // XYZZ coordinates: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ == 0.
 // Invariants of every stored point: X < 8q, Y <= 4q, ZZ, ZZZ < 2q (products), limbs normalised.
-struct xyzz { fe X, Y, ZZ, ZZZ; };
-struct aff { fe x, y; };  // x, y < 2q
+struct xyzz { cf X, Y, ZZ, ZZZ; };
+struct aff { cf x, y; };  // x, y < 2q
 
 __device__ __forceinline__ xyzz pt_inf() {
-    xyzz p; p.X = fe_zero(); p.Y = fe_zero(); p.ZZ = fe_zero(); p.ZZZ = fe_zero();
+    xyzz p; p.X = cf_zero(); p.Y = cf_zero(); p.ZZ = cf_zero(); p.ZZZ = cf_zero();
     return p;
 }
-__device__ __forceinline__ bool pt_is_inf(const xyzz& p) { return fe_is_zero_m(p.ZZ); }
+__device__ __forceinline__ bool pt_is_inf(const xyzz& p) { return cf_is_zero_m(p.ZZ); }
 // shared tail of the addition formulas: given U1 (= X1 scaled, < 8q), S1 (<= 4q), P, R and PP = P^2
-__device__ __forceinline__ void pt_finish(xyzz& r, const fe& U1, const fe& S1, const fe& P, const fe& Rr, const fe& PP) {
-    const fe PPP = fe_mul(P, PP), Q = fe_mul(U1, PP);                      // < 2q each
-    r.X = fe_sub<4>(fe_sub<2>(fe_sqr(Rr), PPP), fe_dbl(Q));                 // < 2q + 2q + 4q = 8q
-    r.Y = fe_sub<2>(fe_mul(Rr, fe_sub<8>(Q, r.X)), fe_mul(S1, PPP));        // (Q - X3 < 10q) ; Y3 < 4q
+__device__ __forceinline__ void pt_finish(xyzz& r, const cf& U1, const cf& S1, const cf& P, const cf& Rr, const cf& PP) {
+    const cf PPP = cf_mul(P, PP), Q = cf_mul(U1, PP);                      // < 2q each
+    r.X = cf_sub<4>(cf_sub<2>(cf_sqr(Rr), PPP), cf_dbl(Q));                 // < 2q + 2q + 4q = 8q
+    r.Y = cf_sub<2>(cf_mul(Rr, cf_sub<8>(Q, r.X)), cf_mul(S1, PPP));        // (Q - X3 < 10q) ; Y3 < 4q
 }
 __device__ xyzz pt_dbl_aff(const aff& a) {  // mdbl-2008-s-1 (a = 0)
-    const fe U = fe_dbl(a.y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(a.x, V);
-    const fe xx = fe_sqr(a.x), M = fe_add(fe_dbl(xx), xx);                  // < 6q
+    const cf U = cf_dbl(a.y), V = cf_sqr(U), W = cf_mul(U, V), S = cf_mul(a.x, V);
+    const cf xx = cf_sqr(a.x), M = cf_add(cf_dbl(xx), xx);                  // < 6q
     xyzz r;
-    r.X = fe_sub<4>(fe_sqr(M), fe_dbl(S));                                  // < 6q
-    r.Y = fe_sub<2>(fe_mul(M, fe_sub<8>(S, r.X)), fe_mul(W, a.y));
+    r.X = cf_sub<4>(cf_sqr(M), cf_dbl(S));                                  // < 6q
+    r.Y = cf_sub<2>(cf_mul(M, cf_sub<8>(S, r.X)), cf_mul(W, a.y));
     r.ZZ = V; r.ZZZ = W;
     return r;
 }
 __device__ xyzz pt_dbl(const xyzz& p) {  // dbl-2008-s-1 (a = 0)
     if (pt_is_inf(p)) return p;
-    const fe U = fe_dbl(p.Y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.X, V);   // U <= 8q
-    const fe xx = fe_sqr(p.X), M = fe_add(fe_dbl(xx), xx);                  // < 6q
+    const cf U = cf_dbl(p.Y), V = cf_sqr(U), W = cf_mul(U, V), S = cf_mul(p.X, V);   // U <= 8q
+    const cf xx = cf_sqr(p.X), M = cf_add(cf_dbl(xx), xx);                  // < 6q
     xyzz r;
-    r.X = fe_sub<4>(fe_sqr(M), fe_dbl(S));                                  // < 6q
-    r.Y = fe_sub<2>(fe_mul(M, fe_sub<8>(S, r.X)), fe_mul(W, p.Y));
-    r.ZZ = fe_mul(V, p.ZZ); r.ZZZ = fe_mul(W, p.ZZZ);
+    r.X = cf_sub<4>(cf_sqr(M), cf_dbl(S));                                  // < 6q
+    r.Y = cf_sub<2>(cf_mul(M, cf_sub<8>(S, r.X)), cf_mul(W, p.Y));
+    r.ZZ = cf_mul(V, p.ZZ); r.ZZZ = cf_mul(W, p.ZZZ);
     return r;
 }
 __device__ xyzz pt_madd(const xyzz& p, const aff& a) {  // madd-2008-s
-    if (pt_is_inf(p)) { xyzz r; r.X = a.x; r.Y = a.y; r.ZZ = fe_one(); r.ZZZ = fe_one(); return r; }
-    const fe U2 = fe_mul(a.x, p.ZZ), S2 = fe_mul(a.y, p.ZZZ);
-    const fe P = fe_sub<8>(U2, p.X), Rr = fe_sub<4>(S2, p.Y);               // < 10q, < 6q
-    const fe PP = fe_sqr(P);
-    if (fe_is_zero_m(PP)) return fe_is_zero_m(fe_sqr(Rr)) ? pt_dbl_aff(a) : pt_inf();  // q prime: P^2 = 0 <=> P = 0
+    if (pt_is_inf(p)) { xyzz r; r.X = a.x; r.Y = a.y; r.ZZ = cf_one(); r.ZZZ = cf_one(); return r; }
+    const cf U2 = cf_mul(a.x, p.ZZ), S2 = cf_mul(a.y, p.ZZZ);
+    const cf P = cf_sub<8>(U2, p.X), Rr = cf_sub<4>(S2, p.Y);               // < 10q, < 6q
+    const cf PP = cf_sqr(P);
+    if (cf_is_zero_m(PP)) return cf_is_zero_m(cf_sqr(Rr)) ? pt_dbl_aff(a) : pt_inf();  // q prime: P^2 = 0 <=> P = 0
     xyzz r;
     pt_finish(r, p.X, p.Y, P, Rr, PP);
-    r.ZZ = fe_mul(p.ZZ, PP); r.ZZZ = fe_mul(p.ZZZ, fe_mul(P, PP));
+    r.ZZ = cf_mul(p.ZZ, PP); r.ZZZ = cf_mul(p.ZZZ, cf_mul(P, PP));
     return r;
 }
 __device__ xyzz pt_add(const xyzz& p, const xyzz& q) {  // add-2008-s
     if (pt_is_inf(p)) return q;
     if (pt_is_inf(q)) return p;
-    const fe U1 = fe_mul(p.X, q.ZZ), U2 = fe_mul(q.X, p.ZZ), S1 = fe_mul(p.Y, q.ZZZ), S2 = fe_mul(q.Y, p.ZZZ);
-    const fe P = fe_sub<2>(U2, U1), Rr = fe_sub<2>(S2, S1);                 // < 4q
-    const fe PP = fe_sqr(P);
-    if (fe_is_zero_m(PP)) return fe_is_zero_m(fe_sqr(Rr)) ? pt_dbl(p) : pt_inf();
+    const cf U1 = cf_mul(p.X, q.ZZ), U2 = cf_mul(q.X, p.ZZ), S1 = cf_mul(p.Y, q.ZZZ), S2 = cf_mul(q.Y, p.ZZZ);
+    const cf P = cf_sub<2>(U2, U1), Rr = cf_sub<2>(S2, S1);                 // < 4q
+    const cf PP = cf_sqr(P);
+    if (cf_is_zero_m(PP)) return cf_is_zero_m(cf_sqr(Rr)) ? pt_dbl(p) : pt_inf();
     xyzz r;
     pt_finish(r, U1, S1, P, Rr, PP);
-    r.ZZ = fe_mul(fe_mul(p.ZZ, q.ZZ), PP); r.ZZZ = fe_mul(fe_mul(p.ZZZ, q.ZZZ), fe_mul(P, PP));
+    r.ZZ = cf_mul(cf_mul(p.ZZ, q.ZZ), PP); r.ZZZ = cf_mul(cf_mul(p.ZZZ, q.ZZZ), cf_mul(P, PP));
     return r;
 }
 __device__ __forceinline__ xyzz pt_neg(const xyzz& p) {
     xyzz r = p;
-    r.Y = fe_sub<4>(fe_zero(), p.Y);                                        // 4q - Y <= 4q
+    r.Y = cf_sub<4>(cf_zero(), p.Y);                                        // 4q - Y <= 4q
     return r;
 }
 // affine (external layout) of a finite point: x = X/ZZ, y = Y/ZZZ; 1/ZZ = (ZZ/ZZZ)^2 because ZZ^3 = ZZZ^2
-__device__ void pt_to_std(const xyzz& p, u32 (&x)[NL], u32 (&y)[NL]) {
-    const fe izzz = fe_inv(p.ZZZ), t = fe_mul(p.ZZ, izzz), izz = fe_sqr(t);
-    fe_to_std(fe_mul(p.X, izz), x); fe_to_std(fe_mul(p.Y, izzz), y);
+__device__ void pt_to_std(const xyzz& p, u32* x, u32* y) {   // CW_STD words each
+    const cf izzz = cf_inv(p.ZZZ), t = cf_mul(p.ZZ, izzz), izz = cf_sqr(t);
+    cf_to_std(cf_mul(p.X, izz), x); cf_to_std(cf_mul(p.Y, izzz), y);
 }
 
 constexpr int C_BITS = 16, N_WIN = 16, N_BUCKET = 1 << C_BITS;  // 254-bit scalars: 16 windows of 16 bits
@@ -216,22 +305,17 @@ __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__
 }
 
 // ---- bases: external 2*NL words per point -> internal 2*NR limbs, padded to PTW words for 16-byte loads
-constexpr int PTW = (2 * NR + 3) / 4 * 4;
+constexpr int PTW = (2 * CW_INT + 3) / 4 * 4;
 __global__ __launch_bounds__(256) void msm_convert_kernel(const u32* __restrict__ bases, u64 n, u32* __restrict__ conv) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 wx[NL], wy[NL];
-    const uint4* p = (const uint4*)(bases + i * (2 * NL));
+    u32 w[2 * CW_STD];
+    const uint4* p = (const uint4*)(bases + i * (2 * CW_STD));
 #pragma unroll
-    for (int k = 0; k < NL / 4; ++k) {
-        const uint4 vx = p[k], vy = p[NL / 4 + k];
-        wx[4 * k] = vx.x; wx[4 * k + 1] = vx.y; wx[4 * k + 2] = vx.z; wx[4 * k + 3] = vx.w;
-        wy[4 * k] = vy.x; wy[4 * k + 1] = vy.y; wy[4 * k + 2] = vy.z; wy[4 * k + 3] = vy.w;
-    }
-    const fe x = fe_from_std(wx), y = fe_from_std(wy);
+    for (int k = 0; k < 2 * CW_STD / 4; ++k) { const uint4 v = p[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    const cf x = cf_from_std(w), y = cf_from_std(w + CW_STD);
     u32* o = conv + i * PTW;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { o[k] = x.l[k]; o[NR + k] = y.l[k]; }
+    cf_store_int(x, o); cf_store_int(y, o + CW_INT);
 }
 __device__ __forceinline__ aff load_aff(const u32* __restrict__ conv, u32 i) {
     u32 w[PTW];
@@ -239,8 +323,7 @@ __device__ __forceinline__ aff load_aff(const u32* __restrict__ conv, u32 i) {
 #pragma unroll
     for (int k = 0; k < PTW / 4; ++k) { const uint4 v = p[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
     aff a;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) { a.x.l[k] = w[k]; a.y.l[k] = w[NR + k]; }
+    a.x = cf_load_int(w); a.y = cf_load_int(w + CW_INT);
     return a;
 }
 // Load balance: a wave runs as long as its fullest bucket, and bucket sizes are Poisson(n / 2^16).  Buckets are
@@ -305,38 +388,38 @@ __global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __rest
     }
     S_out[g] = run; A_out[g] = acc;
 }
-__global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*NL words + flag */) {
+__global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */) {
     if (threadIdx.x | blockIdx.x) return;
     xyzz acc = pt_inf();
     for (int w = N_WIN - 1; w >= 0; --w) {
         for (int k = 0; k < C_BITS; ++k) acc = pt_dbl(acc);
         acc = pt_add(acc, win[w]);
     }
-    if (pt_is_inf(acc)) { for (int i = 0; i < 2 * NL; ++i) out[i] = 0; out[2 * NL] = 1; return; }
-    u32 x[NL], y[NL];
+    if (pt_is_inf(acc)) { for (int i = 0; i < 2 * CW_STD; ++i) out[i] = 0; out[2 * CW_STD] = 1; return; }
+    u32 x[CW_STD], y[CW_STD];
     pt_to_std(acc, x, y);
-    for (int i = 0; i < NL; ++i) { out[i] = x[i]; out[NL + i] = y[i]; }
-    out[2 * NL] = 0;
+    for (int i = 0; i < CW_STD; ++i) { out[i] = x[i]; out[CW_STD + i] = y[i]; }
+    out[2 * CW_STD] = 0;
 }
 
 // synthetic bases for benches/tests: P_i = [k_i]G, G = the curve's generator; k_i 64-bit, non-zero
 __global__ __launch_bounds__(64) void g1_mul_generator_kernel(const u64* __restrict__ k, u64 n, u32* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 gx[NL], gy[NL];
-    for (int j = 0; j < NL; ++j) { gx[j] = GEN_X(j); gy[j] = GEN_Y(j); }
-    aff g; g.x = fe_from_std(gx); g.y = fe_from_std(gy);
+    u32 gx[CW_STD], gy[CW_STD];
+    for (int j = 0; j < CW_STD; ++j) { gx[j] = GEN_X(j); gy[j] = GEN_Y(j); }
+    aff g; g.x = cf_from_std(gx); g.y = cf_from_std(gy);
     const u64 e = k[i];
     xyzz acc = pt_inf();
     for (int b = 63; b >= 0; --b) {
         acc = pt_dbl(acc);
         if ((e >> b) & 1) acc = pt_madd(acc, g);
     }
-    u32* o = out + i * (2 * NL);
-    if (pt_is_inf(acc)) { for (int j = 0; j < 2 * NL; ++j) o[j] = 0; return; }
-    u32 x[NL], y[NL];
+    u32* o = out + i * (2 * CW_STD);
+    if (pt_is_inf(acc)) { for (int j = 0; j < 2 * CW_STD; ++j) o[j] = 0; return; }
+    u32 x[CW_STD], y[CW_STD];
     pt_to_std(acc, x, y);
-    for (int j = 0; j < NL; ++j) { o[j] = x[j]; o[NL + j] = y[j]; }
+    for (int j = 0; j < CW_STD; ++j) { o[j] = x[j]; o[CW_STD + j] = y[j]; }
 }
 
 void g1_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
@@ -345,7 +428,7 @@ void g1_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t
     ZK_HIP(hipGetLastError());
 }
 
-// d_out: 2*NL + 1 u32 words (x, y Montgomery, infinity flag)
+// d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag)
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;

@@ -87,6 +87,11 @@ void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipSt
 // BLS12-381: bases n*96 B, scalars n*32 B; d_out 25 u32 (x, y, inf flag)
 void msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
 void g1_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
+// G2 (Fq2 coordinates: x.c0 || x.c1 || y.c0 || y.c1): 128 B / 192 B per point; d_out = that + a flag word
+void msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
+void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
+void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
+void g2_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
 // ---- BN128-field hashing (poseidon_bn128.hip); digests = 4 raw (Montgomery, R = 2^256) limbs
 void bn128_load_constants(const char* path);
 void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st);

@@ -151,6 +151,15 @@ int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, 
 int zk_msm_g1_bls12_381(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
 int zk_msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
 int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
+/* G2 (the B-query of a Groth16 proving key): the same entry points over the sextic twist, coordinates in
+ * Fq2 = Fq[u]/(u^2 + 1).  A point is x.c0 || x.c1 || y.c0 || y.c1 (pairing_ce's G2Affine), each Fq as above:
+ * 128 B (BN254) / 192 B (BLS12-381); `_dev` output = the point followed by a 4-byte infinity flag.              */
+int zk_msm_g2_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
+int zk_msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+int zk_g2_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
+int zk_msm_g2_bls12_381(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
+int zk_msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+int zk_g2_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);
 /* synthetic CRS for benches and tests: d_bases[i] = [d_k[i]] G, G = (1, 2), k_i a non-zero 64-bit integer
  * (what generate_random_parameters, groth16.rs:39,82, does with secret exponents).                     */
 int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream);

@@ -21,6 +21,12 @@
 #define EC_B 3
 #define EC_GX {1, 0, 0, 0}
 #define EC_GY {2, 0, 0, 0}
+#define EC_B2C0 {0x3267e6dc24a138e5ULL, 0xb5b4c5e559dbefa3ULL, 0x81be18991be06ac3ULL, 0x2b149d40ceb8aaaeULL}   /* b' = 3/(9 + u) */
+#define EC_B2C1 {0xe4a2bd0685c315d2ULL, 0xa74fa084e52d1852ULL, 0xcd2cafadeed8fdf4ULL, 0x009713b03af0fed4ULL}
+#define EC_G2X0 {0x46debd5cd992f6edULL, 0x674322d4f75edaddULL, 0x426a00665e5c4479ULL, 0x1800deef121f1e76ULL}   /* G2 generator of EIP-197 */
+#define EC_G2X1 {0x97e485b7aef312c2ULL, 0xf1aa493335a9e712ULL, 0x7260bfb731fb5d25ULL, 0x198e9393920d483aULL}
+#define EC_G2Y0 {0x4ce6cc0166fa7daaULL, 0xe3d1e7690c43d37bULL, 0x4aab71808dcb408fULL, 0x12c85ea5db8c6debULL}
+#define EC_G2Y1 {0x55acdadcd122975bULL, 0xbc4b313370b38ef3ULL, 0xec9e99ad690c3395ULL, 0x090689d0585ff075ULL}
 #define EC_X(name) orc_bn254_##name
 #include "ec_impl.h"
 

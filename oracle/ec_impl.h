@@ -198,3 +198,144 @@ int EC_X(msm)(const uint64_t *bases, const uint64_t *scalars, uint64_t n, unsign
     memcpy(out, &r.x, FQB); memcpy(out + EC_NL, &r.y, FQB);
     return r.inf;
 }
+
+/* ---- G2: the sextic twist y^2 = x^3 + b' over Fq2 = Fq[u]/(u^2 + 1) ---------------------------------------
+ * Needs EC_B2C0, EC_B2C1 (b' = c0 + c1 u, canonical limbs) and EC_G2X0/X1/Y0/Y1 (generator, canonical limbs).
+ * Points travel as pairing_ce keeps G2Affine: x.c0 || x.c1 || y.c0 || y.c1, each Fq in Montgomery form. */
+typedef struct { fq_t c0, c1; } fq2_t;
+typedef struct { fq2_t x, y; int inf; } aff2_t;
+typedef struct { fq2_t x, y, z; } jac2_t;
+#define PT2W (4 * EC_NL)
+static fq_t fq_neg(fq_t a) { fq_t z; memset(&z, 0, sizeof z); return fq_sub(z, a); }
+static fq2_t f2_add(fq2_t a, fq2_t b) { fq2_t r = {fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; return r; }
+static fq2_t f2_sub(fq2_t a, fq2_t b) { fq2_t r = {fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; return r; }
+static fq2_t f2_mul(fq2_t a, fq2_t b) {
+    fq2_t r = {fq_sub(fq_mul(a.c0, b.c0), fq_mul(a.c1, b.c1)), fq_add(fq_mul(a.c0, b.c1), fq_mul(a.c1, b.c0))};
+    return r;
+}
+static fq2_t f2_sqr(fq2_t a) { return f2_mul(a, a); }
+static int f2_is_zero(fq2_t a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+static int f2_eq(fq2_t a, fq2_t b) { return fq_eq(a.c0, b.c0) && fq_eq(a.c1, b.c1); }
+static fq2_t f2_inv(fq2_t a) {
+    fq_t n = fq_inv(fq_add(fq_sqr(a.c0), fq_sqr(a.c1)));
+    fq2_t r = {fq_mul(a.c0, n), fq_mul(fq_neg(a.c1), n)};
+    return r;
+}
+static fq2_t f2_load(const uint64_t *p) { fq2_t x; x.c0 = fq_load(p); x.c1 = fq_load(p + EC_NL); return x; }
+static void f2_store(uint64_t *p, fq2_t x) { memcpy(p, &x.c0, FQB); memcpy(p + EC_NL, &x.c1, FQB); }
+static fq2_t f2_one(void) { fq2_t r; r.c0 = R1; memset(&r.c1, 0, sizeof r.c1); return r; }
+
+static jac2_t jac2_inf(void) { jac2_t p; memset(&p, 0, sizeof p); return p; }
+static jac2_t jac2_dbl(jac2_t p) { /* dbl-2009-l, a = 0 */
+    if (f2_is_zero(p.z)) return p;
+    fq2_t A = f2_sqr(p.x), B = f2_sqr(p.y), C = f2_sqr(B);
+    fq2_t D = f2_sub(f2_sub(f2_sqr(f2_add(p.x, B)), A), C); D = f2_add(D, D);
+    fq2_t E = f2_add(f2_add(A, A), A), F = f2_sqr(E);
+    jac2_t r;
+    r.x = f2_sub(F, f2_add(D, D));
+    fq2_t C8 = f2_add(C, C); C8 = f2_add(C8, C8); C8 = f2_add(C8, C8);
+    r.y = f2_sub(f2_mul(E, f2_sub(D, r.x)), C8);
+    r.z = f2_mul(p.y, p.z); r.z = f2_add(r.z, r.z);
+    return r;
+}
+static jac2_t jac2_add_aff(jac2_t p, const aff2_t *q) { /* madd-2007-bl */
+    if (q->inf) return p;
+    if (f2_is_zero(p.z)) { jac2_t r; r.x = q->x; r.y = q->y; r.z = f2_one(); return r; }
+    fq2_t Z1Z1 = f2_sqr(p.z), U2 = f2_mul(q->x, Z1Z1), S2 = f2_mul(f2_mul(q->y, p.z), Z1Z1);
+    if (f2_eq(U2, p.x)) { if (f2_eq(S2, p.y)) return jac2_dbl(p); return jac2_inf(); }
+    fq2_t H = f2_sub(U2, p.x), HH = f2_sqr(H), I = f2_add(HH, HH); I = f2_add(I, I);
+    fq2_t J = f2_mul(H, I), r_ = f2_sub(S2, p.y); r_ = f2_add(r_, r_);
+    fq2_t V = f2_mul(p.x, I);
+    jac2_t r;
+    r.x = f2_sub(f2_sub(f2_sqr(r_), J), f2_add(V, V));
+    fq2_t YJ = f2_mul(p.y, J);
+    r.y = f2_sub(f2_mul(r_, f2_sub(V, r.x)), f2_add(YJ, YJ));
+    r.z = f2_sub(f2_sub(f2_sqr(f2_add(p.z, H)), Z1Z1), HH);
+    return r;
+}
+static jac2_t jac2_add(jac2_t p, jac2_t q) { /* add-2007-bl */
+    if (f2_is_zero(p.z)) return q;
+    if (f2_is_zero(q.z)) return p;
+    fq2_t Z1Z1 = f2_sqr(p.z), Z2Z2 = f2_sqr(q.z);
+    fq2_t U1 = f2_mul(p.x, Z2Z2), U2 = f2_mul(q.x, Z1Z1);
+    fq2_t S1 = f2_mul(f2_mul(p.y, q.z), Z2Z2), S2 = f2_mul(f2_mul(q.y, p.z), Z1Z1);
+    if (f2_eq(U1, U2)) { if (f2_eq(S1, S2)) return jac2_dbl(p); return jac2_inf(); }
+    fq2_t H = f2_sub(U2, U1), I = f2_sqr(f2_add(H, H)), J = f2_mul(H, I);
+    fq2_t r_ = f2_sub(S2, S1); r_ = f2_add(r_, r_);
+    fq2_t V = f2_mul(U1, I);
+    jac2_t r;
+    r.x = f2_sub(f2_sub(f2_sqr(r_), J), f2_add(V, V));
+    fq2_t SJ = f2_mul(S1, J);
+    r.y = f2_sub(f2_mul(r_, f2_sub(V, r.x)), f2_add(SJ, SJ));
+    r.z = f2_mul(f2_sub(f2_sub(f2_sqr(f2_add(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+static aff2_t jac2_to_aff(jac2_t p) {
+    aff2_t a; memset(&a, 0, sizeof a);
+    if (f2_is_zero(p.z)) { a.inf = 1; return a; }
+    fq2_t zi = f2_inv(p.z), zi2 = f2_sqr(zi);
+    a.x = f2_mul(p.x, zi2); a.y = f2_mul(p.y, f2_mul(zi2, zi));
+    return a;
+}
+static aff2_t aff2_load(const uint64_t *p) { aff2_t a; a.x = f2_load(p); a.y = f2_load(p + 2 * EC_NL); a.inf = 0; return a; }
+
+void EC_X(g2_generator)(uint64_t *out) {
+    const fq_t x0 = {EC_G2X0}, x1 = {EC_G2X1}, y0 = {EC_G2Y0}, y1 = {EC_G2Y1};
+    fq2_t x = {fq_mul(x0, R2), fq_mul(x1, R2)}, y = {fq_mul(y0, R2), fq_mul(y1, R2)};
+    f2_store(out, x); f2_store(out + 2 * EC_NL, y);
+}
+int EC_X(g2_on_curve)(const uint64_t *p) {
+    const fq_t b0 = {EC_B2C0}, b1 = {EC_B2C1};
+    fq2_t b = {fq_mul(b0, R2), fq_mul(b1, R2)};
+    fq2_t x = f2_load(p), y = f2_load(p + 2 * EC_NL);
+    return f2_eq(f2_sqr(y), f2_add(f2_mul(f2_sqr(x), x), b));
+}
+int EC_X(g2_scalar_mul)(const uint64_t *p, const uint64_t k[4], uint64_t *out) {
+    aff2_t a = aff2_load(p);
+    jac2_t acc = jac2_inf();
+    for (int i = 255; i >= 0; --i) { acc = jac2_dbl(acc); if ((k[i / 64] >> (i % 64)) & 1) acc = jac2_add_aff(acc, &a); }
+    aff2_t r = jac2_to_aff(acc);
+    f2_store(out, r.x); f2_store(out + 2 * EC_NL, r.y);
+    return r.inf;
+}
+void EC_X(g2_make_bases)(uint64_t n, uint64_t a, uint64_t b, uint64_t *out /* n * PT2W */) {
+    uint64_t g[PT2W], tmp[PT2W], ka[4] = {a, 0, 0, 0}, kb[4] = {b, 0, 0, 0};
+    EC_X(g2_generator)(g);
+    EC_X(g2_scalar_mul)(g, kb, tmp); aff2_t step = aff2_load(tmp);
+    EC_X(g2_scalar_mul)(g, ka, tmp); aff2_t first = aff2_load(tmp);
+    jac2_t cur; cur.x = first.x; cur.y = first.y; cur.z = f2_one();
+    for (uint64_t i = 0; i < n; ++i) {              /* sizes used in tests are small: one inversion per point */
+        aff2_t p = jac2_to_aff(cur);
+        f2_store(out + PT2W * i, p.x); f2_store(out + PT2W * i + 2 * EC_NL, p.y);
+        cur = jac2_add_aff(cur, &step);
+    }
+}
+int EC_X(g2_msm)(const uint64_t *bases, const uint64_t *scalars, uint64_t n, unsigned c, uint64_t *out) {
+    unsigned nw = (256 + c - 1) / c;
+    size_t nb = ((size_t)1 << c) - 1;
+    jac2_t *wres = (jac2_t *)malloc(nw * sizeof(jac2_t));
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (unsigned w = 0; w < nw; ++w) {
+        jac2_t *bk = (jac2_t *)calloc(nb, sizeof(jac2_t));
+        for (uint64_t i = 0; i < n; ++i) {
+            unsigned bit = w * c; uint64_t limb = bit / 64, off = bit % 64;
+            if (limb > 3) continue;
+            uint64_t v = scalars[4 * i + limb] >> off;
+            if (off + c > 64 && limb < 3) v |= scalars[4 * i + limb + 1] << (64 - off);
+            v &= ((uint64_t)1 << c) - 1;
+            if (!v) continue;
+            aff2_t a = aff2_load(bases + PT2W * i);
+            bk[v - 1] = jac2_add_aff(bk[v - 1], &a);
+        }
+        jac2_t run = jac2_inf(), sum = jac2_inf();
+        for (size_t k = nb; k-- > 0;) { run = jac2_add(run, bk[k]); sum = jac2_add(sum, run); }
+        wres[w] = sum;
+        free(bk);
+    }
+    jac2_t acc = jac2_inf();
+    for (unsigned w = nw; w-- > 0;) { for (unsigned k = 0; k < c; ++k) acc = jac2_dbl(acc); acc = jac2_add(acc, wres[w]); }
+    free(wres);
+    aff2_t r = jac2_to_aff(acc);
+    f2_store(out, r.x); f2_store(out + 2 * EC_NL, r.y);
+    return r.inf;
+}

@@ -130,9 +130,9 @@ class Oracle:
         """the same over the BLS12-381 scalar field (oracle/bls12381_hash.c)"""
         return BN128Hash(self.lib, "bls12381")
 
-    def curve(self, name):
-        """G1 arithmetic of `name` in ("bn254", "bls12_381") (oracle/ec.c, ec_bls12_381.c over ec_impl.h)."""
-        return Curve(self.lib, name)
+    def curve(self, name, g2=False):
+        """G1 (or, g2=True, G2) arithmetic of `name` in ("bn254", "bls12_381") (oracle/ec.c, ec_bls12_381.c over ec_impl.h)."""
+        return Curve(self.lib, name, g2)
 
     # -- prover glue (oracle/stark_steps.c)
     def f3_ntt(self, v, bits, inverse=False):
@@ -289,10 +289,12 @@ class Curve:
     PARAMS = {"bn254": (4, 21888242871839275222246405745257275088548364400416034343698204186575808495617),
               "bls12_381": (6, 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001)}
 
-    def __init__(self, lib, name):
+    def __init__(self, lib, name, g2=False):
+        """g2: the same interface over the twist (points = 4*nl words x.c0 || x.c1 || y.c0 || y.c1)"""
         self.nl, self.r = self.PARAMS[name]
-        self.name = name
-        f = lambda n: getattr(lib, "orc_%s_%s" % (name, n))
+        self.name, self.g2 = name, g2
+        self.pw = (4 if g2 else 2) * self.nl                       # words per affine point
+        f = lambda n: getattr(lib, "orc_%s_%s%s" % (name, "g2_" if g2 and not n.startswith("fq_") else "", n))
         self._gen, self._on, self._mul, self._bases, self._msm, self._from_mont = (
             f("generator"), f("on_curve"), f("scalar_mul"), f("make_bases"), f("msm"), f("fq_from_mont"))
         self._gen.argtypes = [_u64p]; self._gen.restype = None
@@ -303,21 +305,22 @@ class Curve:
         self._from_mont.argtypes = [_u64p, _u64p]; self._from_mont.restype = None
 
     def generator(self):
-        o = np.zeros(2 * self.nl, np.uint64); self._gen(o); return o
+        o = np.zeros(self.pw, np.uint64); self._gen(o); return o
     def on_curve(self, p):
         return bool(self._on(_a(p)))
     def fq_from_mont(self, a):
         o = np.zeros(self.nl, np.uint64); self._from_mont(_a(a), o); return o
     def scalar_mul(self, p, k):
-        o = np.zeros(2 * self.nl, np.uint64); inf = self._mul(_a(p), _a(k), o); return o, bool(inf)
+        o = np.zeros(self.pw, np.uint64); inf = self._mul(_a(p), _a(k), o); return o, bool(inf)
     def make_bases(self, n, a, b):
-        o = np.zeros(2 * self.nl * n, np.uint64); self._bases(n, a, b, o); return o
+        o = np.zeros(self.pw * n, np.uint64); self._bases(n, a, b, o); return o
     def msm(self, bases, scalars, c=8):
-        bases = _a(bases); o = np.zeros(2 * self.nl, np.uint64)
-        inf = self._msm(bases, _a(scalars), bases.size // (2 * self.nl), c, o); return o, bool(inf)
+        bases = _a(bases); o = np.zeros(self.pw, np.uint64)
+        inf = self._msm(bases, _a(scalars), bases.size // self.pw, c, o); return o, bool(inf)
     def affine_ints(self, p):
+        """canonical integers of the coordinates: (x, y) for G1, (x.c0, x.c1, y.c0, y.c1) for G2"""
         to_int = lambda w: sum(int(v) << (64 * i) for i, v in enumerate(w))
-        return to_int(self.fq_from_mont(p[:self.nl])), to_int(self.fq_from_mont(p[self.nl:]))
+        return tuple(to_int(self.fq_from_mont(p[i * self.nl:(i + 1) * self.nl])) for i in range(self.pw // self.nl))
 
 
 def load():

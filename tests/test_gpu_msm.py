@@ -217,3 +217,45 @@ def test_bls_msm_large_closed_form(zk, orc, logn):
     if logn == 16:                                              # and the oracle's own Pippenger on the same bases
         exp2, _ = cv.msm(d_bases.to_host(), scal, 13)
         assert np.array_equal(out[:12], exp2)
+
+
+# ---- G2: zk_msm_g2_bn254 / zk_msm_g2_bls12_381 (Fq2 coordinates) ------------------------------------------
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_g2_msm_matches_oracle_and_closed_form(zk, orc, curve):
+    cv = orc.curve(curve, g2=True)
+    rng = np.random.default_rng(len(curve))
+    for n in (1, 2, 33, 300):
+        bases = cv.make_bases(n, 3, 5)
+        scal = rand_scalars(rng, n)
+        if n >= 33:
+            scal.reshape(-1, 4)[0] = 0; scal.reshape(-1, 4)[1] = words(cv.r - 1); scal.reshape(-1, 4)[2] = words(1)
+        got, inf = zk.msm_g1(bases, scal, curve, group="g2")
+        exp, einf = cv.msm(bases, scal, 8)
+        assert inf == einf and np.array_equal(got, exp), n
+    one = cv.make_bases(1, 5, 1)
+    assert zk.msm_g1(np.concatenate([one, one]), np.concatenate([words(9), words(cv.r - 9)]), curve, group="g2")[1]   # P - P
+    assert zk.msm_g1(np.zeros(0, np.uint64), np.zeros(0, np.uint64), curve, group="g2")[1]
+    n = 200                                                                     # the same base 200 times: doublings in buckets
+    got, inf = zk.msm_g1(np.tile(one, n), np.tile(words(0x0123456789abcdef0123456789abcdef), n), curve, group="g2")
+    exp, einf = cv.scalar_mul(cv.generator(), words(5 * n * 0x0123456789abcdef0123456789abcdef % cv.r))
+    assert inf == einf and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("curve,logn", [("bn254", 16), ("bn254", 20), ("bls12_381", 16)])
+def test_g2_msm_large_closed_form(zk, orc, curve, logn):
+    cv = orc.curve(curve, g2=True)
+    n = 1 << logn
+    rng = np.random.default_rng(2000 + logn)
+    k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
+    scal = rand_scalars(rng, n)
+    d_bases = zk.g1_mul_generator(zk.DevArray.from_host(k), curve, group="g2")
+    hb = d_bases.to_host().reshape(n, -1)
+    for i in (0, 1, n - 1):                                                     # the device-made bases are the claimed multiples
+        exp, _ = cv.scalar_mul(cv.generator(), words(int(k[i])))
+        assert np.array_equal(hb[i], exp) and cv.on_curve(hb[i])
+    out = zk.msm_g1_dev(d_bases, zk.DevArray.from_host(scal), n, curve, group="g2").to_host()
+    s4 = scal.reshape(-1, 4).astype(object)
+    sv = s4[:, 0] + (s4[:, 1] << 64) + (s4[:, 2] << 128) + (s4[:, 3] << 192)
+    kk = int((sv * k.astype(object)).sum() % cv.r)
+    exp, einf = cv.scalar_mul(cv.generator(), words(kk))
+    assert (int(out[cv.pw]) & 0xFFFFFFFF) == int(einf) and np.array_equal(out[:cv.pw], exp)

@@ -129,3 +129,56 @@ def test_bls12_381_msm_matches_closed_form(orc):
         assert inf == einf and (inf or np.array_equal(got, exp)), (n, c)
     one = cv.make_bases(1, 5, 1)
     assert cv.msm(np.concatenate([one, one]), np.concatenate([words(9), words(cv.r - 9)]), 6)[1]
+
+
+# ---- G2 (oracle/ec_impl.h, second half): the twist over Fq2 = Fq[u]/(u^2 + 1) --------------------------------
+def _f2mul(a, b, q):
+    return ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+
+
+def _py_affine_mul_f2(k, P, q):
+    """textbook affine double-and-add over Fq2 with Python integers (independent of the C oracle)"""
+    inv = lambda a: (lambda n: (a[0] * n % q, -a[1] * n % q))(pow((a[0] * a[0] + a[1] * a[1]) % q, -1, q))
+    sub = lambda a, b: ((a[0] - b[0]) % q, (a[1] - b[1]) % q)
+    def add(A, B):
+        if A is None: return B
+        if B is None: return A
+        (x1, y1), (x2, y2) = A, B
+        if x1 == x2:
+            if ((y1[0] + y2[0]) % q, (y1[1] + y2[1]) % q) == (0, 0): return None
+            xx = _f2mul(x1, x1, q)
+            lam = _f2mul(((3 * xx[0]) % q, (3 * xx[1]) % q), inv(((2 * y1[0]) % q, (2 * y1[1]) % q)), q)
+        else:
+            lam = _f2mul(sub(y2, y1), inv(sub(x2, x1)), q)
+        x3 = sub(sub(_f2mul(lam, lam, q), x1), x2)
+        return x3, sub(_f2mul(lam, sub(x1, x3), q), y1)
+    acc = None
+    while k:
+        if k & 1: acc = add(acc, P)
+        P = add(P, P); k >>= 1
+    return acc
+
+
+import pytest
+
+
+@pytest.mark.parametrize("name,q", [("bn254", Q), ("bls12_381", BLS_Q)])
+def test_g2_generator_group_law_and_msm(orc, name, q):
+    cv = orc.curve(name, g2=True)
+    g = cv.generator()
+    gi = cv.affine_ints(g)
+    assert cv.on_curve(g) and cv.scalar_mul(g, words(cv.r))[1]                 # on the twist, order r
+    for k in (2, 3, 0xdeadbeefcafebabe1234567):
+        got, inf = cv.scalar_mul(g, words(k))
+        ex, ey = _py_affine_mul_f2(k, ((gi[0], gi[1]), (gi[2], gi[3])), q)
+        assert not inf and cv.affine_ints(got) == (ex[0], ex[1], ey[0], ey[1])
+    rng = np.random.default_rng(2)
+    for n, c in ((1, 4), (33, 5), (300, 8)):
+        a, b = 3, 5
+        bases = cv.make_bases(n, a, b)
+        s = [int.from_bytes(rng.bytes(32), "little") % cv.r for _ in range(n)]
+        scal = np.concatenate([words(v) for v in s])
+        got, inf = cv.msm(bases, scal, c)
+        k = sum(si * (a + b * i) for i, si in enumerate(s)) % cv.r
+        exp, einf = cv.scalar_mul(g, words(k))
+        assert inf == einf and np.array_equal(got, exp), (n, c)
