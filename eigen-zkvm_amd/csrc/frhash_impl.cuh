@@ -2,7 +2,10 @@
 // namespace, which provides the fe29 constants (NL, NR, Q29, ...), RRP29 (R'^2 mod r), FH_NRP (partial rounds of
 // t = 2..17), FH_OUT_IDX (the state word Poseidon::hash returns: 0 for BN128, 1 for BLS12-381), FH_NAME and
 // FH_FN(name) (host entry points).  No include guard on purpose.
-#define FQ_MUL_ATTR __noinline__   // called from run-time loops over t: one copy keeps the kernels small
+#ifndef ZK_FRHASH_MUL_ATTR
+#define ZK_FRHASH_MUL_ATTR __forceinline__
+#endif
+#define FQ_MUL_ATTR ZK_FRHASH_MUL_ATTR   // inlined into the (not unrolled) loops over t: a dozen call sites per kernel
 
 namespace {
 #include "fe29_impl.cuh"
