@@ -1,21 +1,20 @@
-// G1 multi-scalar multiplication (Pippenger bucket method) for BN254 and BLS12-381 on gfx950.
+// Multi-scalar multiplication (Pippenger bucket method) on G1 and G2 of BN254 and BLS12-381 for gfx950.
 //
 // Stands behind groth16/src/groth16.rs:88-96 (Groth16::prove -> bellman_ce::create_random_proof ->
-// multiexp; the arithmetic itself is third-party).  Data layout = bellman's:
-// bases n x 64 B affine (x, y), Fq in Montgomery form (R = 2^256), little-endian limbs; scalars
-// n x 32 B canonical little-endian; result 64 B affine + infinity flag.
+// multiexp; the arithmetic itself is third-party).  Data layout = bellman's / pairing_ce's:
+// bases n x 64 B (BN254 G1) affine (x, y), Fq in Montgomery form (R = 2^256), little-endian limbs; scalars
+// n x 32 B canonical little-endian; result affine + infinity flag.  96 B points for BLS12-381, twice that for G2.
 //
-// Pipeline (all on the device, one stream):
+// Pipeline (msm_impl.cuh; all on the device, one stream):
 //   0. bases: external 32-bit-limb Montgomery form -> internal 29-bit limbs (one product per coordinate)
-//   1. digits: 16-bit windows (c = 16, 16 windows); histogram of (window, digit) keys with atomics
-//   2. exclusive scan of the 2^20 counters -> bucket offsets
-//   3. scatter point indices into bucket order (atomic cursors)
-//   4. bucket accumulation: one lane per bucket, XYZZ += affine (8M + 2S per point), points
-//      gathered by index (64 B each)
-//   5. per-window reduction sum_k k*B_k: radix-16 hierarchy of (S, A) block summaries, 4 levels,
+//   1. bucket sort of the 16 n (point, window) pairs by key = window * 2^16 + digit (c = 16): two LDS-histogram
+//      partition passes, no device-scope atomics
+//   2. bucket ids ordered by decreasing size (counting sort), so that the lanes of a wave finish together
+//   3. bucket accumulation: one lane per bucket, XYZZ += affine (8M + 2S per point), points gathered by index
+//   4. per-window reduction sum_k k*B_k: radix-16 hierarchy of (S, A) block summaries, 4 levels,
 //      2^16 .. 2^4 lanes; the serial chain per lane is 47 point additions
-//   6. Horner over the windows + conversion to affine (one lane)
-// Field: 29-bit limbs with 64-bit column accumulators, lazily reduced (msm_impl.cuh).
+//   5. Horner over the windows + conversion to affine (one lane)
+// Field: 29-bit limbs with 64-bit column accumulators, lazily reduced (fe29_impl.cuh); Fq2 on top of it for G2.
 // Integer-ALU bound (about 10 Fq products per point and window); HBM traffic is 96 B per point.
 #include "zk_internal.h"
 
