@@ -146,3 +146,21 @@ def test_native_driver_bls12381_zkin_equals_oracle_zkin(zk, orc, name):
     assert list(got.keys()) == list(exp.keys())
     for k in exp:
         assert got[k] == exp[k], k
+
+
+def test_native_driver_device_resident_trace_gives_the_same_proof(zk, orc):
+    """zk_stark_gen_dev (trace already in HBM, borrowed) == zk_stark_gen (host trace); the trace is left untouched."""
+    import importlib
+    import numpy as np
+    import stark_prover as SP
+    import starkinfo as SI
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    pil_f, const_f, cm_f = CASES["plookup_gl"]
+    pil = json.load(open(D / pil_f))
+    su = SP.setup(pil, D / const_f, GL_STRUCT, orc)
+    ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"), json.dumps(SI.to_json(su["starkinfo"], su["program"])), json.dumps(GL_STRUCT))
+    cm = np.fromfile(D / cm_f, dtype="<u8")
+    d_cm = zk.DevArray.from_host(cm)
+    assert ns.gen(d_cm) == ns.gen(cm)
+    assert np.array_equal(d_cm.to_host(), cm)
