@@ -47,6 +47,8 @@ EXPORTS = [
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
     "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
+    "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
+    "zk_groth16_setup_new", "zk_groth16_setup_info", "zk_groth16_prove", "zk_groth16_prove_dev", "zk_groth16_wtns_payload", "zk_groth16_setup_free",
 ]
 
 # include/zkgpu.h enums
@@ -179,6 +181,18 @@ def _load():
         "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
         "zk_string_free": (None, [vp]),
         "zk_stark_setup_free": (C.c_int, [vp]),
+        "zk_fr_bn254_ntt": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int]),
+        "zk_fr_bn254_ntt_dev": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, vp]),
+        "zk_fr_bls12_381_ntt": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int]),
+        "zk_fr_bls12_381_ntt_dev": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, vp]),
+        "zk_fr_bn254_quotient_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
+        "zk_fr_bls12_381_quotient_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
+        "zk_groth16_setup_new": (vp, [C.c_char_p, vp, C.c_size_t, vp, C.c_size_t]),
+        "zk_groth16_setup_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "zk_groth16_prove": (vp, [vp, vp, C.c_uint64, vp, vp, vp]),
+        "zk_groth16_prove_dev": (vp, [vp, vp, C.c_uint64, vp, vp, vp, vp]),
+        "zk_groth16_wtns_payload": (C.c_int, [vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "zk_groth16_setup_free": (C.c_int, [vp]),
         "zk_msm_g1_bn254": (C.c_int, [vp, vp, C.c_uint64, vp, C.POINTER(C.c_int)]),
         "zk_msm_g1_bn254_dev": (C.c_int, [vp, vp, C.c_uint64, vp, vp]),
         "zk_g1_bn254_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),

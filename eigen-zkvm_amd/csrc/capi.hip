@@ -701,4 +701,76 @@ const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t) { return t ? (const
 const uint64_t* zk_merkle_nodes_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->nodes.p : nullptr; }
 int zk_merkle_free(zk_merkle_t* t) { delete t; return 0; }
 
+// ---- Groth16 (groth16.hip) ------------------------------------------------------------------------------------
+#define ZK_FR_NTT(NAME)                                                                                                  \
+    int zk_fr_##NAME##_ntt_dev(uint64_t* d, uint32_t log_n, int inverse, int coset, void* stream) {                      \
+        return guard([&] { ZK_REQUIRE(d, "fr ntt: null data"); fr_##NAME##_ntt_dev((u64*)d, (int)log_n, inverse != 0, coset != 0, (hipStream_t)stream); }); \
+    }                                                                                                                    \
+    int zk_fr_##NAME##_ntt(uint64_t* data, uint32_t log_n, int inverse, int coset) {                                     \
+        return guard([&] {                                                                                               \
+            ZK_REQUIRE(data, "fr ntt: null data");                                                                       \
+            ZK_REQUIRE(log_n <= 32, "fr ntt: domain too large");                                                         \
+            const size_t bytes = ((size_t)32) << log_n;                                                                  \
+            DevBuf d; d.reserve(bytes);                                                                                  \
+            ZK_HIP(hipMemcpy(d.p, data, bytes, hipMemcpyHostToDevice));                                                  \
+            fr_##NAME##_ntt_dev((u64*)d.p, (int)log_n, inverse != 0, coset != 0, nullptr);                               \
+            ZK_HIP(hipStreamSynchronize(nullptr));                                                                       \
+            ZK_HIP(hipMemcpy(data, d.p, bytes, hipMemcpyDeviceToHost));                                                  \
+        });                                                                                                              \
+    }                                                                                                                    \
+    int zk_fr_##NAME##_quotient_dev(uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n, void* stream) {   \
+        return guard([&] { ZK_REQUIRE(a && b && c, "fr quotient: null data"); fr_##NAME##_quotient_dev((u64*)a, (const u64*)b, (const u64*)c, (int)log_n, (hipStream_t)stream); }); \
+    }
+ZK_FR_NTT(bn254)
+ZK_FR_NTT(bls12_381)
+#undef ZK_FR_NTT
+
+struct zk_groth16_setup { Groth16Setup* impl; };
+zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len) {
+    zk_groth16_setup_t* out = nullptr;
+    if (guard([&] { Groth16Setup* g = groth16_setup_new(curve, r1cs, r1cs_len, params, params_len); out = new zk_groth16_setup{g}; }) != 0) return nullptr;
+    return out;
+}
+int zk_groth16_setup_info(const zk_groth16_setup_t* s, uint32_t* n_wires, uint32_t* n_inputs, uint32_t* domain_log) {
+    return guard([&] {
+        ZK_REQUIRE(s && s->impl, "groth16: null setup");
+        if (n_wires) *n_wires = s->impl->num_wires();
+        if (n_inputs) *n_inputs = s->impl->num_inputs();
+        if (domain_log) *domain_log = s->impl->domain_log();
+    });
+}
+static char* groth16_prove_any(zk_groth16_setup_t* s, const void* witness, bool on_device, uint64_t n_wires, const uint64_t* r, const uint64_t* s_, void* proof, uint64_t* d_h) {
+    char* out = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(s && s->impl, "groth16: null setup");
+            ZK_REQUIRE(witness && r && s_, "groth16: null argument");
+            Groth16Setup* g = s->impl;
+            ZK_REQUIRE(n_wires == g->num_wires(), "groth16: the witness has " + std::to_string(n_wires) + " values, the circuit has " + std::to_string(g->num_wires()) + " wires");
+            auto lt = [&](const u32* v) { for (int i = 7; i >= 0; --i) { if (v[i] < g->modulus[i]) return true; if (v[i] > g->modulus[i]) return false; } return false; };
+            ZK_REQUIRE(lt((const u32*)r) && lt((const u32*)s_), "groth16: r and s must be canonical field elements");
+            if (!on_device) {   // Fr::from_repr (reader.rs:131-134) rejects non-canonical values
+                const u32* w = (const u32*)witness;
+                for (uint64_t i = 0; i < n_wires; ++i) ZK_REQUIRE(lt(w + 8 * i), "groth16: witness value " + std::to_string(i) + " is not a canonical field element");
+            }
+            std::string js;
+            g->prove(witness, on_device, (const u64*)r, (const u64*)s_, (u32*)proof, &js, (u64*)d_h);
+            out = (char*)malloc(js.size() + 1);
+            ZK_REQUIRE(out, "out of memory");
+            memcpy(out, js.c_str(), js.size() + 1);
+        }) != 0) return nullptr;
+    return out;
+}
+char* zk_groth16_prove(zk_groth16_setup_t* s, const void* witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof) {
+    return groth16_prove_any(s, witness, false, n_wires, r, s_, proof, nullptr);
+}
+char* zk_groth16_prove_dev(zk_groth16_setup_t* s, const void* d_witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof, uint64_t* d_h) {
+    return groth16_prove_any(s, d_witness, true, n_wires, r, s_, proof, d_h);
+}
+int zk_groth16_wtns_payload(const void* wtns, size_t len, const char* curve, uint64_t* offset, uint64_t* n_values) {
+    return guard([&] { ZK_REQUIRE(wtns && offset && n_values, "wtns: null argument"); groth16_wtns_payload(wtns, len, curve, offset, n_values); });
+}
+int zk_groth16_setup_free(zk_groth16_setup_t* s) {
+    return guard([&] { if (s) { delete s->impl; delete s; } });
+}
+
 }  // extern "C"

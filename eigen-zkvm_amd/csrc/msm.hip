@@ -53,6 +53,10 @@ __host__ __device__ constexpr u32 Q8_29(int i) {
     constexpr u32 v[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
     return v[i];
 }
+__host__ __device__ constexpr u32 RRP29(int i) {  // R'^2 mod q: canonical integers -> internal form (key files store canonical coordinates)
+    constexpr u32 v[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u, 0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};
+    return v[i];
+}
 namespace g1 {
 __host__ __device__ constexpr u32 GEN_X(int i) {  // G = (1, 2), external Montgomery form: R mod q
     constexpr u32 r[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
@@ -126,6 +130,10 @@ __host__ __device__ constexpr u32 Q8_29(int i) {
     constexpr u32 v[14] = {0x1ffd5558u, 0x1fbfffffu, 0x07ffff73u, 0x1fffeb15u, 0x1b120f55u, 0x0a83dac3u, 0x17ece61au, 0x04f38512u, 0x1b23ba5cu, 0x10d2eb35u, 0x16374f6cu, 0x17fe69a4u, 0x0088f51cu, 0x00000068u};
     return v[i];
 }
+__host__ __device__ constexpr u32 RRP29(int i) {  // R'^2 mod q
+    constexpr u32 v[14] = {0x15bef7aeu, 0x1031cd0eu, 0x02dd93e8u, 0x09226323u, 0x0e6e2cd2u, 0x11684daau, 0x1170e5dbu, 0x088e25b1u, 0x1b366399u, 0x1c536f47u, 0x0d1f9cbcu, 0x0278b67fu, 0x1ea66a2bu, 0x0000000cu};
+    return v[i];
+}
 namespace g1 {
 // the G1 generator of the BLS12-381 specification, external Montgomery form (R = 2^384)
 __host__ __device__ constexpr u32 GEN_X(int i) {
@@ -183,6 +191,10 @@ void g1_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, h
 }
 
 // G2: points n x 4 coordinates-words (x.c0, x.c1, y.c0, y.c1), i.e. 128 B (BN254) / 192 B (BLS12-381) each
+void fq_bn254_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st) { bn254::g1::fq_canon_to_mont_dev(d, n, st); }
+void fq_bn254_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) { bn254::g1::fq_mont_to_canon_dev(d, n, st); }
+void fq_bls12_381_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st) { bls12_381::g1::fq_canon_to_mont_dev(d, n, st); }
+void fq_bls12_381_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) { bls12_381::g1::fq_mont_to_canon_dev(d, n, st); }
 void msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { bn254::g2::msm_g1_dev(d_bases, d_scalars, n, d_out, st); }
 void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) { bn254::g2::g1_mul_generator_dev(d_k, n, d_bases, st); }
 void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { bls12_381::g2::msm_g1_dev(d_bases, d_scalars, n, d_out, st); }

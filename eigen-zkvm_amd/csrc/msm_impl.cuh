@@ -428,6 +428,52 @@ void g1_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t
     ZK_HIP(hipGetLastError());
 }
 
+#ifndef MSM_G2
+// Fq elements in place: canonical integers (what bellman's key files and proof.json carry) <-> Montgomery R = 2^(32 NL)
+__global__ __launch_bounds__(256) void fq_convert_kernel(u32* __restrict__ v, u64 n, int to_mont) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[NL];
+    for (int k = 0; k < NL; ++k) w[k] = v[i * NL + k];
+    if (to_mont) {
+        fe x;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int bit = LB * k, wi = bit >> 5, s = bit & 31;
+            u32 t = wi < NL ? w[wi] >> s : 0;
+            if (s > 32 - LB && wi + 1 < NL) t |= w[wi + 1] << (32 - s);
+            x.l[k] = t & LMASK;
+        }
+        fe c;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) c.l[k] = RRP29(k);
+        fe_to_std(fe_mul(x, c), w);
+    } else {
+        fe one = fe_zero(); one.l[0] = 1;
+        const fe x = fe_canon(fe_mul(fe_from_std(w), one));
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int bit = 32 * j, k = bit / LB, s = bit % LB;
+            u32 t = x.l[k] >> s;
+            if (k + 1 < NR) t |= x.l[k + 1] << (LB - s);
+            if (k + 2 < NR && 2 * LB - s < 32) t |= x.l[k + 2] << (2 * LB - s);
+            w[j] = t;
+        }
+    }
+    for (int k = 0; k < NL; ++k) v[i * NL + k] = w[k];
+}
+void fq_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fq_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u32*)d, n, 1);
+    ZK_HIP(hipGetLastError());
+}
+void fq_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fq_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u32*)d, n, 0);
+    ZK_HIP(hipGetLastError());
+}
+#endif
+
 // d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag)
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <string>
 #include <stdexcept>
+#include <vector>
 #include "gl.cuh"
 
 namespace zk {
@@ -105,5 +106,40 @@ uint64_t bls12381_merkle_n_nodes(uint64_t height);
 void bls12381_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
 void bls12381_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
+// base-field elements in place: canonical integers <-> Montgomery (msm.hip); n = number of Fq elements
+void fq_bn254_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st);
+void fq_bn254_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st);
+void fq_bls12_381_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st);
+void fq_bls12_381_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st);
+
+// ---- Groth16 around the multi-scalar sums (groth16.hip): scalar-field transforms, the quotient, the prover ----
+// bellman's EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} on 2^logn Fr elements (4 x u64 Montgomery), in place
+void fr_bn254_ntt_dev(u64* d_data, int logn, bool inverse, bool coset, hipStream_t st);
+void fr_bls12_381_ntt_dev(u64* d_data, int logn, bool inverse, bool coset, hipStream_t st);
+// a <- coefficients of (A B - C) / (X^n - 1) from the row evaluations a, b, c (prover.rs create_proof's h block)
+void fr_bn254_quotient_dev(u64* d_a, const u64* d_b, const u64* d_c, int logn, hipStream_t st);
+void fr_bls12_381_quotient_dev(u64* d_a, const u64* d_b, const u64* d_c, int logn, hipStream_t st);
+namespace g16 {
+struct Lc { std::vector<u32> col, coeff; };            // coeff: 8 x u32 canonical per term
+struct Row { Lc lc[3]; };
+struct R1cs { uint32_t n_wires = 0, n_pub_out = 0, n_pub_in = 0, n_prv_in = 0; std::vector<Row> rows; };
+struct PointVec { uint64_t n = 0; std::vector<u32> w; std::vector<char> inf; };   // canonical little-endian words
+struct Params { PointVec vk[6]; PointVec ic, h, l, a, b_g1, b_g2; };               // vk: alpha_g1 beta_g1 beta_g2 gamma_g2 delta_g1 delta_g2
+std::string words_to_dec(const u32* w, int n);
+}
+struct Groth16Setup {
+    virtual ~Groth16Setup() {}
+    // witness: n_wires x 32 B canonical (host or device); proof_out: A || B || C affine Montgomery words; d_h_out:
+    // optional device buffer for the quotient's (2^domain_log - 1) x 32 B canonical coefficients
+    virtual void prove(const void* witness, bool on_device, const u64 r[4], const u64 s[4], u32* proof_out, std::string* json, u64* d_h_out) = 0;
+    virtual uint32_t num_wires() const = 0;
+    virtual uint32_t num_inputs() const = 0;
+    virtual uint32_t domain_log() const = 0;
+    std::string curve;
+    std::vector<u32> modulus;     // Fr, 8 words
+    size_t proof_words = 0;
+};
+Groth16Setup* groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len);
+void groth16_wtns_payload(const void* wtns, size_t len, const char* curve, uint64_t* offset, uint64_t* n);
 
 }  // namespace zk

@@ -250,6 +250,40 @@ char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t 
 void zk_string_free(char* s);
 int zk_stark_setup_free(zk_stark_setup_t* s);
 
+/* ---- Groth16 around the multi-scalar sums (`zkit groth16_prove`, groth16/src/api.rs:144-205) ----
+ * The reference hands the whole proof to bellman_ce::groth16::create_random_proof (groth16/src/groth16.rs:88-96;
+ * third-party).  These entry points keep everything after witness generation on the device.
+ *
+ * zk_fr_*_ntt stand behind bellman's EvaluationDomain::{fft, ifft, coset_fft, icoset_fft}: 2^log_n elements of
+ * the curve's scalar field (4 x u64 Montgomery R = 2^256, i.e. the raw limbs of an Fr), natural order in and
+ * out, in place; omega = Fr::root_of_unity()^(2^(S - log_n)), coset generator Fr::multiplicative_generator() = 7.
+ * zk_fr_*_quotient stand behind create_proof's `h` block: from the per-row evaluations a, b, c (2^log_n each)
+ * to the coefficients of (A B - C)/(X^n - 1), written over a (bellman then drops the last one).              */
+int zk_fr_bn254_ntt(uint64_t* data, uint32_t log_n, int inverse, int coset);
+int zk_fr_bn254_ntt_dev(uint64_t* d_data, uint32_t log_n, int inverse, int coset, void* stream);
+int zk_fr_bls12_381_ntt(uint64_t* data, uint32_t log_n, int inverse, int coset);
+int zk_fr_bls12_381_ntt_dev(uint64_t* d_data, uint32_t log_n, int inverse, int coset, void* stream);
+int zk_fr_bn254_quotient_dev(uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c, uint32_t log_n, void* stream);
+int zk_fr_bls12_381_quotient_dev(uint64_t* d_a, const uint64_t* d_b, const uint64_t* d_c, uint32_t log_n, void* stream);
+/* zk_groth16_setup_new stands behind api.rs:161-171 (read_pk_from_file + create_circuit_from_file): `curve` is the
+ * reference's curve_type string ("BN128" | "BLS12381"), `r1cs` the bytes of the circom .r1cs file
+ * (algebraic/src/r1cs_file.rs), `params` the bytes of the proving key as bellman's Parameters::write lays it out
+ * (unchecked read: points are not tested for curve membership, as with checked = false).  The circuit is the one
+ * algebraic/src/circom_circuit.rs:94-160 synthesises; a key whose query sizes do not match it is an error.
+ * zk_groth16_prove: `witness` = n_wires x 32 B little-endian canonical values (the body of a .wtns file, see
+ * zk_groth16_wtns_payload; reader.rs:86-137), r and s = the two blinding scalars create_random_proof draws from its
+ * rng (canonical, < the field modulus), `proof` (optional) receives A || B || C as affine Montgomery coordinates
+ * (BN254: 64 + 128 + 64 B; BLS12-381: 96 + 192 + 96 B; G2 as x.c0 || x.c1 || y.c0 || y.c1).  Returns proof.json
+ * as json_utils.rs:305-315 renders it (malloc'ed; zk_string_free), NULL on error.                              */
+typedef struct zk_groth16_setup zk_groth16_setup_t;
+zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len);
+int zk_groth16_setup_info(const zk_groth16_setup_t* s, uint32_t* n_wires, uint32_t* n_inputs, uint32_t* domain_log);
+char* zk_groth16_prove(zk_groth16_setup_t* s, const void* witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof);
+/* same with the witness already in HBM; d_h (optional) receives the quotient's 2^domain_log - 1 canonical coefficients */
+char* zk_groth16_prove_dev(zk_groth16_setup_t* s, const void* d_witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof, uint64_t* d_h);
+int zk_groth16_wtns_payload(const void* wtns, size_t len, const char* curve, uint64_t* offset, uint64_t* n_values);
+int zk_groth16_setup_free(zk_groth16_setup_t* s);
+
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
  * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as

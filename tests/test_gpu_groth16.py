@@ -1,0 +1,157 @@
+"""Parity of the Groth16 device path (csrc/groth16.hip, frntt_impl.cuh, groth16_impl.cuh; through the C ABI) against
+the oracle (oracle/groth16_impl.h, oracle/groth16.py) -- bit exact: field elements as Montgomery limbs, proof
+points as affine coordinates.  SURVEY.md 8(f)-2."""
+import importlib, json, pathlib, random, sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+import groth16 as G  # noqa: E402
+CURVES = (("bn254", "BN128"), ("bls12_381", "BLS12381"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu(zk):
+    assert zk.lib().zk_device_count() >= 1, "no GPU visible (the product has no CPU fallback)"
+    zk.init(0)
+
+
+@pytest.fixture(scope="module")
+def g16(orc):
+    return {cv: G.Groth16Oracle(orc, cv) for cv, _ in CURVES}
+
+
+@pytest.fixture(scope="module")
+def dev(zk):
+    return importlib.import_module("eigen_zkvm_amd.groth16")
+
+
+def rand_fr(g, rng, n):
+    return g.to_mont(g.fr_array([rng.randrange(g.r) for _ in range(n)]))
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 12])
+def test_transforms_match_oracle(g16, dev, cv, tag, log_n):
+    """every radix plan (remainder pass of 2 / 4 first, then radix 8), all four EvaluationDomain transforms"""
+    g = g16[cv]; rng = random.Random(1000 + log_n)
+    x = rand_fr(g, rng, 1 << log_n)
+    for inverse in (False, True):
+        for coset in (False, True):
+            got = dev.fr_ntt(x, tag, inverse=inverse, coset=coset)
+            assert np.array_equal(got, g.ntt(x, inverse=inverse, coset=coset)), (log_n, inverse, coset)
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+def test_transform_edge_values_and_round_trip(zk, g16, dev, cv, tag):
+    g = g16[cv]; r = g.r; log_n = 14; n = 1 << log_n; rng = random.Random(5)
+    vals = [0, 1, r - 1, r - 2, 2, (r - 1) // 2] + [rng.randrange(r) for _ in range(n - 6)]
+    x = g.to_mont(g.fr_array(vals))
+    d = zk.DevArray.from_host(x.reshape(-1))
+    dev.fr_ntt(d, tag); dev.fr_ntt(d, tag, inverse=True)
+    assert np.array_equal(d.to_host().reshape(-1, 4), x)
+    dev.fr_ntt(d, tag, coset=True)
+    assert np.array_equal(d.to_host().reshape(-1, 4), g.ntt(x, coset=True))
+    dev.fr_ntt(d, tag, inverse=True, coset=True)
+    assert np.array_equal(d.to_host().reshape(-1, 4), x)
+    z = np.zeros_like(x)
+    assert np.array_equal(dev.fr_ntt(z, tag), z)                            # all-zero vector
+    one_hot = z.copy(); one_hot[0] = g.to_mont(g.fr_array([1]))[0]
+    assert np.array_equal(dev.fr_ntt(one_hot, tag), np.tile(one_hot[0], (n, 1)))   # delta -> constant
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+def test_transform_is_linear_at_2_20(zk, g16, dev, cv, tag):
+    """a size the oracle is not asked to match element by element: adding a one-hot vector at position p changes
+    the transform by the geometric row w^(p i), and the inverse transform returns the input"""
+    g = g16[cv]; log_n = 20; n = 1 << log_n
+    rng = np.random.default_rng(7)
+    a = np.concatenate([rng.integers(0, 2**64, size=(n, 3), dtype=np.uint64), rng.integers(0, 2**60, size=(n, 1), dtype=np.uint64)], axis=1)
+    p = 12345; R = (1 << 256) % g.r                                        # rows are Montgomery residues < 2^252 < r
+    e = a.copy(); e[p] = g.fr_array([(g.fr_ints(a[p:p + 1])[0] + R) % g.r])[0]
+    fa = dev.fr_ntt(a, tag); fe_ = dev.fr_ntt(e, tag)
+    w = g.omega(log_n)
+    for i in (0, 1, 2, 77, n // 2, n - 1):
+        d = (g.fr_ints(fe_[i:i + 1])[0] - g.fr_ints(fa[i:i + 1])[0]) % g.r
+        assert d == pow(w, p * i, g.r) * R % g.r, i
+    assert np.array_equal(dev.fr_ntt(fa, tag, inverse=True), a)
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+@pytest.mark.parametrize("log_n", [1, 4, 9, 11])
+def test_quotient_matches_oracle(zk, g16, dev, cv, tag, log_n):
+    g = g16[cv]; rng = random.Random(31 + log_n); n = 1 << log_n
+    a, b = rand_fr(g, rng, n), rand_fr(g, rng, n)
+    sat = g.to_mont(g.fr_array([x * y % g.r for x, y in zip(g.fr_ints(g.from_mont(a)), g.fr_ints(g.from_mont(b)))]))
+    for c in (sat, rand_fr(g, rng, n)):                                    # satisfied rows, and arbitrary ones
+        da, db, dc = (zk.DevArray.from_host(v.reshape(-1)) for v in (a, b, c))
+        dev.fr_quotient(da, db, dc, tag)
+        assert np.array_equal(da.to_host().reshape(-1, 4), g.quotient(a, b, c))
+
+
+def _case(g, n_mul, seed):
+    rng = random.Random(seed)
+    r1cs, wit = G.synthetic_r1cs(g.r, n_mul, seed=seed)
+    P = g.setup(r1cs, *[rng.randrange(1, g.r) for _ in range(5)])
+    return r1cs, wit, P, rng.randrange(g.r), rng.randrange(g.r)
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+@pytest.mark.parametrize("n_mul", [6, 40, 300])
+def test_proof_matches_oracle_and_the_verification_equation(zk, g16, dev, cv, tag, n_mul):
+    """the device proof == the oracle's create_proof restatement == the unique valid proof for (witness, r, s)
+    computed in the exponent from the trapdoor; proof.json carries the same points"""
+    g = g16[cv]
+    r1cs, wit, P, rr, ss = _case(g, n_mul, 100 + n_mul)
+    S = dev.Groth16Setup(tag, g.r1cs_bytes(r1cs), g.params_bytes(P))
+    assert (S.n_wires, S.n_inputs, S.domain_log) == (r1cs["n_wires"], P["cir"]["num_inputs"], P["cir"]["log_m"])
+    w = dev.wtns_values(g.wtns_bytes(wit), tag)
+    assert g.fr_ints(w) == wit
+    js, pts = S.prove(w, rr, ss)
+    exp = g.expected_proof(P, wit, rr, ss)
+    nl = g.nl
+    assert np.array_equal(pts[:2 * nl], exp["a"]) and np.array_equal(pts[2 * nl:6 * nl], exp["b"]) and np.array_equal(pts[6 * nl:], exp["c"])
+    if n_mul <= 40:
+        orc_pr = g.prove(P, wit, rr, ss)
+        assert js == json.loads(g.proof_json(orc_pr))
+        # the quotient the device fed to the `h` sum
+        d_h = zk.DevArray(4 * ((1 << S.domain_log) - 1), zero=True)
+        js2, _ = S.prove(zk.DevArray.from_host(w.reshape(-1)), rr, ss, d_h=d_h)
+        assert js2 == js and g.fr_ints(d_h.to_host()) == orc_pr["h"]
+    else:
+        assert js == json.loads(g.proof_json(exp))
+    # fresh r, s re-randomise the proof; the same (r, s) reproduces it
+    js3, _ = S.prove(w)
+    assert js3 != js and S.prove(w, rr, ss)[0] == js
+    S.free()
+
+
+def test_setup_and_prove_errors(zk, g16, dev):
+    g = g16["bn254"]
+    r1cs, wit, P, rr, ss = _case(g, 6, 3)
+    rb, pb = g.r1cs_bytes(r1cs), g.params_bytes(P)
+    with pytest.raises(zk.ZkError, match="unknown curve"):
+        dev.Groth16Setup("BN254", rb, pb)
+    with pytest.raises(zk.ZkError, match="Invalid magic number"):
+        dev.Groth16Setup("BN128", b"xxxx" + rb[4:], pb)
+    with pytest.raises(zk.ZkError, match="prime is not the scalar field"):
+        dev.Groth16Setup("BLS12381", rb, pb)
+    with pytest.raises(zk.ZkError, match="truncated"):
+        dev.Groth16Setup("BN128", rb, pb[:-7])
+    r2, _ = G.synthetic_r1cs(g.r, 9, seed=4)
+    with pytest.raises(zk.ZkError, match="proving key"):
+        dev.Groth16Setup("BN128", g.r1cs_bytes(r2), pb)                    # key of another circuit
+    S = dev.Groth16Setup("BN128", rb, pb)
+    w = g.fr_array(wit)
+    with pytest.raises(zk.ZkError, match="wires"):
+        S.prove(w[:-1], rr, ss)
+    bad = w.copy(); bad[3] = g.fr_array([g.r])[0]
+    with pytest.raises(zk.ZkError, match="not a canonical field element"):
+        S.prove(bad, rr, ss)
+    with pytest.raises(zk.ZkError, match="Invalid file header"):
+        dev.wtns_values(b"wtnx" + g.wtns_bytes(wit)[4:], "BN128")
+    with pytest.raises(zk.ZkError, match="invalid curve prime"):
+        dev.wtns_values(g.wtns_bytes(wit), "BLS12381")
+    S.free()
