@@ -102,11 +102,21 @@ __device__ __forceinline__ fe fe_canon(const fe& a) {
     for (int i = 0; i < NR; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
     return r;
 }
-__device__ fe fe_inv(const fe& a) {  // a^(q-2); q - 2 differs from q in limb 0 only
+__host__ __device__ constexpr u32 fe_qm2_limb(int i) {   // limb i of q - 2 (the borrow may run past limb 0: BLS12-381's r = 1 mod 2^29)
+    long long borrow = 2;
+    u32 out = 0;
+    for (int k = 0; k <= i; ++k) {
+        long long v = (long long)Q29(k) - borrow;
+        borrow = 0;
+        if (v < 0) { v += (1ll << LB); borrow = 1; }
+        out = (u32)v;
+    }
+    return out;
+}
+__device__ fe fe_inv(const fe& a) {  // a^(q-2)
     fe r = fe_one();
     for (int i = NR - 1; i >= 0; --i) {
-        u32 w = Q29(i);
-        if (i == 0) w -= 2;
+        const u32 w = fe_qm2_limb(i);
         for (int b = LB - 1; b >= 0; --b) {
             r = fe_sqr(r);
             if ((w >> b) & 1) r = fe_mul(r, a);
