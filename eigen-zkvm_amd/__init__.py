@@ -48,7 +48,7 @@ EXPORTS = [
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
     "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
-    "zk_groth16_setup_new", "zk_groth16_setup_info", "zk_groth16_prove", "zk_groth16_prove_dev", "zk_groth16_wtns_payload", "zk_groth16_setup_free",
+    "zk_fq_bn254_convert_dev", "zk_fq_bls12_381_convert_dev", "zk_groth16_setup_new", "zk_groth16_setup_info", "zk_groth16_prove", "zk_groth16_prove_dev", "zk_groth16_wtns_payload", "zk_groth16_setup_free",
 ]
 
 # include/zkgpu.h enums
@@ -187,6 +187,8 @@ def _load():
         "zk_fr_bls12_381_ntt_dev": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, vp]),
         "zk_fr_bn254_quotient_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "zk_fr_bls12_381_quotient_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
+        "zk_fq_bn254_convert_dev": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
+        "zk_fq_bls12_381_convert_dev": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
         "zk_groth16_setup_new": (vp, [C.c_char_p, vp, C.c_size_t, vp, C.c_size_t]),
         "zk_groth16_setup_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "zk_groth16_prove": (vp, [vp, vp, C.c_uint64, vp, vp, vp]),

@@ -725,6 +725,12 @@ ZK_FR_NTT(bn254)
 ZK_FR_NTT(bls12_381)
 #undef ZK_FR_NTT
 
+int zk_fq_bn254_convert_dev(void* d, uint64_t n, int to_mont, void* stream) {
+    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bn254_canon_to_mont_dev(d, n, (hipStream_t)stream); else fq_bn254_mont_to_canon_dev(d, n, (hipStream_t)stream); });
+}
+int zk_fq_bls12_381_convert_dev(void* d, uint64_t n, int to_mont, void* stream) {
+    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bls12_381_canon_to_mont_dev(d, n, (hipStream_t)stream); else fq_bls12_381_mont_to_canon_dev(d, n, (hipStream_t)stream); });
+}
 struct zk_groth16_setup { Groth16Setup* impl; };
 zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len) {
     zk_groth16_setup_t* out = nullptr;

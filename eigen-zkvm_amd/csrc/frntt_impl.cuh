@@ -224,13 +224,61 @@ __global__ __launch_bounds__(256) void frn_r1cs_eval_kernel(const u64* __restric
     }
     soa_store(out, n, i, acc);
 }
-// density-indexed scalars: out[i] = idx[i] >= 0 ? w[idx[i]] : 0 (8 x u32 canonical each)
-__global__ __launch_bounds__(256) void frn_gather_kernel(const u32* __restrict__ wit, const int* __restrict__ idx, u64 n, u32* __restrict__ out) {
+__device__ __forceinline__ void fe_store_canon(const fe& a /* Montgomery, < 68q */, u32* __restrict__ out) {
+    fe one = fe_zero(); one.l[0] = 1;
+    const fe x = fe_canon(fe_mul(a, one));
+#pragma unroll
+    for (int jj = 0; jj < NL; ++jj) {
+        const int bit = 32 * jj, k = bit / LB, s = bit % LB;
+        u32 v = x.l[k] >> s;
+        if (k + 1 < NR) v |= x.l[k + 1] << (LB - s);
+        if (k + 2 < NR && 2 * LB - s < 32) v |= x.l[k + 2] << (2 * LB - s);
+        out[jj] = v;
+    }
+}
+// density-indexed scalars (8 x u32 canonical each): out[i] = scale * w[idx[i]] (idx < 0: 0).  wit: canonical values,
+// wit_fe: the same in internal form (element-major), used when a scale is given
+__global__ __launch_bounds__(256) void frn_gather_kernel(const u32* __restrict__ wit, const u32* __restrict__ wit_fe, const int* __restrict__ idx, u64 n,
+                                                         const fe* __restrict__ scale, u32* __restrict__ out) {
     const u64 i = blockIdx.x * 256ull + threadIdx.x;
     if (i >= n) return;
     const int s = idx[i];
+    if (!scale || s < 0) {
 #pragma unroll
-    for (int k = 0; k < NL; ++k) out[i * NL + k] = s >= 0 ? wit[(u64)s * NL + k] : 0u;
+        for (int k = 0; k < NL; ++k) out[i * NL + k] = s >= 0 ? wit[(u64)s * NL + k] : 0u;
+        return;
+    }
+    fe x;
+#pragma unroll
+    for (int l = 0; l < NR; ++l) x.l[l] = wit_fe[(u64)s * NR + l];
+    fe_store_canon(fe_mul(x, *scale), out + i * NL);
+}
+// the blinding scalars r, s (canonical, rs[0..8) and rs[8..16)): their internal forms and the tail entries of the
+// three scalar vectors: (r, 1), (s, 1), (r), (s r, s)
+__global__ void frn_blind_kernel(const u32* __restrict__ rs, fe* __restrict__ rs_fe, u32* __restrict__ tail_a, u32* __restrict__ tail_b,
+                                 u32* __restrict__ tail_cb, u32* __restrict__ tail_ca) {
+    if (threadIdx.x || blockIdx.x) return;
+    fe v[2];
+    for (int t = 0; t < 2; ++t) {
+        fe x;
+        for (int k = 0; k < NR; ++k) {
+            const int bit = LB * k, wi = bit >> 5, sh = bit & 31;
+            u32 u = wi < NL ? rs[8 * t + wi] >> sh : 0;
+            if (sh > 32 - LB && wi + 1 < NL) u |= rs[8 * t + wi + 1] << (32 - sh);
+            x.l[k] = u & LMASK;
+        }
+        fe c;
+        for (int k = 0; k < NR; ++k) c.l[k] = RRP29(k);
+        v[t] = fe_mul(x, c);
+        rs_fe[t] = v[t];
+    }
+    for (int k = 0; k < NL; ++k) {
+        tail_a[k] = rs[k]; tail_a[NL + k] = k == 0;
+        tail_b[k] = rs[8 + k]; tail_b[NL + k] = k == 0;
+        tail_cb[k] = rs[k];
+        tail_ca[NL + k] = rs[8 + k];
+    }
+    fe_store_canon(fe_mul(v[0], v[1]), tail_ca);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------

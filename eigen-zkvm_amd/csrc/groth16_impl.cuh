@@ -16,9 +16,14 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
     DevBuf rp[3], cl[3], cf[3];
     DevBuf a_idx, b_idx, l_idx;
     u64 na = 0, nb = 0, nh = 0;
-    DevBuf h, l, a, b1, b2;
-    std::vector<u32> alpha1, beta1, delta1, beta2, delta2;   // Montgomery, host copies for the final sums
-    std::vector<std::vector<u32>> ic;
+    // One base array per group, laid out so that the proof is three multi-scalar sums with no scalar
+    // multiplications left over (prover.rs's g_a, g_b, g_c with the blinding terms folded in as extra bases):
+    //   G1: [ h (nh) | l (n_aux) | b_g1 (nb) | beta_g1 | a (na) | delta_g1 | alpha_g1 ]
+    //        g_a = sum over the tail [a | delta | alpha] of (w_a, r, 1)
+    //        g_c = sum over everything of (h, w_l, r w_b, r, s w_a, s r, s)
+    //   G2: [ b_g2 (nb) | delta_g2 | beta_g2 ],  g_b = sum of (w_b, s, 1)
+    DevBuf g1b, g2b;
+    u64 off_l = 0, off_b = 0, off_a = 0, n_g1 = 0;
 
     static constexpr size_t P1 = 2 * G16_CW, P2 = 4 * G16_CW;   // u32 words per affine point
 
@@ -88,70 +93,56 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         // bases: canonical coordinates -> Montgomery on the device; a point at infinity (only `l` may hold one: a wire
         // no row mentions) gets a valid stand-in and a zero scalar through l_idx
         ZK_REQUIRE(!pk.vk[0].inf[0], "groth16: alpha_g1 is the point at infinity");
-        auto upload_pts = [&](DevBuf& d, const g16::PointVec& v, size_t pw, u64 count, bool allow_inf, const char* what) {
-            d.reserve(std::max<size_t>(count, 1) * pw * 4);
+        off_l = nh; off_b = off_l + n_aux; off_a = off_b + nb + 1; n_g1 = off_a + na + 2;
+        g1b.reserve(n_g1 * P1 * 4); g2b.reserve((nb + 2) * P2 * 4);
+        auto put = [&](DevBuf& d, u64 at, const g16::PointVec& v, size_t pw, u64 count, bool allow_inf, const char* what) {
             if (count == 0) return;
             std::vector<u32> tmp(v.w.begin(), v.w.begin() + count * pw);
             for (u64 i = 0; i < count; ++i)
                 if (v.inf[i]) {
-                    ZK_REQUIRE(allow_inf, std::string("groth16: proving key `") + what + "` query holds the point at infinity");
-                    std::copy(pk.vk[0].w.begin(), pk.vk[0].w.begin() + pw, tmp.begin() + i * pw);
+                    ZK_REQUIRE(allow_inf, std::string("groth16: key element `") + what + "` is the point at infinity");
+                    std::copy(pk.vk[0].w.begin(), pk.vk[0].w.begin() + P1, tmp.begin() + i * pw);   // stand-in (G1 only), zero scalar via l_idx
                 }
-            ZK_HIP(hipMemcpy(d.p, tmp.data(), count * pw * 4, hipMemcpyHostToDevice));
-            G16_FQ_TO_MONT(d.p, count * pw / G16_CW, st);
+            ZK_HIP(hipMemcpy((u32*)d.p + at * pw, tmp.data(), count * pw * 4, hipMemcpyHostToDevice));
         };
-        upload_pts(h, pk.h, P1, nh, false, "h");
-        upload_pts(l, pk.l, P1, n_aux, true, "l");
-        upload_pts(a, pk.a, P1, na, false, "a");
-        upload_pts(b1, pk.b_g1, P1, nb, false, "b_g1");
-        upload_pts(b2, pk.b_g2, P2, nb, false, "b_g2");
-        auto to_mont_host = [&](const g16::PointVec& v, size_t pw, u64 i, const char* what) {
-            ZK_REQUIRE(!v.inf[i], std::string("groth16: verifying key element ") + what + " is the point at infinity");
-            DevBuf d; d.reserve(pw * 4);
-            ZK_HIP(hipMemcpy(d.p, v.w.data() + i * pw, pw * 4, hipMemcpyHostToDevice));
-            G16_FQ_TO_MONT(d.p, pw / G16_CW, st);
-            std::vector<u32> o(pw);
-            ZK_HIP(hipMemcpy(o.data(), d.p, pw * 4, hipMemcpyDeviceToHost));
-            return o;
-        };
-        alpha1 = to_mont_host(pk.vk[0], P1, 0, "alpha_g1"); beta1 = to_mont_host(pk.vk[1], P1, 0, "beta_g1");
-        beta2 = to_mont_host(pk.vk[2], P2, 0, "beta_g2"); delta1 = to_mont_host(pk.vk[4], P1, 0, "delta_g1");
-        delta2 = to_mont_host(pk.vk[5], P2, 0, "delta_g2");
+        put(g1b, 0, pk.h, P1, nh, false, "h");
+        put(g1b, off_l, pk.l, P1, n_aux, true, "l");
+        put(g1b, off_b, pk.b_g1, P1, nb, false, "b_g1");
+        put(g1b, off_b + nb, pk.vk[1], P1, 1, false, "beta_g1");
+        put(g1b, off_a, pk.a, P1, na, false, "a");
+        put(g1b, off_a + na, pk.vk[4], P1, 1, false, "delta_g1");
+        put(g1b, off_a + na + 1, pk.vk[0], P1, 1, false, "alpha_g1");
+        put(g2b, 0, pk.b_g2, P2, nb, false, "b_g2");
+        put(g2b, nb, pk.vk[5], P2, 1, false, "delta_g2");
+        put(g2b, nb + 1, pk.vk[2], P2, 1, false, "beta_g2");
+        G16_FQ_TO_MONT(g1b.p, n_g1 * P1 / G16_CW, st);
+        G16_FQ_TO_MONT(g2b.p, (nb + 2) * P2 / G16_CW, st);
         ZK_HIP(hipStreamSynchronize(st));
         (void)frn_domain(logm, st);
-    }
-
-    struct Term { const u32* pt; bool inf; u32 k[8]; };
-    // sum of a handful of terms through the same multi-scalar kernels
-    std::vector<u32> small_sum(bool g2, const std::vector<Term>& terms, bool* inf_out, hipStream_t st) const {
-        const size_t pw = g2 ? P2 : P1;
-        std::vector<u32> bases, sc;
-        for (const Term& t : terms) {
-            bool zero = true;
-            for (int i = 0; i < 8; ++i) zero = zero && t.k[i] == 0;
-            if (t.inf || zero) continue;
-            bases.insert(bases.end(), t.pt, t.pt + pw);
-            sc.insert(sc.end(), t.k, t.k + 8);
-        }
-        std::vector<u32> out(pw + 1, 0);
-        if (sc.empty()) { *inf_out = true; return out; }
-        DevBuf db, ds, dout;
-        db.reserve(bases.size() * 4); ds.reserve(sc.size() * 4); dout.reserve((pw + 1) * 4);
-        ZK_HIP(hipMemcpy(db.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
-        ZK_HIP(hipMemcpy(ds.p, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
-        if (g2) G16_MSM_G2(db.p, ds.p, sc.size() / 8, dout.p, st); else G16_MSM_G1(db.p, ds.p, sc.size() / 8, dout.p, st);
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_HIP(hipMemcpy(out.data(), dout.p, (pw + 1) * 4, hipMemcpyDeviceToHost));
-        *inf_out = out[pw] != 0;
-        return out;
     }
 
     uint32_t num_wires() const override { return n_wires; }
     uint32_t num_inputs() const override { return ni; }
     uint32_t domain_log() const override { return (uint32_t)logm; }
 
+    // Three independent chains share the device: g_b (G2, the longest) and g_a start as soon as the witness is
+    // resident; row evaluations, the quotient and g_c run beside them.  Each multi-scalar sum ends in a short
+    // latency-bound tail (bucket hierarchy + window Horner on a few waves) that the other chains' bulk work hides.
+    hipStream_t streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_ready = nullptr;
+    int device = -1;
+    ~G16_FN(SetupImpl)() override {
+        for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+    }
+
     void prove(const void* witness, bool on_device, const u64 r_[4], const u64 s_[4], u32* proof_out, std::string* json, u64* d_h_out) override {
-        hipStream_t st = nullptr;
+        if (!streams[0]) {
+            ZK_HIP(hipGetDevice(&device));
+            for (auto& st : streams) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            ZK_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        }
+        hipStream_t st = streams[0];
         const FrDomain& D = frn_domain(logm, st);
         DevBuf wit_c, wit_fe;
         const u32* d_wit = (const u32*)witness;
@@ -162,48 +153,61 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         }
         wit_fe.reserve((size_t)n_wires * NR * 4);
         hipLaunchKernelGGL(frn_canon_to_fe_kernel, dim3(frn_blocks(n_wires)), dim3(256), 0, st, d_wit, (u32*)wit_fe.p, (u64)n_wires);
-        // a_i, b_i, c_i per row (ProvingAssignment::enforce), zero-padded to the domain
-        DevBuf ev[6];
-        for (auto& e : ev) e.reserve(m * NR * 4);
-        for (int w = 0; w < 3; ++w)
-            hipLaunchKernelGGL(frn_r1cs_eval_kernel, dim3(frn_blocks(m)), dim3(256), 0, st, (const u64*)rp[w].p, (const u32*)cl[w].p, (const u32*)cf[w].p,
-                               (const u32*)wit_fe.p, n_rows, (u32*)ev[w].p, m);
-        ZK_HIP(hipGetLastError());
-        u32* hq = frn_quotient(D, (u32*)ev[0].p, (u32*)ev[1].p, (u32*)ev[2].p, (u32*)ev[3].p, (u32*)ev[4].p, (u32*)ev[5].p, st);
-        DevBuf hs, sl, sa, sb, o_h, o_l, o_a, o_b1, o_b2;
-        hs.reserve(std::max<u64>(nh, 1) * 32);
-        if (nh) hipLaunchKernelGGL(frn_to_canon_kernel, dim3(frn_blocks(nh)), dim3(256), 0, st, (const u32*)hq, (u32*)hs.p, m, nh);
-        if (d_h_out && nh) ZK_HIP(hipMemcpyAsync(d_h_out, hs.p, nh * 32, hipMemcpyDeviceToDevice, st));
-        auto gather = [&](DevBuf& d, const DevBuf& idx, u64 n) {
-            d.reserve(std::max<u64>(n, 1) * 32);
-            if (n) hipLaunchKernelGGL(frn_gather_kernel, dim3(frn_blocks(n)), dim3(256), 0, st, d_wit, (const int*)idx.p, n, (u32*)d.p);
+        // scalars of the three sums (see the base layout above)
+        DevBuf scC, scA, scB, blind, o_a, o_b, o_c;
+        scC.reserve(n_g1 * 32); scA.reserve((na + 2) * 32); scB.reserve((nb + 2) * 32); blind.reserve(64 + 2 * NR * 4);
+        o_a.reserve((P1 + 1) * 4); o_b.reserve((P2 + 1) * 4); o_c.reserve((P1 + 1) * 4);
+        u32* C0 = (u32*)scC.p;
+        ZK_HIP(hipMemcpyAsync(blind.p, r_, 32, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipMemcpyAsync((u32*)blind.p + 8, s_, 32, hipMemcpyHostToDevice, st));
+        fe* rs_fe = (fe*)((u32*)blind.p + 16);
+        hipLaunchKernelGGL(frn_blind_kernel, dim3(1), dim3(64), 0, st, (const u32*)blind.p, rs_fe, (u32*)scA.p + na * 8, (u32*)scB.p + nb * 8,
+                           C0 + (off_b + nb) * 8, C0 + (off_a + na) * 8);
+        auto gather = [&](u32* out, const DevBuf& idx, u64 n, const fe* scale) {
+            if (n) hipLaunchKernelGGL(frn_gather_kernel, dim3(frn_blocks(n)), dim3(256), 0, st, d_wit, (const u32*)wit_fe.p, (const int*)idx.p, n, scale, out);
         };
-        gather(sl, l_idx, n_aux); gather(sa, a_idx, na); gather(sb, b_idx, nb);
+        gather((u32*)scB.p, b_idx, nb, nullptr);
+        gather((u32*)scA.p, a_idx, na, nullptr);
         ZK_HIP(hipGetLastError());
-        auto run = [&](bool g2, const DevBuf& bases, const DevBuf& sc, u64 n, DevBuf& out) {
-            const size_t pw = g2 ? P2 : P1;
-            out.reserve((pw + 1) * 4);
-            if (n == 0) { std::vector<u32> z(pw + 1, 0); z[pw] = 1; ZK_HIP(hipMemcpyAsync(out.p, z.data(), (pw + 1) * 4, hipMemcpyHostToDevice, st)); ZK_HIP(hipStreamSynchronize(st)); return; }
-            if (g2) G16_MSM_G2(bases.p, sc.p, n, out.p, st); else G16_MSM_G1(bases.p, sc.p, n, out.p, st);
+        ZK_HIP(hipEventRecord(ev_ready, st));
+        std::exception_ptr err[2];
+        auto side = [&](int k) {
+            try {
+                ZK_HIP(hipSetDevice(device));
+                ZK_HIP(hipStreamWaitEvent(streams[k + 1], ev_ready, 0));
+                if (k == 0) G16_MSM_G2(g2b.p, scB.p, nb + 2, o_b.p, streams[1]);
+                else G16_MSM_G1((const u32*)g1b.p + off_a * P1, scA.p, na + 2, o_a.p, streams[2]);
+            } catch (...) { err[k] = std::current_exception(); }
         };
-        run(false, h, hs, nh, o_h); run(false, l, sl, n_aux, o_l); run(false, a, sa, na, o_a); run(false, b1, sb, nb, o_b1); run(true, b2, sb, nb, o_b2);
-        ZK_HIP(hipStreamSynchronize(st));
-        std::vector<u32> r_h(P1 + 1), r_l(P1 + 1), r_a(P1 + 1), r_b1(P1 + 1), r_b2(P2 + 1);
-        ZK_HIP(hipMemcpy(r_h.data(), o_h.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(r_l.data(), o_l.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(r_a.data(), o_a.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(r_b1.data(), o_b1.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(r_b2.data(), o_b2.p, (P2 + 1) * 4, hipMemcpyDeviceToHost));
-        // prover.rs: g_a = delta r + alpha + a;  g_b = delta2 s + beta2 + b2;
-        // g_c = delta rs + alpha s + beta1 r + a s + b1 r + h + l  =  h + l + g_a s + (beta1 + b1) r
-        auto term = [](const u32* pt, bool inf, const u64 k[4]) { Term t; t.pt = pt; t.inf = inf; std::memcpy(t.k, k, 32); return t; };
-        const u64 one[4] = {1, 0, 0, 0};
-        bool ia = false, ib = false, ic_ = false;
-        std::vector<u32> A = small_sum(false, {term(delta1.data(), false, r_), term(alpha1.data(), false, one), term(r_a.data(), r_a[P1] != 0, one)}, &ia, st);
-        std::vector<u32> B = small_sum(true, {term(delta2.data(), false, s_), term(beta2.data(), false, one), term(r_b2.data(), r_b2[P2] != 0, one)}, &ib, st);
-        std::vector<u32> Cc = small_sum(false, {term(r_h.data(), r_h[P1] != 0, one), term(r_l.data(), r_l[P1] != 0, one), term(A.data(), ia, s_),
-                                               term(beta1.data(), false, r_), term(r_b1.data(), r_b1[P1] != 0, r_)}, &ic_, st);
-        ZK_REQUIRE(!ia && !ib && !ic_, "groth16: a proof element is the point at infinity");
+        std::thread tb(side, 0), ta(side, 1);
+        std::exception_ptr main_err;
+        try {
+            // a_i, b_i, c_i per row (ProvingAssignment::enforce), zero-padded to the domain
+            DevBuf ev[6];
+            for (auto& e : ev) e.reserve(m * NR * 4);
+            for (int w = 0; w < 3; ++w)
+                hipLaunchKernelGGL(frn_r1cs_eval_kernel, dim3(frn_blocks(m)), dim3(256), 0, st, (const u64*)rp[w].p, (const u32*)cl[w].p, (const u32*)cf[w].p,
+                                   (const u32*)wit_fe.p, n_rows, (u32*)ev[w].p, m);
+            ZK_HIP(hipGetLastError());
+            u32* hq = frn_quotient(D, (u32*)ev[0].p, (u32*)ev[1].p, (u32*)ev[2].p, (u32*)ev[3].p, (u32*)ev[4].p, (u32*)ev[5].p, st);
+            if (nh) hipLaunchKernelGGL(frn_to_canon_kernel, dim3(frn_blocks(nh)), dim3(256), 0, st, (const u32*)hq, C0, m, nh);
+            if (d_h_out && nh) ZK_HIP(hipMemcpyAsync(d_h_out, C0, nh * 32, hipMemcpyDeviceToDevice, st));
+            gather(C0 + off_l * 8, l_idx, n_aux, nullptr);
+            gather(C0 + off_b * 8, b_idx, nb, rs_fe);            // r w_b
+            gather(C0 + off_a * 8, a_idx, na, rs_fe + 1);        // s w_a
+            ZK_HIP(hipGetLastError());
+            G16_MSM_G1(g1b.p, scC.p, n_g1, o_c.p, st);
+            ZK_HIP(hipStreamSynchronize(st));                     // ev[] goes back to the pool
+        } catch (...) { main_err = std::current_exception(); }
+        tb.join(); ta.join();
+        for (auto& s2 : streams) (void)hipStreamSynchronize(s2);
+        if (main_err) std::rethrow_exception(main_err);
+        for (auto& e : err) if (e) std::rethrow_exception(e);
+        std::vector<u32> A(P1 + 1), B(P2 + 1), Cc(P1 + 1);
+        ZK_HIP(hipMemcpy(A.data(), o_a.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(B.data(), o_b.p, (P2 + 1) * 4, hipMemcpyDeviceToHost));
+        ZK_HIP(hipMemcpy(Cc.data(), o_c.p, (P1 + 1) * 4, hipMemcpyDeviceToHost));
+        ZK_REQUIRE(!A[P1] && !B[P2] && !Cc[P1], "groth16: a proof element is the point at infinity");
         if (proof_out) {
             std::memcpy(proof_out, A.data(), P1 * 4);
             std::memcpy(proof_out + P1, B.data(), P2 * 4);

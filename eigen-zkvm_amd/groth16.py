@@ -92,3 +92,9 @@ class Groth16Setup:
             self.free()
         except Exception:
             pass
+
+
+def fq_convert(d_elems, curve="BN128", to_mont=True, stream=0):
+    """Fq::from_repr / into_repr on a DevArray of base-field elements, in place"""
+    nl = _FQ_WORDS[curve]
+    _check(getattr(lib(), "zk_fq_%s_convert_dev" % _NAME[curve])(d_elems.ptr, d_elems.n // nl, int(to_mont), stream)); return d_elems

@@ -275,6 +275,11 @@ int zk_fr_bls12_381_quotient_dev(uint64_t* d_a, const uint64_t* d_b, const uint6
  * rng (canonical, < the field modulus), `proof` (optional) receives A || B || C as affine Montgomery coordinates
  * (BN254: 64 + 128 + 64 B; BLS12-381: 96 + 192 + 96 B; G2 as x.c0 || x.c1 || y.c0 || y.c1).  Returns proof.json
  * as json_utils.rs:305-315 renders it (malloc'ed; zk_string_free), NULL on error.                              */
+/* base-field elements in place on the device: to_mont = 1: canonical integers (what key files and proof.json carry,
+ * Fq::from_repr) -> Montgomery limbs (what the multi-scalar sums take); to_mont = 0: the inverse (Fq::into_repr).
+ * n_elems elements of 32 B (BN254) / 48 B (BLS12-381), little-endian words.                                    */
+int zk_fq_bn254_convert_dev(void* d_elems, uint64_t n_elems, int to_mont, void* stream);
+int zk_fq_bls12_381_convert_dev(void* d_elems, uint64_t n_elems, int to_mont, void* stream);
 typedef struct zk_groth16_setup zk_groth16_setup_t;
 zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len);
 int zk_groth16_setup_info(const zk_groth16_setup_t* s, uint32_t* n_wires, uint32_t* n_inputs, uint32_t* domain_log);
