@@ -178,6 +178,48 @@ def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
     return res
 
 
+def groth16_leg(zk, curve, log_rows, cpu_baseline):
+    """one Groth16 proof of a synthetic satisfied circom-shaped circuit of 2^log_rows rows
+    (tools/groth16_bench.py: ~0.7 M / 0.5 M dense A / B columns at 2^20), key and witness resident in HBM.  The key
+    holds arbitrary valid points, so proofs made here do not verify; validity is tests/test_gpu_groth16.py's job."""
+    import importlib
+    sys.path.insert(0, str(ROOT / "tools"))
+    import groth16_bench as GB
+    dev = importlib.import_module("eigen_zkvm_amd.groth16")
+    rb, wit, ni, n_wires = GB.make_circuit(GB.FR[curve], log_rows)
+    pb = GB.make_params(zk, dev, curve, ni, n_wires, log_rows, GB.density(rb, ni, n_wires))
+    S = dev.Groth16Setup(curve, rb, pb)
+    d_w = zk.DevArray.from_host(wit.reshape(-1))
+    d_h = zk.DevArray(4 * ((1 << log_rows) - 1), zero=True)
+    S.prove(d_w, 5, 7, d_h=d_h)
+    assert S.domain_log == log_rows
+    ts, th = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); S.prove(d_w, 5, 7); ts.append(time.perf_counter() - t0)
+    for _ in range(2):
+        t0 = time.perf_counter(); S.prove(wit, 5, 7); th.append(time.perf_counter() - t0)
+    res = {"workload": "Groth16 %s proof, synthetic circuit of 2^%d rows, %d wires; quotient (7 Fr transforms) + 3 multi-scalar sums" % (curve, log_rows, n_wires),
+           "ms": round(min(ts) * 1e3, 2), "ms_from_host_witness": round(min(th) * 1e3, 2), "value": round((1 << log_rows) / min(ts) / 1e6, 2), "unit": "Mrows/s"}
+    if cpu_baseline:
+        import oracle_lib
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import groth16 as G
+        orc = oracle_lib.load()
+        g = G.Groth16Oracle(orc, GB.NAME[curve])
+        lg = min(log_rows, 18); n = 1 << lg
+        rng = np.random.default_rng(5)
+        mk = lambda: np.concatenate([rng.integers(0, 2**64, size=(n, 3), dtype=np.uint64), rng.integers(0, 2**60, size=(n, 1), dtype=np.uint64)], axis=1)
+        a, b, c = mk(), mk(), mk()
+        t0 = time.perf_counter(); hq = g.quotient(a, b, c); cpu_s = time.perf_counter() - t0
+        da, db, dc = (zk.DevArray.from_host(v.reshape(-1)) for v in (a, b, c))
+        dev.fr_quotient(da, db, dc, curve)
+        assert np.array_equal(da.to_host().reshape(-1, 4), hq), "GPU quotient != oracle"
+        res["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 4), "unit": "Mrows/s", "cores": orc.threads(), "kind": "port",
+                               "sample": "quotient only (7 transforms + pointwise) of 2^%d rows, oracle/groth16_impl.h, %.2f s; the sums' CPU rate is msm_g1_*'s cpu_baseline" % (lg, cpu_s)}
+    S.free()
+    return res
+
+
 def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
     """Second component of BASELINE's metric, "BN254 G1 MSM Mpts/s" (config 4): n = 2^22 uniform scalars
     below r, bases [k_i]G generated on the device, everything resident in HBM when the clock starts;
@@ -234,6 +276,8 @@ def main():
     ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 Merkle leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the BN254 MSM leg")
     ap.add_argument("--msm-logn", type=int, default=22)
+    ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 leg")
+    ap.add_argument("--groth16-log-rows", type=int, default=20)
     args = ap.parse_args()
 
     import numpy as np
@@ -325,6 +369,9 @@ def main():
             out["msm_g1_bls12_381"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
         if not args.no_bn128 and world == 1:
             out["merkle_bn128"] = bn128_merkle_leg(zk, 20, 12, not args.no_cpu_baseline)
+        if not args.no_groth16 and world == 1:
+            out["groth16_prove_bn128"] = groth16_leg(zk, "BN128", args.groth16_log_rows, not args.no_cpu_baseline)
+            out["groth16_prove_bls12381"] = groth16_leg(zk, "BLS12381", args.groth16_log_rows, False)
         if not args.no_prove and world == 1:
             out["stark_prove"] = prove_leg(zk, args.prove_nbits)
         if agg is not None:
