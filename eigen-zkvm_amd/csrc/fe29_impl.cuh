@@ -82,6 +82,38 @@ __device__ FQ_MUL_ATTR fe fe_mul(const fe& a, const fe& b) {
     }
     return r;
 }
+// (a*b + c*d)/R' mod q with ONE reduction: both sets of partial products accumulate in the same 64-bit columns
+// (3 NR * 2^58 < 2^64).  Bounds: A*B + C*D <= 168 (BN254) for a result < 2q.  Half the work of two products and
+// a renormalised sum -- the Fq2 product (msm_impl.cuh) is two of these.
+__device__ __forceinline__ fe fe_mul2(const fe& a, const fe& b, const fe& c, const fe& d) {
+    u64 t[2 * NR];
+#pragma unroll
+    for (int i = 0; i < 2 * NR; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t[i + j] += (u64)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t[i + j] += (u64)c.l[i] * d.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const u32 m = ((u32)t[i] * QINV29) & LMASK;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t[i + j] += (u64)m * Q29(j);
+        t[i + 1] += t[i] >> LB;
+    }
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (k + 1 < NR) { r.l[k] = (u32)t[NR + k] & LMASK; t[NR + k + 1] += t[NR + k] >> LB; }
+        else r.l[k] = (u32)t[NR + k];
+    }
+    return r;
+}
 __device__ __forceinline__ fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 // x == 0 (mod q) for a product x (< 2q, normalised): x is 0 or q
 __device__ __forceinline__ bool fe_is_zero_m(const fe& a) {

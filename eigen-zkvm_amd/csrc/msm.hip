@@ -81,17 +81,24 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
                            0xc71856eeu, 0x64095b56u, 0x327d3cbbu, 0xdc57f922u, 0x33351076u, 0x55f935beu, 0x93fd6482u, 0x0da4a0e6u};
     return v[i];
 }
-// The Fq2 products (cf_mul / cf_sqr, six Fq products each) are real functions here: with everything inlined, as for G1,
-// a G2 point addition is > 128 KB of code, beyond the reach of s_branch, and kernels of that size built by hipcc
-// (ROCm 7.2) did not terminate on the device (seen twice: 12 x 32-bit limbs inlined for BLS12-381 G1, and this)
+// Code-size hazard: with everything inlined, as for G1, a G2 point addition built from six-product Fq2 multiplications
+// was > 128 KB of code, beyond the reach of s_branch, and kernels of that size built by hipcc (ROCm 7.2) did not
+// terminate on the device (seen twice: 12 x 32-bit limbs inlined for BLS12-381 G1, and this).  With the two-reduction
+// Fq2 product (fe_mul2) a BN254 addition is ~70 KB: the Fq2 products are inlined into the point formulas, the hot
+// mixed addition into the accumulate kernel, and the cold formulas (pt_add, pt_dbl, pt_dbl_aff) stay real functions.
+// BLS12-381 (14 limbs, 2.4 x the code) keeps cf_mul / cf_sqr as functions.
 #ifdef ZK_G2_FQ_NOINLINE
 #undef FQ_MUL_ATTR
 #define FQ_MUL_ATTR __noinline__
 #endif
+#define MSM_G2_INLINE_CF   // 9 x 29-bit limbs: the Fq2 products are small enough to inline; the rare point formulas stay out of line
 #define MSM_G2
 namespace {
 #include "msm_impl.cuh"
 }
+#undef MSM_G2_INLINE_CF
+#undef CF_MUL_ATTR
+#undef PT_COLD_ATTR
 #undef MSM_G2
 #undef FQ_MUL_ATTR
 }  // namespace g2
@@ -161,9 +168,12 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
                            0xdf64b05du, 0xadc0fc92u, 0x2b1461dcu, 0x18aa270au, 0x3be4eba0u, 0x86adac6au, 0xc93da33au, 0x79495c4eu, 0xa43ccaedu, 0xe7175850u, 0x63de1bf2u, 0x0b2bc2a1u};
     return v[i];
 }
-// The Fq2 products (cf_mul / cf_sqr, six Fq products each) are real functions here: with everything inlined, as for G1,
-// a G2 point addition is > 128 KB of code, beyond the reach of s_branch, and kernels of that size built by hipcc
-// (ROCm 7.2) did not terminate on the device (seen twice: 12 x 32-bit limbs inlined for BLS12-381 G1, and this)
+// Code-size hazard: with everything inlined, as for G1, a G2 point addition built from six-product Fq2 multiplications
+// was > 128 KB of code, beyond the reach of s_branch, and kernels of that size built by hipcc (ROCm 7.2) did not
+// terminate on the device (seen twice: 12 x 32-bit limbs inlined for BLS12-381 G1, and this).  With the two-reduction
+// Fq2 product (fe_mul2) a BN254 addition is ~70 KB: the Fq2 products are inlined into the point formulas, the hot
+// mixed addition into the accumulate kernel, and the cold formulas (pt_add, pt_dbl, pt_dbl_aff) stay real functions.
+// BLS12-381 (14 limbs, 2.4 x the code) keeps cf_mul / cf_sqr as functions.
 #ifdef ZK_G2_FQ_NOINLINE
 #undef FQ_MUL_ATTR
 #define FQ_MUL_ATTR __noinline__
@@ -172,6 +182,8 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 namespace {
 #include "msm_impl.cuh"
 }
+#undef CF_MUL_ATTR
+#undef PT_COLD_ATTR
 #undef MSM_G2
 #undef FQ_MUL_ATTR
 }  // namespace g2

@@ -55,16 +55,26 @@ __device__ __forceinline__ cf cf_one() { cf r; r.c0 = fe_one(); r.c1 = fe_zero()
 __device__ __forceinline__ cf cf_add(const cf& a, const cf& b) { cf r; r.c0 = fe_add(a.c0, b.c0); r.c1 = fe_add(a.c1, b.c1); return r; }
 __device__ __forceinline__ cf cf_dbl(const cf& a) { return cf_add(a, a); }
 template <int M> __device__ __forceinline__ cf cf_sub(const cf& a, const cf& b) { cf r; r.c0 = fe_sub<M>(a.c0, b.c0); r.c1 = fe_sub<M>(a.c1, b.c1); return r; }
-__device__ __noinline__ cf cf_mul(const cf& a, const cf& b) {   // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, components < 2q
+// (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u with one reduction per component (fe_mul2): the subtrahend enters as
+// a1 (8q - b1).  Requires b.c1 <= 8q and, for components a < Aq, b < Bq, A (B + 8) <= 168 (BN254; every call site
+// below keeps the operand with the larger bound first: the worst is 10q x 6q = 140).  Components of the result < 2q.
+#ifdef MSM_G2_INLINE_CF
+#define CF_MUL_ATTR __forceinline__
+#define PT_COLD_ATTR __noinline__
+#else
+#define CF_MUL_ATTR __noinline__
+#define PT_COLD_ATTR
+#endif
+__device__ CF_MUL_ATTR cf cf_mul(const cf& a, const cf& b) {
     cf r;
-    r.c0 = fe_renorm(fe_sub<2>(fe_mul(a.c0, b.c0), fe_mul(a.c1, b.c1)));
-    r.c1 = fe_renorm(fe_add(fe_mul(a.c0, b.c1), fe_mul(a.c1, b.c0)));
+    r.c0 = fe_mul2(a.c0, b.c0, a.c1, fe_sub<8>(fe_zero(), b.c1));
+    r.c1 = fe_mul2(a.c0, b.c1, a.c1, b.c0);
     return r;
 }
-__device__ __noinline__ cf cf_sqr(const cf& a) {
+__device__ CF_MUL_ATTR cf cf_sqr(const cf& a) {   // a <= 8q (or c0 < 10q with c1 < 2q): a0^2 + a1 (8q - a1), 2 a0 a1
     cf r;
-    r.c0 = fe_renorm(fe_sub<2>(fe_sqr(a.c0), fe_sqr(a.c1)));
-    r.c1 = fe_renorm(fe_dbl(fe_mul(a.c0, a.c1)));
+    r.c0 = fe_mul2(a.c0, a.c0, a.c1, fe_sub<8>(fe_zero(), a.c1));
+    r.c1 = fe_mul(fe_dbl(a.c0), a.c1);
     return r;
 }
 __device__ __forceinline__ bool cf_is_zero_m(const cf& a) { return fe_is_zero_m(a.c0) && fe_is_zero_m(a.c1); }
@@ -112,31 +122,38 @@ __device__ __forceinline__ bool pt_is_inf(const xyzz& p) { return cf_is_zero_m(p
 __device__ __forceinline__ void pt_finish(xyzz& r, const cf& U1, const cf& S1, const cf& P, const cf& Rr, const cf& PP) {
     const cf PPP = cf_mul(P, PP), Q = cf_mul(U1, PP);                      // < 2q each
     r.X = cf_sub<4>(cf_sub<2>(cf_sqr(Rr), PPP), cf_dbl(Q));                 // < 2q + 2q + 4q = 8q
-    r.Y = cf_sub<2>(cf_mul(Rr, cf_sub<8>(Q, r.X)), cf_mul(S1, PPP));        // (Q - X3 < 10q) ; Y3 < 4q
+    r.Y = cf_sub<2>(cf_mul(cf_sub<8>(Q, r.X), Rr), cf_mul(S1, PPP));        // (Q - X3 < 10q) first, Rr < 6q ; Y3 < 4q
 }
-__device__ xyzz pt_dbl_aff(const aff& a) {  // mdbl-2008-s-1 (a = 0)
+#ifndef PT_COLD_ATTR
+#define PT_COLD_ATTR
+#endif
+__device__ PT_COLD_ATTR xyzz pt_dbl_aff(const aff& a) {  // mdbl-2008-s-1 (a = 0)
     const cf U = cf_dbl(a.y), V = cf_sqr(U), W = cf_mul(U, V), S = cf_mul(a.x, V);
     const cf xx = cf_sqr(a.x), M = cf_add(cf_dbl(xx), xx);                  // < 6q
     xyzz r;
     r.X = cf_sub<4>(cf_sqr(M), cf_dbl(S));                                  // < 6q
-    r.Y = cf_sub<2>(cf_mul(M, cf_sub<8>(S, r.X)), cf_mul(W, a.y));
+    r.Y = cf_sub<2>(cf_mul(cf_sub<8>(S, r.X), M), cf_mul(W, a.y));
     r.ZZ = V; r.ZZZ = W;
     return r;
 }
-__device__ xyzz pt_dbl(const xyzz& p) {  // dbl-2008-s-1 (a = 0)
+__device__ PT_COLD_ATTR xyzz pt_dbl(const xyzz& p) {  // dbl-2008-s-1 (a = 0)
     if (pt_is_inf(p)) return p;
     const cf U = cf_dbl(p.Y), V = cf_sqr(U), W = cf_mul(U, V), S = cf_mul(p.X, V);   // U <= 8q
     const cf xx = cf_sqr(p.X), M = cf_add(cf_dbl(xx), xx);                  // < 6q
     xyzz r;
     r.X = cf_sub<4>(cf_sqr(M), cf_dbl(S));                                  // < 6q
-    r.Y = cf_sub<2>(cf_mul(M, cf_sub<8>(S, r.X)), cf_mul(W, p.Y));
+    r.Y = cf_sub<2>(cf_mul(cf_sub<8>(S, r.X), M), cf_mul(W, p.Y));
     r.ZZ = cf_mul(V, p.ZZ); r.ZZZ = cf_mul(W, p.ZZZ);
     return r;
 }
-__device__ xyzz pt_madd(const xyzz& p, const aff& a) {  // madd-2008-s
+__device__ __forceinline__ xyzz pt_madd(const xyzz& p, const aff& a) {  // madd-2008-s
     if (pt_is_inf(p)) { xyzz r; r.X = a.x; r.Y = a.y; r.ZZ = cf_one(); r.ZZZ = cf_one(); return r; }
     const cf U2 = cf_mul(a.x, p.ZZ), S2 = cf_mul(a.y, p.ZZZ);
-    const cf P = cf_sub<8>(U2, p.X), Rr = cf_sub<4>(S2, p.Y);               // < 10q, < 6q
+    cf P = cf_sub<8>(U2, p.X);                                              // < 10q
+    const cf Rr = cf_sub<4>(S2, p.Y);                                       // < 6q
+#ifdef MSM_G2
+    P.c1 = fe_renorm(P.c1);                                                 // cf_sqr's bound: c0 < 10q needs c1 < 2q
+#endif
     const cf PP = cf_sqr(P);
     if (cf_is_zero_m(PP)) return cf_is_zero_m(cf_sqr(Rr)) ? pt_dbl_aff(a) : pt_inf();  // q prime: P^2 = 0 <=> P = 0
     xyzz r;
@@ -144,7 +161,7 @@ __device__ xyzz pt_madd(const xyzz& p, const aff& a) {  // madd-2008-s
     r.ZZ = cf_mul(p.ZZ, PP); r.ZZZ = cf_mul(p.ZZZ, cf_mul(P, PP));
     return r;
 }
-__device__ xyzz pt_add(const xyzz& p, const xyzz& q) {  // add-2008-s
+__device__ PT_COLD_ATTR xyzz pt_add(const xyzz& p, const xyzz& q) {  // add-2008-s
     if (pt_is_inf(p)) return q;
     if (pt_is_inf(q)) return p;
     const cf U1 = cf_mul(p.X, q.ZZ), U2 = cf_mul(q.X, p.ZZ), S1 = cf_mul(p.Y, q.ZZZ), S2 = cf_mul(q.Y, p.ZZZ);
@@ -169,7 +186,7 @@ __device__ void pt_to_std(const xyzz& p, u32* x, u32* y) {   // CW_STD words eac
 
 constexpr int C_BITS = 16, N_WIN = 16, N_BUCKET = 1 << C_BITS;  // 254-bit scalars: 16 windows of 16 bits
 
-__global__ void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __restrict__ counts) {
+__global__ __launch_bounds__(256) void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __restrict__ counts) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // one lane per (point, window)
     if (t >= n * N_WIN) return;
     const u64 i = t / N_WIN; const u32 w = t % N_WIN;
@@ -177,7 +194,7 @@ __global__ void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __
     const u32 d = (w & 1) ? word >> 16 : word & 0xFFFF;
     if (d) atomicAdd(&counts[w * N_BUCKET + d], 1u);
 }
-__global__ void msm_scatter_kernel(const u32* __restrict__ scalars, u64 n, const u32* __restrict__ offsets,
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const u32* __restrict__ scalars, u64 n, const u32* __restrict__ offsets,
                                    u32* __restrict__ cursors, u32* __restrict__ idx) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * N_WIN) return;
@@ -208,12 +225,12 @@ __global__ __launch_bounds__(256) void scan_block_kernel(const u32* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) { out[base + k] = ex; ex += v[k]; }
 }
-__global__ void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // a few thousand entries: one lane, serial
+__global__ __launch_bounds__(64) void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // a few thousand entries: one lane, serial
     if (threadIdx.x | blockIdx.x) return;
     u32 acc = 0;
     for (u32 b = 0; b < nb; ++b) { u32 t = block_sum[b]; block_sum[b] = acc; acc += t; }
 }
-__global__ void scan_add_kernel(u32* __restrict__ out, const u32* __restrict__ block_sum) {
+__global__ __launch_bounds__(256) void scan_add_kernel(u32* __restrict__ out, const u32* __restrict__ block_sum) {
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 0] += block_sum[blockIdx.x];
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 1] += block_sum[blockIdx.x];
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 2] += block_sum[blockIdx.x];
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256) void sort_coarse_kernel(const u32* __restrict_
     }
 }
 // grand total of non-zero (point, window) pairs = last scanned entry + last count
-__global__ void sort_total_kernel(const u32* __restrict__ hist, const u32* __restrict__ hist_scanned, u32 last, u32* __restrict__ total) {
+__global__ __launch_bounds__(64) void sort_total_kernel(const u32* __restrict__ hist, const u32* __restrict__ hist_scanned, u32 last, u32* __restrict__ total) {
     if ((threadIdx.x | blockIdx.x) == 0) total[0] = hist_scanned[last] + hist[last];
 }
 __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__ coarse, const u32* __restrict__ hist_scanned, u32 n_blocks, const u32* __restrict__ total,
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(256) void balance_hist_kernel(const u32* __restrict
     __syncthreads();
     for (int k = threadIdx.x; k < BAL_BINS; k += 256) if (h[k]) atomicAdd(&hist[k], h[k]);
 }
-__global__ void balance_scan_kernel(u32* __restrict__ hist) {   // descending exclusive scan of 1024 counters, one lane
+__global__ __launch_bounds__(64) void balance_scan_kernel(u32* __restrict__ hist) {   // descending exclusive scan of 1024 counters, one lane
     if (threadIdx.x | blockIdx.x) return;
     u32 acc = 0;
     for (int k = BAL_BINS - 1; k >= 0; --k) { const u32 v = hist[k]; hist[k] = acc; acc += v; }
@@ -388,7 +405,7 @@ __global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __rest
     }
     S_out[g] = run; A_out[g] = acc;
 }
-__global__ void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */) {
+__global__ __launch_bounds__(64) void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */) {
     if (threadIdx.x | blockIdx.x) return;
     xyzz acc = pt_inf();
     for (int w = N_WIN - 1; w >= 0; --w) {
