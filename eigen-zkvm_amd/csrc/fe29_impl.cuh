@@ -114,6 +114,39 @@ __device__ __forceinline__ fe fe_mul2(const fe& a, const fe& b, const fe& c, con
     }
     return r;
 }
+// Deferred reduction for sums of products: partial products of up to FE_WIDE_MAX pairs accumulate in the 64-bit
+// columns ((FE_WIDE_MAX + 1) NR 2^58 <= 2^64 with the reduction's own products), then ONE Montgomery reduction.
+// Bounds: sum A_i B_i <= 168 (BN254 fields) / 68 (BLS12-381 Fr) for a result < 2q.  A dot product of n terms costs
+// n + ceil(n / 6) column passes instead of 2 n.
+constexpr int FE_WIDE_MAX = 6;
+struct fe_wide { u64 t[2 * NR]; };
+__device__ __forceinline__ void fe_wide_zero(fe_wide& w) {
+#pragma unroll
+    for (int i = 0; i < 2 * NR; ++i) w.t[i] = 0;
+}
+__device__ __forceinline__ void fe_wide_mac(fe_wide& w, const fe& a, const fe& b) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) w.t[i + j] += (u64)a.l[i] * b.l[j];
+    }
+}
+__device__ __forceinline__ fe fe_wide_reduce(fe_wide& w) {   // consumes w
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const u32 m = ((u32)w.t[i] * QINV29) & LMASK;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) w.t[i + j] += (u64)m * Q29(j);
+        w.t[i + 1] += w.t[i] >> LB;
+    }
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        if (k + 1 < NR) { r.l[k] = (u32)w.t[NR + k] & LMASK; w.t[NR + k + 1] += w.t[NR + k] >> LB; }
+        else r.l[k] = (u32)w.t[NR + k];
+    }
+    return r;
+}
 __device__ __forceinline__ fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 // x == 0 (mod q) for a product x (< 2q, normalised): x is 0 or q
 __device__ __forceinline__ bool fe_is_zero_m(const fe& a) {

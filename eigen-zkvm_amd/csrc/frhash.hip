@@ -24,6 +24,7 @@ namespace bn128fr {
 #include "fr29_consts.cuh"
 #define FH_NRP 56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68   // poseidon_bn128_opt.rs:62
 #define FH_OUT_IDX 0                                                            // poseidon_bn128_opt.rs:80-83
+#define FH_AB_LIMIT 168u
 #define FH_NAME "bn128"
 #define FH_FN(name) bn128_##name
 #include "frhash_impl.cuh"
@@ -42,6 +43,8 @@ namespace bls12381fr {
 #include "fr29_consts.cuh"
 #define FH_NRP 55, 55, 56, 56, 56, 56, 57, 57, 57, 57, 57, 57, 57, 57, 59, 59   // poseidon_bls12381_opt.rs:67
 #define FH_OUT_IDX 1                                                            // poseidon_bls12381_opt.rs:94-103
+#undef FH_AB_LIMIT
+#define FH_AB_LIMIT 68u
 #define FH_NAME "bls12381"
 #define FH_FN(name) bls12381_##name
 #include "frhash_impl.cuh"

@@ -33,13 +33,26 @@ __device__ Params g_prm[16];
 
 __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
 
+// Sums of products with deferred reduction (fe29_impl.cuh fe_wide): the tables are canonical (< r), so a group of g
+// products with operands < B r needs g B <= FH_AB_LIMIT (168 for BN254's r, 68 for BLS12-381's).
+constexpr u32 DOT_DENSE = FE_WIDE_MAX;                                       // dense products: state < 3r (6 x 3 = 18)
+constexpr u32 PR_RENORM = 8;                                                 // sparse rounds: running columns renormalised every 8 rounds,
+constexpr u32 DOT_SPARSE = FH_AB_LIMIT / 18 < FE_WIDE_MAX ? FH_AB_LIMIT / 18 : FE_WIDE_MAX;   // < 2r + 8 * 2r = 18r in between
+// sum_{j < n} a[j * stride] * x[j] in groups of `grp`; n > grp: partial results (< 2r each) are added and renormalised
+template <class GetX>
+__device__ __forceinline__ fe dot_products(const fe* __restrict__ a, u32 stride, GetX getx, u32 n, u32 grp) {
+    fe_wide w; fe_wide_zero(w);
+    fe acc = fe_zero();
+    u32 cnt = 0;
+    for (u32 j = 0; j < n; ++j) {
+        fe_wide_mac(w, a[(size_t)j * stride], getx(j));
+        if (++cnt == grp || j + 1 == n) { acc = fe_add(acc, fe_wide_reduce(w)); cnt = 0; fe_wide_zero(w); }
+    }
+    return n > grp ? fe_renorm(acc) : acc;                                   // <= 9 groups: < 18r -> < 2r
+}
 // st <- (sum_j MAT[j][i] st[j])_i, st[j] < 3r in, < 2r out
 __device__ void matmul(const fe* __restrict__ mat, fe* st, fe* tmp, u32 t) {
-    for (u32 i = 0; i < t; ++i) {
-        fe acc = fe_mul(mat[i], st[0]);
-        for (u32 j = 1; j < t; ++j) acc = fe_add(acc, fe_mul(mat[j * t + i], st[j]));   // < 34r
-        tmp[i] = fe_renorm(acc);
-    }
+    for (u32 i = 0; i < t; ++i) tmp[i] = dot_products(mat + i, t, [&](u32 j) { return st[j]; }, t, DOT_DENSE);
     for (u32 i = 0; i < t; ++i) st[i] = tmp[i];
 }
 
@@ -57,11 +70,10 @@ __device__ __noinline__ void poseidon_fr(fe* st, fe* tmp, u32 t) {   // one gene
         pow5(st[0]);
         st[0] = fe_add(st[0], P.c[5 * t + r]);
         const fe* __restrict__ S = P.s + (size_t)(2 * t - 1) * r;
-        fe s0 = fe_mul(S[0], st[0]);
-        for (u32 j = 1; j < t; ++j) s0 = fe_add(s0, fe_mul(S[j], st[j]));               // < 34r
+        const fe s0 = dot_products(S, 1, [&](u32 j) { return st[j]; }, t, DOT_SPARSE);   // st[j] < 18r
         for (u32 k = 1; k < t; ++k) st[k] = fe_add(st[k], fe_mul(S[t + k - 1], st[0])); // grows by < 2r per round
-        st[0] = fe_renorm(s0);
-        if ((r & 15) == 15) for (u32 k = 1; k < t; ++k) st[k] = fe_renorm(st[k]);        // < 2r + 16*2r in between
+        st[0] = s0;
+        if (r % PR_RENORM == PR_RENORM - 1) for (u32 k = 1; k < t; ++k) st[k] = fe_renorm(st[k]);   // < 2r + 8 * 2r in between
     }
     for (u32 k = 1; k < t; ++k) st[k] = fe_renorm(st[k]);
     for (u32 r = 0; r < 3; ++r) {
@@ -98,7 +110,7 @@ __global__ void bn128_convert_kernel(const u32* __restrict__ canon, u64 n, fe* _
     if (i >= n) return;
     u32 w[NL];
     for (int k = 0; k < NL; ++k) w[k] = canon[i * NL + k];
-    out[i] = fe_from_int(w);
+    out[i] = fe_canon(fe_from_int(w));   // < r: the group bounds of dot_products count on it
 }
 // Poseidon::hash_ex on a batch: inp [n][n_in][4] raw, init [4] raw (shared), out [n][n_out][4] raw
 __global__ __launch_bounds__(64) void bn128_poseidon_kernel(const u64* __restrict__ inp, u64 n, u32 n_in, const u64* __restrict__ init,
@@ -166,9 +178,7 @@ __device__ fe coop_matmul(const fe* __restrict__ mat, const fe& x, u32* xs, int 
     coop_put(xs, l, t, x);
     __syncthreads();
     const u32 lc = (u32)l < t ? l : 0;
-    fe acc = fe_mul(mat[lc], coop_get(xs, 0));
-    for (u32 j = 1; j < t; ++j) acc = fe_add(acc, fe_mul(mat[j * t + lc], coop_get(xs, j)));
-    return fe_renorm(acc);
+    return dot_products(mat + lc, t, [&](u32 j) { return coop_get(xs, j); }, t, DOT_DENSE);
 }
 __device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
     const int l = threadIdx.x & 31;
@@ -200,7 +210,7 @@ __device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
             x = fe_renorm(s0);
         } else {
             x = fe_add(x, fe_mul(S[t + (lc > 0 ? lc : 1) - 1], st0));
-            if ((r & 15) == 15) x = fe_renorm(x);
+            if (r % PR_RENORM == PR_RENORM - 1) x = fe_renorm(x);
         }
     }
     if (l != 0) x = fe_renorm(x);
