@@ -145,6 +145,12 @@ namespace bn254fr {
 #define G16_CW 8
 #define G16_MSM_G1 msm_g1_bn254_dev
 #define G16_MSM_G2 msm_g2_bn254_dev
+#define G16_MSM_G1_TABLE_BYTES msm_g1_bn254_fixed_table_bytes
+#define G16_MSM_G2_TABLE_BYTES msm_g2_bn254_fixed_table_bytes
+#define G16_MSM_G1_PREPARE msm_g1_bn254_fixed_prepare_dev
+#define G16_MSM_G2_PREPARE msm_g2_bn254_fixed_prepare_dev
+#define G16_MSM_G1_FIXED msm_g1_bn254_fixed_dev
+#define G16_MSM_G2_FIXED msm_g2_bn254_fixed_dev
 #define G16_FQ_TO_MONT fq_bn254_canon_to_mont_dev
 #define G16_FQ_TO_CANON fq_bn254_mont_to_canon_dev
 #define G16_JSON_CURVE "BN128"
@@ -155,6 +161,12 @@ namespace bn254fr {
 #undef G16_CW
 #undef G16_MSM_G1
 #undef G16_MSM_G2
+#undef G16_MSM_G1_TABLE_BYTES
+#undef G16_MSM_G2_TABLE_BYTES
+#undef G16_MSM_G1_PREPARE
+#undef G16_MSM_G2_PREPARE
+#undef G16_MSM_G1_FIXED
+#undef G16_MSM_G2_FIXED
 #undef G16_FQ_TO_MONT
 #undef G16_FQ_TO_CANON
 #undef G16_JSON_CURVE
@@ -170,6 +182,12 @@ namespace bls12381fr {
 #define G16_CW 12
 #define G16_MSM_G1 msm_g1_bls12_381_dev
 #define G16_MSM_G2 msm_g2_bls12_381_dev
+#define G16_MSM_G1_TABLE_BYTES msm_g1_bls12_381_fixed_table_bytes
+#define G16_MSM_G2_TABLE_BYTES msm_g2_bls12_381_fixed_table_bytes
+#define G16_MSM_G1_PREPARE msm_g1_bls12_381_fixed_prepare_dev
+#define G16_MSM_G2_PREPARE msm_g2_bls12_381_fixed_prepare_dev
+#define G16_MSM_G1_FIXED msm_g1_bls12_381_fixed_dev
+#define G16_MSM_G2_FIXED msm_g2_bls12_381_fixed_dev
 #define G16_FQ_TO_MONT fq_bls12_381_canon_to_mont_dev
 #define G16_FQ_TO_CANON fq_bls12_381_mont_to_canon_dev
 #define G16_JSON_CURVE "BLS12381"

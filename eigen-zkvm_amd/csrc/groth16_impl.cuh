@@ -23,6 +23,10 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
     //        g_c = sum over everything of (h, w_l, r w_b, r, s w_a, s r, s)
     //   G2: [ b_g2 (nb) | delta_g2 | beta_g2 ],  g_b = sum of (w_b, s, 1)
     DevBuf g1b, g2b;
+    // the key never changes: both arrays are expanded once into window tables (2^(16 w) P for the 16 windows, msm_impl.cuh), so a
+    // proof's sums need no doublings; keys too large for the 24-bit point index of the sort keep the plain arrays
+    DevBuf g1t, g2t;
+    bool tables = false;
     u64 off_l = 0, off_b = 0, off_a = 0, n_g1 = 0;
 
     static constexpr size_t P1 = 2 * G16_CW, P2 = 4 * G16_CW;   // u32 words per affine point
@@ -117,6 +121,14 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         put(g2b, nb + 1, pk.vk[2], P2, 1, false, "beta_g2");
         G16_FQ_TO_MONT(g1b.p, n_g1 * P1 / G16_CW, st);
         G16_FQ_TO_MONT(g2b.p, (nb + 2) * P2 / G16_CW, st);
+        tables = n_g1 < (1ull << 24);
+        if (tables) {
+            g1t.reserve(G16_MSM_G1_TABLE_BYTES(n_g1)); g2t.reserve(G16_MSM_G2_TABLE_BYTES(nb + 2));
+            G16_MSM_G1_PREPARE(g1b.p, n_g1, g1t.p, st);
+            G16_MSM_G2_PREPARE(g2b.p, nb + 2, g2t.p, st);
+            ZK_HIP(hipStreamSynchronize(st));
+            g1b.release(); g2b.release();
+        }
         ZK_HIP(hipStreamSynchronize(st));
         (void)frn_domain(logm, st);
     }
@@ -175,8 +187,8 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
             try {
                 ZK_HIP(hipSetDevice(device));
                 ZK_HIP(hipStreamWaitEvent(streams[k + 1], ev_ready, 0));
-                if (k == 0) G16_MSM_G2(g2b.p, scB.p, nb + 2, o_b.p, streams[1]);
-                else G16_MSM_G1((const u32*)g1b.p + off_a * P1, scA.p, na + 2, o_a.p, streams[2]);
+                if (k == 0) { if (tables) G16_MSM_G2_FIXED(g2t.p, nb + 2, 0, scB.p, nb + 2, o_b.p, streams[1]); else G16_MSM_G2(g2b.p, scB.p, nb + 2, o_b.p, streams[1]); }
+                else { if (tables) G16_MSM_G1_FIXED(g1t.p, n_g1, off_a, scA.p, na + 2, o_a.p, streams[2]); else G16_MSM_G1((const u32*)g1b.p + off_a * P1, scA.p, na + 2, o_a.p, streams[2]); }
             } catch (...) { err[k] = std::current_exception(); }
         };
         std::thread tb(side, 0), ta(side, 1);
@@ -196,7 +208,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
             gather(C0 + off_b * 8, b_idx, nb, rs_fe);            // r w_b
             gather(C0 + off_a * 8, a_idx, na, rs_fe + 1);        // s w_a
             ZK_HIP(hipGetLastError());
-            G16_MSM_G1(g1b.p, scC.p, n_g1, o_c.p, st);
+            if (tables) G16_MSM_G1_FIXED(g1t.p, n_g1, 0, scC.p, n_g1, o_c.p, st); else G16_MSM_G1(g1b.p, scC.p, n_g1, o_c.p, st);
             ZK_HIP(hipStreamSynchronize(st));                     // ev[] goes back to the pool
         } catch (...) { main_err = std::current_exception(); }
         tb.join(); ta.join();

@@ -212,4 +212,15 @@ void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipSt
 void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { bls12_381::g2::msm_g1_dev(d_bases, d_scalars, n, d_out, st); }
 void g2_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) { bls12_381::g2::g1_mul_generator_dev(d_k, n, d_bases, st); }
 
+// window tables (fixed bases)
+#define ZK_MSM_FIXED(NAME, NS)                                                                                              \
+    size_t msm_##NAME##_fixed_table_bytes(uint64_t n) { return NS::msm_fixed_table_bytes(n); }                              \
+    void msm_##NAME##_fixed_prepare_dev(const void* b, uint64_t n, void* t, hipStream_t st) { NS::msm_fixed_prepare_dev(b, n, t, st); } \
+    void msm_##NAME##_fixed_dev(const void* t, uint64_t tn, uint64_t off, const void* s, uint64_t n, void* o, hipStream_t st) { NS::msm_fixed_dev(t, tn, off, s, n, o, st); }
+ZK_MSM_FIXED(g1_bn254, bn254::g1)
+ZK_MSM_FIXED(g2_bn254, bn254::g2)
+ZK_MSM_FIXED(g1_bls12_381, bls12_381::g1)
+ZK_MSM_FIXED(g2_bls12_381, bls12_381::g2)
+#undef ZK_MSM_FIXED
+
 }  // namespace zk

@@ -297,8 +297,9 @@ __global__ __launch_bounds__(256) void sort_coarse_kernel(const u32* __restrict_
 __global__ __launch_bounds__(64) void sort_total_kernel(const u32* __restrict__ hist, const u32* __restrict__ hist_scanned, u32 last, u32* __restrict__ total) {
     if ((threadIdx.x | blockIdx.x) == 0) total[0] = hist_scanned[last] + hist[last];
 }
+// idx entries: the point's index, or -- for a window table (msm_fixed_*) -- the index of 2^(16 w) P_i in it
 __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__ coarse, const u32* __restrict__ hist_scanned, u32 n_blocks, const u32* __restrict__ total,
-                                                         u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ idx) {
+                                                         u32* __restrict__ counts, u32* __restrict__ offsets, u32* __restrict__ idx, u32 win_stride, u32 base_off) {
     __shared__ u32 h[256], cur[256];
     const u32 bin = blockIdx.x;
     const u32 start = hist_scanned[(u64)bin * n_blocks];
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__
     __syncthreads();
     for (u32 k = start + threadIdx.x; k < end; k += 256) {
         const u32 e = coarse[k];
-        idx[atomicAdd(&cur[e & 0xFF], 1u)] = e >> 8;
+        idx[atomicAdd(&cur[e & 0xFF], 1u)] = (e >> 8) + base_off + (bin >> 8) * win_stride;
     }
 }
 
@@ -405,11 +406,11 @@ __global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __rest
     }
     S_out[g] = run; A_out[g] = acc;
 }
-__global__ __launch_bounds__(64) void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */) {
+__global__ __launch_bounds__(64) void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */, int weighted) {
     if (threadIdx.x | blockIdx.x) return;
     xyzz acc = pt_inf();
     for (int w = N_WIN - 1; w >= 0; --w) {
-        for (int k = 0; k < C_BITS; ++k) acc = pt_dbl(acc);
+        if (!weighted) for (int k = 0; k < C_BITS; ++k) acc = pt_dbl(acc);   // weighted: the table already holds 2^(16 w) P
         acc = pt_add(acc, win[w]);
     }
     if (pt_is_inf(acc)) { for (int i = 0; i < 2 * CW_STD; ++i) out[i] = 0; out[2 * CW_STD] = 1; return; }
@@ -491,14 +492,43 @@ void fq_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) {
 }
 #endif
 
-// d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag)
-void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
+// ---- window tables for bases that do not change between calls (a Groth16 proving key): entry [w * n + i] =
+// ---- 2^(16 w) P_i in the internal affine layout.  The sum then needs no doublings at all: every (point, window)
+// ---- pair adds the table entry of its window, and the 16 window results are simply added.
+__global__ __launch_bounds__(64) void msm_table_kernel(u32* __restrict__ table, u64 n) {   // window 0 is in place already
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    aff a = load_aff(table, (u32)i);
+    for (int w = 1; w < N_WIN; ++w) {
+        xyzz p = pt_dbl_aff(a);
+        for (int k = 1; k < C_BITS; ++k) p = pt_dbl(p);
+        const cf izzz = cf_inv(p.ZZZ), t = cf_mul(p.ZZ, izzz), izz = cf_sqr(t);   // 1/ZZ = (ZZ/ZZZ)^2
+        a.x = cf_mul(p.X, izz); a.y = cf_mul(p.Y, izzz);
+        u32* o = table + ((u64)w * n + i) * PTW;
+        cf_store_int(a.x, o); cf_store_int(a.y, o + CW_INT);
+    }
+}
+size_t msm_fixed_table_bytes(uint64_t n) { return (size_t)n * N_WIN * PTW * 4; }
+void msm_fixed_prepare_dev(const void* d_bases, uint64_t n, void* d_table, hipStream_t st) {
+    ZK_REQUIRE(n >= 1 && n < (1ull << 24), "msm table: n out of range");
+    hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, n, (u32*)d_table);
+    hipLaunchKernelGGL(msm_table_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (u32*)d_table, n);
+    ZK_HIP(hipGetLastError());
+}
+
+// d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag).  d_table != nullptr: the sum runs over the n points
+// [base_off, base_off + n) of a window table built for table_n points; d_bases is ignored
+static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
+    ZK_REQUIRE(!d_table || (n < (1ull << 24) && base_off + n <= table_n && table_n < (1ull << 24)), "msm table: range out of bounds");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;
     DevBuf counts, offsets, cursors, tops, idx, buckets, S0, A0, S1, A1, conv;
-    conv.reserve((size_t)n * PTW * 4);
-    hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, n, (u32*)conv.p);
-    ZK_HIP(hipGetLastError());
+    if (!d_table) {
+        conv.reserve((size_t)n * PTW * 4);
+        hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, n, (u32*)conv.p);
+        ZK_HIP(hipGetLastError());
+    }
+    const u32* points = d_table ? (const u32*)d_table : (const u32*)conv.p;
     counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
     idx.reserve((size_t)n * N_WIN * 4);
     buckets.reserve(n_keys * sizeof(xyzz));
@@ -522,7 +552,7 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
         // the last coarse bin ends at the number of non-zero pairs: last scanned entry + last count, kept on the device
         hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(64), 0, st, (const u32*)hist.p, (const u32*)hist_scanned.p, (u32)(n_hist - 1), (u32*)tops.p);
         hipLaunchKernelGGL(sort_fine_kernel2, dim3(N_COARSE), dim3(256), 0, st, (const u32*)coarse.p, (const u32*)hist_scanned.p, n_blocks, (const u32*)tops.p,
-                           (u32*)counts.p, (u32*)offsets.p, (u32*)idx.p);
+                           (u32*)counts.p, (u32*)offsets.p, (u32*)idx.p, d_table ? (u32)table_n : 0u, d_table ? (u32)base_off : 0u);
         ZK_HIP(hipGetLastError());
         ZK_HIP(hipStreamSynchronize(st));  // hist/coarse go back to the pool at scope exit
     } else {
@@ -547,7 +577,7 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
     hipLaunchKernelGGL(balance_scan_kernel, dim3(1), dim3(64), 0, st, (u32*)bal.p);
     hipLaunchKernelGGL(balance_scatter_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, st, (const u32*)counts.p, (u32*)bal.p, (u32*)order.p);
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, (const u32*)conv.p,
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, points,
                        (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (const u32*)order.p, (xyzz*)buckets.p);
     ZK_HIP(hipGetLastError());
     // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
@@ -559,8 +589,13 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
         s_in = s_out; a_in = a_out;
     }
     ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, a_in, (u32*)d_out);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, a_in, (u32*)d_out, d_table ? 1 : 0);
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(st));  // the pooled scratch above is released at scope exit
+}
+void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); }
+void msm_fixed_dev(const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
+    ZK_REQUIRE(d_table, "msm table: null table");
+    msm_core(nullptr, d_table, table_n, base_off, d_scalars, n, d_out, st);
 }
 

@@ -44,6 +44,7 @@ struct DevBuf {
         p = pool_alloc(n); bytes = n;
     }
     u64* u() const { return (u64*)p; }
+    void release() { if (p) { pool_free(p); p = nullptr; bytes = 0; } }
 };
 
 // ---- NTT (ntt.hip) ----
@@ -93,6 +94,16 @@ void msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, vo
 void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
 void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
 void g2_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
+// window tables for fixed bases (msm_impl.cuh): table[w * n + i] = 2^(16 w) P_i; a sum over points [off, off + n) of it
+#define ZK_MSM_FIXED_DECL(NAME)                                                                                             \
+    size_t msm_##NAME##_fixed_table_bytes(uint64_t n);                                                                      \
+    void msm_##NAME##_fixed_prepare_dev(const void* d_bases, uint64_t n, void* d_table, hipStream_t st);                     \
+    void msm_##NAME##_fixed_dev(const void* d_table, uint64_t table_n, uint64_t off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
+ZK_MSM_FIXED_DECL(g1_bn254)
+ZK_MSM_FIXED_DECL(g2_bn254)
+ZK_MSM_FIXED_DECL(g1_bls12_381)
+ZK_MSM_FIXED_DECL(g2_bls12_381)
+#undef ZK_MSM_FIXED_DECL
 // ---- BN128-field hashing (poseidon_bn128.hip); digests = 4 raw (Montgomery, R = 2^256) limbs
 void bn128_load_constants(const char* path);
 void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st);
