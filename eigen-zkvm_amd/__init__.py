@@ -47,6 +47,7 @@ EXPORTS = [
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
     "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
+    "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
     "zk_fq_bn254_convert_dev", "zk_fq_bls12_381_convert_dev", "zk_groth16_setup_new", "zk_groth16_setup_info", "zk_groth16_prove", "zk_groth16_prove_dev", "zk_groth16_wtns_payload", "zk_groth16_setup_free",
 ]
@@ -181,6 +182,18 @@ def _load():
         "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
         "zk_string_free": (None, [vp]),
         "zk_stark_setup_free": (C.c_int, [vp]),
+        "zk_msm_g1_bn254_table_bytes": (C.c_size_t, [C.c_uint64]),
+        "zk_msm_g1_bn254_table_build_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g1_bn254_table_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]),
+        "zk_msm_g1_bls12_381_table_bytes": (C.c_size_t, [C.c_uint64]),
+        "zk_msm_g1_bls12_381_table_build_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g1_bls12_381_table_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bn254_table_bytes": (C.c_size_t, [C.c_uint64]),
+        "zk_msm_g2_bn254_table_build_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bn254_table_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bls12_381_table_bytes": (C.c_size_t, [C.c_uint64]),
+        "zk_msm_g2_bls12_381_table_build_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_msm_g2_bls12_381_table_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, vp]),
         "zk_fr_bn254_ntt": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int]),
         "zk_fr_bn254_ntt_dev": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int, vp]),
         "zk_fr_bls12_381_ntt": (C.c_int, [vp, C.c_uint32, C.c_int, C.c_int]),
@@ -639,6 +652,22 @@ def msm_g1_dev(d_bases, d_scalars, n, curve="bn254", stream=0, group="g1"):
     """device-resident variant; returns a DevArray of pw + 1 words (the point, flag in the low 32 bits of the last)."""
     out = DevArray(_CURVES[curve] * (4 if group == "g2" else 2) + 1, zero=True)
     _check(getattr(lib(), "zk_msm_%s_%s_dev" % (group, curve))(d_bases.ptr, d_scalars.ptr, n, out.ptr, stream)); return out
+
+
+class MsmTable:
+    """Window table of n fixed bases (zk_msm_*_table_*): build once, then sum any sub-range without doublings."""
+
+    def __init__(self, d_bases, n, curve="bn254", group="g1", stream=0):
+        self.n, self.curve, self.group = n, curve, group
+        self._pfx = "zk_msm_%s_%s_" % (group, curve)
+        nbytes = getattr(lib(), self._pfx + "table_bytes")(n)
+        self.table = DevArray((nbytes + 7) // 8)
+        _check(getattr(lib(), self._pfx + "table_build_dev")(d_bases.ptr, n, self.table.ptr, stream))
+
+    def msm(self, d_scalars, n=None, offset=0, stream=0):
+        n = self.n - offset if n is None else n
+        out = DevArray(_CURVES[self.curve] * (4 if self.group == "g2" else 2) + 1, zero=True)
+        _check(getattr(lib(), self._pfx + "table_dev")(self.table.ptr, self.n, offset, d_scalars.ptr, n, out.ptr, stream)); return out
 
 
 def msm_g1_bn254_dev(d_bases, d_scalars, n, stream=0):

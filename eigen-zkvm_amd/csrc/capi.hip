@@ -701,6 +701,19 @@ const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t) { return t ? (const
 const uint64_t* zk_merkle_nodes_dev(const zk_merkle_t* t) { return t ? (const uint64_t*)t->nodes.p : nullptr; }
 int zk_merkle_free(zk_merkle_t* t) { delete t; return 0; }
 
+#define ZK_MSM_TABLE_API(NAME)                                                                                              \
+    size_t zk_msm_##NAME##_table_bytes(uint64_t table_n) { return msm_##NAME##_fixed_table_bytes(table_n); }                \
+    int zk_msm_##NAME##_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream) {               \
+        return guard([&] { ZK_REQUIRE(d_bases && d_table, "msm table: null argument"); msm_##NAME##_fixed_prepare_dev(d_bases, table_n, d_table, (hipStream_t)stream); }); \
+    }                                                                                                                       \
+    int zk_msm_##NAME##_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream) { \
+        return guard([&] { ZK_REQUIRE(d_table && d_scalars && d_out, "msm table: null argument"); msm_##NAME##_fixed_dev(d_table, table_n, offset, d_scalars, n, d_out, (hipStream_t)stream); }); \
+    }
+ZK_MSM_TABLE_API(g1_bn254)
+ZK_MSM_TABLE_API(g2_bn254)
+ZK_MSM_TABLE_API(g1_bls12_381)
+ZK_MSM_TABLE_API(g2_bls12_381)
+#undef ZK_MSM_TABLE_API
 // ---- Groth16 (groth16.hip) ------------------------------------------------------------------------------------
 #define ZK_FR_NTT(NAME)                                                                                                  \
     int zk_fr_##NAME##_ntt_dev(uint64_t* d, uint32_t log_n, int inverse, int coset, void* stream) {                      \

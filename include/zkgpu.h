@@ -250,6 +250,23 @@ char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t 
 void zk_string_free(char* s);
 int zk_stark_setup_free(zk_stark_setup_t* s);
 
+/* Window tables for bases that do not change between calls (a Groth16 proving key): the table holds 2^(16 w) P_i for the
+ * 16 windows of every base (16 x the size of the internal point form; *_table_bytes says how much), built once on the
+ * device; a sum over the points [offset, offset + n) of a table built for table_n bases then needs no doublings.
+ * table_n < 2^24.  Same operand formats and the same (bit-identical) result as zk_msm_*_dev.                        */
+size_t zk_msm_g1_bn254_table_bytes(uint64_t table_n);
+int zk_msm_g1_bn254_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream);
+int zk_msm_g1_bn254_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+size_t zk_msm_g2_bn254_table_bytes(uint64_t table_n);
+int zk_msm_g2_bn254_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream);
+int zk_msm_g2_bn254_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+size_t zk_msm_g1_bls12_381_table_bytes(uint64_t table_n);
+int zk_msm_g1_bls12_381_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream);
+int zk_msm_g1_bls12_381_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+size_t zk_msm_g2_bls12_381_table_bytes(uint64_t table_n);
+int zk_msm_g2_bls12_381_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream);
+int zk_msm_g2_bls12_381_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream);
+
 /* ---- Groth16 around the multi-scalar sums (`zkit groth16_prove`, groth16/src/api.rs:144-205) ----
  * The reference hands the whole proof to bellman_ce::groth16::create_random_proof (groth16/src/groth16.rs:88-96;
  * third-party).  These entry points keep everything after witness generation on the device.

@@ -259,3 +259,22 @@ def test_g2_msm_large_closed_form(zk, orc, curve, logn):
     kk = int((sv * k.astype(object)).sum() % cv.r)
     exp, einf = cv.scalar_mul(cv.generator(), words(kk))
     assert (int(out[cv.pw]) & 0xFFFFFFFF) == int(einf) and np.array_equal(out[:cv.pw], exp)
+
+
+@pytest.mark.parametrize("curve,group", [("bn254", "g1"), ("bn254", "g2"), ("bls12_381", "g1"), ("bls12_381", "g2")])
+def test_window_table_sums_equal_plain_sums(zk, orc, curve, group):
+    """zk_msm_*_table_*: the table of 2^(16 w) P_i gives bit-identical sums, for the whole array and for sub-ranges"""
+    n = 3000
+    rng = np.random.default_rng(77)
+    k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
+    d_bases = zk.g1_mul_generator(zk.DevArray.from_host(k), curve, group=group)
+    scal = rand_scalars(rng, n).reshape(n, 4)
+    scal[5] = 0; scal[6] = [1, 0, 0, 0]; scal[7] = [0, 0, 0, 1 << 59]            # zero, one, a top-window-only scalar
+    tab = zk.MsmTable(d_bases, n, curve, group)
+    pw = zk._CURVES[curve] * (4 if group == "g2" else 2)
+    bases = d_bases.to_host().reshape(n, pw)
+    for off, cnt in ((0, n), (0, 1), (7, 1), (100, 1500), (n - 3, 3)):
+        d_s = zk.DevArray.from_host(scal[off:off + cnt].reshape(-1))
+        got = tab.msm(d_s, cnt, off).to_host()
+        exp = zk.msm_g1_dev(zk.DevArray.from_host(bases[off:off + cnt].reshape(-1)), d_s, cnt, curve, group=group).to_host()
+        assert np.array_equal(got, exp), (off, cnt)
