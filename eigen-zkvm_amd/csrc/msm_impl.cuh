@@ -492,6 +492,46 @@ void fq_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) {
 }
 #endif
 
+// ---- bucket reduction for window tables.  All 16 windows carry the same weight there, so buckets of equal digit merge
+// ---- (M_d = sum_w B_{w,d}) and sum_d d M_d = sum_b 2^b T_b with T_b = the plain sum of the M_d whose digit has bit b
+// ---- set: 16 independent tree sums (5 levels of 8) and a 16-step Horner -- 86 dependent point operations instead of
+// ---- the ~230 of the weighted hierarchy + window Horner, which is what a sum costs when n is small.
+__global__ __launch_bounds__(64) void msm_merge_windows_kernel(const xyzz* __restrict__ buckets, xyzz* __restrict__ merged) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;                        // < N_BUCKET
+    xyzz acc = buckets[d];
+    for (int w = 1; w < N_WIN; ++w) acc = pt_add(acc, buckets[(u32)w * N_BUCKET + d]);
+    merged[d] = acc;
+}
+// lane (b, g): the 8 digits number 8 g .. 8 g + 7 among those with bit b set (k-th such digit: a 1 spliced into k at bit b)
+__global__ __launch_bounds__(64) void msm_bit_partials_kernel(const xyzz* __restrict__ merged, xyzz* __restrict__ out /* [16][4096] */) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;                        // < 16 * 4096
+    const u32 b = t >> 12, g = t & 4095;
+    xyzz acc = pt_inf();
+    for (u32 j = 0; j < 8; ++j) {
+        const u32 k = g * 8 + j;
+        const u32 d = ((k >> b) << (b + 1)) | (1u << b) | (k & ((1u << b) - 1));
+        acc = pt_add(acc, merged[d]);
+    }
+    out[t] = acc;
+}
+__global__ __launch_bounds__(64) void msm_sum8_kernel(const xyzz* __restrict__ in, xyzz* __restrict__ out, u32 n_out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out) return;
+    xyzz acc = in[(u64)t * 8];
+    for (u32 j = 1; j < 8; ++j) acc = pt_add(acc, in[(u64)t * 8 + j]);
+    out[t] = acc;
+}
+__global__ __launch_bounds__(64) void msm_final_bits_kernel(const xyzz* __restrict__ T /* [16] */, u32* __restrict__ out) {
+    if (threadIdx.x | blockIdx.x) return;
+    xyzz acc = T[C_BITS - 1];
+    for (int b = C_BITS - 2; b >= 0; --b) { acc = pt_dbl(acc); acc = pt_add(acc, T[b]); }
+    if (pt_is_inf(acc)) { for (int i = 0; i < 2 * CW_STD; ++i) out[i] = 0; out[2 * CW_STD] = 1; return; }
+    u32 x[CW_STD], y[CW_STD];
+    pt_to_std(acc, x, y);
+    for (int i = 0; i < CW_STD; ++i) { out[i] = x[i]; out[CW_STD + i] = y[i]; }
+    out[2 * CW_STD] = 0;
+}
+
 // ---- window tables for bases that do not change between calls (a Groth16 proving key): entry [w * n + i] =
 // ---- 2^(16 w) P_i in the internal affine layout.  The sum then needs no doublings at all: every (point, window)
 // ---- pair adds the table entry of its window, and the 16 window results are simply added.
@@ -533,7 +573,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     idx.reserve((size_t)n * N_WIN * 4);
     buckets.reserve(n_keys * sizeof(xyzz));
     S0.reserve(n_keys / 16 * sizeof(xyzz)); A0.reserve(n_keys / 16 * sizeof(xyzz));
-    S1.reserve(n_keys / 256 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));
+    S1.reserve((size_t)C_BITS * 512 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));   // S1 also serves the bit-partial levels (16 x 512 items)
     const u64 total = n * N_WIN;
     if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
         const u32 n_blocks = (u32)((n + SORT_PTS - 1) / SORT_PTS);
@@ -580,6 +620,21 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, points,
                        (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (const u32*)order.p, (xyzz*)buckets.p);
     ZK_HIP(hipGetLastError());
+    if (d_table) {   // equal window weights: merge, 16 bit-partial tree sums, 16-step Horner
+        xyzz* merged = (xyzz*)S0.p;                       // N_BUCKET items fit: S0 holds n_keys / 16 = N_BUCKET
+        xyzz* pa = (xyzz*)A0.p; xyzz* pb = (xyzz*)S1.p;   // 16 * 4096 = N_BUCKET items, then 1/8 of it per level
+        hipLaunchKernelGGL(msm_merge_windows_kernel, dim3(N_BUCKET / 64), dim3(64), 0, st, (const xyzz*)buckets.p, merged);
+        hipLaunchKernelGGL(msm_bit_partials_kernel, dim3(C_BITS * 4096 / 64), dim3(64), 0, st, (const xyzz*)merged, pa);
+        u32 n_out = C_BITS * 512;
+        for (int level = 0; level < 4; ++level, n_out /= 8) {   // 4096 -> 512 -> 64 -> 8 -> 1 per bit
+            hipLaunchKernelGGL(msm_sum8_kernel, dim3((n_out + 63) / 64), dim3(64), 0, st, (const xyzz*)pa, pb, n_out);
+            std::swap(pa, pb);
+        }
+        hipLaunchKernelGGL(msm_final_bits_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)pa, (u32*)d_out);
+        ZK_HIP(hipGetLastError());
+        ZK_HIP(hipStreamSynchronize(st));
+        return;
+    }
     // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
     const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
     u32 n_out = (u32)(n_keys / 16);
