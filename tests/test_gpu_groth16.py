@@ -155,3 +155,41 @@ def test_setup_and_prove_errors(zk, g16, dev):
     with pytest.raises(zk.ZkError, match="invalid curve prime"):
         dev.wtns_values(g.wtns_bytes(wit), "BLS12381")
     S.free()
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+def test_corner_circuits(zk, g16, dev, cv, tag):
+    """shapes the readers and the density bookkeeping must survive: public inputs next to public outputs, a domain
+    that is exactly full, a circuit whose only rows are bellman's input rows, sections of the .r1cs in another order"""
+    import struct
+    g = g16[cv]; r = g.r; rng = random.Random(77)
+    td = lambda: [rng.randrange(1, r) for _ in range(5)]
+
+    def check(r1cs, wit, rb=None):
+        P = g.setup(r1cs, *td())
+        S = dev.Groth16Setup(tag, rb or g.r1cs_bytes(r1cs), g.params_bytes(P))
+        rr, ss = rng.randrange(r), rng.randrange(r)
+        _, pts = S.prove(g.fr_array(wit), rr, ss)
+        exp = g.expected_proof(P, wit, rr, ss); nl = g.nl
+        assert np.array_equal(pts[:2 * nl], exp["a"]) and np.array_equal(pts[2 * nl:6 * nl], exp["b"]) and np.array_equal(pts[6 * nl:], exp["c"])
+        S.free()
+        return P
+
+    # (1) one public output, two public inputs: out = (in1 + 3 in2) * prv ; aux = out * out
+    w = [1, 0, 5, 7, 11, 0]
+    w[1] = (w[2] + 3 * w[3]) * w[4] % r; w[5] = w[1] * w[1] % r
+    r1 = dict(n_wires=6, n_pub_out=1, n_pub_in=2, n_prv_in=1,
+              constraints=[([(2, 1), (3, 3)], [(4, 1)], [(1, 1)]), ([(1, 1)], [(1, 1)], [(5, 1)])])
+    P = check(r1, w)
+    assert P["cir"]["num_inputs"] == 4 and P["cir"]["log_m"] == 3          # 2 rows + 4 input rows -> 8
+    # (2) a second generated shape (one public output, two private inputs)
+    r2, w2 = G.synthetic_r1cs(r, 5, n_pub=1, n_prv=2, seed=9)
+    check(r2, w2)
+    # (3) no constraint at all: the domain holds the input rows only, h is empty or a single zero
+    r3 = dict(n_wires=3, n_pub_out=1, n_pub_in=0, n_prv_in=1, constraints=[])
+    check(r3, [1, 42, 99])
+    # (4) the same file with its sections in the order 3, 2, 1 (r1cs_file.rs:206-216 indexes them by type)
+    b = g.r1cs_bytes(r1); o = 12; secs = []
+    for _ in range(3):
+        t, n = struct.unpack("<IQ", b[o:o + 12]); secs.append(b[o:o + 12 + n]); o += 12 + n
+    check(r1, w, rb=b[:12] + secs[2] + secs[1] + secs[0])
