@@ -14,6 +14,7 @@
 // R' mod r; the sparse rounds' running columns are renormalised every 16 rounds (< 34r in between).
 #include "zk_internal.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 

@@ -144,6 +144,100 @@ __global__ __launch_bounds__(64) void bn128_leaf_kernel(const u64* __restrict__ 
     }
     store_raw(digest, digests + 4 * i);
 }
+// ---- the same permutation with the state in registers, for the t <= 9 of a row hash of up to 24 columns (the leaves
+// ---- are four fifths of a tree's permutations).  Static indexing only: the loops over the t words are either fully
+// ---- unrolled (dense column sums, sparse rounds) or rolled with the array rotated by one word per trip (S-box layer,
+// ---- columns of the matrix product), so one copy of every product serves all words.  The eight full rounds share one
+// ---- loop body; the sparse rounds sit between its fourth and fifth trip.  Same operation order and renormalisation
+// ---- schedule as poseidon_fr, hence the same bounds.
+template <int T>
+__device__ __forceinline__ void reg_rotate_in(fe (&a)[T], const fe& last) {
+#pragma unroll
+    for (int i = 0; i + 1 < T; ++i) a[i] = a[i + 1];
+    a[T - 1] = last;
+}
+template <int T>
+__device__ __forceinline__ fe reg_dot(const fe* __restrict__ a, u32 stride, const fe (&x)[T], u32 grp) {
+    fe_wide w; fe_wide_zero(w);
+    fe acc = fe_zero();
+    u32 cnt = 0;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        fe_wide_mac(w, a[(size_t)j * stride], x[j]);
+        if (++cnt == grp || j + 1 == T) { acc = fe_add(acc, fe_wide_reduce(w)); cnt = 0; fe_wide_zero(w); }
+    }
+    return (u32)T > grp ? fe_renorm(acc) : acc;
+}
+template <int T>
+__device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
+    const Params P = g_prm[T - 2];
+#pragma unroll
+    for (int i = 0; i < T; ++i) st[i] = fe_add(st[i], P.c[i]);
+#pragma unroll 1
+    for (u32 fr = 0; fr < 8; ++fr) {
+        if (fr == 4) {
+#pragma unroll 1
+            for (u32 r = 0; r < P.n_rp; ++r) {
+                pow5(st[0]);
+                st[0] = fe_add(st[0], P.c[5 * T + r]);
+                const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
+                const fe s0 = reg_dot<T>(S, 1, st, DOT_SPARSE);
+                const bool renorm = r % PR_RENORM == PR_RENORM - 1;
+#pragma unroll 1
+                for (int k = 1; k < T; ++k) {                       // word 1 is updated, then the tail st[1..T) rotates
+                    fe v = fe_add(st[1], fe_mul(S[T + k - 1], st[0]));
+                    if (renorm) v = fe_renorm(v);
+#pragma unroll
+                    for (int i = 1; i + 1 < T; ++i) st[i] = st[i + 1];
+                    st[T - 1] = v;
+                }
+                st[0] = s0;
+            }
+#pragma unroll 1
+            for (int k = 1; k < T; ++k) {
+                const fe v = fe_renorm(st[1]);
+#pragma unroll
+                for (int i = 1; i + 1 < T; ++i) st[i] = st[i + 1];
+                st[T - 1] = v;
+            }
+        }
+        // S-boxes + round constants of the next linear layer (none after the last S-box layer)
+        const fe* __restrict__ c = fr < 3 ? P.c + (fr + 1) * T : fr == 3 ? P.c + 4 * T : P.c + 5 * T + P.n_rp + (fr - 4) * T;
+        const bool has_c = fr < 7;
+#pragma unroll 1
+        for (int i = 0; i < T; ++i) {
+            fe x = st[0];
+            pow5(x);
+            if (has_c) x = fe_add(x, c[i]);
+            reg_rotate_in<T>(st, x);
+        }
+        const fe* __restrict__ mat = fr == 3 ? P.p : P.m;
+        fe out[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) out[i] = fe_zero();
+#pragma unroll 1
+        for (int i = 0; i < T; ++i) reg_rotate_in<T>(out, reg_dot<T>(mat + i, T, st, DOT_DENSE));
+#pragma unroll
+        for (int i = 0; i < T; ++i) st[i] = out[i];
+    }
+}
+// LinearHashBN128::hash_element_array for rows of 5 <= width <= 24 columns: one sponge step of t = NB + 1
+template <int NB>
+__global__ __launch_bounds__(64) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= height) return;
+    const u64* __restrict__ v = rows + i * width;
+    fe st[NB + 1];
+    st[0] = fe_zero();
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const u32 at = 3 * k, len = width - at < 3 ? width - at : 3;
+        st[k + 1] = words_to_fe(v + at, len);
+    }
+    poseidon_fr_reg<NB + 1>(st);
+    store_raw(st[FH_OUT_IDX], digests + 4 * i);
+}
+
 // hash_node (linearhash_bn128.rs:93-103): parent i = Poseidon(16 digests, init 0)
 __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -324,7 +418,19 @@ uint64_t FH_FN(merkle_n_nodes)(uint64_t n_) {  // merklehash_bn128.rs:26-39
 void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     require_tables();
     if (height == 0) return;
-    hipLaunchKernelGGL(bn128_leaf_kernel, dim3((unsigned)((height + 63) / 64)), dim3(64), 0, st, d_rows, width, height, d_digests);
+    const dim3 grid((unsigned)((height + 63) / 64)), blk(64);
+    const u32 nb = width ? (width - 1) / 3 + 1 : 0;
+    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 6;   // tuning knob: largest block count that takes the register kernels
+    switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
+        case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 4: hipLaunchKernelGGL(bn128_leaf_reg_kernel<4>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 5: hipLaunchKernelGGL(bn128_leaf_reg_kernel<5>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 6: hipLaunchKernelGGL(bn128_leaf_reg_kernel<6>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 7: hipLaunchKernelGGL(bn128_leaf_reg_kernel<7>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 8: hipLaunchKernelGGL(bn128_leaf_reg_kernel<8>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        default: hipLaunchKernelGGL(bn128_leaf_kernel, grid, blk, 0, st, d_rows, width, height, d_digests);
+    }
     ZK_HIP(hipGetLastError());
 }
 
