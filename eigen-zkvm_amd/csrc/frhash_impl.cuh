@@ -150,10 +150,13 @@ __global__ __launch_bounds__(64) void bn128_leaf_kernel(const u64* __restrict__ 
 // ---- columns of the matrix product), so one copy of every product serves all words.  The eight full rounds share one
 // ---- loop body; the sparse rounds sit between its fourth and fifth trip.  Same operation order and renormalisation
 // ---- schedule as poseidon_fr, hence the same bounds.
+template <int B, int E, class F>
+__device__ __forceinline__ void fh_static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); fh_static_for<B + 1, E>(f); }
+}
 template <int T>
 __device__ __forceinline__ void reg_rotate_in(fe (&a)[T], const fe& last) {
-#pragma unroll
-    for (int i = 0; i + 1 < T; ++i) a[i] = a[i + 1];
+    fh_static_for<0, T - 1>([&](auto I) { a[decltype(I)::value] = a[decltype(I)::value + 1]; });
     a[T - 1] = last;
 }
 template <int T>
@@ -161,18 +164,17 @@ __device__ __forceinline__ fe reg_dot(const fe* __restrict__ a, u32 stride, cons
     fe_wide w; fe_wide_zero(w);
     fe acc = fe_zero();
     u32 cnt = 0;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
+    fh_static_for<0, T>([&](auto J) {
+        constexpr int j = decltype(J)::value;
         fe_wide_mac(w, a[(size_t)j * stride], x[j]);
         if (++cnt == grp || j + 1 == T) { acc = fe_add(acc, fe_wide_reduce(w)); cnt = 0; fe_wide_zero(w); }
-    }
+    });
     return (u32)T > grp ? fe_renorm(acc) : acc;
 }
 template <int T>
 __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
     const Params P = g_prm[T - 2];
-#pragma unroll
-    for (int i = 0; i < T; ++i) st[i] = fe_add(st[i], P.c[i]);
+    fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = fe_add(st[decltype(I)::value], P.c[decltype(I)::value]); });
 #pragma unroll 1
     for (u32 fr = 0; fr < 8; ++fr) {
         if (fr == 4) {
@@ -187,8 +189,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
                 for (int k = 1; k < T; ++k) {                       // word 1 is updated, then the tail st[1..T) rotates
                     fe v = fe_add(st[1], fe_mul(S[T + k - 1], st[0]));
                     if (renorm) v = fe_renorm(v);
-#pragma unroll
-                    for (int i = 1; i + 1 < T; ++i) st[i] = st[i + 1];
+                    fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
                     st[T - 1] = v;
                 }
                 st[0] = s0;
@@ -196,8 +197,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
 #pragma unroll 1
             for (int k = 1; k < T; ++k) {
                 const fe v = fe_renorm(st[1]);
-#pragma unroll
-                for (int i = 1; i + 1 < T; ++i) st[i] = st[i + 1];
+                fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
                 st[T - 1] = v;
             }
         }
@@ -213,12 +213,10 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
         }
         const fe* __restrict__ mat = fr == 3 ? P.p : P.m;
         fe out[T];
-#pragma unroll
-        for (int i = 0; i < T; ++i) out[i] = fe_zero();
+        fh_static_for<0, T>([&](auto I) { out[decltype(I)::value] = fe_zero(); });
 #pragma unroll 1
         for (int i = 0; i < T; ++i) reg_rotate_in<T>(out, reg_dot<T>(mat + i, T, st, DOT_DENSE));
-#pragma unroll
-        for (int i = 0; i < T; ++i) st[i] = out[i];
+        fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = out[decltype(I)::value]; });
     }
 }
 // LinearHashBN128::hash_element_array for rows of 5 <= width <= 24 columns: one sponge step of t = NB + 1
@@ -229,11 +227,11 @@ __global__ __launch_bounds__(64) void bn128_leaf_reg_kernel(const u64* __restric
     const u64* __restrict__ v = rows + i * width;
     fe st[NB + 1];
     st[0] = fe_zero();
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
+    fh_static_for<0, NB>([&](auto K) {
+        constexpr int k = decltype(K)::value;
         const u32 at = 3 * k, len = width - at < 3 ? width - at : 3;
         st[k + 1] = words_to_fe(v + at, len);
-    }
+    });
     poseidon_fr_reg<NB + 1>(st);
     store_raw(st[FH_OUT_IDX], digests + 4 * i);
 }
@@ -420,7 +418,7 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
     if (height == 0) return;
     const dim3 grid((unsigned)((height + 63) / 64)), blk(64);
     const u32 nb = width ? (width - 1) / 3 + 1 : 0;
-    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 6;   // tuning knob: largest block count that takes the register kernels
+    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 8;   // tuning knob: largest block count that takes the register kernels
     switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
         case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
         case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid, blk, 0, st, d_rows, width, height, d_digests); break;

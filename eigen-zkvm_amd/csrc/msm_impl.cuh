@@ -58,6 +58,8 @@ template <int M> __device__ __forceinline__ cf cf_sub(const cf& a, const cf& b) 
 // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u with one reduction per component (fe_mul2): the subtrahend enters as
 // a1 (8q - b1).  Requires b.c1 <= 8q and, for components a < Aq, b < Bq, A (B + 8) <= 168 (BN254; every call site
 // below keeps the operand with the larger bound first: the worst is 10q x 6q = 140).  Components of the result < 2q.
+#undef CF_MUL_ATTR
+#undef PT_COLD_ATTR
 #ifdef MSM_G2_INLINE_CF
 #define CF_MUL_ATTR __forceinline__
 #define PT_COLD_ATTR __noinline__
