@@ -227,10 +227,16 @@ __global__ __launch_bounds__(256) void scan_block_kernel(const u32* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) { out[base + k] = ex; ex += v[k]; }
 }
-__global__ __launch_bounds__(64) void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // a few thousand entries: one lane, serial
-    if (threadIdx.x | blockIdx.x) return;
-    u32 acc = 0;
-    for (u32 b = 0; b < nb; ++b) { u32 t = block_sum[b]; block_sum[b] = acc; acc += t; }
+__global__ __launch_bounds__(64) void scan_tops_kernel(u32* __restrict__ block_sum, u32 nb) {  // a few thousand entries: one wave, a chunk per lane
+    if (blockIdx.x) return;
+    const u32 per = (nb + 63) / 64, lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    u32 sum = 0;
+    for (u32 b = lo; b < hi; ++b) sum += block_sum[b];
+    u32 incl = sum;                                     // inclusive scan of the chunk sums across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(incl, d, 64); if ((int)threadIdx.x >= d) incl += t; }
+    u32 acc = incl - sum;
+    for (u32 b = lo; b < hi; ++b) { const u32 t = block_sum[b]; block_sum[b] = acc; acc += t; }
 }
 __global__ __launch_bounds__(256) void scan_add_kernel(u32* __restrict__ out, const u32* __restrict__ block_sum) {
     out[blockIdx.x * 1024 + threadIdx.x * 4 + 0] += block_sum[blockIdx.x];
@@ -308,7 +314,14 @@ __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__
     const u32 end = bin + 1 < (u32)N_COARSE ? hist_scanned[(u64)(bin + 1) * n_blocks] : total[0];
     h[threadIdx.x] = 0;
     __syncthreads();
-    for (u32 k = start + threadIdx.x; k < end; k += 256) atomicAdd(&h[coarse[k] & 0xFF], 1u);
+    // four loads in flight per lane: one load per trip left the pass latency-bound at ~1 TB/s
+    for (u32 k = start + threadIdx.x; k < end; k += 1024) {
+        u32 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = k + 256 * u < end ? coarse[k + 256 * u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k + 256 * u < end) atomicAdd(&h[e[u] & 0xFF], 1u);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {  // 256-entry exclusive scan
         u32 acc = start;
@@ -318,9 +331,15 @@ __global__ __launch_bounds__(256) void sort_fine_kernel2(const u32* __restrict__
     counts[bin * 256 + threadIdx.x] = h[threadIdx.x];
     offsets[bin * 256 + threadIdx.x] = cur[threadIdx.x];
     __syncthreads();
-    for (u32 k = start + threadIdx.x; k < end; k += 256) {
-        const u32 e = coarse[k];
-        idx[atomicAdd(&cur[e & 0xFF], 1u)] = (e >> 8) + base_off + (bin >> 8) * win_stride;
+    const u32 add = base_off + (bin >> 8) * win_stride;
+    for (u32 k = start + threadIdx.x; k < end; k += 1024) {
+        u32 e[4], pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = k + 256 * u < end ? coarse[k + 256 * u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pos[u] = k + 256 * u < end ? atomicAdd(&cur[e[u] & 0xFF], 1u) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k + 256 * u < end) idx[pos[u]] = (e[u] >> 8) + add;
     }
 }
 
