@@ -49,6 +49,7 @@ EXPORTS = [
     "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
     "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
+    "zk_c12_exec_new", "zk_c12_exec_dev", "zk_c12_exec_depth", "zk_c12_exec_free",
     "zk_fq_bn254_convert_dev", "zk_fq_bls12_381_convert_dev", "zk_groth16_setup_new", "zk_groth16_setup_info", "zk_groth16_prove", "zk_groth16_prove_dev", "zk_groth16_wtns_payload", "zk_groth16_setup_free",
 ]
 
@@ -202,6 +203,10 @@ def _load():
         "zk_fr_bls12_381_quotient_dev": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "zk_fq_bn254_convert_dev": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
         "zk_fq_bls12_381_convert_dev": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
+        "zk_c12_exec_new": (vp, [C.c_char_p, C.c_size_t, C.c_uint64]),
+        "zk_c12_exec_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp]),
+        "zk_c12_exec_depth": (C.c_uint64, [vp]),
+        "zk_c12_exec_free": (C.c_int, [vp]),
         "zk_groth16_setup_new": (vp, [C.c_char_p, vp, C.c_size_t, vp, C.c_size_t]),
         "zk_groth16_setup_info": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "zk_groth16_prove": (vp, [vp, vp, C.c_uint64, vp, vp, vp]),

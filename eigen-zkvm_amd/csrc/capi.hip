@@ -714,6 +714,21 @@ ZK_MSM_TABLE_API(g2_bn254)
 ZK_MSM_TABLE_API(g1_bls12_381)
 ZK_MSM_TABLE_API(g2_bls12_381)
 #undef ZK_MSM_TABLE_API
+// ---- compressor12 exec (compressor12.hip) ----------------------------------------------------------------------
+struct zk_c12_exec { C12Exec* impl; };
+zk_c12_exec_t* zk_c12_exec_new(const char* exec_json, size_t len, uint64_t n_witness) {
+    zk_c12_exec_t* out = nullptr;
+    if (guard([&] { C12Exec* e = c12_exec_new(exec_json, len, n_witness); out = new zk_c12_exec{e}; }) != 0) return nullptr;
+    return out;
+}
+int zk_c12_exec_dev(const zk_c12_exec_t* e, const uint64_t* d_witness, uint64_t n_witness, uint64_t n_rows, uint64_t* d_cm, void* stream) {
+    return guard([&] { ZK_REQUIRE(e && e->impl, "compressor12: null handle"); c12_exec_dev(e->impl, (const u64*)d_witness, n_witness, n_rows, (u64*)d_cm, (hipStream_t)stream); });
+}
+uint64_t zk_c12_exec_depth(const zk_c12_exec_t* e) { return e && e->impl ? c12_exec_levels(e->impl) : 0; }
+int zk_c12_exec_free(zk_c12_exec_t* e) {
+    return guard([&] { if (e) { c12_exec_free(e->impl); delete e; } });
+}
+
 // ---- Groth16 (groth16.hip) ------------------------------------------------------------------------------------
 #define ZK_FR_NTT(NAME)                                                                                                  \
     int zk_fr_##NAME##_ntt_dev(uint64_t* d, uint32_t log_n, int inverse, int coset, void* stream) {                      \

@@ -123,6 +123,12 @@ void fq_bn254_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st);
 void fq_bls12_381_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st);
 void fq_bls12_381_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st);
 
+// ---- compressor12 exec (compressor12.hip): witness -> committed trace [n_rows][12]
+struct C12Exec;
+C12Exec* c12_exec_new(const char* exec_json, size_t len, uint64_t n_witness);
+void c12_exec_free(C12Exec* e);
+uint64_t c12_exec_levels(const C12Exec* e);
+void c12_exec_dev(const C12Exec* e, const u64* d_witness, uint64_t n_witness, uint64_t n_rows, u64* d_cm, hipStream_t st);
 // ---- Groth16 around the multi-scalar sums (groth16.hip): scalar-field transforms, the quotient, the prover ----
 // bellman's EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} on 2^logn Fr elements (4 x u64 Montgomery), in place
 void fr_bn254_ntt_dev(u64* d_data, int logn, bool inverse, bool coset, hipStream_t st);

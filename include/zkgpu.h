@@ -306,6 +306,18 @@ char* zk_groth16_prove_dev(zk_groth16_setup_t* s, const void* d_witness, uint64_
 int zk_groth16_wtns_payload(const void* wtns, size_t len, const char* curve, uint64_t* offset, uint64_t* n_values);
 int zk_groth16_setup_free(zk_groth16_setup_t* s);
 
+/* ---- compressor12 exec (recursion/src/compressor12/compressor12_exec.rs:17-103) ----------------
+ * The step between a recursive circuit's circom witness and the committed trace of its STARK: the PlonkAdd sums
+ * appended to the witness (:60-66) and the s_map gather into the 12 columns of Compressor.a (:72-94).
+ * zk_c12_exec_new takes the text of the .exec file (a JSON array of u64, compressor12_setup.rs:51-83) and the length of
+ * the circuit's witness; zk_c12_exec_dev writes the [n_rows][12] matrix (the .cm file's content; rows beyond
+ * s_map_column_len are zero) from a witness of one u64 per wire, both in HBM -- ready for zk_stark_gen_dev.            */
+typedef struct zk_c12_exec zk_c12_exec_t;
+zk_c12_exec_t* zk_c12_exec_new(const char* exec_json, size_t len, uint64_t n_witness);
+int zk_c12_exec_dev(const zk_c12_exec_t* e, const uint64_t* d_witness, uint64_t n_witness, uint64_t n_rows, uint64_t* d_cm, void* stream);
+uint64_t zk_c12_exec_depth(const zk_c12_exec_t* e);   /* launches of the addition phase (longest chain of dependent sums) */
+int zk_c12_exec_free(zk_c12_exec_t* e);
+
 /* ---- constraint evaluation (starky/src/interpreter.rs:91-225, stark_gen.rs:752-963) ------------
  * A step's program is the reference's Segment.first (Vec<Section{op,dest,src}>,
  * starkinfo_codegen.rs:76-89) with every Node resolved to an address exactly as
