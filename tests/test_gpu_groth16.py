@@ -193,3 +193,29 @@ def test_corner_circuits(zk, g16, dev, cv, tag):
     for _ in range(3):
         t, n = struct.unpack("<IQ", b[o:o + 12]); secs.append(b[o:o + 12 + n]); o += 12 + n
     check(r1, w, rb=b[:12] + secs[2] + secs[1] + secs[0])
+
+
+@pytest.mark.parametrize("cv,tag", CURVES)
+def test_quotient_of_a_2_16_row_circuit_matches_oracle(zk, g16, dev, cv, tag):
+    """the bench's synthetic circuit (tools/groth16_bench.py) at 2^16 rows: the quotient the device feeds to the `h` sum
+    == the oracle's, coefficient by coefficient, and its dropped top coefficient is zero (the system is satisfied)"""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import groth16_bench as GB
+    g = g16[cv]; log_rows = 16; m = 1 << log_rows
+    rb, wit, ni, n_wires = GB.make_circuit(g.r, log_rows)
+    pb = GB.make_params(zk, dev, tag, ni, n_wires, log_rows, GB.density(rb, ni, n_wires))
+    S = dev.Groth16Setup(tag, rb, pb)
+    d_h = zk.DevArray(4 * (m - 1), zero=True)
+    S.prove(zk.DevArray.from_host(wit.reshape(-1)), 5, 7, d_h=d_h)
+    # the same rows for the oracle, straight from the file's fixed-shape records
+    term = np.dtype([("wire", "<u4"), ("coef", "<u8", 4)])
+    row = np.dtype([("na", "<u4"), ("a", term, 2), ("nb", "<u4"), ("b", term, 1), ("nc", "<u4"), ("c", term, 1)])
+    rec = np.frombuffer(rb, dtype=row, count=m - ni, offset=100)
+    w = g.fr_ints(wit)
+    ev = lambda terms: [sum(int(t["coef"][0]) * w[int(t["wire"])] for t in r_) % g.r for r_ in terms]
+    a = ev(rec["a"]) + [w[i] for i in range(ni)]; b = ev(rec["b"]) + [0] * ni; c = ev(rec["c"]) + [0] * ni
+    M = lambda v: g.to_mont(g.fr_array(v))
+    hq = g.from_mont(g.quotient(M(a), M(b), M(c)))
+    assert g.fr_ints(hq[m - 1:]) == [0]
+    assert np.array_equal(d_h.to_host().reshape(-1, 4), hq[:m - 1])
+    S.free()
