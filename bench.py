@@ -110,6 +110,56 @@ def prove_leg(zk, nbits):
             "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2)}
 
 
+def final_wrap_leg(zk, nbits=18, log_rows=18):
+    """BASELINE config 5, the serial tail on rank 0 after the roots are gathered (test/stark_aggregation.sh:159-210):
+    the compressor's exec step (witness -> trace), the final STARK with BLS12381 hashing and the BLS12-381 Groth16 wrap,
+    each on a synthetic workload of the stated size (the recursive circuits themselves need circom)."""
+    import importlib
+    sys.path.insert(0, str(ROOT / "tools")); sys.path.insert(0, str(ROOT / "oracle"))
+    import synth_pil, groth16_bench as GB, compressor12 as C12
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    dev = importlib.import_module("eigen_zkvm_amd.groth16")
+    c12 = importlib.import_module("eigen_zkvm_amd.compressor12")
+    out = {"workload": "compressor12 exec 2^%d rows + final STARK (20 columns, 2^%d rows, BLS12381 hash) + Groth16 BLS12381 (2^%d rows), rank 0" % (nbits, nbits, log_rows)}
+    # 1. compressor12 exec: 2^nbits rows x 12, as many additions as wires
+    rng = np.random.default_rng(12)
+    n_wit = 1 << (nbits + 1); n_adds = 1 << nbits; rows = 1 << nbits
+    a = (rng.random(n_adds) * (n_wit + np.arange(n_adds))).astype(np.int64)
+    b = (rng.random(n_adds) * (n_wit + np.arange(n_adds))).astype(np.int64)
+    buf = np.empty(2 + 4 * n_adds + 12 * rows, dtype=np.uint64)
+    buf[0], buf[1] = n_adds, rows
+    buf[2:2 + 4 * n_adds:4], buf[3:2 + 4 * n_adds:4] = a, b
+    buf[4:2 + 4 * n_adds:4] = rng.integers(0, C12.P, n_adds, dtype=np.uint64); buf[5:2 + 4 * n_adds:4] = rng.integers(0, C12.P, n_adds, dtype=np.uint64)
+    buf[2 + 4 * n_adds:] = rng.integers(0, n_wit + n_adds, 12 * rows, dtype=np.uint64)
+    text = "[" + ",".join(map(str, buf.tolist())) + "]"
+    E = c12.Compressor12Exec(text, n_wit)
+    d_w = zk.DevArray.from_host(rng.integers(0, C12.P, n_wit, dtype=np.uint64))
+    E.run(d_w, rows)
+    t0 = time.perf_counter(); E.run(d_w, rows); zk.lib().zk_dev_sync()
+    out["c12_exec_ms"] = round((time.perf_counter() - t0) * 1e3, 2); out["c12_exec_depth"] = int(E.depth)
+    E.free()
+    # 2. final STARK, BLS12381 hashing (MerkleTreeBLS12381 + TranscriptBLS12381)
+    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
+    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
+    ss["verificationHashType"] = "BLS12381"
+    pj = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
+    setup = stark.NativeStarkSetup(synth_pil.const_trace(nbits), pj, json.dumps(ss))
+    d_cm = zk.DevArray.from_host(synth_pil.wide_fib_trace(nbits, 10))
+    setup.gen(d_cm)
+    t0 = time.perf_counter(); setup.gen(d_cm); out["final_stark_bls12381_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    setup.free()
+    # 3. Groth16 wrap on BLS12-381
+    rb, wit, ni, n_wires = GB.make_circuit(GB.FR["BLS12381"], log_rows)
+    S = dev.Groth16Setup("BLS12381", rb, GB.make_params(zk, dev, "BLS12381", ni, n_wires, log_rows, GB.density(rb, ni, n_wires)))
+    d_wit = zk.DevArray.from_host(wit.reshape(-1))
+    S.prove(d_wit, 5, 7)
+    t0 = time.perf_counter(); S.prove(d_wit, 5, 7); out["groth16_bls12381_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    S.free()
+    out["ms"] = round(out["c12_exec_ms"] + out["final_stark_bls12381_ms"] + out["groth16_bls12381_ms"], 1)
+    return out
+
+
 def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
     """BASELINE config 5, the sharded part of recursion/stark_aggregation.sh: independent sub-proofs, one
     stream of them per GPU, no collective while proving; the one exchange is the all-gather of each
@@ -349,6 +399,13 @@ def main():
     agg = None
     if (world > 1 or args.agg) and not args.no_prove:                  # every rank takes part
         agg = aggregation_leg(zk, dist, rank, world, args.agg_nbits, dev)
+        if rank == 0:                                                  # the serial tail of the aggregation runs on rank 0
+            try:
+                agg["final_wrap"] = final_wrap_leg(zk)
+            except Exception as e:                                     # never lose the bench line to the extra leg
+                agg["final_wrap"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if dist is not None:
+            dist.barrier()
 
     if rank == 0:
         passes = lib.zk_gl_ntt_passes(nbits)
