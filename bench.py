@@ -115,8 +115,9 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     the compressor's exec step (witness -> trace), the final STARK with BLS12381 hashing and the BLS12-381 Groth16 wrap,
     each on a synthetic workload of the stated size (the recursive circuits themselves need circom)."""
     import importlib
-    sys.path.insert(0, str(ROOT / "tools")); sys.path.insert(0, str(ROOT / "oracle"))
-    import synth_pil, groth16_bench as GB, compressor12 as C12
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth_pil, groth16_bench as GB
+    GLP = 0xFFFFFFFF00000001
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     dev = importlib.import_module("eigen_zkvm_amd.groth16")
     c12 = importlib.import_module("eigen_zkvm_amd.compressor12")
@@ -129,11 +130,11 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     buf = np.empty(2 + 4 * n_adds + 12 * rows, dtype=np.uint64)
     buf[0], buf[1] = n_adds, rows
     buf[2:2 + 4 * n_adds:4], buf[3:2 + 4 * n_adds:4] = a, b
-    buf[4:2 + 4 * n_adds:4] = rng.integers(0, C12.P, n_adds, dtype=np.uint64); buf[5:2 + 4 * n_adds:4] = rng.integers(0, C12.P, n_adds, dtype=np.uint64)
+    buf[4:2 + 4 * n_adds:4] = rng.integers(0, GLP, n_adds, dtype=np.uint64); buf[5:2 + 4 * n_adds:4] = rng.integers(0, GLP, n_adds, dtype=np.uint64)
     buf[2 + 4 * n_adds:] = rng.integers(0, n_wit + n_adds, 12 * rows, dtype=np.uint64)
     text = "[" + ",".join(map(str, buf.tolist())) + "]"
     E = c12.Compressor12Exec(text, n_wit)
-    d_w = zk.DevArray.from_host(rng.integers(0, C12.P, n_wit, dtype=np.uint64))
+    d_w = zk.DevArray.from_host(rng.integers(0, GLP, n_wit, dtype=np.uint64))
     E.run(d_w, rows)
     t0 = time.perf_counter(); E.run(d_w, rows); zk.lib().zk_dev_sync()
     out["c12_exec_ms"] = round((time.perf_counter() - t0) * 1e3, 2); out["c12_exec_depth"] = int(E.depth)
