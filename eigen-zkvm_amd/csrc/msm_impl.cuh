@@ -405,25 +405,28 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restric
     for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(conv, idx[off + k]));
     buckets[key] = acc;
 }
-// One level of the radix-16 hierarchy that computes sum_k k*B_k per window.  An item (S, A) stands
-// for a block of m = 16^level consecutive buckets: S = their sum, A = sum (local index) * bucket.
-// 16 neighbouring blocks combine as S' = sum_j S_j, A' = sum_j A_j + m * sum_j j*S_j (running-sum
-// trick for the last term).  Level 0 reads the buckets themselves (A = 0).  After 4 levels the one
-// item left per window holds A = sum_k k*B_k.  Every level keeps 1/16 of the lanes of the one
-// before: 2^16, 2^12, 2^8, 2^4 -- the serial chain per lane is 47 additions, not 65536.
+// One level of the radix-R hierarchy (R = 2^RLOG) that computes sum_k k*B_k per window.  An item (S, A) stands
+// for a block of m = R^level consecutive buckets: S = their sum, A = sum (local index) * bucket.
+// R neighbouring blocks combine as S' = sum_j S_j, A' = sum_j A_j + m * sum_j j*S_j (running-sum
+// trick for the last term, m = RLOG*level doublings).  Level 0 reads the buckets themselves (A = 0).  After
+// 16/RLOG levels the one item left per window holds A = sum_k k*B_k.  The tail of a sum is the serial chain of
+// these levels: 3R - 1 + RLOG*level point operations each -- 212 in all for R = 16 (first version), 144 for R = 4.
+constexpr int RED_RLOG = 2;
+template <int RLOG>
 __global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __restrict__ S_in, const xyzz* __restrict__ A_in,
                                                               xyzz* __restrict__ S_out, xyzz* __restrict__ A_out,
                                                               u32 n_out, int level) {
+    constexpr int R = 1 << RLOG;
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_out) return;
-    const xyzz* s = S_in + (u64)g * 16;
+    const xyzz* s = S_in + (u64)g * R;
     xyzz run = pt_inf(), acc = pt_inf();
-    for (int j = 15; j >= 1; --j) { run = pt_add(run, s[j]); acc = pt_add(acc, run); }
+    for (int j = R - 1; j >= 1; --j) { run = pt_add(run, s[j]); acc = pt_add(acc, run); }
     run = pt_add(run, s[0]);
     if (level > 0) {
-        for (int k = 0; k < 4 * level; ++k) acc = pt_dbl(acc);
-        const xyzz* a = A_in + (u64)g * 16;
-        for (int j = 0; j < 16; ++j) acc = pt_add(acc, a[j]);
+        for (int k = 0; k < RLOG * level; ++k) acc = pt_dbl(acc);
+        const xyzz* a = A_in + (u64)g * R;
+        for (int j = 0; j < R; ++j) acc = pt_add(acc, a[j]);
     }
     S_out[g] = run; A_out[g] = acc;
 }
@@ -593,8 +596,8 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
     idx.reserve((size_t)n * N_WIN * 4);
     buckets.reserve(n_keys * sizeof(xyzz));
-    S0.reserve(n_keys / 16 * sizeof(xyzz)); A0.reserve(n_keys / 16 * sizeof(xyzz));
-    S1.reserve((size_t)C_BITS * 512 * sizeof(xyzz)); A1.reserve(n_keys / 256 * sizeof(xyzz));   // S1 also serves the bit-partial levels (16 x 512 items)
+    S0.reserve((n_keys >> RED_RLOG) * sizeof(xyzz)); A0.reserve((n_keys >> RED_RLOG) * sizeof(xyzz));   // >= N_BUCKET items: the table path's merged / partial arrays fit
+    S1.reserve(std::max<size_t>((size_t)C_BITS * 512, n_keys >> (2 * RED_RLOG)) * sizeof(xyzz)); A1.reserve((n_keys >> (2 * RED_RLOG)) * sizeof(xyzz));   // S1 also serves the bit-partial levels (16 x 512 items)
     const u64 total = n * N_WIN;
     if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
         const u32 n_blocks = (u32)((n + SORT_PTS - 1) / SORT_PTS);
@@ -656,12 +659,12 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         ZK_HIP(hipStreamSynchronize(st));
         return;
     }
-    // radix-16 reduction hierarchy: ping-pong (S, A) arrays of n_keys/16 items
+    // reduction hierarchy: ping-pong (S, A) arrays of n_keys / R and n_keys / R^2 items
     const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
-    u32 n_out = (u32)(n_keys / 16);
-    for (int level = 0; level < C_BITS / 4; ++level, n_out /= 16) {
+    u32 n_out = (u32)(n_keys >> RED_RLOG);
+    for (int level = 0; level < C_BITS / RED_RLOG; ++level, n_out >>= RED_RLOG) {
         xyzz* s_out = (xyzz*)(level & 1 ? S1.p : S0.p); xyzz* a_out = (xyzz*)(level & 1 ? A1.p : A0.p);
-        hipLaunchKernelGGL(msm_reduce_level_kernel, dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
+        hipLaunchKernelGGL(msm_reduce_level_kernel<RED_RLOG>, dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
         s_in = s_out; a_in = a_out;
     }
     ZK_HIP(hipGetLastError());
