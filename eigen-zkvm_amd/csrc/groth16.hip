@@ -13,6 +13,7 @@
 // function of (key, circuit, witness).
 #include "zk_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>

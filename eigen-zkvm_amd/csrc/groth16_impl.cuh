@@ -121,7 +121,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         put(g2b, nb + 1, pk.vk[2], P2, 1, false, "beta_g2");
         G16_FQ_TO_MONT(g1b.p, n_g1 * P1 / G16_CW, st);
         G16_FQ_TO_MONT(g2b.p, (nb + 2) * P2 / G16_CW, st);
-        tables = n_g1 < (1ull << 24);
+        tables = n_g1 < (1ull << 24) && !getenv("ZK_GROTH16_NO_TABLES");   // the knob keeps the plain-array path testable at small sizes
         if (tables) {
             g1t.reserve(G16_MSM_G1_TABLE_BYTES(n_g1)); g2t.reserve(G16_MSM_G2_TABLE_BYTES(nb + 2));
             G16_MSM_G1_PREPARE(g1b.p, n_g1, g1t.p, st);

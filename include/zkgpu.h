@@ -291,7 +291,9 @@ int zk_fr_bls12_381_quotient_dev(uint64_t* d_a, const uint64_t* d_b, const uint6
  * zk_groth16_wtns_payload; reader.rs:86-137), r and s = the two blinding scalars create_random_proof draws from its
  * rng (canonical, < the field modulus), `proof` (optional) receives A || B || C as affine Montgomery coordinates
  * (BN254: 64 + 128 + 64 B; BLS12-381: 96 + 192 + 96 B; G2 as x.c0 || x.c1 || y.c0 || y.c1).  Returns proof.json
- * as json_utils.rs:305-315 renders it (malloc'ed; zk_string_free), NULL on error.                              */
+ * as json_utils.rs:305-315 renders it (malloc'ed; zk_string_free), NULL on error.  A setup is bound to the device
+ * current at its creation, keeps the key resident there (as window tables, 16 x the key, when it has fewer than 2^24
+ * G1 bases) and is not re-entrant: one zk_groth16_prove at a time per setup.                                      */
 /* base-field elements in place on the device: to_mont = 1: canonical integers (what key files and proof.json carry,
  * Fq::from_repr) -> Montgomery limbs (what the multi-scalar sums take); to_mont = 0: the inverse (Fq::into_repr).
  * n_elems elements of 32 B (BN254) / 48 B (BLS12-381), little-endian words.                                    */

@@ -219,3 +219,16 @@ def test_quotient_of_a_2_16_row_circuit_matches_oracle(zk, g16, dev, cv, tag):
     assert g.fr_ints(hq[m - 1:]) == [0]
     assert np.array_equal(d_h.to_host().reshape(-1, 4), hq[:m - 1])
     S.free()
+
+
+def test_plain_key_arrays_give_the_same_proof(zk, g16, dev, monkeypatch):
+    """keys of 2^24 bases and more skip the window tables (24-bit point index): the same proof either way"""
+    g = g16["bn254"]
+    r1cs, wit, P, rr, ss = _case(g, 40, 140)
+    rb, pb, w = g.r1cs_bytes(r1cs), g.params_bytes(P), g.fr_array(wit)
+    S = dev.Groth16Setup("BN128", rb, pb); js_tab, pts_tab = S.prove(w, rr, ss); S.free()
+    monkeypatch.setenv("ZK_GROTH16_NO_TABLES", "1")
+    S = dev.Groth16Setup("BN128", rb, pb); js_plain, pts_plain = S.prove(w, rr, ss); S.free()
+    assert js_plain == js_tab and np.array_equal(pts_plain, pts_tab)
+    exp = g.expected_proof(P, wit, rr, ss)
+    assert np.array_equal(pts_plain[:2 * g.nl], exp["a"]) and np.array_equal(pts_plain[6 * g.nl:], exp["c"])
