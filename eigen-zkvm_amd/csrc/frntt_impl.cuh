@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void frn_pow_table_kernel(const fe* __restrict
     soa_store(out, n, i, acc);
 }
 
+// compile-time loops: with `#pragma unroll` the 8-element array x[] stayed in the private segment (304 B of scratch per
+// lane, passes three times slower)
+template <int B, int E, class F>
+__device__ __forceinline__ void frn_static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); frn_static_for<B + 1, E>(f); }
+}
 template <int LOGR>
 __global__ __launch_bounds__(256) void frn_pass_kernel(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ W, int logn, int logL, int inverse,
                                                        const u32* __restrict__ pre, const u32* __restrict__ post, u64 post_n) {
@@ -77,49 +83,50 @@ __global__ __launch_bounds__(256) void frn_pass_kernel(const u32* __restrict__ i
     if (j >= M) return;
     const u64 k = j & ((1ull << logL) - 1);
     fe x[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
+    frn_static_for<0, R>([&](auto T) {
+        constexpr int t = decltype(T)::value;
         const u64 idx = j + (u64)t * M;
         x[t] = soa_load(in, N, idx);
         if (pre) x[t] = fe_mul(x[t], soa_load(pre, N, idx));
-    }
+    });
     if (logL > 0) {
         if (!pre) x[0] = fe_renorm(x[0]);
-#pragma unroll
-        for (int t = 1; t < R; ++t) {
+        frn_static_for<1, R>([&](auto T) {
+            constexpr int t = decltype(T)::value;
             u64 e = (k * (u64)t) << (logn - logL - LOGR);
             if (inverse) e = (N - e) & (N - 1);
             x[t] = fe_mul(x[t], soa_load(W, N, e));
-        }
+        });
     }
     // decimation in frequency: natural order in, bit-reversed order out
-#pragma unroll
-    for (int s = LOGR - 1; s >= 0; --s) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int u = 0; u < R; ++u) {
-            if (u & half) continue;
-            const fe a = x[u], b = x[u + half];
-            x[u] = fe_add(a, b);
-            fe d = s == LOGR - 1 ? fe_sub<2>(a, b) : s == LOGR - 2 ? fe_sub<4>(a, b) : fe_sub<8>(a, b);
-            const int p = u & (half - 1);
-            if (p) {
-                u64 e = (N >> (s + 1)) * (u64)p;
-                if (inverse) e = N - e;
-                d = fe_mul(d, soa_load(W, N, e));          // wave-uniform address
+    frn_static_for<0, LOGR>([&](auto SI) {
+        constexpr int s = LOGR - 1 - decltype(SI)::value, half = 1 << s;
+        frn_static_for<0, R>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if constexpr ((u & half) == 0) {
+                const fe a = x[u], b = x[u + half];
+                x[u] = fe_add(a, b);
+                fe d = fe_sub<(2 << (LOGR - 1 - s))>(a, b);       // biases 2q, 4q, 8q for inputs < 2q, 4q, 8q
+                constexpr int p = u & (half - 1);
+                if constexpr (p != 0) {
+                    u64 e = (N >> (s + 1)) * (u64)p;
+                    if (inverse) e = N - e;
+                    d = fe_mul(d, soa_load(W, N, e));              // wave-uniform address
+                }
+                x[u + half] = d;
             }
-            x[u + half] = d;
-        }
-    }
+        });
+    });
     const u64 obase = ((j - k) << LOGR) + k;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-        const int tt = (int)(__brev((unsigned)t) >> (32 - LOGR));
+    frn_static_for<0, R>([&](auto T) {
+        constexpr int t = decltype(T)::value;
+        int tt = 0;
+        for (int b = 0; b < LOGR; ++b) tt |= ((t >> b) & 1) << (LOGR - 1 - b);
         const u64 o = obase + ((u64)tt << logL);
         fe v = x[t];
         if (post) v = fe_mul(v, soa_load(post, post_n, post_n == 1 ? 0 : o));
         soa_store(out, N, o, v);
-    }
+    });
 }
 // n == 1 and other degenerate shapes: v[i] *= pre[i] * post[i]
 __global__ __launch_bounds__(256) void frn_scale_kernel(u32* __restrict__ v, u64 n, const u32* __restrict__ pre, const u32* __restrict__ post, u64 post_n) {
