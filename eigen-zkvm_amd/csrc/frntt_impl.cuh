@@ -74,10 +74,13 @@ template <int B, int E, class F>
 __device__ __forceinline__ void frn_static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); frn_static_for<B + 1, E>(f); }
 }
+struct FrnBatch { const u32* in[3]; u32* out[3]; };   // up to three vectors per launch (blockIdx.y): the a, b, c of the quotient
 template <int LOGR>
-__global__ __launch_bounds__(256) void frn_pass_kernel(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ W, int logn, int logL, int inverse,
+__global__ __launch_bounds__(256) void frn_pass_kernel(const FrnBatch bt, const u32* __restrict__ W, int logn, int logL, int inverse,
                                                        const u32* __restrict__ pre, const u32* __restrict__ post, u64 post_n) {
     constexpr int R = 1 << LOGR;
+    const u32* __restrict__ in = bt.in[blockIdx.y];
+    u32* __restrict__ out = bt.out[blockIdx.y];
     const u64 N = 1ull << logn, M = N >> LOGR;
     const u64 j = blockIdx.x * 256ull + threadIdx.x;
     if (j >= M) return;
@@ -326,16 +329,17 @@ static const FrDomain& frn_domain(int logn, hipStream_t st) {
 // one transform over limb-major buffers: src -> (ping-pong) -> returns the buffer holding the result (a or b).
 // pre: n-entry table applied on load of the first pass; post: table (post_n = n) or one element (post_n = 1) on the
 // stores of the last.  Input contract: values < 2q when pre == nullptr.
-static u32* frn_transform(const FrDomain& D, u32* a, u32* b, bool inverse, const u32* pre, const u32* post, u64 post_n, hipStream_t st) {
+// nb <= 3 vectors at once: a[i] -> (ping-pong with b[i]) ; returns true when the results are in b[], false when in a[]
+static bool frn_transform_batch(const FrDomain& D, u32* const* a, u32* const* b, int nb, bool inverse, const u32* pre, const u32* post, u64 post_n, hipStream_t st) {
     const int logn = D.logn;
     const u64 n = 1ull << logn;
     if (logn == 0) {
-        hipLaunchKernelGGL(frn_scale_kernel, dim3(1), dim3(256), 0, st, a, n, pre, post, post_n);
+        for (int i = 0; i < nb; ++i) hipLaunchKernelGGL(frn_scale_kernel, dim3(1), dim3(256), 0, st, a[i], n, pre, post, post_n);
         ZK_HIP(hipGetLastError());
-        return a;
+        return false;
     }
     int logL = 0;
-    u32 *src = a, *dst = b;
+    bool in_b = false;
     const int rem = logn % 3;
     const int n_pass = logn / 3 + (rem ? 1 : 0);
     for (int p = 0; p < n_pass; ++p) {
@@ -343,16 +347,21 @@ static u32* frn_transform(const FrDomain& D, u32* a, u32* b, bool inverse, const
         const u32* pr = p == 0 ? pre : nullptr;
         const u32* po = p == n_pass - 1 ? post : nullptr;
         const u64 threads = n >> lr;
-        const dim3 grid(frn_blocks(threads)), blk(256);
+        const dim3 grid(frn_blocks(threads), (unsigned)nb), blk(256);
         const u32* W = (const u32*)D.W.p;
-        if (lr == 1) hipLaunchKernelGGL(frn_pass_kernel<1>, grid, blk, 0, st, (const u32*)src, dst, W, logn, logL, (int)inverse, pr, po, post_n);
-        else if (lr == 2) hipLaunchKernelGGL(frn_pass_kernel<2>, grid, blk, 0, st, (const u32*)src, dst, W, logn, logL, (int)inverse, pr, po, post_n);
-        else hipLaunchKernelGGL(frn_pass_kernel<3>, grid, blk, 0, st, (const u32*)src, dst, W, logn, logL, (int)inverse, pr, po, post_n);
+        FrnBatch bt{};
+        for (int i = 0; i < nb; ++i) { bt.in[i] = in_b ? b[i] : a[i]; bt.out[i] = in_b ? a[i] : b[i]; }
+        if (lr == 1) hipLaunchKernelGGL(frn_pass_kernel<1>, grid, blk, 0, st, bt, W, logn, logL, (int)inverse, pr, po, post_n);
+        else if (lr == 2) hipLaunchKernelGGL(frn_pass_kernel<2>, grid, blk, 0, st, bt, W, logn, logL, (int)inverse, pr, po, post_n);
+        else hipLaunchKernelGGL(frn_pass_kernel<3>, grid, blk, 0, st, bt, W, logn, logL, (int)inverse, pr, po, post_n);
         ZK_HIP(hipGetLastError());
         logL += lr;
-        std::swap(src, dst);
+        in_b = !in_b;
     }
-    return src;
+    return in_b;
+}
+static u32* frn_transform(const FrDomain& D, u32* a, u32* b, bool inverse, const u32* pre, const u32* post, u64 post_n, hipStream_t st) {
+    return frn_transform_batch(D, &a, &b, 1, inverse, pre, post, post_n, st) ? b : a;
 }
 
 // EvaluationDomain::{fft, ifft, coset_fft, icoset_fft} on n = 2^logn elements of bellman's Fr (4 x u64 Montgomery,
@@ -379,12 +388,8 @@ static u32* frn_quotient(const FrDomain& D, u32* a, u32* b, u32* c, u32* t0, u32
     const u32 *GP = (const u32*)D.GP.p, *GIP = (const u32*)D.GIP.p, *minv = (const u32*)D.minv();
     u32* v[3] = {a, b, c};
     u32* s[3] = {t0, t1, t2};
-    for (int i = 0; i < 3; ++i) {
-        u32* r1 = frn_transform(D, v[i], s[i], true, nullptr, minv, 1, st);          // ifft
-        u32* o1 = r1 == v[i] ? s[i] : v[i];
-        u32* r2 = frn_transform(D, r1, o1, false, GP, nullptr, n, st);               // coset_fft
-        if (r2 != v[i]) { s[i] = v[i]; v[i] = r2; }
-    }
+    if (frn_transform_batch(D, v, s, 3, true, nullptr, minv, 1, st)) for (int i = 0; i < 3; ++i) std::swap(v[i], s[i]);   // ifft x 3
+    if (frn_transform_batch(D, v, s, 3, false, GP, nullptr, n, st)) for (int i = 0; i < 3; ++i) std::swap(v[i], s[i]);    // coset_fft x 3
     hipLaunchKernelGGL(frn_quotient_pointwise_kernel, dim3(frn_blocks(n)), dim3(256), 0, st, v[0], (const u32*)v[1], (const u32*)v[2], D.zinv(), n);
     ZK_HIP(hipGetLastError());
     return frn_transform(D, v[0], s[0], true, nullptr, GIP, n, st);                  // icoset_fft
