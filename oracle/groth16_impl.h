@@ -88,7 +88,7 @@ static void fft_core(fr_t *a, unsigned log_n, fr_t omega) {
         fr_t *tw = (fr_t *)malloc(m * sizeof(fr_t));
         tw[0] = fr_one();
         for (uint64_t j = 1; j < m; ++j) tw[j] = fr_mul(tw[j - 1], w_m);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= (1u << 15))
         for (uint64_t x = 0; x < n / 2; ++x) {
             const uint64_t j = x & (m - 1), k = (x - j) * 2;
             const fr_t t = fr_mul(a[k + j + m], tw[j]);
@@ -100,14 +100,14 @@ static void fft_core(fr_t *a, unsigned log_n, fr_t omega) {
     }
 }
 static void scale_all(fr_t *a, uint64_t n, fr_t s) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= (1u << 15))
     for (uint64_t i = 0; i < n; ++i) a[i] = fr_mul(a[i], s);
 }
 static void distribute_powers(fr_t *a, uint64_t n, fr_t g) {   /* a[i] *= g^i */
     fr_t *p = (fr_t *)malloc(n * sizeof(fr_t));
     p[0] = fr_one();
     for (uint64_t i = 1; i < n; ++i) p[i] = fr_mul(p[i - 1], g);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= (1u << 15))
     for (uint64_t i = 0; i < n; ++i) a[i] = fr_mul(a[i], p[i]);
     free(p);
 }
@@ -134,14 +134,14 @@ void G16_X(quotient)(uint64_t *a_, uint64_t *b_, uint64_t *c_, unsigned log_n) {
     G16_X(fr_ntt)(b_, log_n, 1, 0); G16_X(fr_ntt)(b_, log_n, 0, 1);
     G16_X(fr_ntt)(c_, log_n, 1, 0); G16_X(fr_ntt)(c_, log_n, 0, 1);
     const fr_t zinv = fr_inv(fr_sub(fr_pow_u64(fr_from_u64(7), n), fr_one()));   /* divide_by_z_on_coset */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n >= (1u << 15))
     for (uint64_t i = 0; i < n; ++i) a[i] = fr_mul(fr_sub(fr_mul(a[i], b[i]), c[i]), zinv);
     G16_X(fr_ntt)(a_, log_n, 1, 1);
 }
 
 /* ProvingAssignment::enforce's eval(): out[i] = sum_k coeff[k] * w[col[k]] over row i of a CSR matrix (Montgomery) */
 void G16_X(r1cs_eval)(const uint64_t *row_ptr, const uint32_t *cols, const uint64_t *coeffs, const uint64_t *w, uint64_t n_rows, uint64_t *out) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (n_rows >= (1u << 15))
     for (uint64_t i = 0; i < n_rows; ++i) {
         fr_t acc; memset(&acc, 0, sizeof acc);
         for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
