@@ -302,3 +302,18 @@ def synthetic_r1cs(r, n_mul, n_pub=2, n_prv=3, seed=1):
     w.append(rng.randrange(r))                                                      # a wire no row mentions
     r1cs = dict(n_wires=len(w), n_pub_out=n_pub, n_pub_in=0, n_prv_in=n_prv, constraints=cons)
     return r1cs, w
+
+
+def verifier_inputs(g, P, proof, witness):
+    """(vk, proof, public inputs) as the integer tuples oracle/pairing_bn254.groth16_verify takes; proof: dict a, b, c of
+    word arrays (Groth16Oracle.prove) or the proof.json dict a device / oracle run serialised"""
+    vk = P["vk"]
+    out_vk = dict(alpha_g1=g.g1.affine_ints(vk["alpha_g1"]), beta_g2=g.g2.affine_ints(vk["beta_g2"]), gamma_g2=g.g2.affine_ints(vk["gamma_g2"]),
+                  delta_g2=g.g2.affine_ints(vk["delta_g2"]), ic=[g.g1.affine_ints(p) for p in vk["ic"]])
+    if "pi_a" in proof:
+        pr = dict(a=(int(proof["pi_a"]["x"]), int(proof["pi_a"]["y"])), c=(int(proof["pi_c"]["x"]), int(proof["pi_c"]["y"])),
+                  b=(int(proof["pi_b"]["x"][0]), int(proof["pi_b"]["x"][1]), int(proof["pi_b"]["y"][0]), int(proof["pi_b"]["y"][1])))
+    else:
+        pr = dict(a=g.g1.affine_ints(proof["a"]), b=g.g2.affine_ints(proof["b"]), c=g.g1.affine_ints(proof["c"]))
+    ni = P["cir"]["num_inputs"]
+    return out_vk, pr, [int(w) for w in witness[1:ni]]

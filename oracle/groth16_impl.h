@@ -9,10 +9,12 @@
  *   h(X) = (A(X) B(X) - C(X)) / (X^m - 1) from the per-constraint evaluations a_i, b_i, c_i:
  *   3 x ifft, 3 x coset_fft (coset generator g = Fr::multiplicative_generator() = 7), pointwise a*b - c,
  *   times (g^m - 1)^-1, icoset_fft, drop the top coefficient.
- * omega for a 2^k domain = ROOT^(2^(S-k)), ROOT = 7^((r-1)/2^S) (ff's derive macro).  PARITY UNPINNED by the
- * reference (it holds no proving key, witness or quotient vector; its proofs are randomised); pinned by algebra in
- * tests/test_oracle_groth16.py: the transform against the O(n^2) definition, h against direct polynomial division,
- * and whole proofs against the Groth16 verification equation evaluated in the exponent with a known trapdoor. */
+ * omega for a 2^k domain = ROOT^(2^(S-k)), ROOT = 7^((r-1)/2^S) (ff's derive macro).  The reference holds no proving
+ * key, witness or quotient vector and its proofs are randomised, so no byte of a proof can be compared; the pins are
+ * (tests/test_oracle_groth16.py, tests/test_oracle_pairing.py): the transform against the O(n^2) definition, h against
+ * polynomial division, whole proofs against the verification equation evaluated in the exponent with a known trapdoor,
+ * AND against the equation itself through oracle/pairing_bn254.py, a pairing verifier that accepts the reference's own
+ * proof fixture (groth16/test-vectors/proof.json under verification_key.json, public input 33). */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
