@@ -13,7 +13,7 @@
  * key, witness or quotient vector and its proofs are randomised, so no byte of a proof can be compared; the pins are
  * (tests/test_oracle_groth16.py, tests/test_oracle_pairing.py): the transform against the O(n^2) definition, h against
  * polynomial division, whole proofs against the verification equation evaluated in the exponent with a known trapdoor,
- * AND against the equation itself through oracle/pairing_bn254.py, a pairing verifier that accepts the reference's own
+ * AND against the equation itself through oracle/pairing.py, a pairing verifier that accepts the reference's own
  * proof fixture (groth16/test-vectors/proof.json under verification_key.json, public input 33). */
 #include <stdint.h>
 #include <stdlib.h>

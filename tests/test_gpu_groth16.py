@@ -234,15 +234,18 @@ def test_plain_key_arrays_give_the_same_proof(zk, g16, dev, monkeypatch):
     assert np.array_equal(pts_plain[:2 * g.nl], exp["a"]) and np.array_equal(pts_plain[6 * g.nl:], exp["c"])
 
 
-def test_device_proof_is_accepted_by_the_pairing_verifier(zk, g16, dev):
+@pytest.mark.parametrize("cv,tag", CURVES)
+def test_device_proof_is_accepted_by_the_pairing_verifier(zk, g16, dev, cv, tag):
     """the verification equation itself, e(A, B) = e(alpha, beta) e(sum x_i IC_i, gamma) e(C, delta), evaluated by the
-    pure-Python pairing that accepts the reference's own proof fixture (tests/test_oracle_pairing.py)"""
-    import pairing_bn254 as PB
-    g = g16["bn254"]
+    pure-Python pairing (oracle/pairing.py) whose BN254 instance accepts the reference's own proof fixture
+    (tests/test_oracle_pairing.py)"""
+    import pairing as PG
+    C = PG.BN254 if cv == "bn254" else PG.BLS12_381
+    g = g16[cv]
     r1cs, wit, P, _, _ = _case(g, 12, 77)
-    S = dev.Groth16Setup("BN128", g.r1cs_bytes(r1cs), g.params_bytes(P))
+    S = dev.Groth16Setup(tag, g.r1cs_bytes(r1cs), g.params_bytes(P))
     js, _ = S.prove(g.fr_array(wit))                                        # r, s drawn by the host mirror
     S.free()
     vk, proof, pub = G.verifier_inputs(g, P, js, wit)
-    assert PB.groth16_verify(vk, proof, pub)
-    assert not PB.groth16_verify(vk, proof, [(pub[0] + 1) % g.r] + pub[1:])
+    assert C.groth16_verify(vk, proof, pub)
+    assert not C.groth16_verify(vk, proof, [(pub[0] + 1) % g.r] + pub[1:])
