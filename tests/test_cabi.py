@@ -1,6 +1,7 @@
 """CPU-side checks of the boundary: libzkgpu.so loads without a GPU and exports every symbol
 include/zkgpu.h declares (no compute calls here)."""
 import ctypes, pathlib, re
+import pytest
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
@@ -61,3 +62,25 @@ def test_program_compiles_without_gpu(zk):
     p = zk.Program([zk.instr(zk.OP_MUL, zk.opnd(zk.OPND_TMP, id=0, dim=1), zk.opnd(zk.OPND_NUMBER, value=3), zk.opnd(zk.OPND_NUMBER, value=5))])
     src = zk.lib().zk_program_source(p._h)
     assert src and b"zk_eval_kernel" in src
+
+
+def test_groth16_and_compressor_readers_without_gpu(zk):
+    """the file readers run on the host: the reference's .wtns fixture (test/single/witness.wtns) and the header errors of
+    reader.rs:86-137 / r1cs_file.rs:185-200 / compressor12_exec.rs:110-125 surface before any device work"""
+    import importlib
+    dev = importlib.import_module("eigen_zkvm_amd.groth16")
+    b = (ROOT / "tests" / "golden" / "groth16" / "witness.wtns").read_bytes()
+    w = dev.wtns_values(b, "BN128")
+    assert w[:, 0].tolist() == [1, 11210000, 1121, 10000] and not w[:, 1:].any()
+    for bad, msg in ((b"wtnx" + b[4:], "Invalid file header"), (b[:8] + b"\x03\x00\x00\x00" + b[12:], "invalid num sections"), (b[:-1], "truncated")):
+        with pytest.raises(zk.ZkError, match=msg):
+            dev.wtns_values(bad, "BN128")
+    with pytest.raises(zk.ZkError, match="invalid curve prime"):
+        dev.wtns_values(b, "BLS12381")
+    lib = zk.lib(); err = lambda: lib.zk_last_error().decode()
+    r1 = (ROOT / "tests" / "golden" / "groth16" / "mycircuit_bls12381.r1cs").read_bytes()
+    assert not lib.zk_groth16_setup_new(b"BN128", r1, len(r1), b"x", 1) and "prime is not the scalar field" in err()
+    assert not lib.zk_groth16_setup_new(b"BLS12381", b"r1cx" + r1[4:], len(r1), b"x", 1) and "Invalid magic number" in err()
+    assert not lib.zk_groth16_setup_new(b"BLS12381", r1, len(r1), b"x", 1) and "truncated" in err()       # the circuit parses; the key does not
+    assert not lib.zk_c12_exec_new(b"[1,0,5,6,7]", 11, 10) and "length does not match" in err()
+    assert not lib.zk_c12_exec_new(b"[1,0,12,0,1,1]", 14, 10) and "does not exist yet" in err()

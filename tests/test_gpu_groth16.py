@@ -249,3 +249,10 @@ def test_device_proof_is_accepted_by_the_pairing_verifier(zk, g16, dev, cv, tag)
     vk, proof, pub = G.verifier_inputs(g, P, js, wit)
     assert C.groth16_verify(vk, proof, pub)
     assert not C.groth16_verify(vk, proof, [(pub[0] + 1) % g.r] + pub[1:])
+
+
+def test_wtns_fixture_of_the_reference_is_read(zk, dev):
+    """test/single/witness.wtns of the reference (a snarkjs-written BN254 witness): [1, 11210000, 1121, 10000]"""
+    b = (ROOT / "tests" / "golden" / "groth16" / "witness.wtns").read_bytes()
+    w = dev.wtns_values(b, "BN128")
+    assert w.shape == (4, 4) and w[:, 0].tolist() == [1, 11210000, 1121, 10000] and not w[:, 1:].any()
