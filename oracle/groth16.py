@@ -317,3 +317,28 @@ def verifier_inputs(g, P, proof, witness):
         pr = dict(a=g.g1.affine_ints(proof["a"]), b=g.g2.affine_ints(proof["b"]), c=g.g1.affine_ints(proof["c"]))
     ni = P["cir"]["num_inputs"]
     return out_vk, pr, [int(w) for w in witness[1:ni]]
+
+
+def read_r1cs(b):
+    """the inverse of Groth16Oracle.r1cs_bytes for files other tools wrote (algebraic/src/r1cs_file.rs:50-118, 185-270):
+    -> (prime, r1cs dict); terms sorted by wire as the reference does while reading (:83)"""
+    assert b[:4] == b"r1cs" and struct.unpack("<I", b[4:8])[0] == 1
+    n_sec = struct.unpack("<I", b[8:12])[0]
+    o, secs = 12, {}
+    for _ in range(n_sec):
+        t, n = struct.unpack("<IQ", b[o:o + 12]); secs[t] = b[o + 12:o + 12 + n]; o += 12 + n
+    h = secs[1]
+    fs = struct.unpack("<I", h[:4])[0]
+    prime = int.from_bytes(h[4:4 + fs], "little")
+    n_wires, n_out, n_in, n_prv, _labels, n_cons = struct.unpack("<IIIIQI", h[4 + fs:])
+    c, o, cons = secs[2], 0, []
+    for _ in range(n_cons):
+        row = []
+        for _lc in range(3):
+            nv = struct.unpack("<I", c[o:o + 4])[0]; o += 4
+            lc = []
+            for _k in range(nv):
+                lc.append((struct.unpack("<I", c[o:o + 4])[0], int.from_bytes(c[o + 4:o + 4 + fs], "little"))); o += 4 + fs
+            row.append(sorted(lc, key=lambda t: t[0]))
+        cons.append(tuple(row))
+    return prime, dict(n_wires=n_wires, n_pub_out=n_out, n_pub_in=n_in, n_prv_in=n_prv, constraints=cons)

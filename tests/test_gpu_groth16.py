@@ -256,3 +256,24 @@ def test_wtns_fixture_of_the_reference_is_read(zk, dev):
     b = (ROOT / "tests" / "golden" / "groth16" / "witness.wtns").read_bytes()
     w = dev.wtns_values(b, "BN128")
     assert w.shape == (4, 4) and w[:, 0].tolist() == [1, 11210000, 1121, 10000] and not w[:, 1:].any()
+
+
+def test_reference_r1cs_fixture_end_to_end(zk, g16, dev):
+    """groth16/test-vectors/mycircuit_bls12381.r1cs (c <== a * b, circom-written): the file as it is through the device
+    reader, a key from the restated setup, witness 3 * 11 = 33, and the pairing verifier on the result"""
+    import pairing as PG
+    g = g16["bls12_381"]; rng = random.Random(3)
+    rb = (ROOT / "tests" / "golden" / "groth16" / "mycircuit_bls12381.r1cs").read_bytes()
+    prime, r1cs = G.read_r1cs(rb)
+    assert prime == g.r and (r1cs["n_wires"], len(r1cs["constraints"])) == (4, 1)
+    wit = [1, 33, 3, 11]                                                    # ONE, out c, in a, in b
+    (A, B, Cc), = r1cs["constraints"]
+    ev = lambda lc: sum(c * wit[j] for j, c in lc) % g.r
+    assert ev(A) * ev(B) % g.r == ev(Cc)                                    # circom writes -a * b = -c
+    P = g.setup(r1cs, *[rng.randrange(1, g.r) for _ in range(5)])
+    S = dev.Groth16Setup("BLS12381", rb, g.params_bytes(P))
+    js, _ = S.prove(g.fr_array(wit))
+    S.free()
+    vk, proof, pub = G.verifier_inputs(g, P, js, wit)
+    assert pub == [33] and PG.BLS12_381.groth16_verify(vk, proof, pub)
+    assert not PG.BLS12_381.groth16_verify(vk, proof, [34])
