@@ -278,3 +278,18 @@ def test_window_table_sums_equal_plain_sums(zk, orc, curve, group):
         got = tab.msm(d_s, cnt, off).to_host()
         exp = zk.msm_g1_dev(zk.DevArray.from_host(bases[off:off + cnt].reshape(-1)), d_s, cnt, curve, group=group).to_host()
         assert np.array_equal(got, exp), (off, cnt)
+
+
+def test_window_table_cancellation_and_duplicates(zk, orc):
+    """the same corner cases through the table path: P*9 + P*(r-9) = infinity across the merged windows and bit partials,
+    and one base repeated 300 times (every addition inside a bucket is a doubling or P + 2P ...)"""
+    one = orc.bn254_make_bases(1, 5, 1)
+    tab = zk.MsmTable(zk.DevArray.from_host(np.concatenate([one, one])), 2, "bn254", "g1")
+    out = tab.msm(zk.DevArray.from_host(np.concatenate([words(9), words(R - 9)]))).to_host()
+    assert int(out[8]) & 0xFFFFFFFF == 1                                   # infinity flag
+    n = 300
+    tab = zk.MsmTable(zk.DevArray.from_host(np.tile(one, n)), n, "bn254", "g1")
+    k = 0x0123456789abcdef0123456789abcdef
+    out = tab.msm(zk.DevArray.from_host(np.tile(words(k), n))).to_host()
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(5 * n * k % R))
+    assert not einf and int(out[8]) & 0xFFFFFFFF == 0 and np.array_equal(out[:8], exp)
