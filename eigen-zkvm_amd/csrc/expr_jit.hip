@@ -39,9 +39,52 @@ DEV f3 sub31(f3 a, u64 b) { return f3{{gl::sub(a.v[0], b), a.v[1], a.v[2]}}; }  
 DEV f3 sub13(u64 a, f3 b) { return f3{{gl::sub(a, b.v[0]), gl::neg(b.v[1]), gl::neg(b.v[2])}}; }  // f3g.rs:389-392
 DEV f3 mul31(f3 a, u64 b) { return gl::f3_muls(a, b); }                                      // f3g.rs:412-416
 DEV f3 mul13(u64 a, f3 b) { return gl::f3_muls(b, a); }                                      // f3g.rs:436-441
+// Horner chains over a challenge v with base-field terms, acc <- v * acc + d (the shape of the FRI and quotient
+// polynomials' generated code), are evaluated as sum_j d_j * v^(e_j): field arithmetic is exact, so the value -- and its
+// canonical word -- is the same, at 18 multiply-adds per term instead of a cubic-extension product.  pw holds the powers,
+// each component split in three 22-bit limbs (two words); six accumulators per component take the 22x32-bit partial
+// products without carries (up to 2^10 terms), one reduction per component at the end.
+DEV void pacc(u64 (&A)[3][6], const u64* __restrict__ w, u64 d) {
+    const unsigned x0 = (unsigned)d, x1 = (unsigned)(d >> 32);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u64 w0 = w[2 * k], w1 = w[2 * k + 1];
+        const unsigned l0 = (unsigned)w0, l1 = (unsigned)(w0 >> 32), l2 = (unsigned)w1;
+        A[k][0] += (u64)l0 * x0; A[k][1] += (u64)l1 * x0; A[k][2] += (u64)l2 * x0;
+        A[k][3] += (u64)l0 * x1; A[k][4] += (u64)l1 * x1; A[k][5] += (u64)l2 * x1;
+    }
+}
+DEV u64 pfin1(const u64 (&a)[6]) {
+    typedef unsigned __int128 u128;
+    const u128 X0 = (u128)a[0] + ((u128)a[1] << 22) + ((u128)a[2] << 44);
+    const u128 X1 = (u128)a[3] + ((u128)a[4] << 22) + ((u128)a[5] << 44);
+    const u64 X1l = (u64)X1, X1h = (u64)(X1 >> 64);                       // X1 * 2^32 = X1l * 2^32 + X1h * 2^96 = X1l * 2^32 - X1h
+    const u128 W = X0 + ((u128)X1l << 32) + (u128)(0xFFFFFFFF00000001ull - X1h);
+    return gl::reduce_words((unsigned)W, (unsigned)(W >> 32), (unsigned)(W >> 64), (unsigned)(W >> 96));
+}
+DEV f3 pfin(const u64 (&A)[3][6]) { return f3{{pfin1(A[0]), pfin1(A[1]), pfin1(A[2])}}; }
+DEV void psplit(u64* __restrict__ o, f3 p) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const u64 x = p.v[k];
+        o[2 * k] = (x & 0x3FFFFFull) | (((x >> 22) & 0x3FFFFFull) << 32);
+        o[2 * k + 1] = x >> 44;
+    }
+}
 )ZKJIT";
 
-struct Val { std::string name; int dim; };
+struct CTerm { std::string expr; int e; int sign; };       // a uniform cubic-extension operand (an eval) times v^e, added or subtracted
+struct Val {
+    std::string name; int dim;
+    // ch != NOT_LAZY: not materialised; the value is sum_j terms[j].first * v^terms[j].second + sum_k +-cterms[k].expr * v^e
+    // with v = challenge[ch]; ch == ANY_CH: no power of a challenge has been applied yet (all exponents are 0)
+    static constexpr int NOT_LAZY = -1, ANY_CH = -2;
+    int ch = NOT_LAZY;
+    std::vector<std::pair<std::string, int>> terms;
+    std::vector<CTerm> cterms;
+    bool lazy() const { return ch != NOT_LAZY; }
+};
+struct ChainConst { int ch; std::vector<CTerm> cterms; };   // sum of a chain's uniform terms: computed once per launch
 
 struct Gen {
     std::ostringstream body;
@@ -49,16 +92,46 @@ struct Gen {
     std::map<std::pair<uint32_t, uint32_t>, Val> fwd, fwd_prime;   // (buf, column) -> value this lane wrote at row i / i+next
     std::map<std::pair<uint32_t, uint32_t>, bool> written, prime_read;
     int n_val = 0;
+    std::map<int, int> max_exp;                                     // challenge id -> highest power a materialised chain needs
+    std::vector<ChainConst> chain_consts;
 
     std::string fresh() { return "v" + std::to_string(n_val++); }
 
-    Val load(const zk_operand& o) {
+    // emits the evaluation of a deferred Horner chain and turns v into an ordinary cubic-extension value
+    void materialise(Val& v) {
+        const std::string name = fresh();
+        if (v.ch == Val::ANY_CH) {                              // never met a challenge: plain sums
+            std::string d0 = v.terms[0].first;
+            for (size_t j = 1; j < v.terms.size(); ++j) { const std::string t = fresh(); body << "    const u64 " << t << " = gl::add(" << d0 << ", " << v.terms[j].first << ");\n"; d0 = t; }
+            std::string cur = fresh();
+            body << "    const f3 " << cur << " = f3{{" << d0 << ", 0, 0}};\n";
+            for (auto& ct : v.cterms) { const std::string t = fresh(); body << "    const f3 " << t << " = gl::f3_" << (ct.sign > 0 ? "add" : "sub") << "(" << cur << ", " << ct.expr << ");\n"; cur = t; }
+            body << "    const f3 " << name << " = " << cur << ";\n";
+        } else {
+            const std::string acc = fresh();
+            body << "    u64 " << acc << "[3][6] = {};\n";
+            int& mx = max_exp[v.ch];
+            for (auto& t : v.terms) {
+                mx = std::max(mx, t.second);
+                body << "    pacc(" << acc << ", PW" << v.ch << "(" << t.second << "), " << t.first << ");\n";
+            }
+            if (v.cterms.empty()) body << "    const f3 " << name << " = pfin(" << acc << ");\n";
+            else {
+                for (auto& ct : v.cterms) mx = std::max(mx, ct.e);
+                body << "    const f3 " << name << " = gl::f3_add(pfin(" << acc << "), ld3(KC(" << chain_consts.size() << ")));\n";
+                chain_consts.push_back(ChainConst{v.ch, v.cterms});
+            }
+        }
+        v.name = name; v.ch = Val::NOT_LAZY; v.terms.clear(); v.cterms.clear();
+    }
+    Val load(const zk_operand& o, bool keep_lazy = false) {
         ZK_REQUIRE(o.dim == 1 || o.dim == 3, "eval program: operand dim must be 1 or 3");
         std::ostringstream e;
         switch (o.kind) {
             case ZK_OPND_TMP: {
                 auto it = tmp.find(o.id);
                 ZK_REQUIRE(it != tmp.end(), "eval program: tmp read before write");
+                if (it->second.lazy() && !keep_lazy) materialise(it->second);   // the tmp keeps the materialised name for later readers
                 return it->second;
             }
             case ZK_OPND_MEM: {
@@ -95,8 +168,9 @@ struct Gen {
         }
     }
 
-    void store(const zk_operand& d, const Val& v) {
+    void store(const zk_operand& d, Val v) {
         if (d.kind == ZK_OPND_TMP) { tmp[d.id] = v; return; }                      // interpreter.rs:149-152
+        if (v.lazy()) materialise(v);
         ZK_REQUIRE(d.kind == ZK_OPND_MEM && d.buf < 16, "eval program: destination must be tmp or a section cell");
         // A primed destination (set_ref -> eval_map with prime, interpreter.rs:331-345) stores the value of row
         // i+next into row i+next's cell; the lane of that row stores the same field element there.
@@ -111,7 +185,42 @@ struct Gen {
     }
 
     void instr(const zk_instr& in) {
-        if (in.op == ZK_OP_COPY) { store(in.dest, load(in.src[0])); return; }
+        if (in.op == ZK_OP_COPY) { store(in.dest, load(in.src[0], in.dest.kind == ZK_OPND_TMP)); return; }
+        // Horner steps over a challenge stay symbolic: v * (base-field value | chain), chain + base-field value, chain + chain,
+        // and the FRI polynomial's terms (column - eval): a base-field value minus a uniform cubic-extension operand
+        if (in.op == ZK_OP_MUL || in.op == ZK_OP_ADD || in.op == ZK_OP_SUB) {
+            const bool c0 = in.src[0].kind == ZK_OPND_CHALLENGE, c1 = in.src[1].kind == ZK_OPND_CHALLENGE;
+            auto compatible = [](const Val& x, const Val& y) { return x.ch == y.ch || x.ch == Val::ANY_CH || y.ch == Val::ANY_CH; };
+            auto merge = [](Val x, const Val& y) {
+                if (x.ch == Val::ANY_CH) x.ch = y.ch;
+                x.terms.insert(x.terms.end(), y.terms.begin(), y.terms.end());
+                x.cterms.insert(x.cterms.end(), y.cterms.begin(), y.cterms.end());
+                return x;
+            };
+            if (in.op == ZK_OP_MUL && c0 != c1) {
+                const int ch = (int)(c0 ? in.src[0] : in.src[1]).id;
+                Val o = load(c0 ? in.src[1] : in.src[0], true);
+                if (o.lazy() && (o.ch == ch || o.ch == Val::ANY_CH)) {
+                    o.ch = ch;
+                    for (auto& t : o.terms) ++t.second;
+                    for (auto& t : o.cterms) ++t.e;
+                    store(in.dest, o); return;
+                }
+                if (!o.lazy() && o.dim == 1) { Val r{"", 3}; r.ch = ch; r.terms.push_back({o.name, 1}); store(in.dest, r); return; }
+            } else if (in.op == ZK_OP_ADD && !c0 && !c1) {
+                Val a = load(in.src[0], true), b = load(in.src[1], true);
+                if (a.lazy() && !b.lazy() && b.dim == 1) { a.terms.push_back({b.name, 0}); store(in.dest, a); return; }
+                if (b.lazy() && !a.lazy() && a.dim == 1) { b.terms.push_back({a.name, 0}); store(in.dest, b); return; }
+                if (a.lazy() && b.lazy() && compatible(a, b)) { store(in.dest, merge(a, b)); return; }
+            } else if (in.op == ZK_OP_SUB && in.src[1].kind == ZK_OPND_EVAL && in.src[0].kind != ZK_OPND_CHALLENGE) {
+                Val a = load(in.src[0], true);
+                if (!a.lazy() && a.dim == 1) {
+                    Val r{"", 3}; r.ch = Val::ANY_CH; r.terms.push_back({a.name, 0});
+                    r.cterms.push_back(CTerm{"ld3(c.evals + " + std::to_string(3 * in.src[1].id) + ")", 0, -1});
+                    store(in.dest, r); return;
+                }
+            }
+        }
         Val a = load(in.src[0]), b = load(in.src[1]);
         const char* fn = in.op == ZK_OP_ADD ? "add" : in.op == ZK_OP_SUB ? "sub" : in.op == ZK_OP_MUL ? "mul" : nullptr;
         ZK_REQUIRE(fn, "eval program: unknown op");
@@ -139,8 +248,10 @@ struct zk_program {
     std::string source;
     std::vector<char> code;
     hipModule_t module = nullptr;
-    hipFunction_t fn = nullptr;
+    hipFunction_t fn = nullptr, fn_pow = nullptr;
     uint32_t n_instr = 0;
+    uint32_t pow_entries = 0;      // (challenge, exponent) pairs of the power table, 6 words each
+    void* d_pow = nullptr;
 };
 
 extern "C" {
@@ -155,9 +266,32 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
         for (uint32_t k = 0; k < n_instr; ++k) g.instr(code[k]);
         for (auto& kv : g.prime_read)   // rows are evaluated concurrently: a column cannot be both written and read at i+next
             ZK_REQUIRE(!g.written.count(kv.first), "eval program: a column is written and read at the next row in the same step");
-        std::ostringstream src;
-        src << ZK_GL_JIT_SRC << JIT_HELPERS
-            << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next) {\n"
+        std::ostringstream src, powk;
+        src << ZK_GL_JIT_SRC << JIT_HELPERS;
+        // the power table: one lane per challenge writes v^0 .. v^max, split for pacc, then the constants of the chains on v
+        uint32_t off = 0, lane = 0;
+        std::map<int, uint32_t> off_of;
+        for (auto& kv : g.max_exp) { off_of[kv.first] = off; off += (uint32_t)kv.second + 1; }
+        const uint32_t pow_words = off * 6;
+        src << "#define KC(n) (pw + " << pow_words << " + 3 * (n))\n";
+        for (auto& kv : g.max_exp) {
+            const uint32_t o = off_of[kv.first];
+            src << "#define PW" << kv.first << "(e) (pw + (" << o << " + (e)) * 6)\n";
+            powk << "    if (threadIdx.x == " << lane++ << ") {\n        const f3 v = ld3(c.challenges + " << 3 * kv.first << "); f3 P[" << kv.second + 2 << "]; P[0] = f3{{1, 0, 0}};\n"
+                 << "        for (int e = 0; e <= " << kv.second << "; ++e) { psplit(pw + (" << o << " + e) * 6, P[e]); P[e + 1] = gl::f3_mul(P[e], v); }\n";
+            for (size_t n = 0; n < g.chain_consts.size(); ++n) {
+                if (g.chain_consts[n].ch != kv.first) continue;
+                powk << "        { f3 k = f3{{0, 0, 0}};\n";
+                for (auto& ct : g.chain_consts[n].cterms)
+                    powk << "          k = gl::f3_" << (ct.sign > 0 ? "add" : "sub") << "(k, gl::f3_mul(" << ct.expr << ", P[" << ct.e << "]));\n";
+                powk << "          u64* o = pw + " << pow_words << " + 3 * " << n << "; o[0] = k.v[0]; o[1] = k.v[1]; o[2] = k.v[2]; }\n";
+            }
+            powk << "    }\n";
+        }
+        ZK_REQUIRE(lane <= 64, "eval program: too many challenges with Horner chains");
+        p->pow_entries = (pow_words + 3 * (uint32_t)g.chain_consts.size() + 5) / 6;
+        src << "extern \"C\" __global__ __launch_bounds__(64) void zk_pow_kernel(const EvalCtx c, u64* __restrict__ pw) {\n" << powk.str() << "}\n"
+            << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw) {\n"
             << "    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;\n"
             << "    if (i >= n) return;\n"
             << "    const u64 ip = (i + next) & (n - 1);\n"
@@ -191,8 +325,16 @@ int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_d
         if (!p->module) {  // load lazily: compiling needs no GPU, running does
             ZK_HIP(hipModuleLoadData(&p->module, p->code.data()));
             ZK_HIP(hipModuleGetFunction(&p->fn, p->module, "zk_eval_kernel"));
+            ZK_HIP(hipModuleGetFunction(&p->fn_pow, p->module, "zk_pow_kernel"));
+            if (p->pow_entries) ZK_HIP(hipMalloc(&p->d_pow, (size_t)p->pow_entries * 48));
         }
-        struct { zk_eval_ctx c; uint64_t n; uint64_t next; } args{*ctx, 1ull << nbits_domain, next};
+        if (p->pow_entries) {   // powers of this run's challenges, on the same stream
+            struct { zk_eval_ctx c; void* pw; } pa{*ctx, p->d_pow};
+            size_t psz = sizeof(pa);
+            void* pcfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
+            ZK_HIP(hipModuleLaunchKernel(p->fn_pow, 1, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, nullptr, pcfg));
+        }
+        struct { zk_eval_ctx c; uint64_t n; uint64_t next; const void* pw; } args{*ctx, 1ull << nbits_domain, next, p->d_pow};
         size_t size = sizeof(args);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         const uint64_t blocks = (args.n + 255) / 256;
@@ -202,6 +344,7 @@ int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_d
 }
 
 int zk_program_free(zk_program_t* p) {
+    if (p && p->d_pow) (void)hipFree(p->d_pow);
     if (p && p->module) (void)hipModuleUnload(p->module);
     delete p;
     return 0;
