@@ -108,17 +108,25 @@ struct Gen {
             for (auto& ct : v.cterms) { const std::string t = fresh(); body << "    const f3 " << t << " = gl::f3_" << (ct.sign > 0 ? "add" : "sub") << "(" << cur << ", " << ct.expr << ");\n"; cur = t; }
             body << "    const f3 " << name << " = " << cur << ";\n";
         } else {
-            const std::string acc = fresh();
-            body << "    u64 " << acc << "[3][6] = {};\n";
+            // the carry-free accumulators of pacc hold 2^10 partial products of 54 bits: longer chains go in groups
+            constexpr size_t GROUP = 512;
             int& mx = max_exp[v.ch];
-            for (auto& t : v.terms) {
-                mx = std::max(mx, t.second);
-                body << "    pacc(" << acc << ", PW" << v.ch << "(" << t.second << "), " << t.first << ");\n";
+            std::string sum;
+            for (size_t g0 = 0; g0 < v.terms.size() || g0 == 0; g0 += GROUP) {
+                const std::string acc = fresh();
+                body << "    u64 " << acc << "[3][6] = {};\n";
+                for (size_t j = g0; j < std::min(v.terms.size(), g0 + GROUP); ++j) {
+                    mx = std::max(mx, v.terms[j].second);
+                    body << "    pacc(" << acc << ", PW" << v.ch << "(" << v.terms[j].second << "), " << v.terms[j].first << ");\n";
+                }
+                const std::string part = "pfin(" + acc + ")";
+                if (sum.empty()) sum = part;
+                else { const std::string t = fresh(); body << "    const f3 " << t << " = gl::f3_add(" << sum << ", " << part << ");\n"; sum = t; }
             }
-            if (v.cterms.empty()) body << "    const f3 " << name << " = pfin(" << acc << ");\n";
+            if (v.cterms.empty()) body << "    const f3 " << name << " = " << sum << ";\n";
             else {
                 for (auto& ct : v.cterms) mx = std::max(mx, ct.e);
-                body << "    const f3 " << name << " = gl::f3_add(pfin(" << acc << "), ld3(KC(" << chain_consts.size() << ")));\n";
+                body << "    const f3 " << name << " = gl::f3_add(" << sum << ", ld3(KC(" << chain_consts.size() << ")));\n";
                 chain_consts.push_back(ChainConst{v.ch, v.cterms});
             }
         }

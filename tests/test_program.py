@@ -67,8 +67,10 @@ def _fib_like_program():
 def test_program_compiles_without_gpu(zk):
     prog = _compile(zk, _fib_like_program())
     src = prog.source
-    assert "zk_eval_kernel" in src and "gl::f3_mul" in src and "mul31" in src and "sub13" in src
-    assert src.count("= gl::mul(") == 4
+    body = src[src.index("void zk_eval_kernel"):]
+    assert "mul31" in body and "sub13" in body and body.count("= gl::mul(") == 4
+    assert body.count("pacc(") == 4 and "gl::f3_mul" not in body       # vc * t6 + t7 and vc * (vc * t6 + t7): sums over powers of vc
+    assert "void zk_pow_kernel" in src
 
 
 def test_program_rejects_bad_code(zk):
@@ -102,3 +104,48 @@ def test_program_matches_reference_interpreter(zk, orc, nbits, ext):
                x=[int(v) for v in x.to_host()], zi=[int(v) for v in zi])
     assert [int(v) for v in d["q"].to_host()] == bufs["q"]
     assert [int(v) for v in d["cm3"].to_host()] == bufs["cm3"]
+
+
+def _long_chain_program(n_terms):
+    """acc <- v * acc + cm1[j] over more terms than one group of the deferred sum holds, then (column - eval) terms on
+    a second challenge, as the FRI polynomial's generated code does"""
+    ch = lambda i: {"kind": "challenge", "id": i}
+    ev = lambda i: {"kind": "eval", "id": i}
+    prog = [("mul", T(0), ch(2), M("cm1", 0, 2))]
+    t = 0
+    for j in range(1, n_terms):
+        prog.append(("add", T(t + 1), T(t), M("cm1", j % 2, 2, prime=bool(j % 3 == 0))))
+        prog.append(("mul", T(t + 2), T(t + 1), ch(2)))
+        t += 2
+    prog.append(("sub", T(t + 1), M("cm1", 0, 2), ev(0)))
+    prog.append(("mul", T(t + 2), T(t + 1), ch(5)))
+    prog.append(("sub", T(t + 3), M("cm1", 1, 2), ev(3)))
+    prog.append(("add", T(t + 4), T(t + 2), T(t + 3)))
+    prog.append(("mul", T(t + 5), ch(5), T(t + 4)))
+    prog.append(("add", T(t + 6), T(t), T(t + 5)))
+    prog.append(("mul", M("q", 0, 3, dim=3), T(t + 6), {"kind": "xDivXSubXi"}))
+    return prog
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_terms", [3, 700, 1300])
+def test_long_horner_chains_match_reference_interpreter(zk, orc, n_terms):
+    import interp
+    zk.init(0)
+    nbits, ext = 4, 1
+    rng = np.random.default_rng(n_terms)
+    n = 1 << (nbits + ext); nxt = 1 << ext
+    program = _long_chain_program(n_terms)
+    cm1 = rng.integers(0, P, size=2 * n, dtype=np.uint64)
+    cm1[:4] = [0, P - 1, 1, P - 2]
+    chal = rng.integers(0, P, size=24, dtype=np.uint64); evals = rng.integers(0, P, size=12, dtype=np.uint64)
+    xd = rng.integers(0, P, size=3 * n, dtype=np.uint64)
+    d = {"cm1": zk.DevArray.from_host(cm1), "q": zk.DevArray(3 * n, zero=True)}
+    prog = _compile(zk, program)
+    assert prog.source.count("pfin(") >= 1 + (n_terms + 511) // 512
+    prog.run({BUF[k]: v for k, v in d.items()}, nbits + ext, nxt, challenges=zk.DevArray.from_host(chal),
+             evals=zk.DevArray.from_host(evals), xdiv=zk.DevArray.from_host(xd))
+    bufs = {"cm1": [int(v) for v in cm1], "q": [0] * (3 * n)}
+    interp.run(program, bufs, n, nxt, challenges=chal.reshape(8, 3).astype(object).tolist(), evals=evals.reshape(4, 3).astype(object).tolist(),
+               xdiv=[int(v) for v in xd])
+    assert [int(v) for v in d["q"].to_host()] == bufs["q"]
