@@ -303,7 +303,8 @@ typedef struct zk_groth16_setup zk_groth16_setup_t;
 zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len);
 int zk_groth16_setup_info(const zk_groth16_setup_t* s, uint32_t* n_wires, uint32_t* n_inputs, uint32_t* domain_log);
 char* zk_groth16_prove(zk_groth16_setup_t* s, const void* witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof);
-/* same with the witness already in HBM; d_h (optional) receives the quotient's 2^domain_log - 1 canonical coefficients */
+/* same with the witness already in HBM (its values are taken as canonical: the host-side range check of zk_groth16_prove is
+ * not repeated); d_h (optional) receives the quotient's 2^domain_log - 1 canonical coefficients */
 char* zk_groth16_prove_dev(zk_groth16_setup_t* s, const void* d_witness, uint64_t n_wires, const uint64_t r[4], const uint64_t s_[4], void* proof, uint64_t* d_h);
 int zk_groth16_wtns_payload(const void* wtns, size_t len, const char* curve, uint64_t* offset, uint64_t* n_values);
 int zk_groth16_setup_free(zk_groth16_setup_t* s);
