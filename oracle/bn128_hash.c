@@ -10,7 +10,7 @@
  *
  * A digest (ElementDigest<4, Fr>) holds the RAW limbs of an Fr, i.e. its Montgomery form a*2^256 mod r
  * (digest.rs:45-53 from_scalar = into_raw_repr); this file speaks that format at its boundary ("raw").
- * Parameter tables: oracle/poseidon_bn128_constants.bin (tools/gen_poseidon_bn128_constants.py). */
+ * Parameter tables: eigen-zkvm_amd/data/poseidon_bn128_constants.bin (a data table, one copy in the tree) (tools/gen_poseidon_bn128_constants.py). */
 #define FH_X(name) orc_bn128_##name
 #define FH_RMOD {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL}
 #define FH_R2 {1997599621687373223ULL, 6052339484930628067ULL, 10108755138030829701ULL, 150537098327114917ULL}   /* linearhash_bn128.rs:80-85 */

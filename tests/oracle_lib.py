@@ -198,7 +198,7 @@ class BN128Hash:
         self.field, self.R = field, self.MODULI[field]
         self.lib = L = self._Lib(lib, field)
         L.orc_bn128_load_constants.argtypes = [C.c_char_p]; L.orc_bn128_load_constants.restype = C.c_int
-        path = str(pathlib.Path(__file__).resolve().parent.parent / "oracle" / ("poseidon_%s_constants.bin" % field))
+        path = str(pathlib.Path(__file__).resolve().parent.parent / "eigen-zkvm_amd" / "data" / ("poseidon_%s_constants.bin" % field))
         assert L.orc_bn128_load_constants(path.encode()) == 0, "cannot load " + path
         L.orc_bn128_hash.argtypes = [_u64p, C.c_uint32, _u64p, _u64p]; L.orc_bn128_hash.restype = C.c_int
         L.orc_bn128_fr_to_mont.argtypes = [_u64p, _u64p]; L.orc_bn128_fr_from_mont.argtypes = [_u64p, _u64p]

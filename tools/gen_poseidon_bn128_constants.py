@@ -63,9 +63,9 @@ def convert(name, src, R, NRP):
             assert 0 <= v < R
             out += v.to_bytes(32, "little")
         total += len(vals)
-    for dst in (ROOT / "eigen-zkvm_amd" / "data" / ("poseidon_%s_constants.bin" % name), ROOT / "oracle" / ("poseidon_%s_constants.bin" % name)):
-        dst.write_bytes(out)
-        print("wrote", dst, len(out), "bytes,", total, "constants")
+    dst = ROOT / "eigen-zkvm_amd" / "data" / ("poseidon_%s_constants.bin" % name)
+    dst.write_bytes(out)
+    print("wrote", dst, len(out), "bytes,", total, "constants")
 
 
 if __name__ == "__main__":
