@@ -69,45 +69,67 @@ def gather_roots(dist, root4, device):
     return [o.tolist() for o in out]
 
 
-def prove_leg(zk, nbits):
-    """Third component of BASELINE's metric, "starky prove ms at 2^24 rows": one full GL-hash STARK
-    proof (LDE + Poseidon Merkle + constraint evaluation + FRI, stark_gen.rs:193-557) of the synthetic
-    wide-Fibonacci PIL (20 committed columns ~ the Poseidon PIL's 19, tools/synth_pil.py), trace
-    resident in host memory as `zkit stark_prove` has it after loading the .cm file.  The prover
-    program comes from the committed fixture tests/golden/widefib_w10.program.json."""
+def prove_leg(zk, nbits, verify=True):
+    """Third component of BASELINE's metric, "starky prove ms at 2^24 rows": one full GL-hash STARK proof
+    (stark_gen.rs:193-557: LDE + Poseidon Merkle + constraint evaluation + FRI) of BASELINE's own workload, the
+    PoseidonG PIL (starkjs/poseidon/poseidong.pil; compiled form tests/golden/poseidong.pil.json): 19 committed +
+    18 constant columns, 36 intermediate columns (cm3), quotient in 2 x 3 columns (cm4), every 31-row slot of the trace
+    hashing its own input (tools/tracegen.c).  Timed with the trace resident in HBM (`ms`) and handed over in host
+    memory as `zkit stark_prove` has it after loading the .cm file (`ms_from_host_trace`).  After the clock stops the
+    restated verifier (oracle/stark_prover.py, stark_verify.rs:20-136) checks the timed proof: `verified`."""
     import importlib
     sys.path.insert(0, str(ROOT / "tools"))
-    import synth_pil
+    import poseidong as PG
     stark = importlib.import_module("eigen_zkvm_amd.stark")
-    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
-    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
-    cm, const = synth_pil.wide_fib_trace(nbits, 10), synth_pil.const_trace(nbits)
-    prog_json = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
+    ss = PG.stark_struct(nbits)
+    pj = PG.program(nbits)
+    info = pj["starkinfo"]
+    const, cm = PG.consts(nbits), PG.trace(nbits, None, PG.FIRST_ZERO, seed=nbits)
     t0 = time.perf_counter()
-    setup = stark.NativeStarkSetup(const, prog_json, json.dumps(ss))       # C++ driver inside libzkgpu
+    setup = stark.NativeStarkSetup(const, json.dumps(pj), json.dumps(ss))    # C++ driver inside libzkgpu
     zk.lib().zk_dev_sync()
     setup_s = time.perf_counter() - t0
+    del const
     times, times_h2d = [], []
-    for _ in range(3):                                                     # trace handed over in host memory
-        t0 = time.perf_counter()
-        proof = setup.gen(cm)
-        times_h2d.append((time.perf_counter() - t0) * 1e3)
     d_cm = zk.DevArray.from_host(cm)                                        # trace resident in HBM when the clock starts
-    for _ in range(3):
+    for _ in range(4):
         t0 = time.perf_counter()
         proof_dev = setup.gen(d_cm)
         times.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(2):                                                     # trace handed over in host memory
+        t0 = time.perf_counter()
+        proof = setup.gen(cm)
+        times_h2d.append((time.perf_counter() - t0) * 1e3)
     assert proof_dev == proof
-    # Poseidon permutations of one proof: 4 per row of the 20-column tree + one per interior node of
-    # tree1 and tree4 (the zero-width tree2/tree3 cost one per level)
     n_ext = 1 << (nbits + 1)
-    perms = 4 * n_ext + 2 * n_ext
-    return {"workload": "wide-Fibonacci PIL, 20 committed + 1 constant column, nBits=%d, nBitsExt=%d, GL hash, "
-                        "%d queries, FRI steps %s" % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]]),
-            "ms": round(min(times), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
-            "poseidon_perms_per_proof": perms, "root1": proof["root1"],
-            "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2)}
+    sN = info["map_sectionsN"]
+    perms = sum((_linearhash_perms(sN[s]) + 1) * n_ext for s in ("cm1_2ns", "cm3_2ns", "cm4_2ns"))
+    out = {"workload": "BASELINE config 3 PIL at the headline size: PoseidonG (starkjs/poseidon/poseidong.pil), nBits=%d, nBitsExt=%d, "
+                       "GL hash, %d queries, FRI steps %s; trace = %d Poseidon permutations, one input per 31-row slot"
+                       % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]], (1 << nbits) // 31),
+           "columns": {"cm1": info["n_cm1"], "const": info["n_constants"], "cm2": info["n_cm2"], "cm3": info["n_cm3"],
+                       "cm4_words": sN["cm4_2ns"], "q_deg": info["q_deg"], "q_dim": info["q_dim"], "evals": len(info["ev_map"])},
+           "ms": round(min(times[1:]), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
+           "poseidon_perms_per_proof": perms, "root1": proof["root1"],
+           "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2), "stand_in": False}
+    if verify:                                                              # the checker, after the clock has stopped
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import oracle_lib, stark_prover as SP, starkinfo as SI
+        vinfo, vprog, _ = SI.generate(PG.pil(nbits), ss)
+        p = SP.from_zkin(proof_dev)
+        out["verified"] = bool(SP.stark_verify(p, [int(v) for v in setup.const_root()], vinfo, vprog, ss, oracle_lib.load()))
+    setup.free()
+    return out
+
+
+def _linearhash_perms(w):
+    """Poseidon permutations of one LinearHash row of w words (linearhash.rs:79-145)"""
+    if w <= 4:
+        return 0
+    bs = max(8, (w + 3) // 4)
+    n_b = (w + bs - 1) // bs
+    perms = sum(((min(bs, w - i * bs) + 7) // 8) if min(bs, w - i * bs) > 4 else 0 for i in range(n_b))
+    return perms + ((4 * n_b + 7) // 8 if 4 * n_b > 4 else 0)
 
 
 def final_wrap_leg(zk, nbits=18, log_rows=18):

@@ -139,3 +139,54 @@ def run_at(program, bufs, n, next_, i, **kw):
                 raise ValueError("public calculator writes to a section")
         return r
     return rec_run()
+
+
+# ---- the same programs through oracle/interp.c (sizes the Python loop cannot reach) -----------------------------
+_KIND = {"tmp": 0, "mem": 1, "number": 2, "public": 3, "challenge": 4, "eval": 5, "x": 6, "Zi": 7, "xDivXSubXi": 8, "xDivXSubWXi": 9}
+_OP = {"add": 0, "sub": 1, "mul": 2, "copy": 3}
+
+
+def encode(program, buf_index):
+    """[(op, dest, src0, src1)] -> flat int64 words for orc_interp_run (19 per instruction); returns (words, n_tmp)"""
+    import numpy as np
+
+    def enc(o):
+        if o is None:
+            return [2, 0, 0, 0, 0, 0]
+        k = o["kind"]
+        if k == "tmp":
+            return [0, o["id"], 0, 0, 0, 0]
+        if k == "mem":
+            return [1, buf_index[o["buf"]], o["id"], o["stride"], o.get("dim", 1), 1 if o.get("prime") else 0]
+        if k == "number":
+            v = o["value"] % P
+            return [2, v - (1 << 64) if v >= (1 << 63) else v, 0, 0, 0, 0]
+        if k in ("public", "challenge", "eval"):
+            return [_KIND[k], o["id"], 0, 0, 0, 0]
+        return [_KIND[k], 0, 0, 0, 0, 0]
+    words, n_tmp = [], 0
+    for op, dest, s0, s1 in program:
+        words += [_OP[op]] + enc(dest) + enc(s0) + enc(s1)
+        for o in (dest, s0, s1):
+            if o is not None and o["kind"] == "tmp":
+                n_tmp = max(n_tmp, o["id"] + 1)
+    return np.array(words, np.int64), n_tmp
+
+
+def run_c(lib, program, bufs, n, next_, publics=(), challenges=(), evals=(), x=None, zi=None, xdiv=None, xdivw=None):
+    """bufs: dict name -> numpy uint64 array (mutated in place by the C interpreter)"""
+    import ctypes as C
+    import numpy as np
+    names = sorted(bufs)
+    code, n_tmp = encode(program, {k: i for i, k in enumerate(names)})
+    arr = lambda v: np.ascontiguousarray(np.asarray(v if v is not None and len(v) else [0], dtype=np.uint64).reshape(-1))
+    ptrs = (C.c_void_p * max(1, len(names)))(*[bufs[k].ctypes.data for k in names])
+    for k in names:
+        assert bufs[k].dtype == np.uint64 and bufs[k].flags["C_CONTIGUOUS"]
+    pub, ch, ev, xx, zz, xd, xw = arr(publics), arr(challenges), arr(evals), arr(x), arr(zi), arr(xdiv), arr(xdivw)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.orc_interp_run.restype = C.c_int
+    rc = lib.orc_interp_run(p(code), C.c_uint64(len(program)), C.c_uint64(n_tmp), ptrs, C.c_uint64(len(names)), C.c_uint64(n), C.c_uint64(next_),
+                            p(pub), p(ch), p(ev), p(xx), p(zz), C.c_uint64(0 if zi is None else len(zz)), p(xd), p(xw))
+    if rc:
+        raise ValueError("orc_interp_run: malformed program")

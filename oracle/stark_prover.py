@@ -31,6 +31,8 @@ def parse_pil_number(s):  # types.rs:221-233
 
 
 def load_trace(path, n_cols):
+    if isinstance(path, np.ndarray):
+        return np.ascontiguousarray(path, dtype=np.uint64).reshape(-1)
     a = np.fromfile(path, dtype="<u8")                                   # polsarray.rs:137-217
     assert a.size % n_cols == 0
     return a
@@ -144,33 +146,49 @@ def group_proof(orc, nodes, elements, width, height, idx):
     return row, [[int(x) for x in lvl] for lvl in path]
 
 
-def stark_gen(cm_path, su, stark_struct, orc):
+class _Ints:
+    """numpy section seen as Python ints (the pure-Python evaluator does its arithmetic on ints)"""
+    def __init__(self, a): self.a = a
+    def __getitem__(self, i): return int(self.a[i])
+
+
+def _powers(base, n, first=1):
+    out = np.empty(n, np.uint64); v = first % P
+    for k in range(n):
+        out[k] = v; v = v * base % P
+    return out
+
+
+def stark_gen(cm_path, su, stark_struct, orc, use_c=True):
+    """cm_path: a .cm file or the trace itself (flat uint64 array).  use_c: constraint programs run through
+    oracle/interp.c (same semantics as oracle/interp.py, which use_c=False selects; compared in tests/test_oracle_interp.py)"""
     info, prog = su["starkinfo"], su["program"]
     nbits, nbits_ext = stark_struct["nBits"], stark_struct["nBitsExt"]
     ext = nbits_ext - nbits
     N, Next = 1 << nbits, 1 << nbits_ext
     sN = info["map_sectionsN"]
-    bufs = {"cm1_n": [int(v) for v in load_trace(cm_path, info["n_cm1"])],
-            "const_n": [int(v) for v in su["const_n"]], "const_2ns": [int(v) for v in su["const_2ns"]]}
+    cm1 = np.ascontiguousarray(cm_path, dtype=np.uint64).reshape(-1).copy() if isinstance(cm_path, np.ndarray) else load_trace(cm_path, info["n_cm1"])
+    bufs = {"cm1_n": cm1, "const_n": np.ascontiguousarray(su["const_n"], dtype=np.uint64),
+            "const_2ns": np.ascontiguousarray(su["const_2ns"], dtype=np.uint64)}
     assert len(bufs["cm1_n"]) == N * sN["cm1_n"]
     for s in ("cm2_n", "cm3_n", "tmpexp_n"):
-        bufs[s] = [0] * (sN[s] * N)
+        bufs[s] = np.zeros(sN[s] * N, np.uint64)
     for s in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns"):
-        bufs[s] = [0] * (sN[s] * Next)
-    bufs["q_2ns"] = [0] * (info["q_dim"] * Next)
-    bufs["f_2ns"] = [0] * (3 * Next)
+        bufs[s] = np.zeros(sN[s] * Next, np.uint64)
+    bufs["q_2ns"] = np.zeros(info["q_dim"] * Next, np.uint64)
+    bufs["f_2ns"] = np.zeros(3 * Next, np.uint64)
     w, w_ext = orc.root(nbits), orc.root(nbits_ext)
-    x_n, x_2ns = [pow(w, k, P) for k in range(N)], [49 * pow(w_ext, k, P) % P for k in range(Next)]
-    zi = [int(v) for v in orc.zh_inv(nbits, ext)]
+    x_n, x_2ns = _powers(w, N), _powers(w_ext, Next, 49)
+    zi = orc.zh_inv(nbits, ext)
     challenge = [[0, 0, 0] for _ in range(8)]
     evals = []
     publics = []
     for i, pe in enumerate(info["publics"]):                                 # stark_gen.rs:256-270
         if pe["polType"] == "cmP":
-            publics.append(bufs["cm1_n"][pe["idx"] * sN["cm1_n"] + pe["polId"]])
+            publics.append(int(bufs["cm1_n"][pe["idx"] * sN["cm1_n"] + pe["polId"]]))
         elif pe["polType"] == "imP":                                         # calculate_exp_at_point :558-572
             code = compile_segment(prog["publics_code"][i], info, "n")
-            v = interp.run_at(code, bufs, N, 1, pe["idx"], publics=publics, challenges=challenge, x=x_n)
+            v = interp.run_at(code, {k: _Ints(b) for k, b in bufs.items()}, N, 1, pe["idx"], publics=publics, challenges=challenge, x=_Ints(x_n))
             assert len(v) == 1
             publics.append(v[0])
         else:
@@ -178,16 +196,27 @@ def stark_gen(cm_path, su, stark_struct, orc):
     tr = orc.transcript()
     for p in publics:
         tr.put([p])
+    extra = {}
 
     def run(seg_name, dom):
         n, nxt = (N, 1) if dom == "n" else (Next, 1 << ext)
-        interp.run(compile_segment(prog[seg_name], info, dom), bufs, n, nxt, publics=publics, challenges=challenge,
-                   evals=evals, x=x_n if dom == "n" else x_2ns, zi=zi, xdiv=bufs.get("xDivXSubXi"), xdivw=bufs.get("xDivXSubWXi"))
+        code = compile_segment(prog[seg_name], info, dom)
+        kw = dict(publics=publics, challenges=challenge, evals=evals, x=x_n if dom == "n" else x_2ns, zi=zi,
+                  xdiv=extra.get("xDivXSubXi"), xdivw=extra.get("xDivXSubWXi"))
+        if use_c:
+            interp.run_c(orc.lib, code, bufs, n, nxt, **kw)
+            return
+        used = {o["buf"] for c in code for o in c[1:] if o is not None and o["kind"] == "mem"}
+        lists = {k: [int(v) for v in bufs[k]] for k in used}
+        kw = {k: ([int(t) for t in v] if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        interp.run(code, lists, n, nxt, **kw)
+        for k in {c[1]["buf"] for c in code if c[1]["kind"] == "mem"}:
+            bufs[k][:] = np.array(lists[k], np.uint64)
 
     def extend_and_merkelize(sec):                                           # stark_gen.rs:709-732
         width = sN[sec + "_n"]
-        e = orc.lde(np.array(bufs[sec + "_n"], np.uint64), width, nbits, nbits_ext) if width else np.zeros(0, np.uint64)
-        bufs[sec + "_2ns"] = [int(v) for v in e]
+        e = orc.lde(bufs[sec + "_n"], width, nbits, nbits_ext) if width else np.zeros(0, np.uint64)
+        bufs[sec + "_2ns"] = e
         return {"nodes": orc.merkelize(e, width, Next), "elements": e, "width": width}
 
     tree1 = extend_and_merkelize("cm1")
@@ -206,26 +235,26 @@ def stark_gen(cm_path, su, stark_struct, orc):
     tr.put(tree2["nodes"][-4:])
     challenge[2] = [int(v) for v in tr.get_field()]
     challenge[3] = [int(v) for v in tr.get_field()]
-    bufs["tmpexp_n"] = [0] * len(bufs["tmpexp_n"])      # output-only section of the step: starts from zero (stark_gen.rs:944-951)
+    bufs["tmpexp_n"][:] = 0                             # output-only section of the step: starts from zero (stark_gen.rs:944-951)
     run("step3prev", "n")
     n_cm = info["n_cm1"] + info["n_cm2"]
     for o in info["pu_ctx"] + info["pe_ctx"] + info["ci_ctx"]:               # stark_gen.rs:329-353
         num, den = get_pol(bufs, info, info["exp2pol"][o["num_id"]], N), get_pol(bufs, info, info["exp2pol"][o["den_id"]], N)
         z, ok = orc.calculate_z(num, den)
         assert ok, "z does not close"
-        set_pol(bufs, info, info["cm_n"][n_cm], [int(v) for v in z], N)
+        set_pol(bufs, info, info["cm_n"][n_cm], z, N)
         n_cm += 1
-    bufs["tmpexp_n"] = [0] * len(bufs["tmpexp_n"])
+    bufs["tmpexp_n"][:] = 0
     run("step3", "n")
     tree3 = extend_and_merkelize("cm3")
     tr.put(tree3["nodes"][-4:])
     challenge[4] = [int(v) for v in tr.get_field()]
     run("step42ns", "2ns")
     q_dim, q_deg = info["q_dim"], info["q_deg"]
-    qq1 = orc.ntt(np.array(bufs["q_2ns"], np.uint64), q_dim, nbits_ext, inverse=True)      # :375-396
+    qq1 = orc.ntt(bufs["q_2ns"], q_dim, nbits_ext, inverse=True)             # :375-396
     qq2 = orc.qsplit(qq1, nbits, nbits_ext, q_dim, q_deg)
     cm4 = orc.ntt(qq2, q_dim * q_deg, nbits_ext) if q_deg > 0 else np.zeros(0, np.uint64)
-    bufs["cm4_2ns"] = [int(v) for v in cm4]
+    bufs["cm4_2ns"] = cm4
     tree4 = {"nodes": orc.merkelize(cm4, sN["cm4_2ns"], Next), "elements": cm4, "width": sN["cm4_2ns"]}
     tr.put(tree4["nodes"][-4:])
     challenge[7] = [int(v) for v in tr.get_field()]                          # xi
@@ -237,16 +266,16 @@ def stark_gen(cm_path, su, stark_struct, orc):
         else:
             p = info["var_pol_map"][info["cm_2ns"][ev["id"]]]
             buf, width, off, dim = bufs[p["section"]], sN[p["section"]], p["section_pos"], p["dim"]
-        evals.append([int(v) for v in orc.eval_dot(np.array(buf, np.uint64), width, off, dim, nbits, ext, LpEv if ev["prime"] else LEv)])
+        evals.append([int(v) for v in orc.eval_dot(buf, width, off, dim, nbits, ext, LpEv if ev["prime"] else LEv)])
     for e in evals:
         tr.put(e)
     challenge[5] = [int(v) for v in tr.get_field()]
     challenge[6] = [int(v) for v in tr.get_field()]
-    bufs["xDivXSubXi"] = [int(v) for v in orc.xdivxsub(xi, nbits_ext)]       # :481-522
+    extra["xDivXSubXi"] = orc.xdivxsub(xi, nbits_ext)                        # :481-522
     wxi = np.array([int(v) * w % P for v in challenge[7]], np.uint64)
-    bufs["xDivXSubWXi"] = [int(v) for v in orc.xdivxsub(wxi, nbits_ext)]
+    extra["xDivXSubWXi"] = orc.xdivxsub(wxi, nbits_ext)
     run("step52ns", "2ns")
-    fri_pol = np.array(bufs["f_2ns"], np.uint64)
+    fri_pol = bufs["f_2ns"]
     trees = [tree1, tree2, tree3, tree4, {"nodes": su["const_tree"], "elements": su["const_2ns"], "width": info["n_constants"]}]
 
     def query_pol(idx):
@@ -274,19 +303,15 @@ def calculate_h1h2(f, t):                                                    # s
 def get_pol(bufs, info, pol_id, n):                                           # stark_gen.rs:683-707
     p = info["var_pol_map"][pol_id]
     b, size, off = bufs[p["section"]], info["map_sectionsN"][p["section"]], p["section_pos"]
-    out = np.zeros(3 * n, np.uint64)
-    for i in range(n):
-        for k in range(p["dim"]):
-            out[3 * i + k] = b[off + i * size + k]
-    return out
+    out = np.zeros((n, 3), np.uint64)
+    out[:, :p["dim"]] = np.asarray(b, np.uint64).reshape(n, size)[:, off:off + p["dim"]]
+    return out.reshape(-1)
 
 
 def set_pol(bufs, info, pol_id, pol3, n):                                     # stark_gen.rs:594-622
     p = info["var_pol_map"][pol_id]
     b, size, off = bufs[p["section"]], info["map_sectionsN"][p["section"]], p["section_pos"]
-    for i in range(n):
-        for k in range(p["dim"]):
-            b[off + i * size + k] = pol3[3 * i + k]
+    b.reshape(n, size)[:, off:off + p["dim"]] = np.array(pol3, np.uint64).reshape(n, 3)[:, :p["dim"]]
 
 
 def fri_prove(orc, tr, pol, stark_struct, query_pol):                         # fri.rs:84-184
@@ -375,6 +400,23 @@ def to_zkin(proof):
 
 
 # ---- stark_verify.rs ---------------------------------------------------------------------------------
+def from_zkin(z):
+    """inverse of to_zkin (GL digests): the proof structure stark_verify takes, from the zkin JSON a prover wrote
+    (serializer.rs:146-261) -- lets the restated verifier check proofs that only exist as zkin text"""
+    dg = lambda d: [int(d), 0, 0, 0] if isinstance(d, str) else [int(v) for v in d]
+    n_steps = 1 + sum(1 for k in z if k.startswith("s") and k.endswith("_root"))
+    path = lambda p: [[int(v) for v in lvl] for lvl in p]
+    n_q = len(z["s0_vals1"])
+    queries = [{"root": None, "pol_queries": [[([int(v) for v in z["s0_vals" + nm][q]], path(z["s0_siblings" + nm][q]))
+                                                for nm in ("1", "2", "3", "4", "C")] for q in range(n_q)]}]
+    for i in range(1, n_steps):
+        queries.append({"root": dg(z["s%d_root" % i]),
+                        "pol_queries": [[([int(v) for v in z["s%d_vals" % i][q]], path(z["s%d_siblings" % i][q]))] for q in range(n_q)]})
+    return {"rootC": dg(z["rootC"]), "root1": dg(z["root1"]), "root2": dg(z["root2"]), "root3": dg(z["root3"]), "root4": dg(z["root4"]),
+            "evals": [[int(v) for v in e] for e in z["evals"]], "publics": [int(v) for v in z["publics"]],
+            "fri_proof": {"queries": queries, "last": [[int(v) for v in e] for e in z["finalPol"]]}}
+
+
 def f3(v):
     return tuple(int(x) for x in v)
 

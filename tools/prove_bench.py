@@ -9,6 +9,34 @@ import importlib
 import zkgpu_loader, synth_pil
 
 
+def poseidong_main(args):
+    import poseidong as PG
+    zk = zkgpu_loader.load(); zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    for nbits in args.nbits:
+        ss = PG.stark_struct(nbits, hash_type=args.hash)
+        pj = PG.program(nbits)
+        const, cm = PG.consts(nbits), PG.trace(nbits, None, PG.FIRST_ZERO, seed=nbits)
+        t0 = time.perf_counter()
+        setup = stark.NativeStarkSetup(const, json.dumps(pj), json.dumps(ss))
+        zk.lib().zk_dev_sync()
+        t_setup = time.perf_counter() - t0
+        d_cm = zk.DevArray.from_host(cm)
+        times = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter(); proof = setup.gen(d_cm); times.append(time.perf_counter() - t0)
+        out = {"workload": "PoseidonG PIL, nBits=%d, %s hash, %d queries" % (nbits, args.hash, ss["nQueries"]),
+               "setup_s": round(t_setup, 3), "stark_gen_ms": [round(t * 1e3, 1) for t in times], "root1": proof["root1"]}
+        if args.verify and args.hash == "GL":
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import stark_prover as SP, starkinfo as SI, oracle_lib
+            vinfo, vprog, _ = SI.generate(PG.pil(nbits), ss)
+            p = SP.from_zkin(proof)
+            out["verified"] = bool(SP.stark_verify(p, p["rootC"], vinfo, vprog, ss, oracle_lib.load()))
+        setup.free()
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nbits", type=int, nargs="+", default=[16])
@@ -17,7 +45,10 @@ def main():
     ap.add_argument("--hash", default="GL", choices=["GL", "BN128", "BLS12381"], help="verificationHashType")
     ap.add_argument("--python-driver", action="store_true", help="eigen-zkvm_amd/stark.py step-by-step driver instead of zk_stark_gen")
     ap.add_argument("--verify", action="store_true", help="check the proof with the oracle's restated verifier")
+    ap.add_argument("--pil", default="poseidong", choices=["poseidong", "widefib"], help="PoseidonG (BASELINE config 3) or the wide-Fibonacci stand-in")
     args = ap.parse_args()
+    if args.pil == "poseidong":
+        return poseidong_main(args)
     assert args.w == 10, "only the committed W=10 program fixture is available"
     zk = zkgpu_loader.load(); zk.init(0)
     stark = importlib.import_module("eigen_zkvm_amd.stark")

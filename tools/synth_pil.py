@@ -53,8 +53,10 @@ def rescale(info, nbits):
     import copy
     info = copy.deepcopy(info)
     N, Next = 1 << nbits, 1 << (nbits + 1)
-    for p in info["publics"]:
-        p["idx"] = N - 1
+    old_n = info["map_deg"]["cm1_n"]
+    for p in info["publics"]:                      # publics declared at row N-1 follow the size, the others stay
+        if p["idx"] == old_n - 1:
+            p["idx"] = N - 1
     acc = 0
     for s, deg in (("cm1_n", N), ("cm2_n", N), ("cm3_n", N), ("cm4_n", N), ("tmpexp_n", N), ("cm1_2ns", Next),
                    ("cm2_2ns", Next), ("cm3_2ns", Next), ("cm4_2ns", Next), ("q_2ns", Next), ("f_2ns", Next)):
