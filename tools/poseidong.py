@@ -22,7 +22,11 @@ FIRST_COUNT = list(range(12))
 
 
 def _lib():
-    lib = C.CDLL(str(ROOT / "tools" / "libtracegen.so"))
+    so, src = ROOT / "tools" / "libtracegen.so", ROOT / "tools" / "tracegen.c"
+    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        import subprocess
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(so)])
+    lib = C.CDLL(str(so))
     lib.poseidong_trace.restype = C.c_int
     return lib
 
