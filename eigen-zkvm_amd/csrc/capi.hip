@@ -14,38 +14,87 @@ void set_error(const std::string& msg) { t_err = msg; }
 
 // ---- caching device allocator -------------------------------------------------------------------
 namespace {
+struct Block { size_t bytes = 0; std::vector<hipEvent_t> pending; };   // events recorded when the block was freed
 std::mutex g_pool_mu;
 std::multimap<size_t, void*> g_pool_free;   // size -> idle block
-std::map<void*, size_t> g_pool_size;        // every block handed out by pool_alloc
+std::map<void*, Block> g_pool_blocks;       // every block handed out by pool_alloc
+std::vector<hipStream_t> g_streams{nullptr};  // streams the library has been asked to work on
+std::vector<hipEvent_t> g_event_cache;
+thread_local hipStream_t t_stream = nullptr;
+
+hipEvent_t event_get() {                     // g_pool_mu held
+    if (!g_event_cache.empty()) { hipEvent_t e = g_event_cache.back(); g_event_cache.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return e;
+}
+}
+hipStream_t cur_stream() { return t_stream; }
+void reset_cur_stream() { t_stream = nullptr; }
+hipStream_t on_stream(hipStream_t st) {
+    t_stream = st;
+    if (st) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        bool known = false;
+        for (hipStream_t s : g_streams) known |= s == st;
+        if (!known) g_streams.push_back(st);
+    }
+    return st;
 }
 void* pool_alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_pool_free.find(bytes);
-        if (it != g_pool_free.end()) { void* p = it->second; g_pool_free.erase(it); return p; }
+        if (it != g_pool_free.end()) {
+            void* p = it->second; g_pool_free.erase(it);
+            Block& b = g_pool_blocks[p];
+            for (hipEvent_t e : b.pending) {                          // whoever used the block last finishes first
+                (void)hipStreamWaitEvent(t_stream, e, 0);
+                g_event_cache.push_back(e);
+            }
+            b.pending.clear();
+            return p;
+        }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+        (void)hipGetLastError();                                      // the failed attempt must not surface at a later check
         pool_trim();
         ZK_HIP(hipMalloc(&p, bytes));
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool_size[p] = bytes;
+    g_pool_blocks[p].bytes = bytes;
     return p;
 }
 void pool_free(void* p) {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool_size.find(p);
-    if (it == g_pool_size.end()) { (void)hipFree(p); return; }
-    g_pool_free.emplace(it->second, p);
+    auto it = g_pool_blocks.find(p);
+    if (it == g_pool_blocks.end()) { (void)hipFree(p); return; }
+    if (g_streams.size() > 1) {                                       // several streams in play: order the next user behind all of them
+        for (hipStream_t st : g_streams) {
+            hipEvent_t e = event_get();
+            if (hipEventRecord(e, st) == hipSuccess) it->second.pending.push_back(e);
+            else { (void)hipGetLastError(); g_event_cache.push_back(e); }   // a destroyed stream has nothing in flight
+        }
+    }
+    g_pool_free.emplace(it->second.bytes, p);
 }
 void pool_trim() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (auto& kv : g_pool_free) { (void)hipFree(kv.second); g_pool_size.erase(kv.second); }
+    for (auto& kv : g_pool_free) {
+        Block& b = g_pool_blocks[kv.second];
+        for (hipEvent_t e : b.pending) { (void)hipEventSynchronize(e); g_event_cache.push_back(e); }
+        (void)hipFree(kv.second); g_pool_blocks.erase(kv.second);
+    }
     g_pool_free.clear();
+}
+void forget_stream(hipStream_t st) {                                  // before hipStreamDestroy
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 1; i < g_streams.size(); ++i)
+        if (g_streams[i] == st) { g_streams.erase(g_streams.begin() + i); break; }
 }
 
 namespace {
@@ -55,6 +104,7 @@ DevBuf g_ws_a, g_ws_b, g_ws_c;  // grow-only staging for the host-pointer API
 
 template <class F>
 int guard(F&& f) {
+    reset_cur_stream();
     try { f(); return 0; }
     catch (const std::exception& e) { set_error(e.what()); return -1; }
     catch (...) { set_error("unknown error"); return -1; }
@@ -128,7 +178,7 @@ int zk_gl_ntt_dev(const uint64_t* d_src, uint64_t* d_dst, uint64_t* d_tmp, uint3
     return guard([&] {
         ZK_REQUIRE(nbits <= 32, "zk_gl_ntt: nbits > 32");
         ZK_REQUIRE(d_tmp != nullptr || ntt_num_passes(nbits) == 1 || n_pols == 0, "zk_gl_ntt_dev: d_tmp required");
-        ntt_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, inverse != 0, (hipStream_t)stream);
+        ntt_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, inverse != 0, on_stream((hipStream_t)stream));
     });
 }
 
@@ -136,7 +186,7 @@ int zk_gl_lde_dev(const uint64_t* d_src, uint32_t n_pols, uint32_t nbits, uint64
                   uint32_t nbits_ext, void* stream) {
     return guard([&] {
         ZK_REQUIRE(d_tmp != nullptr || n_pols == 0, "zk_gl_lde_dev: d_tmp required");
-        lde_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, nbits_ext, (hipStream_t)stream);
+        lde_dev((const u64*)d_src, (u64*)d_dst, (u64*)d_tmp, n_pols, nbits, nbits_ext, on_stream((hipStream_t)stream));
     });
 }
 
@@ -186,7 +236,7 @@ int zk_gl_poseidon(const uint64_t in[8], const uint64_t cap[4], uint64_t* out, u
 }
 
 int zk_gl_linearhash_rows_dev(const uint64_t* d_rows, uint32_t width, uint64_t height, uint64_t* d_digests, void* stream) {
-    return guard([&] { linearhash_rows_dev((const u64*)d_rows, width, height, (u64*)d_digests, (hipStream_t)stream); });
+    return guard([&] { linearhash_rows_dev((const u64*)d_rows, width, height, (u64*)d_digests, on_stream((hipStream_t)stream)); });
 }
 
 int zk_gl_linearhash(const uint64_t* v, size_t n, uint64_t out[4]) {
@@ -233,7 +283,7 @@ zk_merkle_t* zk_gl_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_
     int rc = guard([&] {
         ZK_REQUIRE((d_buff || width == 0) && height >= 1, "zk_gl_merkelize_dev: empty matrix");
         t = new zk_merkle();
-        make_tree((const u64*)d_buff, t, width, height, (hipStream_t)stream);
+        make_tree((const u64*)d_buff, t, width, height, on_stream((hipStream_t)stream));
     });
     if (rc != 0) { delete t; return nullptr; }
     return t;
@@ -284,7 +334,7 @@ zk_transcript_t* zk_transcript_new(void) {
     return t;
 }
 int zk_transcript_put_dev(zk_transcript_t* t, const uint64_t* d_src, size_t n, void* stream) {
-    return guard([&] { ZK_REQUIRE(t, "transcript: null"); transcript_put_dev(t->state.p, (const u64*)d_src, n, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(t, "transcript: null"); transcript_put_dev(t->state.p, (const u64*)d_src, n, on_stream((hipStream_t)stream)); });
 }
 int zk_transcript_put(zk_transcript_t* t, const uint64_t* src, size_t n) {
     return guard([&] {
@@ -297,7 +347,7 @@ int zk_transcript_put(zk_transcript_t* t, const uint64_t* src, size_t n) {
     });
 }
 int zk_transcript_get_field_dev(zk_transcript_t* t, uint64_t* d_out3, void* stream) {
-    return guard([&] { ZK_REQUIRE(t && d_out3, "transcript: null"); transcript_get_dev(t->state.p, (u64*)d_out3, 3, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(t && d_out3, "transcript: null"); transcript_get_dev(t->state.p, (u64*)d_out3, 3, on_stream((hipStream_t)stream)); });
 }
 static int transcript_get_host(zk_transcript_t* t, uint64_t* out, uint32_t n_words) {
     return guard([&] {
@@ -321,39 +371,39 @@ int zk_transcript_free(zk_transcript_t* t) { delete t; return 0; }
 // ---- FRI / stark_gen glue ----------------------------------------------------------------------
 int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits, const uint64_t* d_special_x,
                     uint64_t shift_inv, uint64_t* d_out, void* stream) {
-    return guard([&] { fri_fold_dev((const u64*)d_pol, pol_bits, step_bits, (const u64*)d_special_x, shift_inv, (u64*)d_out, (hipStream_t)stream); });
+    return guard([&] { fri_fold_dev((const u64*)d_pol, pol_bits, step_bits, (const u64*)d_special_x, shift_inv, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_fri_transpose_dev(const uint64_t* d_pol, uint64_t n, uint32_t tbits, uint64_t* d_out, void* stream) {
-    return guard([&] { fri_transpose_dev((const u64*)d_pol, n, tbits, (u64*)d_out, (hipStream_t)stream); });
+    return guard([&] { fri_transpose_dev((const u64*)d_pol, n, tbits, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_x_table_dev(uint32_t nbits, uint64_t shift, uint64_t* d_out, void* stream) {
-    return guard([&] { ZK_REQUIRE(nbits <= 32, "x_table: nbits > 32"); x_table_dev(nbits, shift, (u64*)d_out, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(nbits <= 32, "x_table: nbits > 32"); x_table_dev(nbits, shift, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_zh_inv_dev(uint32_t nbits, uint32_t extend_bits, uint64_t* d_out, void* stream) {
-    return guard([&] { ZK_REQUIRE(extend_bits <= 16, "zh_inv: extend_bits > 16"); zh_inv_dev(nbits, extend_bits, (u64*)d_out, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(extend_bits <= 16, "zh_inv: extend_bits > 16"); zh_inv_dev(nbits, extend_bits, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_xdivxsub_dev(const uint64_t* d_xi, uint64_t mulw, uint32_t nbits_ext, uint64_t* d_out, void* stream) {
-    return guard([&] { ZK_REQUIRE(nbits_ext <= 32, "xdivxsub: nbits_ext > 32"); xdivxsub_dev((const u64*)d_xi, mulw, nbits_ext, (u64*)d_out, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(nbits_ext <= 32, "xdivxsub: nbits_ext > 32"); xdivxsub_dev((const u64*)d_xi, mulw, nbits_ext, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_lev_dev(const uint64_t* d_xi, uint32_t nbits, int prime, uint64_t* d_out, uint64_t* d_tmp, uint64_t* d_tmp2, void* stream) {
-    return guard([&] { lev_dev((const u64*)d_xi, nbits, prime != 0, (u64*)d_out, (u64*)d_tmp, (u64*)d_tmp2, (hipStream_t)stream); });
+    return guard([&] { lev_dev((const u64*)d_xi, nbits, prime != 0, (u64*)d_out, (u64*)d_tmp, (u64*)d_tmp2, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const uint64_t* d_LEv,
                        const uint64_t* d_LpEv, uint64_t* d_out, void* stream) {
     return guard([&] {
         static_assert(sizeof(zk_eval_desc) == sizeof(EvalDescHost), "eval descriptor layout");
-        evals_dev((const EvalDescHost*)descs, n_ev, nbits, ext, (const u64*)d_LEv, (const u64*)d_LpEv, (u64*)d_out, (hipStream_t)stream);
+        evals_dev((const EvalDescHost*)descs, n_ev, nbits, ext, (const u64*)d_LEv, (const u64*)d_LpEv, (u64*)d_out, on_stream((hipStream_t)stream));
     });
 }
 int zk_stark_qsplit_dev(const uint64_t* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, uint64_t* d_qq2, void* stream) {
-    return guard([&] { qsplit_dev((const u64*)d_qq1, nbits, q_dim, q_deg, (u64*)d_qq2, (hipStream_t)stream); });
+    return guard([&] { qsplit_dev((const u64*)d_qq1, nbits, q_dim, q_deg, (u64*)d_qq2, on_stream((hipStream_t)stream)); });
 }
 
 int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
-    return guard([&] { msm_g1_bn254_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });
+    return guard([&] { msm_g1_bn254_dev(d_bases, d_scalars, n, d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {
-    return guard([&] { g1_bn254_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });
+    return guard([&] { g1_bn254_mul_generator_dev((const u64*)d_k, n, d_bases, on_stream((hipStream_t)stream)); });
 }
 int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {
     return guard([&] {
@@ -376,10 +426,10 @@ int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* ou
 // G2 variants: same contract, points of PB bytes
 #define ZK_MSM_G2(NAME, PB)                                                                                               \
     int zk_g2_##NAME##_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {                 \
-        return guard([&] { g2_##NAME##_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });          \
+        return guard([&] { g2_##NAME##_mul_generator_dev((const u64*)d_k, n, d_bases, on_stream((hipStream_t)stream)); });          \
     }                                                                                                                   \
     int zk_msm_g2_##NAME##_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {       \
-        return guard([&] { msm_g2_##NAME##_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });                   \
+        return guard([&] { msm_g2_##NAME##_dev(d_bases, d_scalars, n, d_out, on_stream((hipStream_t)stream)); });                   \
     }                                                                                                                   \
     int zk_msm_g2_##NAME(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {               \
         return guard([&] {                                                                                              \
@@ -403,10 +453,10 @@ ZK_MSM_G2(bls12_381, 192)
 #undef ZK_MSM_G2
 
 int zk_g1_bls12_381_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases, void* stream) {
-    return guard([&] { g1_bls12_381_mul_generator_dev((const u64*)d_k, n, d_bases, (hipStream_t)stream); });
+    return guard([&] { g1_bls12_381_mul_generator_dev((const u64*)d_k, n, d_bases, on_stream((hipStream_t)stream)); });
 }
 int zk_msm_g1_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream) {
-    return guard([&] { msm_g1_bls12_381_dev(d_bases, d_scalars, n, d_out, (hipStream_t)stream); });
+    return guard([&] { msm_g1_bls12_381_dev(d_bases, d_scalars, n, d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_msm_g1_bls12_381(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity) {
     return guard([&] {
@@ -552,7 +602,7 @@ T* fr_merkelize(const FrOps& F, const uint64_t* buff, bool on_device, uint32_t w
             t->width = width; t->height = height;
             t->n_nodes = F.n_nodes(height); t->depth = fr_depth(height);
             t->nodes.reserve(t->n_nodes * 32);
-            F.merkelize_dev(t->d_elements, width, height, t->nodes.u(), on_device ? (hipStream_t)stream : nullptr);
+            F.merkelize_dev(t->d_elements, width, height, t->nodes.u(), on_device ? on_stream((hipStream_t)stream) : nullptr);
             if (!on_device) ZK_HIP(hipStreamSynchronize(nullptr));
         }) != 0) { delete t; return nullptr; }
     return t;
@@ -643,7 +693,7 @@ extern "C" {
     }                                                                                                                   \
     int zk_##P##_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out, \
                               uint64_t* d_out, void* stream) {                                                          \
-        return guard([&] { OPS.poseidon_dev((const u64*)d_inp, n, n_in, (const u64*)d_init_state, n_out, (u64*)d_out, (hipStream_t)stream); }); \
+        return guard([&] { OPS.poseidon_dev((const u64*)d_inp, n, n_in, (const u64*)d_init_state, n_out, (u64*)d_out, on_stream((hipStream_t)stream)); }); \
     }                                                                                                                   \
     int zk_##P##_linearhash(const uint64_t* v, size_t n, uint64_t out[4]) { return fr_linearhash(OPS, v, n, out); }       \
     uint64_t zk_##P##_merkle_n_nodes(uint64_t height) { return height ? OPS.n_nodes(height) : 0; }                        \
@@ -680,18 +730,18 @@ ZK_FRHASH_CAPI(bls12381, FR_BLS12381)
 #undef ZK_FRHASH_CAPI
 
 int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, uint64_t* d_out3, void* stream) {
-    return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, (hipStream_t)stream); });
+    return guard([&] { pol_get_dev((const u64*)d_buf, width, offset, dim, n, (u64*)d_out3, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const uint64_t* d_in3, void* stream) {
-    return guard([&] { pol_set_dev((u64*)d_buf, width, offset, dim, n, (const u64*)d_in3, (hipStream_t)stream); });
+    return guard([&] { pol_set_dev((u64*)d_buf, width, offset, dim, n, (const u64*)d_in3, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream) {
     return guard([&] {
         ZK_REQUIRE(n >= 1, "calculate_Z: empty polynomial");
         DevBuf work; work.reserve((n + n / 1024 + 8) * 24);
         u64 h[3];
-        calculate_z_dev((const u64*)d_num3, (const u64*)d_den3, n, (u64*)d_z3, work.u(), work.u() + 3 * (n + n / 1024 + 4), (hipStream_t)stream);
-        ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        calculate_z_dev((const u64*)d_num3, (const u64*)d_den3, n, (u64*)d_z3, work.u(), work.u() + 3 * (n + n / 1024 + 4), on_stream((hipStream_t)stream));
+        ZK_HIP(hipStreamSynchronize(on_stream((hipStream_t)stream)));
         ZK_HIP(hipMemcpy(h, work.u() + 3 * (n + n / 1024 + 4), 24, hipMemcpyDeviceToHost));
         ZK_REQUIRE(h[0] == 1 && h[1] == 0 && h[2] == 0, "calculate_Z: z does not close (grand product != 1)");
     });
@@ -704,10 +754,10 @@ int zk_merkle_free(zk_merkle_t* t) { delete t; return 0; }
 #define ZK_MSM_TABLE_API(NAME)                                                                                              \
     size_t zk_msm_##NAME##_table_bytes(uint64_t table_n) { return msm_##NAME##_fixed_table_bytes(table_n); }                \
     int zk_msm_##NAME##_table_build_dev(const void* d_bases, uint64_t table_n, void* d_table, void* stream) {               \
-        return guard([&] { ZK_REQUIRE(d_bases && d_table, "msm table: null argument"); msm_##NAME##_fixed_prepare_dev(d_bases, table_n, d_table, (hipStream_t)stream); }); \
+        return guard([&] { ZK_REQUIRE(d_bases && d_table, "msm table: null argument"); msm_##NAME##_fixed_prepare_dev(d_bases, table_n, d_table, on_stream((hipStream_t)stream)); }); \
     }                                                                                                                       \
     int zk_msm_##NAME##_table_dev(const void* d_table, uint64_t table_n, uint64_t offset, const void* d_scalars, uint64_t n, void* d_out, void* stream) { \
-        return guard([&] { ZK_REQUIRE(d_table && d_scalars && d_out, "msm table: null argument"); msm_##NAME##_fixed_dev(d_table, table_n, offset, d_scalars, n, d_out, (hipStream_t)stream); }); \
+        return guard([&] { ZK_REQUIRE(d_table && d_scalars && d_out, "msm table: null argument"); msm_##NAME##_fixed_dev(d_table, table_n, offset, d_scalars, n, d_out, on_stream((hipStream_t)stream)); }); \
     }
 ZK_MSM_TABLE_API(g1_bn254)
 ZK_MSM_TABLE_API(g2_bn254)
@@ -722,7 +772,7 @@ zk_c12_exec_t* zk_c12_exec_new(const char* exec_json, size_t len, uint64_t n_wit
     return out;
 }
 int zk_c12_exec_dev(const zk_c12_exec_t* e, const uint64_t* d_witness, uint64_t n_witness, uint64_t n_rows, uint64_t* d_cm, void* stream) {
-    return guard([&] { ZK_REQUIRE(e && e->impl, "compressor12: null handle"); c12_exec_dev(e->impl, (const u64*)d_witness, n_witness, n_rows, (u64*)d_cm, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(e && e->impl, "compressor12: null handle"); c12_exec_dev(e->impl, (const u64*)d_witness, n_witness, n_rows, (u64*)d_cm, on_stream((hipStream_t)stream)); });
 }
 uint64_t zk_c12_exec_depth(const zk_c12_exec_t* e) { return e && e->impl ? c12_exec_levels(e->impl) : 0; }
 int zk_c12_exec_free(zk_c12_exec_t* e) {
@@ -732,7 +782,7 @@ int zk_c12_exec_free(zk_c12_exec_t* e) {
 // ---- Groth16 (groth16.hip) ------------------------------------------------------------------------------------
 #define ZK_FR_NTT(NAME)                                                                                                  \
     int zk_fr_##NAME##_ntt_dev(uint64_t* d, uint32_t log_n, int inverse, int coset, void* stream) {                      \
-        return guard([&] { ZK_REQUIRE(d, "fr ntt: null data"); fr_##NAME##_ntt_dev((u64*)d, (int)log_n, inverse != 0, coset != 0, (hipStream_t)stream); }); \
+        return guard([&] { ZK_REQUIRE(d, "fr ntt: null data"); fr_##NAME##_ntt_dev((u64*)d, (int)log_n, inverse != 0, coset != 0, on_stream((hipStream_t)stream)); }); \
     }                                                                                                                    \
     int zk_fr_##NAME##_ntt(uint64_t* data, uint32_t log_n, int inverse, int coset) {                                     \
         return guard([&] {                                                                                               \
@@ -747,17 +797,17 @@ int zk_c12_exec_free(zk_c12_exec_t* e) {
         });                                                                                                              \
     }                                                                                                                    \
     int zk_fr_##NAME##_quotient_dev(uint64_t* a, const uint64_t* b, const uint64_t* c, uint32_t log_n, void* stream) {   \
-        return guard([&] { ZK_REQUIRE(a && b && c, "fr quotient: null data"); fr_##NAME##_quotient_dev((u64*)a, (const u64*)b, (const u64*)c, (int)log_n, (hipStream_t)stream); }); \
+        return guard([&] { ZK_REQUIRE(a && b && c, "fr quotient: null data"); fr_##NAME##_quotient_dev((u64*)a, (const u64*)b, (const u64*)c, (int)log_n, on_stream((hipStream_t)stream)); }); \
     }
 ZK_FR_NTT(bn254)
 ZK_FR_NTT(bls12_381)
 #undef ZK_FR_NTT
 
 int zk_fq_bn254_convert_dev(void* d, uint64_t n, int to_mont, void* stream) {
-    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bn254_canon_to_mont_dev(d, n, (hipStream_t)stream); else fq_bn254_mont_to_canon_dev(d, n, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bn254_canon_to_mont_dev(d, n, on_stream((hipStream_t)stream)); else fq_bn254_mont_to_canon_dev(d, n, on_stream((hipStream_t)stream)); });
 }
 int zk_fq_bls12_381_convert_dev(void* d, uint64_t n, int to_mont, void* stream) {
-    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bls12_381_canon_to_mont_dev(d, n, (hipStream_t)stream); else fq_bls12_381_mont_to_canon_dev(d, n, (hipStream_t)stream); });
+    return guard([&] { ZK_REQUIRE(d || n == 0, "fq convert: null data"); if (to_mont) fq_bls12_381_canon_to_mont_dev(d, n, on_stream((hipStream_t)stream)); else fq_bls12_381_mont_to_canon_dev(d, n, on_stream((hipStream_t)stream)); });
 }
 struct zk_groth16_setup { Groth16Setup* impl; };
 zk_groth16_setup_t* zk_groth16_setup_new(const char* curve, const void* r1cs, size_t r1cs_len, const void* params, size_t params_len) {

@@ -90,7 +90,21 @@ struct Gen {
     std::ostringstream body;
     std::map<uint32_t, Val> tmp;                                   // tmp id -> current SSA value
     std::map<std::pair<uint32_t, uint32_t>, Val> fwd, fwd_prime;   // (buf, column) -> value this lane wrote at row i / i+next
-    std::map<std::pair<uint32_t, uint32_t>, bool> written, prime_read;
+    // Rows are evaluated concurrently (one lane per row), the reference evaluates them in order inside a chunk
+    // (stark_gen.rs:752-783).  The two agree unless a cell is touched by two different rows' lanes with at least one
+    // write: a write at row i and a read (or another write) of an overlapping cell range at row i+next, in either
+    // order.  Reads served from this lane's own earlier store (fwd / fwd_prime) never reach memory and are not recorded.
+    struct Access { uint32_t buf, id, dim; bool prime; };
+    std::vector<Access> mem_reads, mem_writes;
+    void check_row_hazards() const {
+        auto overlap = [](const Access& a, const Access& b) { return a.buf == b.buf && a.id < b.id + b.dim && b.id < a.id + a.dim; };
+        for (const Access& w : mem_writes) {
+            for (const Access& r : mem_reads)
+                ZK_REQUIRE(!(overlap(w, r) && w.prime != r.prime), "eval program: a column is written at one row and read at the next row in the same step");
+            for (const Access& w2 : mem_writes)
+                ZK_REQUIRE(!(overlap(w, w2) && w.prime != w2.prime), "eval program: a column is written at both the current and the next row in the same step");
+        }
+    }
     int n_val = 0;
     std::map<int, int> max_exp;                                     // challenge id -> highest power a materialised chain needs
     std::vector<ChainConst> chain_consts;
@@ -151,8 +165,8 @@ struct Gen {
                 } else {
                     auto it = fwd_prime.find(key);   // this lane computed the next-row value itself (e.g. t' of a plookup)
                     if (it != fwd_prime.end() && it->second.dim == o.dim) return it->second;
-                    prime_read[key] = true;
                 }
+                mem_reads.push_back(Access{(uint32_t)o.buf, o.id, (uint32_t)o.dim, o.prime != 0});
                 e << "c.bufs[" << (int)o.buf << "] + " << (o.prime ? "ip" : "i") << " * " << o.stride << "ull + " << o.id;
                 Val v{fresh(), o.dim};
                 if (o.dim == 1) body << "    const u64 " << v.name << " = (" << e.str() << ")[0];\n";
@@ -188,8 +202,9 @@ struct Gen {
         else body << "    { u64* p = " << e.str() << "; p[0] = " << v.name << ".v[0]; p[1] = " << v.name << ".v[1]; p[2] = "
                   << v.name << ".v[2]; }\n";                                          // interpreter.rs:153-159
         auto key = std::make_pair((uint32_t)d.buf, d.id);
+        mem_writes.push_back(Access{(uint32_t)d.buf, d.id, (uint32_t)v.dim, d.prime != 0});
         if (d.prime) { fwd_prime[key] = v; return; }
-        fwd[key] = v; written[key] = true;
+        fwd[key] = v;
     }
 
     void instr(const zk_instr& in) {
@@ -272,8 +287,7 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
         p->n_instr = n_instr;
         Gen g;
         for (uint32_t k = 0; k < n_instr; ++k) g.instr(code[k]);
-        for (auto& kv : g.prime_read)   // rows are evaluated concurrently: a column cannot be both written and read at i+next
-            ZK_REQUIRE(!g.written.count(kv.first), "eval program: a column is written and read at the next row in the same step");
+        g.check_row_hazards();
         std::ostringstream src, powk;
         src << ZK_GL_JIT_SRC << JIT_HELPERS;
         // the power table: one lane per challenge writes v^0 .. v^max, split for pacc, then the constants of the chains on v
@@ -340,13 +354,13 @@ int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_d
             struct { zk_eval_ctx c; void* pw; } pa{*ctx, p->d_pow};
             size_t psz = sizeof(pa);
             void* pcfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
-            ZK_HIP(hipModuleLaunchKernel(p->fn_pow, 1, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, nullptr, pcfg));
+            ZK_HIP(hipModuleLaunchKernel(p->fn_pow, 1, 1, 1, 64, 1, 1, 0, on_stream((hipStream_t)stream), nullptr, pcfg));
         }
         struct { zk_eval_ctx c; uint64_t n; uint64_t next; const void* pw; } args{*ctx, 1ull << nbits_domain, next, p->d_pow};
         size_t size = sizeof(args);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
         const uint64_t blocks = (args.n + 255) / 256;
-        ZK_HIP(hipModuleLaunchKernel(p->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, cfg));
+        ZK_HIP(hipModuleLaunchKernel(p->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, on_stream((hipStream_t)stream), nullptr, cfg));
         return 0;
     } catch (const std::exception& e) { set_error(e.what()); return -1; }
 }

@@ -144,7 +144,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
     hipEvent_t ev_ready = nullptr;
     int device = -1;
     ~G16_FN(SetupImpl)() override {
-        for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
+        for (auto& st : streams) if (st) { forget_stream(st); (void)hipStreamDestroy(st); }
         if (ev_ready) (void)hipEventDestroy(ev_ready);
     }
 
@@ -154,7 +154,8 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
             for (auto& st : streams) ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
             ZK_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
         }
-        hipStream_t st = streams[0];
+        on_stream(streams[1]); on_stream(streams[2]);                    // all three are registered with the pool;
+        hipStream_t st = on_stream(streams[0]);                          // this thread issues on streams[0]
         const FrDomain& D = frn_domain(logm, st);
         DevBuf wit_c, wit_fe;
         const u32* d_wit = (const u32*)witness;
@@ -186,6 +187,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         auto side = [&](int k) {
             try {
                 ZK_HIP(hipSetDevice(device));
+                on_stream(streams[k + 1]);                                  // this thread's allocations are ordered on its own stream
                 ZK_HIP(hipStreamWaitEvent(streams[k + 1], ev_ready, 0));
                 if (k == 0) { if (tables) G16_MSM_G2_FIXED(g2t.p, nb + 2, 0, scB.p, nb + 2, o_b.p, streams[1]); else G16_MSM_G2(g2b.p, scB.p, nb + 2, o_b.p, streams[1]); }
                 else { if (tables) G16_MSM_G1_FIXED(g1t.p, n_g1, off_a, scA.p, na + 2, o_a.p, streams[2]); else G16_MSM_G1((const u32*)g1b.p + off_a * P1, scA.p, na + 2, o_a.p, streams[2]); }

@@ -467,6 +467,10 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             u64 v[3];
             ZK_HIP(hipStreamSynchronize(st));
             ZK_HIP(hipMemcpy(v, ptr[S_SCRATCH] + 3 * idx, 24, hipMemcpyDeviceToHost));
+            // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value.
+            // Every operand a public calculator can see is base-field at this point (columns, numbers, earlier publics,
+            // x; the challenges are still F3G::ZERO of dim 1), so an extension-valued result means a malformed program.
+            ZK_REQUIRE(v[1] == 0 && v[2] == 0, "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
             publics.push_back(v[0]);
         } else throw Error("Invalid public type " + ty);
     }
@@ -666,6 +670,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
 
 template <class F>
 int guard(F&& f) {
+    reset_cur_stream();
     try { f(); return 0; }
     catch (const std::exception& e) { set_error(e.what()); return -1; }
     catch (...) { set_error("unknown error"); return -1; }

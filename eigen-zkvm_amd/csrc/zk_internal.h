@@ -28,10 +28,20 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 // ---- device buffers ----
 // Size-keyed free list in front of hipMalloc/hipFree (capi.hip): a prover allocates the same
 // multi-GB sections for every proof, and hipFree/hipMalloc of such buffers costs hundreds of ms and
-// synchronises the device.  pool_free keeps the block (stream-ordered reuse is safe: one stream).
+// synchronises the device.  Reuse is ordered across streams: the library keeps the set of streams it has been
+// asked to work on (`on_stream`); pool_free records an event on each of them and pool_alloc makes the calling
+// thread's current stream wait for the events of the block it hands out, so a block freed with kernels still in
+// flight on stream A is never written early by stream B.  With a single stream in use (the common case) no event
+// is needed: reuse is stream ordered.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
 void pool_trim();  // hipFree everything cached
+// registers `st` as a stream the library works on and makes it the calling thread's current stream (the one
+// pool_alloc orders reuse against); returns st.  Every entry point that takes a stream goes through it.
+hipStream_t on_stream(hipStream_t st);
+hipStream_t cur_stream();
+void reset_cur_stream();  // back to the null stream (entry of every C-ABI call)
+void forget_stream(hipStream_t st);  // call before destroying a registered stream
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;

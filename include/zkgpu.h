@@ -49,6 +49,10 @@ int zk_gl_ntt(const uint64_t* src, uint64_t* dst, uint32_t n_pols, uint32_t nbit
 /* replaces fft_p::interpolate (fft_p.rs:255-261): LDE on the coset 49*<w_ext>;
  * src [1<<nbits][n_pols] -> dst [1<<nbits_ext][n_pols]; n_pols == 0 is a no-op (:262-264).   */
 int zk_gl_lde(const uint64_t* src, uint32_t n_pols, uint32_t nbits, uint64_t* dst, uint32_t nbits_ext);
+/* Streams.  Every `*_dev` entry point takes the HIP stream to issue on (NULL = the default stream).  Scratch memory
+ * comes from a caching allocator inside the library; it orders the reuse of a block behind the work of every stream
+ * the library has been handed so far, so calls on different streams (and from different host threads) may be mixed.
+ * Handles (trees, transcripts, setups) are not re-entrant: one call at a time per handle.                            */
 /* device-resident forms.  d_tmp: scratch of (1<<nbits)*n_pols words (ntt) or
  * (1<<nbits_ext)*n_pols words (lde); may be NULL when zk_gl_ntt_passes(nbits) == 1 (ntt only). */
 int zk_gl_ntt_dev(const uint64_t* d_src, uint64_t* d_dst, uint64_t* d_tmp, uint32_t n_pols,
@@ -102,7 +106,9 @@ int zk_transcript_free(zk_transcript_t* t);
 /* ---- FRI (starky/src/fri.rs:84-184) ----------------------------------------------------------
  * one folding step (fri.rs:101-126): d_pol [1<<pol_bits][3] -> d_out [1<<step_bits][3];
  * d_special_x = the step's challenge (3 device words); shift_inv = (49^-1)^(2^(nBitsExt-pol_bits)).
- * pol_bits - step_bits <= 6.  step_bits == pol_bits copies (step 0 of the reference).            */
+ * pol_bits - step_bits <= 6 (a limit of this build: the reference folds any number of bits, fri.rs:112-126, but none
+ * of its StarkStructs -- starky/data/*.starkStruct*.json -- folds more than 5; a larger step returns an error).
+ * step_bits == pol_bits copies (step 0 of the reference).                                                          */
 int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits,
                     const uint64_t* d_special_x, uint64_t shift_inv, uint64_t* d_out, void* stream);
 /* get_transposed_buffer (fri.rs:299-317): [n] F3G -> [1<<tbits][n>>tbits][3] words */
