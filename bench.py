@@ -33,13 +33,35 @@ sys.path.insert(0, str(ROOT / "tests"))
 NBITS = 24
 SEED = 0x9E3779B97F4A7C15
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Integer-ALU ceilings (profiles/r02/ubench_valu.txt, tools/ubench_valu.hip on this chip): a v_mad_u64_u32 -- the 32x32->64
+# multiply-add every field product here is built from -- issues once per 4.25 cycles per SIMD at the nominal 2.4 GHz, so
+# the chip retires at most 1024 SIMDs * 64 lanes * 2.4e9 / 4.25 = 37 T of them per second.
+VALU_MAD_PER_S = 1024 * 64 * 2.4e9 / 4.25
+# Fewest multiply-adds one Poseidon-GL permutation takes in the form the kernels use (csrc/poseidon.hip): 118 S-boxes x 4
+# products x 4 + 7 dense MDS x 288 (small constants: 2 per term) + pre-sparse matrix 12 x 72 + 22 sparse rounds x (72 + 44).
+POSEIDON_MADS = 118 * 16 + 7 * 288 + 12 * 72 + 22 * (72 + 44)
+# A BN254 Fq product in 9 x 29-bit limbs: 81 + 81 multiply-adds (product + Montgomery reduction), csrc/fe29_impl.cuh;
+# a mixed point addition (madd-2008-s) is 8 products + 2 squares... counted as 11 products with the doubling check.
+FQ_MADS = {"bn254": 2 * 9 * 9, "bls12_381": 2 * 14 * 14}
+PADD_PRODUCTS = 11
 
 
-# HBM bytes per ntt_pass_kernel launch from the PMC counters (profiles/r01/pmc_hbm_traffic.txt:
-# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950
-# correction, calibrated on a 1 GiB copy in the same run): 2*65729 KiB read + 131072 KiB written at
-# 2^24 -- the pass moves exactly its compulsory 16 B/element, no re-reads.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {24: (2 * 65729.2 + 131072.0) * 1024}
+def pmc_traffic(nbits):
+    """roofline.traffic: HBM bytes per ntt_pass_kernel launch from the PMC counters -- rocprofv3 --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate passes with the gfx950 fetch correction calibrated on a 1 GiB copy of the same run
+    (tools/gpu_pmc.sh -> tools/pmc_summarize.py -> profiles/rNN/pmc_hbm_traffic.json).  Counters cannot be read by the
+    run that is being timed, so the number is taken from the newest committed profile and only if that profile was
+    collected on the kernel sources this build has (src_sha16); otherwise null."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import pmc_summarize
+    files = sorted(ROOT.glob("profiles/r*/pmc_hbm_traffic.json"))
+    if not files or nbits != 24:
+        return None, "no PMC profile for this size"
+    d = json.loads(files[-1].read_text())
+    rel = str(files[-1].relative_to(ROOT))
+    if d.get("src_sha16") != pmc_summarize.ntt_src_sha16() or not d.get("ntt_pass_2p24"):
+        return None, "%s was collected on other kernel sources" % rel
+    return d["ntt_pass_2p24"]["bytes_per_launch"], rel
 
 
 def shard_units(n_units, rank, world):
@@ -58,15 +80,17 @@ def max_over_ranks(dist, values, device):
 
 
 def gather_roots(dist, root4, device):
-    """All-gather of each rank's 4-word Merkle root (32 B): the one exchange step of sharded
-    aggregation.  Returns a [world][4] list."""
+    """All-gather of each rank's Merkle roots (4 u64 words each; every rank passes the same number of words): the one
+    exchange step of sharded aggregation.  Returns a [world][n_words] list."""
     import torch
-    t = torch.tensor([int(v) for v in root4], dtype=torch.int64, device=device)
+    to_i64 = lambda v: int(v) - (1 << 64) if int(v) >= (1 << 63) else int(v)   # u64 words travel as two's-complement int64
+    to_u64 = lambda v: int(v) + (1 << 64) if int(v) < 0 else int(v)
+    t = torch.tensor([to_i64(v) for v in root4], dtype=torch.int64, device=device)
     if dist is None:
-        return [t.tolist()]
+        return [[to_u64(v) for v in t.tolist()]]
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
-    return [o.tolist() for o in out]
+    return [[to_u64(v) for v in o.tolist()] for o in out]
 
 
 def prove_leg(zk, nbits, verify=True):
@@ -132,6 +156,40 @@ def _linearhash_perms(w):
     return perms + ((4 * n_b + 7) // 8 if 4 * n_b > 4 else 0)
 
 
+def poseidon_leg(zk, log_height, width, cpu_baseline):
+    """Poseidon-GL Merkle tree (merklehash.rs:293-346) over an HBM-resident [2^log_height][width] matrix -- 73 % of a proof.
+    Integer-ALU bound: `roofline` rates the permutations per second against the multiply-add issue ceiling."""
+    h = 1 << log_height
+    rng = np.random.default_rng(0x905E)
+    rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
+    d = zk.DevArray.from_host(rows)
+    times = []
+    for _ in range(5):
+        zk.lib().zk_dev_sync()
+        t0 = time.perf_counter()
+        tr = zk.MerkleTreeGL(); tr.merkelize_dev(d.ptr, width, h); zk.lib().zk_dev_sync()
+        times.append(time.perf_counter() - t0)
+        root = [int(v) for v in tr.root()]; tr.free()
+    perms = (_linearhash_perms(width) + 1) * h
+    rate = perms / min(times[1:])
+    peak = VALU_MAD_PER_S / POSEIDON_MADS
+    res = {"workload": "MerkleTreeGL, 2^%d rows x %d columns, HBM-resident" % (log_height, width), "ms": round(min(times[1:]) * 1e3, 2),
+           "permutations": perms, "value": round(rate / 1e9, 3), "unit": "Gperm/s",
+           "roofline": {"bound": "int-alu", "kernel": "linearhash_rows_kernel + merkle_level_kernel", "achieved": round(rate / 1e9, 3),
+                        "peak": round(peak / 1e9, 3), "unit": "Gperm/s", "frac": round(rate / peak, 4),
+                        "model": "%d v_mad_u64_u32 per permutation at the measured issue rate (profiles/r02/ubench_valu.txt)" % POSEIDON_MADS}}
+    if cpu_baseline:
+        import oracle_lib
+        orc = oracle_lib.load()
+        m = 1 << 18                                                      # bounded CPU sample: the first 2^18 rows
+        t0 = time.perf_counter(); exp = orc.merkelize(rows[:m * width], width, m); cpu_s = time.perf_counter() - t0
+        ts = zk.MerkleTreeGL(); ts.merkelize(rows[:m * width], width, m)
+        assert np.array_equal(ts.nodes(), exp), "GPU Merkle tree != CPU oracle"
+        res["cpu_baseline"] = {"value": round((_linearhash_perms(width) + 1) * m / cpu_s / 1e9, 5), "unit": "Gperm/s", "cores": orc.threads(),
+                               "kind": "port", "sample": "2^18-row tree of the same matrix, oracle/oracle.c (OpenMP over rows), %.2f s" % cpu_s}
+    return res
+
+
 def final_wrap_leg(zk, nbits=18, log_rows=18):
     """BASELINE config 5, the serial tail on rank 0 after the roots are gathered (test/stark_aggregation.sh:159-210):
     the compressor's exec step (witness -> trace), the final STARK with BLS12381 hashing and the BLS12-381 Groth16 wrap,
@@ -183,36 +241,72 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     return out
 
 
-def aggregation_leg(zk, dist, rank, world, nbits, device, n_proofs=2):
-    """BASELINE config 5, the sharded part of recursion/stark_aggregation.sh: independent sub-proofs, one
-    stream of them per GPU, no collective while proving; the one exchange is the all-gather of each
-    rank's root (32 B).  Every rank proves `n_proofs` witnesses of the same PIL with its own inputs."""
-    import importlib, torch
-    sys.path.insert(0, str(ROOT / "tools"))
-    import synth_pil
-    stark = importlib.import_module("eigen_zkvm_amd.stark")
-    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
-    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
-    prog_json = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
-    setup = stark.NativeStarkSetup(synth_pil.const_trace(nbits), prog_json, json.dumps(ss))
-    traces = [synth_pil.wide_fib_trace(nbits, 10, seed=1000 * rank + i) for i in range(n_proofs)]
-    proof = setup.gen(traces[0])                                         # warm-up (pool, JIT modules)
-    torch.cuda.synchronize()
+class GpuTaskProver:
+    """The three STARKs of one recursion task (test/recursive_proof_to_snark.sh:37-40, :68-71, :98-102) on this rank's GPU:
+    one setup per circuit (constants extended and merkelized once), per-task witnesses uploaded to HBM before the clock
+    starts, proofs through zk_stark_gen_dev."""
+
+    def __init__(self, zk):
+        import importlib
+        sys.path.insert(0, str(ROOT / "tools"))
+        import aggregation_workload as AW
+        stark = importlib.import_module("eigen_zkvm_amd.stark")
+        self.zk, self.AW = zk, AW
+        self.circ = {"c12": AW.Circuit(AW.STRUCTS["c12"]["nBits"]), "r1": AW.Circuit(AW.STRUCTS["r1"]["nBits"])}
+        consts = {"fib": AW.fib_consts(), "c12": self.circ["c12"].consts, "r1": self.circ["r1"].consts}
+        self.setups = {k: stark.NativeStarkSetup(consts[k], json.dumps(AW.program(k)), json.dumps(AW.STRUCTS[k])) for k in ("fib", "c12", "r1")}
+        self.sizes = {k: AW.STRUCTS[k]["nBits"] for k in self.setups}
+
+    def inputs(self, task):
+        D = self.zk.DevArray.from_host
+        return [("fib", D(self.AW.fib_trace(task))), ("c12", D(self.circ["c12"].witness(task))), ("r1", D(self.circ["r1"].witness(task)))]
+
+    def prove(self, inputs):
+        """-> the root of the committed trace of each of the task's three proofs, [[4 words]] * 3"""
+        roots = []
+        for kind, d_cm in inputs:
+            z = self.setups[kind].gen(d_cm)
+            r = z["root1"]
+            roots.append([int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])])
+        return roots
+
+    def sync(self):
+        self.zk.lib().zk_dev_sync()
+
+    def describe(self):
+        return "Fibonacci 2^10 (2 columns) + compressor-shaped circuit 2^15 and 2^18 (12 columns, PLONK gates, 12-column connection; tools/pil/c12_shape.pil), GL hash"
+
+
+def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
+    """BASELINE config 5, the sharded part of test/stark_aggregation.sh:70-73: a FIXED set of `n_tasks` independent recursion
+    tasks, task u on rank u mod world (shard_units), no collective while proving; the one exchange is the all-gather of the
+    tasks' roots (3 x 32 B per task).  Throughput = tasks / slowest rank's time, so it scales with the GPUs (strong scaling of
+    the 8-task job).  `prover` is GpuTaskProver, or a stub in the CPU tests of this control flow."""
+    units = shard_units(n_tasks, rank, world)
+    inputs = [prover.inputs(u) for u in units]                          # witness generation + upload: before the clock
+    if inputs:
+        prover.prove(inputs[0])                                         # warm-up (pool, JIT modules)
+    prover.sync()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for t in traces:
-        proof = setup.gen(t)
-    zk.lib().zk_dev_sync()
+    roots = [prover.prove(i) for i in inputs]
+    prover.sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
-    r1 = [int(v) for v in (proof["root1"] if isinstance(proof["root1"], list) else [proof["root1"], 0, 0, 0])]
-    roots = gather_roots(dist, [v - (1 << 64) if v >= (1 << 63) else v for v in r1], device)
-    return {"workload": "BASELINE config 5 (sharded part): %d sub-proofs per GPU, wide-Fibonacci PIL 20 columns, nBits=%d, "
-                        "own witness per rank, root all-gather only" % (n_proofs, nbits),
-            "proofs_per_s": round(world * n_proofs / dt, 3), "s": round(dt, 3), "n_gpus": world,
-            "distinct_roots": len({tuple(r) for r in roots})}
+    per_rank = (n_tasks + world - 1) // world
+    flat = [w for task_roots in roots for r in task_roots for w in r]
+    flat += [0] * (per_rank * 12 - len(flat))                           # ranks with one task fewer pad their slot
+    gathered = gather_roots(dist, flat, device)
+    by_task = {}
+    for rk, words in enumerate(gathered):
+        for j, u in enumerate(shard_units(n_tasks, rk, world)):
+            by_task[u] = [words[12 * j + 4 * k: 12 * j + 4 * k + 4] for k in range(3)]
+    return {"workload": "BASELINE config 5 (sharded part): %d recursion tasks, task u on rank u mod %d, each = %s; "
+                        "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
+            "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
+            "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
+            "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
 
 
 def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
@@ -314,6 +408,14 @@ def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
         times.append(time.perf_counter() - t0)
     res = {"workload": "BASELINE config 4: %s G1 Pippenger MSM, n=2^%d, c=16, HBM-resident" % (curve, logn),
            "value": round(n / min(times) / 1e6, 2), "unit": "Mpts/s", "ms": round(min(times) * 1e3, 2)}
+    # integer-ALU roofline: 16 windows x n mixed additions into buckets + 16 x 2^17 in the bucket
+    # reduction, PADD_PRODUCTS Fq products each, against the multiply-add issue ceiling
+    products = (16 * n + 16 * (1 << 17)) * PADD_PRODUCTS
+    peak = VALU_MAD_PER_S / FQ_MADS[curve]
+    res["roofline"] = {"bound": "int-alu", "kernel": "msm_accumulate_kernel (+ sort, bucket reduction)", "achieved": round(products / min(times) / 1e9, 1),
+                       "peak": round(peak / 1e9, 1), "unit": "G Fq products/s", "frac": round(products / min(times) / peak, 4),
+                       "model": "%d Fq products per sum, %d v_mad_u64_u32 per product at the measured issue rate (profiles/r02/ubench_valu.txt)"
+                                % (products, FQ_MADS[curve])}
     if n < (1 << 24):                                                   # window tables index their points with 24 bits
         # the same sum over a window table built once for the (fixed) bases -- what the Groth16 prover uses for its key
         tab = zk.MsmTable(d_bases, n, curve)
@@ -338,11 +440,16 @@ def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
         m = 1 << 18                                                     # bounded CPU sample of the same inputs
         hb = np.empty(m * 2 * nl, np.uint64)
         zk._check(zk.lib().zk_dev_download(zk._ptr(hb), d_bases.ptr, m * 16 * nl))
+        c_bits = 12
+        chunks = max(1, orc.threads() // ((256 + c_bits - 1) // c_bits))   # (window, chunk) tasks over every host thread
         t0 = time.perf_counter()
-        cv.msm(hb, scal[:m].reshape(-1), 14)
+        got, _ = cv.msm_par(hb, scal[:m].reshape(-1), c_bits, chunks)
         cpu_s = time.perf_counter() - t0
-        res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": min(orc.threads(), 19), "kind": "port",
-                               "sample": "first 2^18 points of the same input, oracle/ec_impl.h Pippenger c=14 (OpenMP over its 19 windows), %.2f s" % cpu_s}
+        d_small = zk.msm_g1_dev(d_bases, d_scal, m, curve)
+        assert np.array_equal(d_small.to_host()[:2 * nl], got), "GPU MSM != CPU oracle on the sample"
+        res["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "Mpts/s", "cores": orc.threads(), "kind": "port",
+                               "sample": "first 2^18 points of the same input, oracle/ec_impl.h Pippenger c=%d, %d windows x %d chunks over "
+                                         "all host threads, %.2f s" % (c_bits, (256 + c_bits - 1) // c_bits, chunks, cpu_s)}
     return res
 
 
@@ -355,9 +462,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prove", action="store_true", help="skip the stark_prove leg")
     ap.add_argument("--prove-nbits", type=int, default=24)
-    ap.add_argument("--agg", action="store_true", help="run the aggregation leg even at N=1")
-    ap.add_argument("--agg-nbits", type=int, default=22, help="rows (log2) of each sub-proof of the N>1 aggregation leg")
+    ap.add_argument("--no-agg", action="store_true", help="skip the aggregation leg (BASELINE config 5)")
     ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 Merkle leg")
+    ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon-GL Merkle leg")
     ap.add_argument("--no-msm", action="store_true", help="skip the BN254 MSM leg")
     ap.add_argument("--msm-logn", type=int, default=22)
     ap.add_argument("--no-groth16", action="store_true", help="skip the Groth16 leg")
@@ -421,8 +528,8 @@ def main():
     wall, dev_ms = max_over_ranks(dist, [wall, dev_ms], dev)
 
     agg = None
-    if (world > 1 or args.agg) and not args.no_prove:                  # every rank takes part
-        agg = aggregation_leg(zk, dist, rank, world, args.agg_nbits, dev)
+    if not args.no_agg and not args.no_prove:                          # every rank takes part (N = 1: all 8 tasks on this GPU)
+        agg = aggregation_leg(GpuTaskProver(zk), dist, rank, world, dev)
         if rank == 0:                                                  # the serial tail of the aggregation runs on rank 0
             try:
                 agg["final_wrap"] = final_wrap_leg(zk)
@@ -439,6 +546,7 @@ def main():
         achieved = alg_bytes_per_launch / (launch_us * 1e-6) / 1e9
         pass_gbs = 16.0 * n / (launch_us * 1e-6) / 1e9
         value = world * 2.0 * n * args.steps / wall / 1e9
+        traffic, traffic_src = pmc_traffic(nbits)
         out = {
             "metric": "Goldilocks NTT GElems/s + BN254 G1 MSM Mpts/s; starky prove ms at 2^24 rows",
             "value": round(value, 3), "unit": "GElem/s (Goldilocks NTT, 2^%d, fwd+inv)" % nbits,
@@ -451,13 +559,15 @@ def main():
                        "passes_per_transform": passes, "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "ntt_pass_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(nbits), "launch_us": round(launch_us, 2),
+                         "traffic": traffic, "traffic_source": traffic_src, "launch_us": round(launch_us, 2),
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
         }
         if not args.no_msm and world == 1:
             out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
             out["msm_g1_bls12_381"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
+        if not args.no_poseidon and world == 1:
+            out["poseidon_merkle_gl"] = poseidon_leg(zk, 22, 19, not args.no_cpu_baseline)
         if not args.no_bn128 and world == 1:
             out["merkle_bn128"] = bn128_merkle_leg(zk, 20, 12, not args.no_cpu_baseline)
         if not args.no_groth16 and world == 1:
@@ -469,15 +579,17 @@ def main():
             out["aggregation"] = agg
         if not args.no_cpu_baseline and world >= 1:
             orc = oracle_lib.load()
+            orc.ntt_blocked(x_host[:1 << 16], 16, False)                 # thread pool warm
             t0 = time.perf_counter()
-            Xc = orc.ntt(x_host, 1, nbits, False)
-            yc = orc.ntt(Xc, 1, nbits, True)
+            Xc = orc.ntt_blocked(x_host, nbits, False)
+            yc = orc.ntt_blocked(Xc, nbits, True)
             cpu_s = time.perf_counter() - t0
             assert np.array_equal(yc, x_host)
             assert np.array_equal(Xc, X.cpu().numpy().view(np.uint64)), "GPU forward NTT != CPU oracle"
             out["cpu_baseline"] = {"value": round(2.0 * n / cpu_s / 1e9, 5), "unit": "GElem/s", "cores": orc.threads(),
-                                   "kind": "port", "sample": "1 step (fwd+inv) of the same 2^%d column, "
-                                   "oracle/oracle.c orc_ntt, %.2f s" % (nbits, cpu_s)}
+                                   "kind": "port", "sample": "1 step (fwd+inv) of the same 2^%d column, oracle/oracle.c orc_ntt_blocked "
+                                   "(in-cache row transforms + transposes over all host threads, the structure of fft_p.rs:174-239), "
+                                   "%.2f s" % (nbits, cpu_s)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -107,7 +107,7 @@ int zk_transcript_free(zk_transcript_t* t);
  * one folding step (fri.rs:101-126): d_pol [1<<pol_bits][3] -> d_out [1<<step_bits][3];
  * d_special_x = the step's challenge (3 device words); shift_inv = (49^-1)^(2^(nBitsExt-pol_bits)).
  * pol_bits - step_bits <= 6 (a limit of this build: the reference folds any number of bits, fri.rs:112-126, but none
- * of its StarkStructs -- starky/data/*.starkStruct*.json -- folds more than 5; a larger step returns an error).
+ * of its StarkStructs -- the starkStruct JSON files under starky/data -- folds more than 5; a larger step returns an error).
  * step_bits == pol_bits copies (step 0 of the reference).                                                          */
 int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits,
                     const uint64_t* d_special_x, uint64_t shift_inv, uint64_t* d_out, void* stream);

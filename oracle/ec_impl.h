@@ -199,6 +199,44 @@ int EC_X(msm)(const uint64_t *bases, const uint64_t *scalars, uint64_t n, unsign
     return r.inf;
 }
 
+/* cpu_baseline of bench.py's MSM lines: the same bucket method with the (window, chunk-of-points) pairs spread over every
+ * host thread (bellman's multiexp splits the work over its worker pool the same way); equals EC_X(msm) point for point. */
+int EC_X(msm_par)(const uint64_t *bases, const uint64_t *scalars, uint64_t n, unsigned c, unsigned chunks, uint64_t *out) {
+    unsigned nw = (256 + c - 1) / c;
+    size_t nb = ((size_t)1 << c) - 1;
+    if (chunks < 1) chunks = 1;
+    jac_t *wres = (jac_t *)malloc((size_t)nw * chunks * sizeof(jac_t));
+    #pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (unsigned w = 0; w < nw; ++w)
+        for (unsigned ch = 0; ch < chunks; ++ch) {
+            const uint64_t lo = n * ch / chunks, hi = n * (ch + 1) / chunks;
+            jac_t *bk = (jac_t *)calloc(nb, sizeof(jac_t));
+            for (uint64_t i = lo; i < hi; ++i) {
+                unsigned bit = w * c; uint64_t limb = bit / 64, off = bit % 64;
+                if (limb > 3) continue;
+                uint64_t v = scalars[4 * i + limb] >> off;
+                if (off + c > 64 && limb < 3) v |= scalars[4 * i + limb + 1] << (64 - off);
+                v &= ((uint64_t)1 << c) - 1;
+                if (!v) continue;
+                aff_t a; a.x = fq_load(bases + PTW * i); a.y = fq_load(bases + PTW * i + EC_NL); a.inf = 0;
+                bk[v - 1] = jac_add_aff(bk[v - 1], &a);
+            }
+            jac_t run = jac_inf(), sum = jac_inf();
+            for (size_t k = nb; k-- > 0;) { run = jac_add(run, bk[k]); sum = jac_add(sum, run); }
+            wres[(size_t)w * chunks + ch] = sum;
+            free(bk);
+        }
+    jac_t acc = jac_inf();
+    for (unsigned w = nw; w-- > 0;) {
+        for (unsigned k = 0; k < c; ++k) acc = jac_dbl(acc);
+        for (unsigned ch = 0; ch < chunks; ++ch) acc = jac_add(acc, wres[(size_t)w * chunks + ch]);
+    }
+    free(wres);
+    aff_t r = jac_to_aff(acc);
+    memcpy(out, &r.x, FQB); memcpy(out + EC_NL, &r.y, FQB);
+    return r.inf;
+}
+
 /* ---- G2: the sextic twist y^2 = x^3 + b' over Fq2 = Fq[u]/(u^2 + 1) ---------------------------------------
  * Needs EC_B2C0, EC_B2C1 (b' = c0 + c1 u, canonical limbs) and EC_G2X0/X1/Y0/Y1 (generator, canonical limbs).
  * Points travel as pairing_ce keeps G2Affine: x.c0 || x.c1 || y.c0 || y.c1, each Fq in Montgomery form. */

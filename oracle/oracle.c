@@ -47,8 +47,12 @@ int orc_threads(void) {
 }
 
 uint32_t orc_bitrev(uint32_t x, unsigned bits) {
-    uint32_t r = 0; /* full 32-bit reversal, then >> (32 - bits): bits of x above `bits` spill in, as in the reference */
-    for (unsigned i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+    uint32_t r = x; /* full 32-bit reversal, then >> (32 - bits): bits of x above `bits` spill in, as in the reference */
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    r = ((r >> 2) & 0x33333333u) | ((r & 0x33333333u) << 2);
+    r = ((r >> 4) & 0x0F0F0F0Fu) | ((r & 0x0F0F0F0Fu) << 4);
+    r = ((r >> 8) & 0x00FF00FFu) | ((r & 0x00FF00FFu) << 8);
+    r = (r >> 16) | (r << 16);
     return bits ? r >> (32 - bits) : 0;
 }
 
@@ -99,6 +103,49 @@ static uint64_t *make_roots(unsigned bits) {
     uint64_t w = gl_root(bits), c = 1;
     for (size_t i = 0; i < half; ++i) { r[i] = c; c = gl_mul(c, w); }
     return r;
+}
+
+int orc_ntt(const uint64_t *src, uint64_t *dst, uint32_t n_pols, uint32_t nbits, int inverse);
+/* ---- cpu_baseline of bench.py's NTT line: one column, every host thread busy, structured as the reference's parallel
+ * transform is (fft_p.rs:174-239: in-cache block transforms separated by full-matrix transposes; here the blocks are the
+ * rows of the sqrt(N) x sqrt(N) view -- the textbook radix-2 above walks the whole 128 MiB column once per stage and says
+ * nothing about what a CPU can do).  Same values as orc_ntt (tests/test_oracle_kat.py compares them). */
+static void transpose_par(const uint64_t *in, uint64_t *out, size_t rows, size_t cols) {   /* out[c][r] = in[r][c] */
+    const size_t T = 32;
+    #pragma omp parallel for collapse(2) schedule(static)
+    for (size_t r0 = 0; r0 < rows; r0 += T)
+        for (size_t c0 = 0; c0 < cols; c0 += T)
+            for (size_t r = r0; r < r0 + T && r < rows; ++r)
+                for (size_t c = c0; c < c0 + T && c < cols; ++c) out[c * rows + r] = in[r * cols + c];
+}
+int orc_ntt_blocked(const uint64_t *src, uint64_t *dst, uint32_t nbits, int inverse) {
+    if (nbits < 4) return orc_ntt(src, dst, 1, nbits, inverse);
+    const unsigned b1 = nbits / 2, b2 = nbits - b1;
+    const size_t n = (size_t)1 << nbits, n1 = (size_t)1 << b1, n2 = (size_t)1 << b2;
+    uint64_t *t = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint64_t *r1 = make_roots(b1), *r2 = make_roots(b2);
+    const uint64_t w = gl_root(nbits);
+    transpose_par(src, t, n1, n2);                                    /* t[i2][i1] */
+    #pragma omp parallel for schedule(static)
+    for (size_t i2 = 0; i2 < n2; ++i2) {
+        uint64_t *row = t + i2 * n1;
+        ntt_column(row, n1, b1, r1);                                  /* -> t[i2][k1] */
+        uint64_t wi = gl_pow(w, i2), f = 1;                           /* twiddle w^(i2 k1) */
+        for (size_t k1 = 0; k1 < n1; ++k1) { row[k1] = gl_mul(row[k1], f); f = gl_mul(f, wi); }
+    }
+    transpose_par(t, dst, n2, n1);                                    /* dst[k1][i2] */
+    #pragma omp parallel for schedule(static)
+    for (size_t k1 = 0; k1 < n1; ++k1) ntt_column(dst + k1 * n2, n2, b2, r2);   /* -> dst[k1][k2] */
+    transpose_par(dst, t, n1, n2);                                    /* t[k2][k1] = X[k1 + n1 k2] */
+    if (!inverse) memcpy(dst, t, n * sizeof(uint64_t));
+    else {                                                            /* fft.rs:74-83 */
+        const uint64_t n_inv = gl_inv(gl_red((uint64_t)n));
+        dst[0] = gl_mul(t[0], n_inv);
+        #pragma omp parallel for schedule(static)
+        for (size_t i = 1; i < n; ++i) dst[i] = gl_mul(t[n - i], n_inv);
+    }
+    free(t); free(r1); free(r2);
+    return 0;
 }
 
 /* fft_p.rs:242-253 fft / ifft: batched NTT over a row-major [1<<nbits][n_pols] matrix.

@@ -27,6 +27,7 @@ class Oracle:
         L.orc_f3_inv.argtypes = [_u64p, _u64p]
         L.orc_f3_pow.argtypes = [_u64p, C.c_uint64, _u64p]
         L.orc_ntt.argtypes = [_u64p, _u64p, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_ntt_blocked.argtypes = [_u64p, _u64p, C.c_uint32, C.c_int]
         L.orc_lde.argtypes = [_u64p, C.c_uint32, C.c_uint32, _u64p, C.c_uint32]
         L.orc_poseidon.argtypes = [_u64p, _u64p, _u64p, C.c_int]
         L.orc_linearhash.argtypes = [_u64p, C.c_size_t, _u64p]
@@ -71,6 +72,10 @@ class Oracle:
     def ntt(self, src, n_pols, nbits, inverse=False):
         src = _a(src); dst = np.empty_like(src)
         self.lib.orc_ntt(src, dst, n_pols, nbits, int(inverse)); return dst
+    def ntt_blocked(self, src, nbits, inverse=False):
+        """one column, all host threads, blocks + transposes like fft_p.rs -- bench.py's cpu_baseline"""
+        src = _a(src); dst = np.empty_like(src)
+        self.lib.orc_ntt_blocked(src, dst, nbits, int(inverse)); return dst
     def lde(self, src, n_pols, nbits, nbits_ext):
         src = _a(src); dst = np.empty((1 << nbits_ext) * n_pols, np.uint64)
         self.lib.orc_lde(src, n_pols, nbits, dst, nbits_ext); return dst
@@ -303,6 +308,9 @@ class Curve:
         self._bases.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _u64p]; self._bases.restype = None
         self._msm.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint, _u64p]; self._msm.restype = C.c_int
         self._from_mont.argtypes = [_u64p, _u64p]; self._from_mont.restype = None
+        if not g2:
+            self._msm_par = getattr(lib, "orc_%s_msm_par" % name)
+            self._msm_par.argtypes = [_u64p, _u64p, C.c_uint64, C.c_uint, C.c_uint, _u64p]; self._msm_par.restype = C.c_int
 
     def generator(self):
         o = np.zeros(self.pw, np.uint64); self._gen(o); return o
@@ -317,6 +325,10 @@ class Curve:
     def msm(self, bases, scalars, c=8):
         bases = _a(bases); o = np.zeros(self.pw, np.uint64)
         inf = self._msm(bases, _a(scalars), bases.size // self.pw, c, o); return o, bool(inf)
+    def msm_par(self, bases, scalars, c=8, chunks=1):
+        """the same sum with (window, chunk) tasks over every host thread -- bench.py's cpu_baseline"""
+        bases = _a(bases); o = np.zeros(self.pw, np.uint64)
+        inf = self._msm_par(bases, _a(scalars), bases.size // self.pw, c, chunks, o); return o, bool(inf)
     def affine_ints(self, p):
         """canonical integers of the coordinates: (x, y) for G1, (x.c0, x.c1, y.c0, y.c1) for G2"""
         to_int = lambda w: sum(int(v) << (64 * i) for i, v in enumerate(w))

@@ -8,6 +8,55 @@ import torch.multiprocessing as mp
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
+class StubProver:
+    """stands in for bench.GpuTaskProver in the control-flow test: "proofs" are hashes of the task number"""
+    def __init__(self): self.proved = []
+    def inputs(self, task): return task
+    def prove(self, task):
+        self.proved.append(task)
+        return [[(task * 1000003 + 17 * k + j) % (1 << 64) if j else (1 << 63) + task for j in range(4)] for k in range(3)]
+    def sync(self): pass
+    def describe(self): return "stub"
+
+
+def _agg_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = StubProver()
+    out = bench.aggregation_leg(pr, dist, rank, world, torch.device("cpu"), n_tasks=7)   # 7: ranks get 4 and 3 tasks
+    dist.barrier()
+    q.put((rank, pr.proved, out))
+    dist.destroy_process_group()
+
+
+def test_aggregation_leg_control_flow_two_ranks():
+    world, port = 2, 29543
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # each rank proves its own tasks once after one warm-up of its first task, nobody else's
+    assert res[0][1] == [0, 0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5]
+    for _, _, out in res:                                    # every rank sees every task's roots after the all-gather
+        assert out["tasks_gathered"] == list(range(7)) and out["distinct_roots"] == 7 and out["n_gpus"] == 2
+        assert out["tasks"] == 7 and out["proofs_per_s"] == round(3 * out["tasks_per_s"], 3) or abs(out["proofs_per_s"] - 3 * out["tasks_per_s"]) < 0.01
+
+
+def test_aggregation_leg_single_rank():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    pr = StubProver()
+    out = bench.aggregation_leg(pr, None, 0, 1, torch.device("cpu"))
+    assert pr.proved == [0] + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, str(ROOT))
     import bench

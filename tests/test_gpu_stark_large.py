@@ -174,3 +174,39 @@ def test_lde_2p24_to_2p25_three_columns(zk, orc):
             acc = _addp(acc, wx)
         wx = _addp(wx, wx)
     assert np.array_equal(es[:, 1], acc)
+
+
+def test_recursion_task_proofs_match_oracle(zk, orc):
+    """BASELINE config 5's unit of work: the three STARKs of one recursion task (tools/aggregation_workload.py) through
+    bench.GpuTaskProver's path -- Fibonacci 2^10 and the compressor-shaped circuit at 2^15: zkin equal to the oracle prover's;
+    at 2^18 (r1.starkStruct.json: 6 queries): accepted by the restated verifier."""
+    import stark_prover as SP, starkinfo as SI, aggregation_workload as AW
+    stark = _stark(zk)
+    task = 5
+    # 2^10 Fibonacci, the reference's own PIL and struct
+    su = SP.setup(AW.fib_pil(), AW.fib_consts(), AW.STRUCTS["fib"], orc)
+    exp = SP.to_zkin(SP.stark_gen(AW.fib_trace(task), su, AW.STRUCTS["fib"], orc))
+    ns = _native(stark, AW.fib_consts(), json.dumps(AW.program("fib")), AW.STRUCTS["fib"])
+    assert ns.gen(zk.DevArray.from_host(AW.fib_trace(task))) == exp
+    ns.free()
+    # 2^15 compressor-shaped circuit
+    c = AW.Circuit(15)
+    ss = AW.STRUCTS["c12"]
+    su = SP.setup(AW.c12_pil(15), c.consts, ss, orc)
+    assert AW.program("c12") == json.loads(json.dumps(SI.to_json(su["starkinfo"], su["program"])))
+    cm = c.witness(task)
+    exp = SP.to_zkin(SP.stark_gen(cm, su, ss, orc))
+    ns = _native(stark, c.consts, json.dumps(AW.program("c12")), ss)
+    got = ns.gen(zk.DevArray.from_host(cm))
+    assert got == exp
+    assert ns.gen(zk.DevArray.from_host(c.witness(task + 1)))["root1"] != got["root1"]   # another task, another witness
+    ns.free()
+    # 2^18: verifier only
+    c = AW.Circuit(18)
+    ss = AW.STRUCTS["r1"]
+    info, prog, _ = SI.generate(AW.c12_pil(18), ss)
+    ns = _native(stark, c.consts, json.dumps(AW.program("r1")), ss)
+    p = SP.from_zkin(ns.gen(zk.DevArray.from_host(c.witness(task))))
+    ns.free()
+    assert len(p["fri_proof"]["queries"][0]["pol_queries"]) == 6
+    assert SP.stark_verify(p, p["rootC"], info, prog, ss, orc)

@@ -1,0 +1,93 @@
+"""Inputs of BASELINE config 5: the three STARKs of one `test/recursive_proof_to_snark.sh` task -- the starkjs Fibonacci
+circuit at 2^10 rows (:37-40, starkStruct.json.gl), a compressor-shaped circuit at 2^15 (:68-71, c12.starkStruct.json) and
+at 2^18 rows (:98-102, r1.starkStruct.json) -- for any of the 8 tasks of test/stark_aggregation.sh:70-73.  The circuits are
+fixed (one setup per size), the witnesses depend on the task.  Input generation only -- nothing here is measured or shipped.
+
+The real compressor circuits are circom-compiled verifiers of the previous proof (no circom here); tools/pil/c12_shape.pil keeps
+their shape: 12 committed columns, PLONK gates, a 12-column connection argument, publics at row 0."""
+import ctypes as C
+import gzip
+import json
+import pathlib
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+GOLD = ROOT / "tests" / "golden"
+FIB_INPUTS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]   # fibonacci.js:63-72 has 4 pairs; 8 tasks need 8
+STRUCTS = {                                                              # starky/data/{starkStruct.json.gl, c12.starkStruct.json, r1.starkStruct.json}
+    "fib": {"nBits": 10, "nBitsExt": 11, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 11}, {"nBits": 7}, {"nBits": 3}]},
+    "c12": {"nBits": 15, "nBitsExt": 16, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 16}, {"nBits": 11}, {"nBits": 7}, {"nBits": 4}]},
+    "r1": {"nBits": 18, "nBitsExt": 19, "nQueries": 6, "verificationHashType": "GL", "steps": [{"nBits": 19}, {"nBits": 13}, {"nBits": 8}, {"nBits": 4}]},
+}
+P = 0xFFFFFFFF00000001
+
+
+def _lib():
+    import poseidong
+    return poseidong._lib()
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def gl_root(nbits):
+    """MG.0[nbits] (constant.rs:54-68)"""
+    w = pow(7, 0xFFFFFFFF, P)
+    for _ in range(32 - nbits):
+        w = w * w % P
+    return w
+
+
+def c12_pil(nbits):
+    """tools/pil/c12_shape.pil compiled for 2^nbits rows (tools/pilc.py)"""
+    import re
+    import pilc
+    src = (ROOT / "tools" / "pil" / "c12_shape.pil").read_text()
+    src = re.sub(r"let N: int = 2\*\*\d+;", "let N: int = 2**%d;" % nbits, src)
+    return pilc.compile_pil(str(ROOT / "tools" / "pil" / "c12_shape.pil"), src)
+
+
+def fib_pil():
+    return json.load(open(GOLD / "starky_data" / "fib.pil.json"))
+
+
+def program(kind):
+    """{"starkinfo", "program"} for "fib" | "c12" | "r1": committed code-generator output (tools/gen_agg_fixtures.py), the
+    compressor-shaped one patched to its size"""
+    import synth_pil
+    name = "fib" if kind == "fib" else "c12shape"
+    d = json.loads(gzip.decompress((GOLD / ("%s.program.json.gz" % name)).read_bytes()))
+    if kind == "fib":
+        return d
+    info = dict(d["starkinfo"]); info["exp2pol"] = {int(k): v for k, v in info["exp2pol"].items()}
+    info = synth_pil.rescale(info, STRUCTS[kind]["nBits"])
+    return {"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]}
+
+
+class Circuit:
+    """one compressor-shaped circuit: constants + wiring, any number of witnesses"""
+
+    def __init__(self, nbits, seed=12):
+        self.nbits = nbits
+        N = 1 << nbits
+        self.consts = np.zeros(N * 26, np.uint64)
+        self.wires = np.zeros(N * 8, np.uint32)
+        _lib().c12s_circuit(C.c_uint(nbits), C.c_uint64(seed), C.c_uint64(gl_root(nbits)), _vp(self.consts), _vp(self.wires))
+
+    def witness(self, task):
+        rng = np.random.default_rng(1000 + task)
+        primary = rng.integers(0, P, size=16, dtype=np.uint64)
+        cm = np.zeros((1 << self.nbits) * 12, np.uint64)
+        _lib().c12s_witness(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), _vp(primary), _vp(cm))
+        return cm
+
+
+def fib_consts():
+    out = np.zeros(2 << 10, np.uint64); _lib().fib_consts(C.c_uint(10), _vp(out)); return out
+
+
+def fib_trace(task):
+    a, b = FIB_INPUTS[task % len(FIB_INPUTS)]
+    out = np.zeros(2 << 10, np.uint64); _lib().fib_trace(C.c_uint(10), C.c_uint64(a), C.c_uint64(b), _vp(out)); return out

@@ -3,6 +3,7 @@
  * row-major [N][2W] little-endian u64, plus splitmix64 columns for the NTT benchmark.
  * Build: gcc -O2 -shared -fPIC tools/tracegen.c -o tools/libtracegen.so */
 #include <stdint.h>
+#include <stdlib.h>
 #define P 0xFFFFFFFF00000001ULL
 static inline uint64_t addp(uint64_t a, uint64_t b) { unsigned __int128 s = (unsigned __int128)a + b; if (s >= P) s -= P; return (uint64_t)s; }
 /* first row a_k = seed + k + 1, b_k = 2k + 3: every seed is a different valid witness (sub-proof input) */
@@ -79,4 +80,87 @@ int poseidong_trace(unsigned nbits, uint64_t n_inputs, const uint64_t first[12],
         }
     }
     return 0;
+}
+
+/* ---- compressor-shaped PLONK circuit (tools/pil/c12_shape.pil; BASELINE config 5's 2^15 and 2^18 STARKs) ---------------
+ * One fixed circuit per size (gate coefficients and wiring from `seed`), many witnesses (one per sub-proof, from its primary
+ * inputs) -- as in test/recursive_proof_to_snark.sh, where every task proves the same verifier circuit on its own input.
+ * Row r: the 8 gate inputs (columns 0,1,3,4,6,7,9,10) read wires drawn from those defined so far, the 4 gate outputs
+ * (columns 2,5,8,11: a2 = C3 a0 a1 + C0 a0 + C1 a1 + C4 with C2 = -1, ...) define new ones.  The copy constraints link the
+ * cells of a wire in a cycle: S[col][row] = k_col' * w^row' for the next cell (row', col') of the same wire, k_0 = 1,
+ * k_i = k^i (helper.rs:16-23, starkinfo_Z.rs:273-423).
+ * const: [N][26] = Global.L1, S[0..11], C[0..11], GATE.  cm: [N][12].  wires: [N][8] input wire ids (the circuit).     */
+#define C12S_PRIMARY 16
+static const int C12S_IN[8] = {0, 1, 3, 4, 6, 7, 9, 10};
+static const int C12S_OUT[4] = {2, 5, 8, 11};
+static inline uint64_t powp(uint64_t a, uint64_t e) { uint64_t r = 1; while (e) { if (e & 1) r = mulp(r, a); a = mulp(a, a); e >>= 1; } return r; }
+void c12s_circuit(unsigned nbits, uint64_t seed, uint64_t root_of_unity /* MG.0[nbits] */, uint64_t *consts, uint32_t *wires) {
+    const uint64_t N = (uint64_t)1 << nbits, K = 12275445934081160404ULL, n_wires = C12S_PRIMARY + 4 * N;
+    uint64_t ks[12]; ks[0] = 1; for (int i = 1; i < 12; ++i) ks[i] = mulp(ks[i - 1], K);
+    int64_t *first = (int64_t *)malloc(n_wires * sizeof(int64_t)), *last = (int64_t *)malloc(n_wires * sizeof(int64_t));
+    int64_t *sigma = (int64_t *)malloc(12 * N * sizeof(int64_t));       /* cell = 12 * row + col */
+    uint64_t *wpow = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint64_t w = 0; w < n_wires; ++w) first[w] = last[w] = -1;
+    wpow[0] = 1; for (uint64_t i = 1; i < N; ++i) wpow[i] = mulp(wpow[i - 1], root_of_unity);
+    uint64_t ctr = 0;
+    for (uint64_t r = 0; r < N; ++r) {
+        uint64_t *o = consts + r * 26;
+        for (int j = 0; j < 26; ++j) o[j] = 0;
+        o[0] = r == 0; o[25] = 1;
+        uint64_t *C = o + 13;
+        C[0] = pg_splitmix(seed, ctr++); C[1] = pg_splitmix(seed, ctr++); C[3] = pg_splitmix(seed, ctr++); C[4] = pg_splitmix(seed, ctr++); C[2] = P - 1;
+        C[6] = pg_splitmix(seed, ctr++); C[7] = pg_splitmix(seed, ctr++); C[9] = pg_splitmix(seed, ctr++); C[10] = pg_splitmix(seed, ctr++); C[8] = P - 1;
+        const uint64_t avail = C12S_PRIMARY + 4 * r;
+        for (int g = 0; g < 12; ++g) {
+            uint64_t w;
+            int is_out = -1;
+            for (int k = 0; k < 4; ++k) if (C12S_OUT[k] == g) is_out = k;
+            if (is_out >= 0) w = avail + is_out;
+            else {
+                int slot = 0; for (int k = 0; k < 8; ++k) if (C12S_IN[k] == g) slot = k;
+                /* row 0 reads the first primary inputs in order (they are the publics); later rows draw recent wires
+                 * more often than old ones, as a compiled circuit does */
+                if (r == 0) w = slot;
+                else { uint64_t x = pg_splitmix(seed ^ 0xC125, ctr++); w = (x & 1) ? avail - 1 - (x >> 1) % (avail < 64 ? avail : 64) : (x >> 1) % avail; }
+                wires[r * 8 + slot] = (uint32_t)w;
+            }
+            const int64_t cell = 12 * (int64_t)r + g;
+            if (first[w] < 0) first[w] = cell; else sigma[last[w]] = cell;
+            last[w] = cell;
+        }
+    }
+    for (uint64_t w = 0; w < n_wires; ++w) if (first[w] >= 0) sigma[last[w]] = first[w];
+    #pragma omp parallel for schedule(static)
+    for (uint64_t r = 0; r < N; ++r)
+        for (int g = 0; g < 12; ++g) { const int64_t t = sigma[12 * r + g]; consts[r * 26 + 1 + g] = mulp(ks[t % 12], wpow[t / 12]); }
+    free(first); free(last); free(sigma); free(wpow);
+}
+void c12s_witness(unsigned nbits, const uint64_t *consts, const uint32_t *wires, const uint64_t primary[C12S_PRIMARY], uint64_t *cm) {
+    const uint64_t N = (uint64_t)1 << nbits;
+    uint64_t *val = (uint64_t *)malloc((C12S_PRIMARY + 4 * N) * sizeof(uint64_t));
+    for (int i = 0; i < C12S_PRIMARY; ++i) val[i] = primary[i] % P;
+    for (uint64_t r = 0; r < N; ++r) {
+        const uint64_t *C = consts + r * 26 + 13;
+        uint64_t *a = cm + r * 12;
+        for (int k = 0; k < 8; ++k) a[C12S_IN[k]] = val[wires[r * 8 + k]];
+        for (int g = 0; g < 4; ++g) {
+            const uint64_t x = a[3 * g], y = a[3 * g + 1], *c = C + (g < 2 ? 0 : 6);
+            a[3 * g + 2] = addp(addp(mulp(c[3], mulp(x, y)), mulp(c[0], x)), addp(mulp(c[1], y), c[4]));
+            val[C12S_PRIMARY + 4 * r + g] = a[3 * g + 2];
+        }
+    }
+    free(val);
+}
+/* the starkjs Fibonacci circuit of the first STARK of a task (fibonacci.js:8-27): const [N][2] = L1, LLAST; cm [N][2] = l1, l2 */
+void fib_consts(unsigned nbits, uint64_t *out) {
+    const uint64_t N = (uint64_t)1 << nbits;
+    for (uint64_t i = 0; i < N; ++i) { out[2 * i] = i == 0; out[2 * i + 1] = i == N - 1; }
+}
+void fib_trace(unsigned nbits, uint64_t in0, uint64_t in1, uint64_t *out) {
+    const uint64_t N = (uint64_t)1 << nbits;
+    out[1] = in0 % P; out[0] = in1 % P;                                   /* l2[0] = input[0], l1[0] = input[1] */
+    for (uint64_t i = 1; i < N; ++i) {
+        out[2 * i + 1] = out[2 * (i - 1)];
+        out[2 * i] = addp(mulp(out[2 * (i - 1) + 1], out[2 * (i - 1) + 1]), mulp(out[2 * (i - 1)], out[2 * (i - 1)]));
+    }
 }
