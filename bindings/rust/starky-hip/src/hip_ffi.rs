@@ -1,0 +1,71 @@
+//! Raw declarations of include/zkgpu.h (the subset the seams below use).  Field elements cross the boundary as canonical
+//! `u64` words -- `FGL::as_int()` on the way in, `FGL::from(u64)` on the way out (fields/src/field_gl.rs:542, :328).
+#![allow(non_camel_case_types)]
+use std::ffi::{c_char, c_int, c_void, CStr};
+
+#[repr(C)]
+pub struct zk_merkle_t {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zk_transcript_t {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct zk_stark_setup_t {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn zk_init(device: c_int) -> c_int;
+    pub fn zk_last_error() -> *const c_char;
+    pub fn zk_device_count() -> c_int;
+
+    pub fn zk_gl_ntt(src: *const u64, dst: *mut u64, n_pols: u32, nbits: u32, inverse: c_int) -> c_int;
+    pub fn zk_gl_lde(src: *const u64, n_pols: u32, nbits: u32, dst: *mut u64, nbits_ext: u32) -> c_int;
+
+    pub fn zk_gl_merkelize(buff: *const u64, width: u32, height: u64) -> *mut zk_merkle_t;
+    pub fn zk_merkle_root(t: *const zk_merkle_t, out: *mut u64) -> c_int;
+    pub fn zk_merkle_group_proof(t: *const zk_merkle_t, idx: u64, row_out: *mut u64, path_out: *mut u64) -> c_int;
+    pub fn zk_merkle_depth(t: *const zk_merkle_t) -> u32;
+    pub fn zk_merkle_elements(t: *const zk_merkle_t, out: *mut u64) -> c_int;
+    pub fn zk_merkle_free(t: *mut zk_merkle_t) -> c_int;
+
+    pub fn zk_transcript_new() -> *mut zk_transcript_t;
+    pub fn zk_transcript_put(t: *mut zk_transcript_t, words: *const u64, n: u64) -> c_int;
+    pub fn zk_transcript_get_field(t: *mut zk_transcript_t, out3: *mut u64) -> c_int;
+    pub fn zk_transcript_get_fields1(t: *mut zk_transcript_t, out: *mut u64) -> c_int;
+    pub fn zk_transcript_get_permutations(t: *mut zk_transcript_t, n: u32, nbits: u32, out: *mut u64) -> c_int;
+    pub fn zk_transcript_free(t: *mut zk_transcript_t) -> c_int;
+
+    pub fn zk_stark_setup_new(
+        starkinfo_program_json: *const c_char,
+        stark_struct_json: *const c_char,
+        const_pols: *const u64,
+        n_words: u64,
+    ) -> *mut zk_stark_setup_t;
+    pub fn zk_stark_setup_const_root(s: *const zk_stark_setup_t, out: *mut u64) -> c_int;
+    pub fn zk_stark_setup_set_prover_addr(s: *mut zk_stark_setup_t, prover_addr: *const c_char) -> c_int;
+    pub fn zk_stark_gen(s: *mut zk_stark_setup_t, cm_pols: *const u64, n_words: u64) -> *mut c_char;
+    pub fn zk_string_free(s: *mut c_char);
+    pub fn zk_stark_setup_free(s: *mut zk_stark_setup_t) -> c_int;
+    pub fn zk_bn128_load_constants(path: *const c_char) -> c_int;
+    pub fn zk_bls12381_load_constants(path: *const c_char) -> c_int;
+}
+
+/// `int` status + `zk_last_error()` -> `anyhow::Result` (the reference's error type on these paths)
+pub fn check(rc: c_int) -> anyhow::Result<()> {
+    if rc == 0 {
+        Ok(())
+    } else {
+        Err(last_error())
+    }
+}
+
+pub fn last_error() -> anyhow::Error {
+    let msg = unsafe { CStr::from_ptr(zk_last_error()) }.to_string_lossy().into_owned();
+    anyhow::anyhow!("libzkgpu: {msg}")
+}
+
+#[allow(dead_code)]
+pub type Opaque = c_void;

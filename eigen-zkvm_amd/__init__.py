@@ -22,7 +22,7 @@ EXPORTS = [
     "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download", "zk_dev_sync", "zk_dev_memset", "zk_dev_trim",
     "zk_gl_ntt", "zk_gl_lde", "zk_gl_ntt_dev", "zk_gl_lde_dev", "zk_gl_ntt_passes",
     "zk_gl_poseidon", "zk_gl_linearhash", "zk_gl_linearhash_rows_dev",
-    "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes",
+    "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes", "zk_merkle_elements",
     "zk_merkle_depth", "zk_merkle_group_proof", "zk_merkle_elements_dev", "zk_merkle_nodes_dev",
     "zk_merkle_free",
     "zk_transcript_new", "zk_transcript_put", "zk_transcript_put_dev", "zk_transcript_get_field",
@@ -119,6 +119,7 @@ def _load():
         "zk_gl_merkelize_dev": (vp, [vp, C.c_uint32, C.c_uint64, vp]),
         "zk_merkle_root": (C.c_int, [vp, vp]),
         "zk_merkle_nodes": (C.c_int, [vp, vp]),
+        "zk_merkle_elements": (C.c_int, [vp, vp]),
         "zk_merkle_depth": (C.c_uint32, [vp]),
         "zk_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "zk_merkle_elements_dev": (vp, [vp]),
@@ -333,6 +334,11 @@ class MerkleTreeGL:
     def nodes(self):
         o = np.zeros(lib().zk_merkle_n_nodes(self.height) * 4, np.uint64)
         _check(lib().zk_merkle_nodes(self._h, _ptr(o))); return o
+
+    def elements(self):
+        """the committed rows (to_extend, merklehash.rs:260-265)"""
+        o = np.zeros(self.height * self.width, np.uint64)
+        _check(lib().zk_merkle_elements(self._h, _ptr(o))); return o
 
     def get_group_proof(self, idx):
         d = lib().zk_merkle_depth(self._h)

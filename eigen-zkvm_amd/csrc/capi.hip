@@ -305,6 +305,14 @@ int zk_merkle_nodes(const zk_merkle_t* t, uint64_t* out) {
     });
 }
 
+int zk_merkle_elements(const zk_merkle_t* t, uint64_t* out) {
+    return guard([&] {
+        ZK_REQUIRE(t && out, "zk_merkle_elements: null");
+        ZK_HIP(hipStreamSynchronize(t->stream));
+        ZK_HIP(hipMemcpy(out, t->d_elements, (size_t)t->height * t->width * 8, hipMemcpyDeviceToHost));
+    });
+}
+
 uint32_t zk_merkle_depth(const zk_merkle_t* t) { return t ? t->depth : 0; }
 
 int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {

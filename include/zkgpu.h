@@ -82,6 +82,8 @@ zk_merkle_t* zk_gl_merkelize(const uint64_t* buff, uint32_t width, uint64_t heig
 zk_merkle_t* zk_gl_merkelize_dev(const uint64_t* d_buff, uint32_t width, uint64_t height, void* stream);
 int zk_merkle_root(const zk_merkle_t* t, uint64_t out[4]);          /* merklehash.rs:455-457    */
 int zk_merkle_nodes(const zk_merkle_t* t, uint64_t* out);           /* all n_nodes*4 words      */
+int zk_merkle_elements(const zk_merkle_t* t, uint64_t* out);        /* the committed rows, height*width words: what
+                                                                       MerkleTree::to_extend reads back (merklehash.rs:260-265) */
 uint32_t zk_merkle_depth(const zk_merkle_t* t);                     /* siblings per proof       */
 /* get_group_proof(idx) (merklehash.rs:430-438): row_out[width], path_out[depth*4];
  * idx >= height is an error, as the reference bails.                                          */

@@ -46,6 +46,16 @@ int orc_threads(void) {
 #endif
 }
 
+/* cap the team at the CPUs this process may really use (tests/oracle_lib.py reads the cgroup quota: a container that sees
+ * 256 logical CPUs but is allowed 16 runs slower with 128 threads than with 16) */
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 uint32_t orc_bitrev(uint32_t x, unsigned bits) {
     uint32_t r = x; /* full 32-bit reversal, then >> (32 - bits): bits of x above `bits` spill in, as in the reference */
     r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);

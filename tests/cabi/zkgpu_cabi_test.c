@@ -1,0 +1,85 @@
+/* A plain-C client of include/zkgpu.h, built with `gcc -std=c99 -I include` and linked against libzkgpu.so: the header must be
+ * valid C, every prototype used here must agree with what the library exports, and the calls must behave as the header says.
+ * (tests/test_cabi_c_client.py builds it; `link` mode runs without a GPU, `run` mode on the GPU box.)
+ *
+ *   zkgpu_cabi_test link
+ *   zkgpu_cabi_test run <starkinfo_program.json> <starkStruct.json> <pols.const> <pols.cm> <out zkin.json>
+ */
+#include "zkgpu.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static char *slurp(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    char *b = (char *)malloc((size_t)n + 1);
+    if (fread(b, 1, (size_t)n, f) != (size_t)n) { fprintf(stderr, "short read %s\n", path); exit(2); }
+    b[n] = 0; fclose(f);
+    if (len) *len = (size_t)n;
+    return b;
+}
+#define CHECK(call) do { if ((call) != 0) { fprintf(stderr, "%s failed: %s\n", #call, zk_last_error()); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    if (argc >= 2 && strcmp(argv[1], "link") == 0) {
+        /* take the address of one entry point per family: an undefined or mistyped symbol fails the build, not the run */
+        void *fns[] = {(void *)zk_init, (void *)zk_gl_ntt, (void *)zk_gl_lde, (void *)zk_gl_ntt_dev, (void *)zk_gl_lde_dev,
+                       (void *)zk_gl_poseidon, (void *)zk_gl_linearhash, (void *)zk_gl_merkelize, (void *)zk_merkle_root,
+                       (void *)zk_merkle_group_proof, (void *)zk_merkle_free, (void *)zk_transcript_new, (void *)zk_fri_fold_dev,
+                       (void *)zk_stark_calculate_z_dev, (void *)zk_msm_g1_bn254, (void *)zk_stark_setup_new, (void *)zk_stark_gen,
+                       (void *)zk_stark_gen_dev, (void *)zk_string_free, (void *)zk_stark_setup_free, (void *)zk_c12_exec_new,
+                       (void *)zk_groth16_setup_new, (void *)zk_program_compile};
+        unsigned n = 0;
+        for (unsigned i = 0; i < sizeof fns / sizeof fns[0]; ++i) n += fns[i] != NULL;
+        printf("linked %u entry points; p = %llu; devices = %d\n", n, (unsigned long long)zk_gl_modulus(), zk_device_count());
+        return zk_gl_modulus() == 0xFFFFFFFF00000001ULL ? 0 : 1;
+    }
+    if (argc != 7 || strcmp(argv[1], "run") != 0) { fprintf(stderr, "usage: see the head of this file\n"); return 2; }
+    if (zk_device_count() < 1) { fprintf(stderr, "no GPU: the library has no CPU fallback\n"); return 3; }
+    CHECK(zk_init(0));
+
+    /* fft_p::fft / ifft through the host-pointer entry points: inverse(forward(x)) == x, 3 columns of 2^12 */
+    enum { NB = 12, W = 3 };
+    const size_t n = ((size_t)1 << NB) * W;
+    uint64_t *x = (uint64_t *)malloc(n * 8), *y = (uint64_t *)malloc(n * 8), *z = (uint64_t *)malloc(n * 8);
+    for (size_t i = 0; i < n; ++i) x[i] = (i * 0x9E3779B97F4A7C15ULL + 12345) % 0xFFFFFFFF00000001ULL;
+    CHECK(zk_gl_ntt(x, y, W, NB, 0));
+    CHECK(zk_gl_ntt(y, z, W, NB, 1));
+    if (memcmp(x, z, n * 8) != 0) { fprintf(stderr, "NTT round trip differs\n"); return 1; }
+    if (zk_gl_ntt(x, x, W, NB, 0) == 0) { fprintf(stderr, "aliased src/dst must be rejected\n"); return 1; }
+    printf("ntt round trip ok; aliasing rejected: %s\n", zk_last_error());
+
+    /* StarkSetup's constant tree by hand: fft_p::interpolate + MerkleTreeGL::merkelize + root */
+    size_t const_bytes, cm_bytes;
+    uint64_t *cst = (uint64_t *)slurp(argv[4], &const_bytes), *cm = (uint64_t *)slurp(argv[5], &cm_bytes);
+    char *prog = slurp(argv[2], NULL), *ss = slurp(argv[3], NULL);
+    const char *nb_s = strstr(ss, "\"nBits\""), *ne_s = strstr(ss, "\"nBitsExt\"");
+    const unsigned nbits = (unsigned)atoi(strchr(nb_s, ':') + 1), nbits_ext = (unsigned)atoi(strchr(ne_s, ':') + 1);
+    const unsigned n_const = (unsigned)(const_bytes / 8 >> nbits);
+    uint64_t *ext = (uint64_t *)malloc(((size_t)n_const << nbits_ext) * 8);
+    CHECK(zk_gl_lde(cst, n_const, nbits, ext, nbits_ext));
+    zk_merkle_t *tree = zk_gl_merkelize(ext, n_const, (uint64_t)1 << nbits_ext);
+    if (!tree) { fprintf(stderr, "merkelize: %s\n", zk_last_error()); return 1; }
+    uint64_t root[4], root2[4];
+    CHECK(zk_merkle_root(tree, root));
+    if (zk_merkle_group_proof(tree, (uint64_t)1 << nbits_ext, ext, ext) == 0) { fprintf(stderr, "idx >= height must be an error\n"); return 1; }
+    CHECK(zk_merkle_free(tree));
+    printf("const_root %llu %llu %llu %llu\n", (unsigned long long)root[0], (unsigned long long)root[1], (unsigned long long)root[2], (unsigned long long)root[3]);
+
+    /* the whole prover: StarkSetup::new + StarkProof::stark_gen */
+    zk_stark_setup_t *su = zk_stark_setup_new(prog, ss, cst, const_bytes / 8);
+    if (!su) { fprintf(stderr, "zk_stark_setup_new: %s\n", zk_last_error()); return 1; }
+    CHECK(zk_stark_setup_const_root(su, root2));
+    if (memcmp(root, root2, 32) != 0) { fprintf(stderr, "setup's constant root differs from the hand-built tree\n"); return 1; }
+    char *zkin = zk_stark_gen(su, cm, cm_bytes / 8);
+    if (!zkin) { fprintf(stderr, "zk_stark_gen: %s\n", zk_last_error()); return 1; }
+    FILE *o = fopen(argv[6], "w"); fputs(zkin, o); fclose(o);
+    printf("proof written: %zu bytes\n", strlen(zkin));
+    zk_string_free(zkin);
+    if (zk_stark_gen(su, cm, cm_bytes / 8 - 1) != NULL) { fprintf(stderr, "a short trace must be rejected\n"); return 1; }
+    CHECK(zk_stark_setup_free(su));
+    free(x); free(y); free(z); free(cst); free(cm); free(prog); free(ss); free(ext);
+    return 0;
+}

@@ -182,6 +182,24 @@ def _a(x):
     return np.ascontiguousarray(np.asarray(x, dtype=np.uint64).reshape(-1))
 
 
+def usable_cpus():
+    """CPUs this process can keep busy: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota_us)"""
+    import math, os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle")])
 
@@ -341,7 +359,10 @@ def load():
         so = ROOT / "oracle" / "liboracle.so"
         if not so.exists():
             build()
-        _cached = Oracle(C.CDLL(str(so)))
+        lib = C.CDLL(str(so))
+        if "OMP_NUM_THREADS" not in __import__("os").environ:        # an explicit setting wins
+            lib.orc_set_threads(C.c_int(usable_cpus()))
+        _cached = Oracle(lib)
     return _cached
 
 

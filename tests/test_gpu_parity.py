@@ -144,6 +144,7 @@ def test_merkle_nodes_and_proofs_match_oracle(zk, orc, height, width):
     t = zk.MerkleTreeGL(); t.merkelize(buff, width, height)
     exp = orc.merkelize(buff, width, height)
     assert np.array_equal(t.nodes(), exp)
+    assert np.array_equal(t.elements(), buff)                            # to_extend (merklehash.rs:260-265)
     for idx in sorted({0, height - 1, height // 2, min(3, height - 1)}):
         row, path = t.get_group_proof(idx)
         assert np.array_equal(row, buff[idx * width:(idx + 1) * width])
