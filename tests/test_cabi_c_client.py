@@ -50,3 +50,22 @@ def test_c_client_proves_the_fib_fixture(zk, orc, golden, tmp_path):
     root = [int(v) for v in out.stdout.split("const_root ")[1].split("\n")[0].split()]
     assert root == golden["const_root_fib_gl"]["root"]                       # stark_setup.rs:100-116, through C
     assert json.load(open(tmp_path / "zkin.json")) == exp
+
+
+@pytest.mark.gpu
+def test_cli_accepts_zkit_stark_prove_flags(zk, orc, tmp_path):
+    """tools/zkgpu_prove.py stark_prove with the flags of test/recursive_proof_to_snark.sh:37-40 on the reference's fixture files"""
+    import stark_prover as SP, starkinfo as SI
+    ss = {"nBits": 10, "nBitsExt": 11, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 11}, {"nBits": 7}, {"nBits": 3}]}
+    su = SP.setup(json.load(open(D / "fib.pil.json")), D / "fib.const", ss, orc)
+    exp = SP.to_zkin(SP.stark_gen(D / "fib.cm", su, ss, orc))
+    (tmp_path / "prog.json").write_text(json.dumps(SI.to_json(su["starkinfo"], su["program"])))
+    (tmp_path / "ss.json").write_text(json.dumps(ss))
+    cmd = [sys.executable, str(ROOT / "tools" / "zkgpu_prove.py"), "stark_prove", "-s", str(tmp_path / "ss.json"), "-p", str(D / "fib.pil.json"),
+           "--o", str(D / "fib.const"), "--m", str(D / "fib.cm"), "-c", str(tmp_path / "v.circom"), "--i", str(tmp_path / "zkin.json"), "--skip_main",
+           "--program", str(tmp_path / "prog.json")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert json.load(open(tmp_path / "zkin.json")) == exp
+    bad = subprocess.run(cmd[:-2] + ["--program", str(tmp_path / "ss.json")], capture_output=True, text=True)   # not a program
+    assert bad.returncode == 1 and "zkgpu_prove:" in bad.stderr

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""zkgpu_prove -- the prover sub-commands of the reference's `eigen-zkit` on libzkgpu (last row):
+
+  zkgpu_prove.py stark_prove -s starkStruct.json -p circuit.pil.json --o circuit.const --m circuit.cm \\
+                             -c verifier.circom --i zkin.json [--norm_stage] [--skip_main] [--agg_stage] [--prover_addr A] \\
+                             [--program starkinfo_program.json]
+  zkgpu_prove.py groth16_prove -c BN128 --r1cs circuit.r1cs -w witness.wtns -p g16.key --public-input public_input.json --proof proof.json
+
+Flags, defaults and file formats are zkit's (zkit/src/main.rs:98-123 StarkProveOpt, :199-217 Groth16ProveOpt;
+starky/src/prove.rs:30-160, groth16/src/api.rs:144-205).  What differs, and why:
+  * stark_prove needs the code generator's output, `{"starkinfo": StarkInfo, "program": Program}` (serde names, starkinfo.rs:27-95):
+    `--program FILE`, or -- when the file is absent -- the library's own generator (zk_starkinfo_generate) if this build has one.
+    The reference runs `StarkInfo::new` in process; with the Rust shim (bindings/rust/starky-hip) that is still what happens.
+  * `-c/--circom`: the circom verifier text comes from `pil2circom` (template rendering, out of scope): the flag is
+    accepted and the file is left untouched.
+  * groth16_prove: `-w` takes the `.wtns` the witness calculator wrote (zkit passes the .wasm and an input.json and runs the
+    calculator in process, api.rs:150-160: WASM execution is out of scope); `-i` is accepted and ignored.
+Exit status 0 on success, 1 with the library's message on stderr otherwise (zkit: anyhow error -> exit 1)."""
+import argparse
+import json
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _zk():
+    import zkgpu_loader
+    zk = zkgpu_loader.load()
+    if zk.lib().zk_device_count() < 1:
+        raise SystemExit("zkgpu_prove: no GPU visible (the library has no CPU fallback)")
+    zk.init(0)
+    return zk
+
+
+def stark_prove(a):
+    import importlib
+    import numpy as np
+    zk = _zk()
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    ss = json.load(open(a.stark_struct))
+    pil = json.load(open(a.piljson))
+    const = np.fromfile(a.const_pols, dtype="<u8")                       # polsarray.rs:137-217: headerless LE u64, row-major
+    cm = np.fromfile(a.cm_pols, dtype="<u8")
+    n = 1 << ss["nBits"]
+    if const.size != n * pil["nConstants"] or cm.size != n * pil["nCommitments"]:
+        raise SystemExit("zkgpu_prove: %s / %s do not hold 2^%d rows of %d / %d columns"
+                         % (a.const_pols, a.cm_pols, ss["nBits"], pil["nConstants"], pil["nCommitments"]))
+    if a.program:
+        program_json = open(a.program).read()
+    elif hasattr(stark, "generate_program"):
+        program_json = stark.generate_program(json.dumps(pil), json.dumps(ss))
+    else:
+        raise SystemExit("zkgpu_prove: --program FILE is required (this build has no code generator)")
+    setup = stark.NativeStarkSetup(const, program_json, json.dumps(ss), prover_addr=a.prover_addr if ss.get("verificationHashType") != "GL" else None)
+    zkin = setup.gen(cm)
+    with open(a.zkin, "w") as f:
+        json.dump(zkin, f)
+    setup.free()
+    print("zkgpu_prove: proof of 2^%d rows written to %s (rootC %s)" % (ss["nBits"], a.zkin, zkin["rootC"]))
+
+
+def groth16_prove(a):
+    import importlib
+    zk = _zk()
+    dev = importlib.import_module("eigen_zkvm_amd.groth16")
+    r1cs, pk, wtns = (pathlib.Path(p).read_bytes() for p in (a.circuit_file, a.pk_file, a.wasm_file))
+    if not wtns.startswith(b"wtns"):
+        raise SystemExit("zkgpu_prove: -w must be the .wtns file of the witness calculator (running the .wasm is out of scope)")
+    setup = dev.Groth16Setup(a.curve_type, r1cs, pk)
+    w = dev.wtns_values(wtns, a.curve_type)
+    proof, _ = setup.prove(w)
+    if a.to_hex:
+        raise SystemExit("zkgpu_prove: -t (hex output) is not implemented")
+    json.dump(proof, open(a.proof_file, "w"))
+    to_int = lambda row: sum(int(v) << (64 * i) for i, v in enumerate(row))
+    json.dump([str(to_int(w[i])) for i in range(1, setup.n_inputs)], open(a.public_input_file, "w"))   # api.rs:175-177
+    setup.free()
+    print("zkgpu_prove: %s proof written to %s" % (a.curve_type, a.proof_file))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="zkgpu_prove", description=__doc__.split("\n")[0])
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    s = sub.add_parser("stark_prove", help="Stark proving (zkit/src/main.rs:98-123)")
+    s.add_argument("-s", "--stark_stuct", dest="stark_struct", default="stark_struct.json")
+    s.add_argument("-p", "--piljson", default="pil.json")
+    s.add_argument("-n", "--norm_stage", action="store_true")
+    s.add_argument("--skip_main", action="store_true")
+    s.add_argument("-a", "--agg_stage", action="store_true")
+    s.add_argument("--o", dest="const_pols", default="pols.const")
+    s.add_argument("--m", dest="cm_pols", default="pols.cm")
+    s.add_argument("-c", "--circom", dest="circom_file", default="stark_verfier.circom")
+    s.add_argument("--i", dest="zkin", default="zkin.json")
+    s.add_argument("--prover_addr", default="273030697313060285579891744179749754319274977764")
+    s.add_argument("--program", help='{"starkinfo", "program"} JSON of the code generator (extension, see the module text)')
+    s.set_defaults(fn=stark_prove)
+    g = sub.add_parser("groth16_prove", help="Prove with groth16 (zkit/src/main.rs:199-217)")
+    g.add_argument("-c", dest="curve_type", default="BN128")
+    g.add_argument("--r1cs", dest="circuit_file", required=True)
+    g.add_argument("-w", dest="wasm_file", required=True)
+    g.add_argument("-p", dest="pk_file", default="g16.zkey")
+    g.add_argument("-i", dest="input_file", default=None)
+    g.add_argument("--public-input", dest="public_input_file", default="public_input.json")
+    g.add_argument("--proof", dest="proof_file", default="proof.json")
+    g.add_argument("-t", dest="to_hex", action="store_true")
+    g.set_defaults(fn=groth16_prove)
+    a = ap.parse_args(argv)
+    try:
+        a.fn(a)
+    except SystemExit:
+        raise
+    except Exception as e:                                                # anyhow error -> message + exit 1
+        print("zkgpu_prove: %s" % e, file=sys.stderr)
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
