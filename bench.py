@@ -220,11 +220,8 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     out["c12_exec_ms"] = round((time.perf_counter() - t0) * 1e3, 2); out["c12_exec_depth"] = int(E.depth)
     E.free()
     # 2. final STARK, BLS12381 hashing (MerkleTreeBLS12381 + TranscriptBLS12381)
-    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
-    info, ss = synth_pil.rescale(d["starkinfo"], nbits), synth_pil.stark_struct(nbits)
-    ss["verificationHashType"] = "BLS12381"
-    pj = json.dumps({"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]})
+    prog, ss = synth_pil.program(nbits, 10, "BLS12381")
+    pj = json.dumps(prog)
     setup = stark.NativeStarkSetup(synth_pil.const_trace(nbits), pj, json.dumps(ss))
     d_cm = zk.DevArray.from_host(synth_pil.wide_fib_trace(nbits, 10))
     setup.gen(d_cm)

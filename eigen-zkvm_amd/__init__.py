@@ -14,7 +14,7 @@ import pathlib
 import numpy as np
 
 _HERE = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libzkgpu.so"
+LIB_PATH = pathlib.Path(os.environ["ZKGPU_LIB"]) if os.environ.get("ZKGPU_LIB") else _HERE / "libzkgpu.so"   # ZKGPU_LIB: an experimental build (tools/)
 P = 0xFFFFFFFF00000001
 
 EXPORTS = [
@@ -46,7 +46,7 @@ EXPORTS = [
     "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_free",
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
-    "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
+    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
     "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
     "zk_c12_exec_new", "zk_c12_exec_dev", "zk_c12_exec_depth", "zk_c12_exec_free",
@@ -177,6 +177,7 @@ def _load():
         "zk_bls12381_transcript_get_field": (C.c_int, [vp, vp]),
         "zk_bls12381_transcript_get_permutations": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "zk_bls12381_transcript_free": (C.c_int, [vp]),
+        "zk_starkinfo_generate": (vp, [C.c_char_p, C.c_char_p]),
         "zk_stark_setup_new": (vp, [C.c_char_p, C.c_char_p, vp, C.c_uint64]),
         "zk_stark_setup_const_root": (C.c_int, [vp, vp]),
         "zk_stark_setup_set_prover_addr": (C.c_int, [vp, C.c_char_p]),

@@ -58,6 +58,59 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const u64* __restrict__ p
     st3(out + 3 * g, gl::f3_muls(r, nx_inv));
 }
 
+// The same fold for reductions of more than 6 bits per step (final.starkStruct.*.json folds 2^17 -> 2^7: 1024 points per
+// group): one workgroup per g, the size-NX inverse transform of all three limbs in LDS (radix-2 decimation in time over
+// bit-reversed loads), then the evaluation at y as 256 per-thread Horner chunks folded pairwise with y^CH, y^2CH, ...
+// Only the last, small FRI steps come here, so clarity wins over speed.
+constexpr int FOLD_BIG_MAX_LOG = 11;
+__global__ __launch_bounds__(256) void fri_fold_big_kernel(const u64* __restrict__ pol, u64 pol2_n, u32 lognx, u64 shift_inv, u64 wi, u64 w_nx_inv,
+                                                           u64 nx_inv, const u64* __restrict__ special_x, u64* __restrict__ out) {
+    extern __shared__ u64 fold_lds[];
+    const u32 NX = 1u << lognx, t = threadIdx.x;
+    u64* buf = fold_lds;                 // [NX][3]
+    u64* tw = fold_lds + 3 * (u64)NX;    // [NX/2]: w_nx^-j
+    const u64 g = blockIdx.x;
+    for (u32 i = t; i < NX; i += 256) {
+        const u32 rv = __brev(i) >> (32 - lognx);
+        const f3 v = ld3(pol + ((u64)i * pol2_n + g) * 3);
+        st3(buf + 3 * (u64)rv, v);
+    }
+    for (u32 j = t; j < NX / 2; j += 256) tw[j] = gl::pow(w_nx_inv, j);
+    __syncthreads();
+    for (u32 s = 1; s <= lognx; ++s) {
+        const u32 half = 1u << (s - 1), stride = NX >> s;
+        for (u32 b = t; b < NX / 2; b += 256) {
+            const u32 j = b & (half - 1), k = ((b >> (s - 1)) << s) + j;
+            const f3 u = ld3(buf + 3 * (u64)k), v = gl::f3_muls(ld3(buf + 3 * (u64)(k + half)), tw[j * stride]);
+            st3(buf + 3 * (u64)k, gl::f3_add(u, v));
+            st3(buf + 3 * (u64)(k + half), gl::f3_sub(u, v));
+        }
+        __syncthreads();
+    }
+    // buf[k] = NX * c_k.  P(y) = sum_k c_k y^k with y = special_x * shift_inv * wi^g
+    const f3 y = gl::f3_muls(ld3(special_x), gl::mul(shift_inv, gl::pow(wi, g)));
+    const u32 CH = NX / 256 ? NX / 256 : 1;                       // coefficients per thread (NX >= 128 here; fewer threads work when NX < 256)
+    const u32 n_part = NX / CH;
+    f3 acc{{0, 0, 0}};
+    if (t < n_part) {
+        acc = ld3(buf + 3 * (u64)(t * CH + CH - 1));
+        for (int j = (int)CH - 2; j >= 0; --j) acc = gl::f3_add(gl::f3_mul(acc, y), ld3(buf + 3 * (u64)(t * CH + j)));
+    }
+    __syncthreads();
+    if (t < n_part) st3(buf + 3 * (u64)t, acc);
+    f3 Y = f3_pow(y, CH);
+    __syncthreads();
+    for (u32 n = n_part; n > 1; n >>= 1) {                        // p[i] = p[2i] + p[2i+1] * Y, Y <- Y^2
+        f3 r{{0, 0, 0}};
+        if (t < n / 2) r = gl::f3_add(ld3(buf + 3 * (u64)(2 * t)), gl::f3_mul(ld3(buf + 3 * (u64)(2 * t + 1)), Y));
+        __syncthreads();
+        if (t < n / 2) st3(buf + 3 * (u64)t, r);
+        Y = gl::f3_mul(Y, Y);
+        __syncthreads();
+    }
+    if (t == 0) st3(out + 3 * g, gl::f3_muls(ld3(buf), nx_inv));
+}
+
 __global__ void copy3_kernel(const u64* __restrict__ in, u64 n, u64* __restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i];
@@ -296,9 +349,15 @@ void fri_fold_dev(const u64* d_pol, uint32_t pol_bits, uint32_t step_bits, const
         ZK_HIP(hipGetLastError());
         return;
     }
-    ZK_REQUIRE(r <= 6, "fri_fold: reduction of more than 6 bits per step is not supported");
+    ZK_REQUIRE(r <= (uint32_t)FOLD_BIG_MAX_LOG, "fri_fold: reduction of more than 11 bits per step is not supported");
     const u64* w256inv = ntt_w256_table(true);
     const u64 wi = gl::hinv(gl::hroot(pol_bits)), nx_inv = gl::hinv(1ull << r);
+    if (r > 6) {
+        const size_t lds = ((size_t)3 << r) * 8 + ((size_t)1 << (r - 1)) * 8;
+        hipLaunchKernelGGL(fri_fold_big_kernel, dim3((unsigned)n2), dim3(256), lds, st, d_pol, n2, r, shift_inv, wi, gl::hinv(gl::hroot(r)), nx_inv, d_special_x, d_out);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
 #define ZK_FOLD(L) hipLaunchKernelGGL((fri_fold_kernel<L>), grid1(n2), dim3(256), 0, st, d_pol, n2, w256inv, shift_inv, wi, nx_inv, d_special_x, d_out)
     switch (r) {
         case 1: ZK_FOLD(1); break; case 2: ZK_FOLD(2); break; case 3: ZK_FOLD(3); break;

@@ -352,6 +352,19 @@ def to_zkin(proof):
     return z
 
 
+def generate_program(pil_json, stark_struct_json):
+    """StarkInfo::new (starkinfo.rs:160-272) inside the library: compiled PIL + StarkStruct (JSON text) -> the
+    '{"starkinfo": ..., "program": ...}' text NativeStarkSetup takes.  Host only, no GPU needed."""
+    import ctypes
+    p = lib().zk_starkinfo_generate(pil_json.encode(), stark_struct_json.encode())
+    if not p:
+        raise ZkError(lib().zk_last_error().decode())
+    try:
+        return ctypes.string_at(p).decode()
+    finally:
+        lib().zk_string_free(p)
+
+
 class NativeStarkSetup:
     """The C++ driver inside libzkgpu (csrc/stark_prover.hip): StarkSetup::new + stark_gen + FRI::prove
     behind zk_stark_setup_new / zk_stark_gen.  `program_json` = '{"starkinfo": ..., "program": ...}' text."""

@@ -108,9 +108,8 @@ int zk_transcript_free(zk_transcript_t* t);
 /* ---- FRI (starky/src/fri.rs:84-184) ----------------------------------------------------------
  * one folding step (fri.rs:101-126): d_pol [1<<pol_bits][3] -> d_out [1<<step_bits][3];
  * d_special_x = the step's challenge (3 device words); shift_inv = (49^-1)^(2^(nBitsExt-pol_bits)).
- * pol_bits - step_bits <= 6 (a limit of this build: the reference folds any number of bits, fri.rs:112-126, but none
- * of its StarkStructs -- the starkStruct JSON files under starky/data -- folds more than 5; a larger step returns an error).
- * step_bits == pol_bits copies (step 0 of the reference).                                                          */
+ * pol_bits - step_bits <= 11 (the reference folds any number of bits, fri.rs:112-126; its largest step is the 10 bits of
+ * final.starkStruct.*.json, 2^17 -> 2^7).  step_bits == pol_bits copies (step 0 of the reference).                   */
 int zk_fri_fold_dev(const uint64_t* d_pol, uint32_t pol_bits, uint32_t step_bits,
                     const uint64_t* d_special_x, uint64_t shift_inv, uint64_t* d_out, void* stream);
 /* get_transposed_buffer (fri.rs:299-317): [n] F3G -> [1<<tbits][n>>tbits][3] words */
@@ -245,6 +244,12 @@ int zk_bls12381_transcript_free(zk_bls12381_transcript_t* t);
  * zkin JSON the reference's serialiser writes (serializer.rs:146-261), malloc'ed: release it with
  * zk_string_free.  NULL on error (zk_last_error), e.g. "z does not close" (stark_gen.rs:663-664).
  * A setup is bound to the device current at creation and is not re-entrant.                         */
+/* The code generator: stands behind StarkInfo::new (starky/src/starkinfo.rs:160-272; called from StarkSetup::new,
+ * stark_setup.rs:45-52).  pil_json = the compiled PIL (types.rs:134-155, what pilcom writes), stark_struct_json = the
+ * StarkStruct.  Returns the JSON zk_stark_setup_new takes, {"starkinfo": StarkInfo, "program": Program} in the reference's
+ * serde names, malloc'ed (zk_string_free); NULL on error, e.g. "stark_deg != pil_deg", "Global.L1 must be defined".
+ * Host only.  A caller that has the Rust front end passes its own serde output instead and never needs this. */
+char* zk_starkinfo_generate(const char* pil_json, const char* stark_struct_json);
 typedef struct zk_stark_setup zk_stark_setup_t;
 zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const char* stark_struct_json,
                                      const uint64_t* const_pols, uint64_t n_words);

@@ -46,10 +46,10 @@ def test_poseidong_zkin_equals_oracle(zk, orc, nbits, n_inputs):
     info = su["starkinfo"]
     assert (info["n_cm1"], info["n_constants"], info["n_cm3"], info["q_deg"], info["q_dim"]) == (19, 18, 36, 2, 3)
     exp = SP.to_zkin(SP.stark_gen(cm, su, ss, orc))
-    # the committed code-generator output the bench uses is what the generator makes at this size
-    fixture = PG.program(nbits)
-    assert fixture == json.loads(json.dumps(SI.to_json(su["starkinfo"], su["program"])))
-    ns = _native(stark, const, json.dumps(fixture), ss)
+    # the product's own code generator (what the bench uses) makes what the oracle's makes
+    program = PG.program(nbits)
+    assert program == json.loads(json.dumps(SI.to_json(su["starkinfo"], su["program"])))
+    ns = _native(stark, const, json.dumps(program), ss)
     got = ns.gen(zk.DevArray.from_host(cm))
     assert list(got) == list(exp)
     for k in exp:

@@ -83,7 +83,9 @@ def test_native_driver_rejects_bad_input(zk):
     with pytest.raises(zk.ZkError):
         stark.NativeStarkSetup(np.zeros(4, np.uint64), "{not json", json.dumps(GL_STRUCT))
     bad = dict(GL_STRUCT, verificationHashType="SHA256")
-    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
+    sys.path.insert(0, str(ROOT / "tools"))
+    import synth_pil
+    d, _ = synth_pil.program(10)
     with pytest.raises(zk.ZkError):                                          # GL, BN128 and BLS12381 only
         stark.NativeStarkSetup(np.zeros(1 << 10, np.uint64), json.dumps(d), json.dumps(bad))
     with pytest.raises(zk.ZkError):                                          # const trace of the wrong size

@@ -46,7 +46,7 @@ def test_transcript_device_side_io(zk, orc):
 
 
 # ---- FRI (fri.rs) ---------------------------------------------------------------------------
-@pytest.mark.parametrize("pol_bits,step_bits", [(5, 5), (3, 2), (6, 2), (11, 7), (7, 3), (12, 6), (13, 12), (16, 11), (18, 13)])
+@pytest.mark.parametrize("pol_bits,step_bits", [(5, 5), (3, 2), (6, 2), (11, 7), (7, 3), (12, 6), (13, 12), (16, 11), (18, 13), (17, 7), (10, 3), (12, 1), (11, 0), (19, 8)])
 def test_fri_fold_matches_oracle(zk, orc, pol_bits, step_bits):
     rng = np.random.default_rng(pol_bits * 100 + step_bits)
     pol = _f3(rng, 1 << pol_bits)

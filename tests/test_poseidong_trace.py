@@ -79,13 +79,6 @@ def test_oracle_proves_and_verifies_poseidong_and_interpreters_agree(orc):
     assert not SP.stark_verify(pb, pb["rootC"], info, su["program"], ss, orc)
 
 
-def test_program_fixture_matches_generator(orc):
-    import starkinfo as SI, poseidong as PG
-    for nbits in (10, 14):
-        info, prog, _ = SI.generate(PG.pil(nbits), PG.stark_struct(nbits))
-        assert PG.program(nbits) == json.loads(json.dumps(SI.to_json(info, prog)))
-
-
 def test_c_interpreter_equals_python_on_reference_fixtures(orc):
     import stark_prover as SP
     D = ROOT / "tests" / "golden" / "starky_data"

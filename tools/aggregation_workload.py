@@ -6,7 +6,6 @@ fixed (one setup per size), the witnesses depend on the task.  Input generation 
 The real compressor circuits are circom-compiled verifiers of the previous proof (no circom here); tools/pil/c12_shape.pil keeps
 their shape: 12 committed columns, PLONK gates, a 12-column connection argument, publics at row 0."""
 import ctypes as C
-import gzip
 import json
 import pathlib
 
@@ -54,16 +53,9 @@ def fib_pil():
 
 
 def program(kind):
-    """{"starkinfo", "program"} for "fib" | "c12" | "r1": committed code-generator output (tools/gen_agg_fixtures.py), the
-    compressor-shaped one patched to its size"""
-    import synth_pil
-    name = "fib" if kind == "fib" else "c12shape"
-    d = json.loads(gzip.decompress((GOLD / ("%s.program.json.gz" % name)).read_bytes()))
-    if kind == "fib":
-        return d
-    info = dict(d["starkinfo"]); info["exp2pol"] = {int(k): v for k, v in info["exp2pol"].items()}
-    info = synth_pil.rescale(info, STRUCTS[kind]["nBits"])
-    return {"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]}
+    """{"starkinfo", "program"} for "fib" | "c12" | "r1" from the product's code generator"""
+    import poseidong
+    return poseidong.native_program(fib_pil() if kind == "fib" else c12_pil(STRUCTS[kind]["nBits"]), STRUCTS[kind])
 
 
 class Circuit:

@@ -86,12 +86,16 @@ def trace(nbits, n_inputs=None, first=FIRST_ZERO, seed=0):
     return out
 
 
-def program(nbits):
-    """{"starkinfo", "program"} of the PoseidonG PIL at 2^nbits rows: the committed code-generator output
-    (tests/golden/poseidong.program.json.gz, tools/gen_poseidong_program.py) with its size-dependent fields patched"""
-    import gzip
-    import synth_pil
-    d = json.loads(gzip.decompress((ROOT / "tests" / "golden" / "poseidong.program.json.gz").read_bytes()))
-    info = dict(d["starkinfo"]); info["exp2pol"] = {int(k): v for k, v in info["exp2pol"].items()}
-    info = synth_pil.rescale(info, nbits)
-    return {"starkinfo": dict(info, exp2pol={str(k): v for k, v in info["exp2pol"].items()}), "program": d["program"]}
+def native_program(pil_dict, ss):
+    """{"starkinfo", "program"} from the product's own code generator (zk_starkinfo_generate, csrc/starkinfo_gen.hip)"""
+    import importlib, sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    import zkgpu_loader
+    zkgpu_loader.load()
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    return json.loads(stark.generate_program(json.dumps(pil_dict), json.dumps(ss)))
+
+
+def program(nbits, ss=None):
+    """{"starkinfo", "program"} of the PoseidonG PIL at 2^nbits rows"""
+    return native_program(pil(nbits), ss or stark_struct(nbits))

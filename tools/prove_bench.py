@@ -49,15 +49,12 @@ def main():
     args = ap.parse_args()
     if args.pil == "poseidong":
         return poseidong_main(args)
-    assert args.w == 10, "only the committed W=10 program fixture is available"
     zk = zkgpu_loader.load(); zk.init(0)
     stark = importlib.import_module("eigen_zkvm_amd.stark")
-    d = json.load(open(ROOT / "tests" / "golden" / "widefib_w10.program.json"))
-    d["starkinfo"]["exp2pol"] = {int(k): v for k, v in d["starkinfo"]["exp2pol"].items()}
     for nbits in args.nbits:
-        info = synth_pil.rescale(d["starkinfo"], nbits)
-        ss = synth_pil.stark_struct(nbits)
-        ss["verificationHashType"] = args.hash
+        prog, ss = synth_pil.program(nbits, args.w, args.hash)
+        info = prog["starkinfo"]; info["exp2pol"] = {int(k): v for k, v in info["exp2pol"].items()}
+        d = {"program": prog["program"]}
         cm = synth_pil.wide_fib_trace(nbits, args.w)
         const = synth_pil.const_trace(nbits)
         t0 = time.perf_counter()

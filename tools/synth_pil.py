@@ -47,22 +47,11 @@ def const_trace(nbits):
     return c
 
 
-def rescale(info, nbits):
-    """patch the size-dependent fields of a starkinfo generated at another nBits (same PIL shape):
-    the public's row index and the section degrees/offsets (starkinfo_map.rs:221-252)."""
-    import copy
-    info = copy.deepcopy(info)
-    N, Next = 1 << nbits, 1 << (nbits + 1)
-    old_n = info["map_deg"]["cm1_n"]
-    for p in info["publics"]:                      # publics declared at row N-1 follow the size, the others stay
-        if p["idx"] == old_n - 1:
-            p["idx"] = N - 1
-    acc = 0
-    for s, deg in (("cm1_n", N), ("cm2_n", N), ("cm3_n", N), ("cm4_n", N), ("tmpexp_n", N), ("cm1_2ns", Next),
-                   ("cm2_2ns", Next), ("cm3_2ns", Next), ("cm4_2ns", Next), ("q_2ns", Next), ("f_2ns", Next)):
-        info["map_offsets"][s] = acc; acc += deg * info["map_sectionsN"][s]; info["map_deg"][s] = deg
-    info["map_total_n"] = acc
-    return info
+def program(nbits, W=10, hash_type="GL"):
+    """({"starkinfo", "program"}, stark_struct) of the wide-Fibonacci PIL from the product's code generator"""
+    import poseidong
+    ss = stark_struct(nbits); ss["verificationHashType"] = hash_type
+    return poseidong.native_program(wide_fib_pil(nbits, W), ss), ss
 
 
 def wide_fib_trace(nbits, W, seed=0):
