@@ -91,9 +91,11 @@ struct Gen {
     std::map<uint32_t, Val> tmp;                                   // tmp id -> current SSA value
     std::map<std::pair<uint32_t, uint32_t>, Val> fwd, fwd_prime;   // (buf, column) -> value this lane wrote at row i / i+next
     // Rows are evaluated concurrently (one lane per row), the reference evaluates them in order inside a chunk
-    // (stark_gen.rs:752-783).  The two agree unless a cell is touched by two different rows' lanes with at least one
-    // write: a write at row i and a read (or another write) of an overlapping cell range at row i+next, in either
-    // order.  Reads served from this lane's own earlier store (fwd / fwd_prime) never reach memory and are not recorded.
+    // (stark_gen.rs:752-783).  The two agree unless one row's lane reads a cell another row's lane writes: a write at row
+    // i and a read of an overlapping cell range at row i+next, in either order.  Reads served from this lane's own
+    // earlier store (fwd / fwd_prime) never reach memory and are not recorded.  Two writes of one cell (the code generator
+    // stores an expression both at row i and, primed, at row i+next: t and t' of a plookup) carry the same field element
+    // -- the same expression evaluated at the same row -- whichever lane lands last.
     struct Access { uint32_t buf, id, dim; bool prime; };
     std::vector<Access> mem_reads, mem_writes;
     void check_row_hazards() const {
@@ -101,8 +103,6 @@ struct Gen {
         for (const Access& w : mem_writes) {
             for (const Access& r : mem_reads)
                 ZK_REQUIRE(!(overlap(w, r) && w.prime != r.prime), "eval program: a column is written at one row and read at the next row in the same step");
-            for (const Access& w2 : mem_writes)
-                ZK_REQUIRE(!(overlap(w, w2) && w.prime != w2.prime), "eval program: a column is written at both the current and the next row in the same step");
         }
     }
     int n_val = 0;

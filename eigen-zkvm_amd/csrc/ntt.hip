@@ -84,13 +84,27 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
         const u64 u = u0 + c;
         const bool live = u < P.inner;
         u64 x[GA][RA];
+        // Whole tile inside the matrix and inside the rows that exist (wave-uniform test): sixteen unconditional loads,
+        // issued back to back.  Otherwise (ragged last tile, or the zero-padded half of an extension's first forward
+        // pass) every load still goes out unconditionally -- of word 0 where there is nothing to read -- and is zeroed afterwards: a
+        // branch per element would serialise the loads behind each other's latency.
+        const bool full = u0 + C <= P.inner && (u64)(R - 1) * P.inner + u0 + C <= P.valid_in;
+        const u64* __restrict__ base = P.in + (u64)(ta * GA) * P.inner + (live ? u : 0);
+        if (full) {
 #pragma unroll
-        for (int g = 0; g < GA; ++g) {
+            for (int g = 0; g < GA; ++g)
 #pragma unroll
-            for (int ja = 0; ja < RA; ++ja) {
-                const u64 idx = (u64)(ja * RB + ta * GA + g) * P.inner + u;
-                x[g][ja] = (live && idx < P.valid_in) ? P.in[idx] : 0;
-            }
+                for (int ja = 0; ja < RA; ++ja) x[g][ja] = base[(u64)(ja * RB + g) * P.inner];
+        } else {
+#pragma unroll
+            for (int g = 0; g < GA; ++g)
+#pragma unroll
+                for (int ja = 0; ja < RA; ++ja) {
+                    const u64 off = (u64)(ja * RB + g) * P.inner;
+                    const bool ok = live && (u64)(ta * GA) * P.inner + off + u < P.valid_in;
+                    const u64 v = *(ok ? base + off : P.in);       // word 0 always exists
+                    x[g][ja] = ok ? v : 0;
+                }
         }
 #ifndef ZK_NTT_NOMATH
 #pragma unroll

@@ -67,8 +67,14 @@ __device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74; any u64 
     u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);
     return gl::mul_nc(x6, x);
 }
+// x^7 + c for a canonical constant c: the addition rides on the multiply-adds of the last product
+__device__ __forceinline__ u64 pow7_add(u64 x, u64 c) {
+    u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);
+    return gl::mul_add_nc(x6, x, c);
+}
 
 // out[i] = sum_j M[j][i] * st[j]  (poseidon_opt.rs:111-119), M[j][i] < 2^6 folded to immediates
+template <bool CANON>
 __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
     u32 lo32[12], hi32[12];
 #pragma unroll
@@ -89,7 +95,7 @@ __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
         const u64 t1 = (h << 32) - h;
         u64 r = l + t1;
         if (r < t1) r += GL_EPS;
-        st[i] = r >= GL_P ? r - GL_P : r;
+        st[i] = (CANON && r >= GL_P) ? r - GL_P : r;                      // inside the permutation any representative does
     }
 }
 
@@ -115,13 +121,14 @@ __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restri
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(pow7(st[i]), tab[T_FC + R * 12 + i]);
-        if (R != 3) { mds_small(st); continue; }
+        for (int i = 0; i < 12; ++i) st[i] = pow7_add(st[i], tab[T_FC + R * 12 + i]);
+        if (R == 7) { mds_small<true>(st); continue; }                    // the permutation's output: canonical words
+        if (R != 3) { mds_small<false>(st); continue; }
         mat_full(tab + T_PT, st);
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
             const u64* __restrict__ SC = tab + T_SC + 11 * r;
-            st[0] = gl::add_nc(pow7(st[0]), tab[T_PC + r]);
+            st[0] = pow7_add(st[0], tab[T_PC + r]);
             u32 x0[12], x1[12];
 #pragma unroll
             for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
@@ -184,7 +191,7 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
     x = gl::add_nc(x, tab[T_C0 + lc]);
 #pragma unroll 1
     for (int R = 0; R < 8; ++R) {
-        x = gl::add_nc(pow7(x), tab[T_FC + R * 12 + lc]);
+        x = pow7_add(x, tab[T_FC + R * 12 + lc]);
         if (R != 3) { x = coop_mds(x, l); continue; }
         {
             u32 x0[12], x1[12];
@@ -193,7 +200,7 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
         }
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
-            const u64 st0 = shfl64(gl::add_nc(pow7(x), tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
+            const u64 st0 = shfl64(pow7_add(x, tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
             u32 x0[12], x1[12];
             coop_gather(l == 0 ? st0 : x, x0, x1);
             const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);           // every lane computes the same s0

@@ -84,8 +84,6 @@ def test_program_rejects_bad_code(zk):
     # overlapping cells of different ids: a dim-3 write at column 0 covers the cell a primed read takes at column 1
     with pytest.raises(zk.ZkError, match="written at one row and read at the next row"):
         _compile(zk, [("copy", T(0), {"kind": "challenge", "id": 4}, None), ("copy", M("cm3", 0, 4, dim=3), T(0), None), ("copy", T(1), M("cm3", 1, 4, prime=True), None)])
-    with pytest.raises(zk.ZkError, match="written at both the current and the next row"):
-        _compile(zk, [("copy", M("cm3", 0, 4), N(1), None), ("copy", M("cm3", 0, 4, prime=True), N(2), None)])
     # a primed store read back primed by the same lane is served from the lane's own value: accepted
     _compile(zk, [("copy", M("cm3", 0, 4, prime=True), N(1), None), ("copy", T(0), M("cm3", 0, 4, prime=True), None), ("copy", M("q", 0, 3), T(0), None)])
 
