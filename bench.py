@@ -267,6 +267,15 @@ class GpuTaskProver:
             roots.append([int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])])
         return roots
 
+    def join(self, root_a, root_b):
+        """One recursive2 step of the aggregation (test/stark_aggregation.sh:80-128: join_zkin + compressor12_exec +
+        stark_prove with r1.starkStruct.json, 2^18 rows): the joined circuit's primary inputs are the two child roots."""
+        primary = [int(w) for w in root_a] + [int(w) for w in root_b] + [0] * 8
+        cm = self.circ["r1"].witness(primary=primary)                         # the exec step (host), then the proof
+        z = self.setups["r1"].gen(self.zk.DevArray.from_host(cm))
+        r = z["root1"]
+        return [int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])]
+
     def sync(self):
         self.zk.lib().zk_dev_sync()
 
@@ -299,11 +308,42 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     for rk, words in enumerate(gathered):
         for j, u in enumerate(shard_units(n_tasks, rk, world)):
             by_task[u] = [words[12 * j + 4 * k: 12 * j + 4 * k + 4] for k in range(3)]
-    return {"workload": "BASELINE config 5 (sharded part): %d recursion tasks, task u on rank u mod %d, each = %s; "
-                        "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
-            "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
-            "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
-            "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
+    out = {"workload": "BASELINE config 5 (sharded part): %d recursion tasks, task u on rank u mod %d, each = %s; "
+                       "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
+           "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
+           "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
+           "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
+    out["join_tree"] = join_tree(prover, dist, rank, world, device, [by_task[u][2] for u in sorted(by_task)])
+    return out
+
+
+def join_tree(prover, dist, rank, world, device, leaves):
+    """The join phase as a tree instead of the reference's chain (test/stark_aggregation.sh:76-156 joins proof
+    k+1 into the running aggregate: NUM_PROOF - 1 sequential recursive2 proofs).  Level l joins neighbours pairwise, join j
+    on rank j mod world, one all-gather of the new roots per level: ceil(log2 n) dependent proofs on the critical path
+    instead of n - 1.  Every rank ends with the same root."""
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nodes, levels, joins = [list(r) for r in leaves], 0, 0
+    while len(nodes) > 1:
+        n_join = len(nodes) // 2
+        mine = shard_units(n_join, rank, world)
+        made = [prover.join(nodes[2 * j], nodes[2 * j + 1]) for j in mine]
+        per_rank = (n_join + world - 1) // world
+        flat = [w for r in made for w in r] + [0] * (4 * (per_rank - len(made)))
+        gathered = gather_roots(dist, flat, device)
+        nxt = [None] * n_join
+        for rk, words in enumerate(gathered):
+            for k, j in enumerate(shard_units(n_join, rk, world)):
+                nxt[j] = words[4 * k: 4 * k + 4]
+        if len(nodes) % 2:
+            nxt.append(nodes[-1])                                          # odd one out moves up unjoined
+        nodes, levels, joins = nxt, levels + 1, joins + n_join
+    prover.sync()
+    dt = time.perf_counter() - t0
+    (dt,) = max_over_ranks(dist, [dt], device)
+    return {"levels": levels, "joins": joins, "chain_depth_of_the_reference": max(0, len(leaves) - 1), "s": round(dt, 4), "root": [int(w) for w in nodes[0]]}
 
 
 def bn128_merkle_leg(zk, log_height, width, cpu_baseline):

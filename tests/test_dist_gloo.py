@@ -15,6 +15,9 @@ class StubProver:
     def prove(self, task):
         self.proved.append(task)
         return [[(task * 1000003 + 17 * k + j) % (1 << 64) if j else (1 << 63) + task for j in range(4)] for k in range(3)]
+    def join(self, a, b):
+        self.joined = getattr(self, "joined", 0) + 1
+        return [(3 * int(a[i]) + 5 * int(b[i]) + 7 + i) % (1 << 64) for i in range(4)]
     def sync(self): pass
     def describe(self): return "stub"
 
@@ -27,7 +30,7 @@ def _agg_worker(rank, world, port, q):
     pr = StubProver()
     out = bench.aggregation_leg(pr, dist, rank, world, torch.device("cpu"), n_tasks=7)   # 7: ranks get 4 and 3 tasks
     dist.barrier()
-    q.put((rank, pr.proved, out))
+    q.put((rank, pr.proved, out, pr.joined))
     dist.destroy_process_group()
 
 
@@ -44,7 +47,19 @@ def test_aggregation_leg_control_flow_two_ranks():
         assert p.exitcode == 0
     # each rank proves its own tasks once after one warm-up of its first task, nobody else's
     assert res[0][1] == [0, 0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5]
-    for _, _, out in res:                                    # every rank sees every task's roots after the all-gather
+    # the join tree over 7 leaves: 3 + 2 + 1 joins in 3 levels, shared between the ranks, same root everywhere and equal
+    # to the tree computed in one process
+    st = StubProver()
+    leaves = [st.prove(u)[2] for u in range(7)]
+    lvl = leaves
+    while len(lvl) > 1:
+        nxt = [st.join(lvl[2 * j], lvl[2 * j + 1]) for j in range(len(lvl) // 2)]
+        lvl = nxt + ([lvl[-1]] if len(lvl) % 2 else [])
+    assert res[0][3] + res[1][3] == 6 and res[0][3] == 4
+    for r in res:
+        jt = r[2]["join_tree"]
+        assert (jt["levels"], jt["joins"], jt["chain_depth_of_the_reference"]) == (3, 6, 6) and jt["root"] == lvl[0]
+    for _, _, out, _ in res:                                 # every rank sees every task's roots after the all-gather
         assert out["tasks_gathered"] == list(range(7)) and out["distinct_roots"] == 7 and out["n_gpus"] == 2
         assert out["tasks"] == 7 and out["proofs_per_s"] == round(3 * out["tasks_per_s"], 3) or abs(out["proofs_per_s"] - 3 * out["tasks_per_s"]) < 0.01
 
@@ -55,6 +70,7 @@ def test_aggregation_leg_single_rank():
     pr = StubProver()
     out = bench.aggregation_leg(pr, None, 0, 1, torch.device("cpu"))
     assert pr.proved == [0] + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+    assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 7)
 
 
 def _worker(rank, world, port, q):

@@ -68,9 +68,12 @@ class Circuit:
         self.wires = np.zeros(N * 8, np.uint32)
         _lib().c12s_circuit(C.c_uint(nbits), C.c_uint64(seed), C.c_uint64(gl_root(nbits)), _vp(self.consts), _vp(self.wires))
 
-    def witness(self, task):
-        rng = np.random.default_rng(1000 + task)
-        primary = rng.integers(0, P, size=16, dtype=np.uint64)
+    def witness(self, task=None, primary=None):
+        """the witness of task `task`, or of the given 16 primary inputs (a join: the two child roots)"""
+        if primary is None:
+            primary = np.random.default_rng(1000 + task).integers(0, P, size=16, dtype=np.uint64)
+        primary = np.ascontiguousarray(np.asarray(primary, dtype=np.uint64) % np.uint64(P))
+        assert primary.size == 16
         cm = np.zeros((1 << self.nbits) * 12, np.uint64)
         _lib().c12s_witness(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), _vp(primary), _vp(cm))
         return cm
