@@ -166,6 +166,17 @@ struct zk_stark_setup {
     u64 const_root[4] = {};
     ProgramPtr step2prev, step3prev, step3, step42ns, step52ns;
     std::vector<ProgramPtr> public_programs;
+    // step3 (the intermediate columns) and their extension may start before the first commitment is hashed when nothing
+    // in stage 3 depends on a challenge: no plookup / permutation / connection columns and no challenge or
+    // expression-section operand in step3 itself.  The transcript order is untouched (stark_gen below).
+    bool early_stage3 = false;
+    hipStream_t side_stream = nullptr;     // memory-bound stage-3 work beside the ALU-bound hashing of tree 1
+    hipEvent_t ev_inputs = nullptr, ev_stage3 = nullptr;
+    ~zk_stark_setup() {
+        if (side_stream) { forget_stream(side_stream); (void)hipStreamDestroy(side_stream); }
+        if (ev_inputs) (void)hipEventDestroy(ev_inputs);
+        if (ev_stage3) (void)hipEventDestroy(ev_stage3);
+    }
 
     PolRef pol(u64 pol_id) const {
         ZK_REQUIRE(pol_id < var_pol_map.size(), "pol id out of range");
@@ -385,6 +396,25 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     S->step42ns = S->compile_segment(P.at("step42ns"), true, false);
     S->step52ns = S->compile_segment(P.at("step52ns"), true, false);
     for (const JVal& seg : P.at("publics_code").arr) S->public_programs.push_back(S->compile_segment(seg, false, true));
+    {
+        bool indep = S->n_cm2 == 0 && I.at("pu_ctx").size() == 0 && I.at("pe_ctx").size() == 0 && I.at("ci_ctx").size() == 0 &&
+                     S->sN[S_CM3_N] > 0 && getenv("ZK_STARK_NO_OVERLAP") == nullptr;
+        if (indep)
+            for (const JVal& c : P.at("step3").at("first").arr) {
+                auto fixed = [](const JVal& n) {
+                    const std::string& t = n.at("type_").str();
+                    return t == "tmp" || t == "cm" || t == "const" || t == "number" || t == "public" || t == "x";
+                };
+                indep = indep && fixed(c.at("dest"));
+                for (const JVal& src : c.at("src").arr) indep = indep && fixed(src);
+            }
+        if (indep) {
+            ZK_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
+            ZK_HIP(hipEventCreateWithFlags(&S->ev_inputs, hipEventDisableTiming));
+            ZK_HIP(hipEventCreateWithFlags(&S->ev_stage3, hipEventDisableTiming));
+            S->early_stage3 = true;
+        }
+    }
     return S.release();
 }
 
@@ -425,14 +455,15 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3);
     d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub));
 
-    auto run = [&](const ProgramPtr& p, bool e) {
+    auto run = [&](const ProgramPtr& p, bool e, hipStream_t on = nullptr) {
         if (!p) return;
         zk_eval_ctx c; memset(&c, 0, sizeof c);
         for (int s = 0; s < S_COUNT; ++s) c.bufs[s] = M(ptr[s]);
         c.publics = C(d_pub.u()); c.challenges = C(d_chal.u()); c.evals = C(d_evals.u());
         c.x = C(e ? x_2ns.u() : x_n.u()); c.zi = C(zi.u()); c.zi_mask = (1ull << ext) - 1;
         c.xdivxsubxi = C(xdiv.u()); c.xdivxsubwxi = C(xdivw.u());
-        ck(zk_program_run_dev(p.get(), &c, e ? nbits_ext : nbits, e ? (1ull << ext) : 1, st));
+        ck(zk_program_run_dev(p.get(), &c, e ? nbits_ext : nbits, e ? (1ull << ext) : 1, on ? on : st));
+        if (on) on_stream(st);                                                     // this thread goes on issuing on `st`
     };
     auto get_pol = [&](u64 pol_id, DevBuf& out) {                                  // stark_gen.rs:683-707
         const PolRef p = S.pol(pol_id);
@@ -491,6 +522,19 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     auto challenge = [&](int i) { tr.get_field_dev(d_chal.u() + 3 * i, st); };
     auto put_root = [&](const TreePtr& t, u64) { tr.put_root(*t, st); };
 
+    // Stage-3 columns that depend on no challenge (setup_new decided): evaluated and extended on the side stream while the
+    // main stream hashes tree 1 -- memory-bound work beside ALU-bound work.  Values and transcript order are the same.
+    const bool stage3_early = S.early_stage3;
+    if (stage3_early) {
+        ZK_HIP(hipEventRecord(S.ev_inputs, st));                                   // tables, cleared sections, publics: issued on `st`
+        ZK_HIP(hipStreamWaitEvent(S.side_stream, S.ev_inputs, 0));
+        run(S.step3, false, S.side_stream);
+        on_stream(S.side_stream);                                                  // the workspace below is used on the side stream
+        keep.emplace_back(new DevBuf); keep.back()->reserve(sN[S_CM3_N] * Next * 8);
+        lde_dev(ptr[S_CM3_N], ptr[S_CM3_2NS], keep.back()->u(), (u32)sN[S_CM3_N], nbits, nbits_ext, S.side_stream);
+        ZK_HIP(hipEventRecord(S.ev_stage3, S.side_stream));
+        on_stream(st);
+    }
     TreePtr tree1 = extend_and_merkelize(S_CM1_N, S_CM1_2NS); put_root(tree1, Next);
     challenge(0); challenge(1);                                                    // u, defVal
     run(S.step2prev, false);
@@ -524,8 +568,15 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         }
     }
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N);
-    run(S.step3, false);
-    TreePtr tree3 = extend_and_merkelize(S_CM3_N, S_CM3_2NS); put_root(tree3, Next);
+    TreePtr tree3;
+    if (stage3_early) {
+        ZK_HIP(hipStreamWaitEvent(st, S.ev_stage3, 0));                            // cm3_n and its extension are ready
+        tree3.reset(new AnyTree(bn128, ptr[S_CM3_2NS], (u32)sN[S_CM3_N], Next, st));
+    } else {
+        run(S.step3, false);
+        tree3 = extend_and_merkelize(S_CM3_N, S_CM3_2NS);
+    }
+    put_root(tree3, Next);
     challenge(4);                                                                  // vc
     run(S.step42ns, true);
     {   // Q split (stark_gen.rs:375-396)

@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/msm -o ms
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$c -o ntt -- python3 tools/pmc_ntt.py > $O/pmc_$c.log 2>&1
 done
-python3 tools/pmc_summarize.py $O/pmc > $O/pmc_hbm_traffic.txt; tail -3 $O/pmc_hbm_traffic.txt
+python3 tools/pmc_summarize.py $O/pmc > $O/pmc_hbm_traffic.txt; cp $O/pmc/pmc_hbm_traffic.json $O/; tail -3 $O/pmc_hbm_traffic.txt
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE \
     --kernel-trace --output-format csv -d $O/sq -o sq -- python3 tools/pmc_ntt.py > $O/sq.log 2>&1
 python3 - <<'PY' > gpurun_out/profiles/pmc_sq.txt

@@ -26,7 +26,7 @@ def main():
             for row in csv.DictReader(open(f)):
                 if row.get("Counter_Name") != c:
                     continue
-                name = row["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[-60:]
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
                 grid = int(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0)
                 acc[(name, grid)].append(float(row["Counter_Value"]))
         for k, v in acc.items():
