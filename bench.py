@@ -190,10 +190,11 @@ def poseidon_leg(zk, log_height, width, cpu_baseline):
     return res
 
 
-def final_wrap_leg(zk, nbits=18, log_rows=18):
-    """BASELINE config 5, the serial tail on rank 0 after the roots are gathered (test/stark_aggregation.sh:159-210):
-    the compressor's exec step (witness -> trace), the final STARK with BLS12381 hashing and the BLS12-381 Groth16 wrap,
-    each on a synthetic workload of the stated size (the recursive circuits themselves need circom)."""
+def final_wrap_leg(zk, nbits=18, log_rows=18, join_root=None):
+    """BASELINE config 5, the serial tail on rank 0 after the joins (test/stark_aggregation.sh:159-210): the compressor's exec
+    step (witness -> trace), the final STARK -- the compressor-shaped circuit with the reference's own
+    final.starkStruct.bls12381.json (2^16 rows, BLS12381 hashing, FRI steps 17 -> 7 -> 3: a 10-bit fold) on a witness derived
+    from the join tree's root -- and the BLS12-381 Groth16 wrap (the recursive circuits themselves need circom)."""
     import importlib
     sys.path.insert(0, str(ROOT / "tools"))
     import synth_pil, groth16_bench as GB
@@ -201,7 +202,9 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     dev = importlib.import_module("eigen_zkvm_amd.groth16")
     c12 = importlib.import_module("eigen_zkvm_amd.compressor12")
-    out = {"workload": "compressor12 exec 2^%d rows + final STARK (20 columns, 2^%d rows, BLS12381 hash) + Groth16 BLS12381 (2^%d rows), rank 0" % (nbits, nbits, log_rows)}
+    import aggregation_workload as AW, poseidong as PG
+    out = {"workload": "compressor12 exec 2^%d rows + final STARK (compressor-shaped circuit, final.starkStruct.bls12381.json: 2^16 rows, BLS12381 hash) "
+                       "+ Groth16 BLS12381 (2^%d rows), rank 0" % (nbits, log_rows)}
     # 1. compressor12 exec: 2^nbits rows x 12, as many additions as wires
     rng = np.random.default_rng(12)
     n_wit = 1 << (nbits + 1); n_adds = 1 << nbits; rows = 1 << nbits
@@ -220,12 +223,14 @@ def final_wrap_leg(zk, nbits=18, log_rows=18):
     out["c12_exec_ms"] = round((time.perf_counter() - t0) * 1e3, 2); out["c12_exec_depth"] = int(E.depth)
     E.free()
     # 2. final STARK, BLS12381 hashing (MerkleTreeBLS12381 + TranscriptBLS12381)
-    prog, ss = synth_pil.program(nbits, 10, "BLS12381")
-    pj = json.dumps(prog)
-    setup = stark.NativeStarkSetup(synth_pil.const_trace(nbits), pj, json.dumps(ss))
-    d_cm = zk.DevArray.from_host(synth_pil.wide_fib_trace(nbits, 10))
+    ss = {"nBits": 16, "nBitsExt": 17, "nQueries": 8, "verificationHashType": "BLS12381", "steps": [{"nBits": 17}, {"nBits": 7}, {"nBits": 3}]}
+    circ = AW.Circuit(16)
+    setup = stark.NativeStarkSetup(circ.consts, json.dumps(PG.native_program(AW.c12_pil(16), ss)), json.dumps(ss))
+    primary = ([int(w) for w in join_root] if join_root else [1, 2, 3, 4]) + [0] * 12
+    d_cm = zk.DevArray.from_host(circ.witness(primary=primary))
     setup.gen(d_cm)
-    t0 = time.perf_counter(); setup.gen(d_cm); out["final_stark_bls12381_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    t0 = time.perf_counter(); z = setup.gen(d_cm); out["final_stark_bls12381_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    out["final_stark_root1"] = z["root1"]
     setup.free()
     # 3. Groth16 wrap on BLS12-381
     rb, wit, ni, n_wires = GB.make_circuit(GB.FR["BLS12381"], log_rows)
@@ -569,7 +574,7 @@ def main():
         agg = aggregation_leg(GpuTaskProver(zk), dist, rank, world, dev)
         if rank == 0:                                                  # the serial tail of the aggregation runs on rank 0
             try:
-                agg["final_wrap"] = final_wrap_leg(zk)
+                agg["final_wrap"] = final_wrap_leg(zk, join_root=agg["join_tree"]["root"])
             except Exception as e:                                     # never lose the bench line to the extra leg
                 agg["final_wrap"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if dist is not None:

@@ -324,6 +324,34 @@ __global__ __launch_bounds__(64) void bn128_level_coop_kernel(const u64* __restr
     x = coop_poseidon_fr(x, xs, 17);
     if (i < n_ops && l == FH_OUT_IDX) store_raw(x, out + 4 * i);
 }
+// LinearHash of a few, possibly very wide rows (the FRI trees of a large fold: final.starkStruct.*.json commits 2^7 rows of 3072
+// words): one lane per row would run 64 sponge steps of 1.2 M instructions each on 128 lanes.  32 lanes per row instead, the
+// sponge steps of linearhash_bn128.rs:105-131 in order, the digest handed from lane FH_OUT_IDX to lane 0 through LDS.
+__global__ __launch_bounds__(64) void bn128_leaf_coop_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    __shared__ u32 xs_all[2][17 * NR];
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    u32* xs = xs_all[g];
+    const u64 i = (u64)blockIdx.x * 2 + g;
+    const u64 ic = i < height ? i : height - 1;                 // an idle group shadows the last row
+    const u64* __restrict__ v = rows + ic * width;
+    const u32 nb = (width - 1) / 3 + 1;
+    fe digest = fe_zero();
+    for (u32 b = 0; b < nb; b += 16) {
+        const u32 sz = nb - b < 16 ? nb - b : 16;
+        fe x = fe_zero();
+        if (l == 0) x = digest;
+        else if ((u32)l <= sz) {
+            const u32 at = 3 * (b + l - 1), len = width - at < 3 ? width - at : 3;
+            x = words_to_fe(v + at, len);
+        }
+        x = coop_poseidon_fr(x, xs, sz + 1);
+        __syncthreads();
+        if (l == FH_OUT_IDX) coop_put(xs, 0, 1, x);
+        __syncthreads();
+        digest = coop_get(xs, 0);
+    }
+    if (i < height && l == 0) store_raw(digest, digests + 4 * i);
+}
 // Poseidon::hash_ex for a handful of permutations (the transcript: one sponge step at a time): 32 lanes each
 __global__ __launch_bounds__(64) void bn128_poseidon_coop_kernel(const u64* __restrict__ inp, u64 n, u32 n_in, const u64* __restrict__ init,
                                                                  u32 n_out, u64* __restrict__ out) {
@@ -418,6 +446,11 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
     if (height == 0) return;
     const dim3 grid((unsigned)((height + 63) / 64)), blk(64);
     const u32 nb = width ? (width - 1) / 3 + 1 : 0;
+    if (width > 4 && height <= 4096) {   // latency-bound: 32 lanes per row
+        hipLaunchKernelGGL(bn128_leaf_coop_kernel, dim3((unsigned)((height + 1) / 2)), blk, 0, st, d_rows, width, height, d_digests);
+        ZK_HIP(hipGetLastError());
+        return;
+    }
     static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 8;   // tuning knob: largest block count that takes the register kernels
     switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
         case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid, blk, 0, st, d_rows, width, height, d_digests); break;

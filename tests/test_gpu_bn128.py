@@ -75,7 +75,8 @@ def test_merkle_root_known_answer(zk, orc):
     assert h.from_mont(t.root()) == 2052732265221205192391066587135329070685482706470940527184785165917406935559
 
 
-@pytest.mark.parametrize("height,width", [(1, 5), (16, 3), (17, 50), (33, 6), (256, 9), (257, 12), (4096, 20), (5000, 1), (1000, 0)])
+@pytest.mark.parametrize("height,width", [(1, 5), (16, 3), (17, 50), (33, 6), (256, 9), (257, 12), (4096, 20), (5000, 1), (1000, 0),
+                                          (128, 3072), (3, 49), (4097, 49), (4096, 145), (2, 7)])   # few wide rows: 32 lanes per row
 def test_merkle_tree_matches_oracle(zk, orc, height, width):
     h = orc.bn128()
     rng = np.random.default_rng(height * 100 + width)

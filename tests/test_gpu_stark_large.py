@@ -210,3 +210,22 @@ def test_recursion_task_proofs_match_oracle(zk, orc):
     ns.free()
     assert len(p["fri_proof"]["queries"][0]["pol_queries"]) == 6
     assert SP.stark_verify(p, p["rootC"], info, prog, ss, orc)
+
+
+def test_final_struct_bls12381_with_10_bit_fold(zk, orc):
+    """the reference's final.starkStruct.bls12381.json (2^16 rows, FRI 17 -> 7 -> 3: ten bits in one fold, BLS12381 hashing) on
+    the compressor-shaped circuit, scaled to 2^12 rows with the same 10-bit first fold: zkin equal to the oracle's"""
+    import stark_prover as SP, starkinfo as SI, aggregation_workload as AW
+    stark = _stark(zk)
+    zk.bn128_init(field="bls12381")
+    nbits = 12
+    ss = {"nBits": nbits, "nBitsExt": nbits + 1, "nQueries": 8, "verificationHashType": "BLS12381", "steps": [{"nBits": 13}, {"nBits": 3}]}
+    c = AW.Circuit(nbits)
+    b = SP.BN128Backend(orc, "bls12381")
+    su = SP.setup(AW.c12_pil(nbits), c.consts, ss, b)
+    cm = c.witness(primary=list(range(1, 17)))
+    exp = SP.to_zkin_bn128(SP.stark_gen(cm, su, ss, b), b, "addr")
+    ns = stark.NativeStarkSetup(c.consts, json.dumps(SI.to_json(su["starkinfo"], su["program"])), json.dumps(ss), prover_addr="addr")
+    got = ns.gen(cm)
+    ns.free()
+    assert got == exp
