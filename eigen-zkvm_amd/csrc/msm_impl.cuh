@@ -402,7 +402,21 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restric
     const u32 key = order[blockIdx.x * blockDim.x + threadIdx.x];  // window * 2^16 + digit, heaviest first
     xyzz acc = pt_inf();
     const u32 n = counts[key], off = offsets[key];
+#ifdef ZK_MSM_NO_PREFETCH
     for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(conv, idx[off + k]));
+#else
+    // the next point's coordinates (and the index after it) are requested before the current addition starts: the gather's
+    // two dependent loads (index, then 2 x NR words at a random address) fly during ~2 500 instructions of arithmetic
+    u32 i_next = n > 1 ? idx[off + 1] : 0;
+    aff cur = n ? load_aff(conv, idx[off]) : aff{};
+    for (u32 k = 0; k < n; ++k) {
+        aff nxt = cur;
+        if (k + 1 < n) nxt = load_aff(conv, i_next);
+        if (k + 2 < n) i_next = idx[off + k + 2];
+        acc = pt_madd(acc, cur);
+        cur = nxt;
+    }
+#endif
     buckets[key] = acc;
 }
 // One level of the radix-R hierarchy (R = 2^RLOG) that computes sum_k k*B_k per window.  An item (S, A) stands
