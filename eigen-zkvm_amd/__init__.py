@@ -30,7 +30,7 @@ EXPORTS = [
     "zk_transcript_free",
     "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
-    "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_free",
+    "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_run_rows_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
     "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
     "zk_msm_g1_bls12_381", "zk_msm_g1_bls12_381_dev", "zk_g1_bls12_381_mul_generator_dev",
@@ -230,6 +230,7 @@ def _load():
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
+        "zk_program_run_rows_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
         "zk_program_free": (C.c_int, [vp]),
         "zk_stark_get_pol_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
         "zk_stark_set_pol_dev": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
@@ -504,7 +505,8 @@ class Program:
         return lib().zk_program_source(self._h).decode()
 
     def run(self, bufs, nbits_domain, next_, publics=None, challenges=None, evals=None, x=None, zi=None,
-            xdiv=None, xdivw=None, stream=0):
+            xdiv=None, xdivw=None, stream=0, rows=None):
+        """rows=(row0, count): evaluate only those rows (zk_program_run_rows_dev)"""
         c = EvalCtx()
         for k, b in bufs.items():
             c.bufs[k] = b.ptr
@@ -512,7 +514,8 @@ class Program:
         c.publics, c.challenges, c.evals, c.x = p(publics), p(challenges), p(evals), p(x)
         c.zi, c.zi_mask = p(zi), (zi.n - 1 if zi is not None else 0)
         c.xdivxsubxi, c.xdivxsubwxi = p(xdiv), p(xdivw)
-        _check(lib().zk_program_run_dev(self._h, C.byref(c), nbits_domain, next_, stream))
+        if rows is None: _check(lib().zk_program_run_dev(self._h, C.byref(c), nbits_domain, next_, stream))
+        else: _check(lib().zk_program_run_rows_dev(self._h, C.byref(c), nbits_domain, next_, rows[0], rows[1], stream))
         _check(lib().zk_dev_sync())
 
     def __del__(self):

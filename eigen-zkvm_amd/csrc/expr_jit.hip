@@ -313,9 +313,10 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
         ZK_REQUIRE(lane <= 64, "eval program: too many challenges with Horner chains");
         p->pow_entries = (pow_words + 3 * (uint32_t)g.chain_consts.size() + 5) / 6;
         src << "extern \"C\" __global__ __launch_bounds__(64) void zk_pow_kernel(const EvalCtx c, u64* __restrict__ pw) {\n" << powk.str() << "}\n"
-            << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw) {\n"
-            << "    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;\n"
-            << "    if (i >= n) return;\n"
+            << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw, const u64 row0, const u64 count) {\n"
+            << "    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;\n"
+            << "    if (k >= count) return;\n"
+            << "    const u64 i = row0 + k;\n"
             << "    const u64 ip = (i + next) & (n - 1);\n"
             << g.body.str() << "}\n";
         p->source = src.str();
@@ -341,9 +342,16 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
 const char* zk_program_source(const zk_program_t* p) { return p ? p->source.c_str() : ""; }
 
 int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, void* stream) {
+    return zk_program_run_rows_dev(p, ctx, nbits_domain, next, 0, nbits_domain <= 32 ? 1ull << nbits_domain : 0, stream);
+}
+
+int zk_program_run_rows_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, uint64_t row0, uint64_t count,
+                            void* stream) {
     try {
         ZK_REQUIRE(p && ctx, "zk_program_run_dev: null");
         ZK_REQUIRE(nbits_domain <= 32, "zk_program_run_dev: domain too large");
+        ZK_REQUIRE(row0 <= (1ull << nbits_domain) && count <= (1ull << nbits_domain) - row0, "zk_program_run_rows_dev: rows outside the domain");
+        if (count == 0) return 0;
         if (!p->module) {  // load lazily: compiling needs no GPU, running does
             ZK_HIP(hipModuleLoadData(&p->module, p->code.data()));
             ZK_HIP(hipModuleGetFunction(&p->fn, p->module, "zk_eval_kernel"));
@@ -356,10 +364,10 @@ int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_d
             void* pcfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psz, HIP_LAUNCH_PARAM_END};
             ZK_HIP(hipModuleLaunchKernel(p->fn_pow, 1, 1, 1, 64, 1, 1, 0, on_stream((hipStream_t)stream), nullptr, pcfg));
         }
-        struct { zk_eval_ctx c; uint64_t n; uint64_t next; const void* pw; } args{*ctx, 1ull << nbits_domain, next, p->d_pow};
+        struct { zk_eval_ctx c; uint64_t n; uint64_t next; const void* pw; uint64_t row0; uint64_t count; } args{*ctx, 1ull << nbits_domain, next, p->d_pow, row0, count};
         size_t size = sizeof(args);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-        const uint64_t blocks = (args.n + 255) / 256;
+        const uint64_t blocks = (count + 255) / 256;
         ZK_HIP(hipModuleLaunchKernel(p->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, on_stream((hipStream_t)stream), nullptr, cfg));
         return 0;
     } catch (const std::exception& e) { set_error(e.what()); return -1; }

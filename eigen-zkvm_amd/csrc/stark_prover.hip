@@ -455,14 +455,15 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3);
     d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub));
 
-    auto run = [&](const ProgramPtr& p, bool e, hipStream_t on = nullptr) {
+    auto run = [&](const ProgramPtr& p, bool e, hipStream_t on = nullptr, u64 row0 = 0, u64 count = ~0ull) {
         if (!p) return;
         zk_eval_ctx c; memset(&c, 0, sizeof c);
         for (int s = 0; s < S_COUNT; ++s) c.bufs[s] = M(ptr[s]);
         c.publics = C(d_pub.u()); c.challenges = C(d_chal.u()); c.evals = C(d_evals.u());
         c.x = C(e ? x_2ns.u() : x_n.u()); c.zi = C(zi.u()); c.zi_mask = (1ull << ext) - 1;
         c.xdivxsubxi = C(xdiv.u()); c.xdivxsubwxi = C(xdivw.u());
-        ck(zk_program_run_dev(p.get(), &c, e ? nbits_ext : nbits, e ? (1ull << ext) : 1, on ? on : st));
+        const u32 nb = e ? nbits_ext : nbits;
+        ck(zk_program_run_rows_dev(p.get(), &c, nb, e ? (1ull << ext) : 1, row0, count == ~0ull ? 1ull << nb : count, on ? on : st));
         if (on) on_stream(st);                                                     // this thread goes on issuing on `st`
     };
     auto get_pol = [&](u64 pol_id, DevBuf& out) {                                  // stark_gen.rs:683-707
@@ -494,7 +495,8 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         } else if (ty == "imP") {                                                  // calculate_exp_at_point :558-572
             if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
             ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
-            run(S.public_programs[i], false);
+            ZK_REQUIRE(idx < N, "public out of range");
+            run(S.public_programs[i], false, nullptr, idx, 1);                     // its one row, not the domain
             u64 v[3];
             ZK_HIP(hipStreamSynchronize(st));
             ZK_HIP(hipMemcpy(v, ptr[S_SCRATCH] + 3 * idx, 24, hipMemcpyDeviceToHost));

@@ -114,6 +114,38 @@ def test_program_matches_reference_interpreter(zk, orc, nbits, ext):
     assert [int(v) for v in d["cm3"].to_host()] == bufs["cm3"]
 
 
+@pytest.mark.gpu
+def test_row_range_run_touches_only_its_rows(zk, orc):
+    """zk_program_run_rows_dev: rows row0..row0+count-1 get what the whole-domain run gives them (primed reads still wrap
+    around the whole domain), every other destination cell is left alone -- how a public calculator is evaluated at its
+    one row (stark_gen.rs:558-572)"""
+    assert zk.lib().zk_device_count() >= 1
+    zk.init(0)
+    nbits, ext = 6, 1
+    rng = np.random.default_rng(99)
+    n = 1 << (nbits + ext); nxt = 1 << ext
+    program = _fib_like_program()
+    cm1 = rng.integers(0, P, size=2 * n, dtype=np.uint64)
+    const = rng.integers(0, 2, size=n, dtype=np.uint64)
+    chal = zk.DevArray.from_host(rng.integers(0, P, size=24, dtype=np.uint64))
+    pub = zk.DevArray.from_host(rng.integers(0, P, size=2, dtype=np.uint64))
+    zi = zk.DevArray.from_host(orc.zh_inv(nbits, ext)); x = zk.x_table(nbits + ext, 49)
+    prog = _compile(zk, program)
+    def go(rows):
+        d = {"cm1": zk.DevArray.from_host(cm1), "const": zk.DevArray.from_host(const),
+             "q": zk.DevArray.from_host(np.full(3 * n, 7, dtype=np.uint64)), "cm3": zk.DevArray.from_host(np.full(4 * n, 7, dtype=np.uint64))}
+        prog.run({BUF[k]: v for k, v in d.items()}, nbits + ext, nxt, publics=pub, challenges=chal, x=x, zi=zi, rows=rows)
+        return d["q"].to_host().reshape(n, 3), d["cm3"].to_host().reshape(n, 4)
+    q_all, c_all = go(None)
+    for row0, count in [(0, 1), (n - 1, 1), (n - 3, 3), (17, 40), (0, n)]:
+        q, c = go((row0, count))
+        inside = np.zeros(n, dtype=bool); inside[row0:row0 + count] = True
+        assert (q[inside] == q_all[inside]).all() and (q[~inside] == 7).all()
+        assert (c[inside] == c_all[inside]).all() and (c[~inside] == 7).all()
+    with pytest.raises(zk.ZkError, match="outside the domain"):
+        go((n - 1, 2))
+
+
 def _long_chain_program(n_terms):
     """acc <- v * acc + cm1[j] over more terms than one group of the deferred sum holds, then (column - eval) terms on
     a second challenge, as the FRI polynomial's generated code does"""
