@@ -246,46 +246,83 @@ def final_wrap_leg(zk, nbits=18, log_rows=18, join_root=None):
 class GpuTaskProver:
     """The three STARKs of one recursion task (test/recursive_proof_to_snark.sh:37-40, :68-71, :98-102) on this rank's GPU:
     one setup per circuit (constants extended and merkelized once), per-task witnesses uploaded to HBM before the clock
-    starts, proofs through zk_stark_gen_dev."""
+    starts, proofs through zk_stark_gen_dev_on.
 
-    def __init__(self, zk):
+    These proofs are small (2^10 ... 2^18 rows): each is a chain of a few hundred launches with the transcript's round trips
+    between them, bound by latency, not by the device.  The reference runs its tasks as parallel processes
+    (test/stark_aggregation.sh:70-73); here `workers` host threads each own a set of setups and a non-blocking stream and take
+    tasks in turn, so several chains are in flight on the one GPU.  Inside a task the three proofs stay in order, as their data
+    dependency in the real pipeline demands."""
+
+    def __init__(self, zk, workers=None):
         import importlib
         sys.path.insert(0, str(ROOT / "tools"))
         import aggregation_workload as AW
         stark = importlib.import_module("eigen_zkvm_amd.stark")
         self.zk, self.AW = zk, AW
+        self.workers = workers if workers is not None else int(os.environ.get("ZK_BENCH_WORKERS", "4"))
         self.circ = {"c12": AW.Circuit(AW.STRUCTS["c12"]["nBits"]), "r1": AW.Circuit(AW.STRUCTS["r1"]["nBits"])}
         consts = {"fib": AW.fib_consts(), "c12": self.circ["c12"].consts, "r1": self.circ["r1"].consts}
-        self.setups = {k: stark.NativeStarkSetup(consts[k], json.dumps(AW.program(k)), json.dumps(AW.STRUCTS[k])) for k in ("fib", "c12", "r1")}
+        mk = lambda k: stark.NativeStarkSetup(consts[k], json.dumps(AW.program(k)), json.dumps(AW.STRUCTS[k]))
+        self.sets = [{k: mk(k) for k in ("fib", "c12", "r1")} for _ in range(self.workers)]
+        self.streams = [zk.Stream() for _ in range(self.workers)]
+        self.setups = self.sets[0]
         self.sizes = {k: AW.STRUCTS[k]["nBits"] for k in self.setups}
 
     def inputs(self, task):
         D = self.zk.DevArray.from_host
         return [("fib", D(self.AW.fib_trace(task))), ("c12", D(self.circ["c12"].witness(task))), ("r1", D(self.circ["r1"].witness(task)))]
 
-    def prove(self, inputs):
-        """-> the root of the committed trace of each of the task's three proofs, [[4 words]] * 3"""
-        roots = []
-        for kind, d_cm in inputs:
-            z = self.setups[kind].gen(d_cm)
-            r = z["root1"]
-            roots.append([int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])])
-        return roots
+    @staticmethod
+    def _root1(zkin_json):
+        """root1 of a proof's JSON text without parsing the megabytes of openings after it (serializer.rs:146-152: rootC, root1, ...)"""
+        i = zkin_json.index('"root1":') + 8
+        j = zkin_json.index(']', i) + 1 if zkin_json[i] == '[' else zkin_json.index(',', i)
+        r = json.loads(zkin_json[i:j])
+        return [int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])]
 
-    def join(self, root_a, root_b):
+    def prove(self, inputs, worker=0):
+        """-> the root of the committed trace of each of the task's three proofs, [[4 words]] * 3"""
+        st = self.streams[worker].handle
+        return [self._root1(self.sets[worker][kind].gen_json(d_cm, st)) for kind, d_cm in inputs]
+
+    def _spread(self, jobs, fn):
+        """jobs[i] -> fn(jobs[i], worker) on worker i mod workers, the workers side by side; results in job order"""
+        import threading
+        out, errs = [None] * len(jobs), []
+        def run(w):
+            try:
+                for i in range(w, len(jobs), self.workers):
+                    out[i] = fn(jobs[i], w)
+            except BaseException as e:                                    # noqa: BLE001 -- re-raised below
+                errs.append(e)
+        threads = [threading.Thread(target=run, args=(w,)) for w in range(min(self.workers, len(jobs)))]
+        for t in threads: t.start()
+        for t in threads: t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    def prove_all(self, inputs_list):
+        return self._spread(inputs_list, self.prove)
+
+    def join(self, root_a, root_b, worker=0):
         """One recursive2 step of the aggregation (test/stark_aggregation.sh:80-128: join_zkin + compressor12_exec +
         stark_prove with r1.starkStruct.json, 2^18 rows): the joined circuit's primary inputs are the two child roots."""
         primary = [int(w) for w in root_a] + [int(w) for w in root_b] + [0] * 8
         cm = self.circ["r1"].witness(primary=primary)                         # the exec step (host), then the proof
-        z = self.setups["r1"].gen(self.zk.DevArray.from_host(cm))
-        r = z["root1"]
-        return [int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])]
+        return self._root1(self.sets[worker]["r1"].gen_json(self.zk.DevArray.from_host(cm), self.streams[worker].handle))
+
+    def join_all(self, pairs):
+        """the joins of one tree level: independent of each other"""
+        return self._spread(pairs, lambda ab, w: self.join(ab[0], ab[1], w))
 
     def sync(self):
         self.zk.lib().zk_dev_sync()
 
     def describe(self):
-        return "Fibonacci 2^10 (2 columns) + compressor-shaped circuit 2^15 and 2^18 (12 columns, PLONK gates, 12-column connection; tools/pil/c12_shape.pil), GL hash"
+        return ("Fibonacci 2^10 (2 columns) + compressor-shaped circuit 2^15 and 2^18 (12 columns, PLONK gates, 12-column connection; "
+                "tools/pil/c12_shape.pil), GL hash; %d tasks in flight per GPU (host threads, one stream each)" % self.workers)
 
 
 def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
@@ -295,13 +332,13 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     the 8-task job).  `prover` is GpuTaskProver, or a stub in the CPU tests of this control flow."""
     units = shard_units(n_tasks, rank, world)
     inputs = [prover.inputs(u) for u in units]                          # witness generation + upload: before the clock
-    if inputs:
-        prover.prove(inputs[0])                                         # warm-up (pool, JIT modules)
+    if inputs:                                                          # warm-up (pool, JIT modules of every worker's setups)
+        prover.prove_all(inputs) if hasattr(prover, "prove_all") else prover.prove(inputs[0])
     prover.sync()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    roots = [prover.prove(i) for i in inputs]
+    roots = prover.prove_all(inputs) if hasattr(prover, "prove_all") else [prover.prove(i) for i in inputs]
     prover.sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
@@ -334,7 +371,8 @@ def join_tree(prover, dist, rank, world, device, leaves):
     while len(nodes) > 1:
         n_join = len(nodes) // 2
         mine = shard_units(n_join, rank, world)
-        made = [prover.join(nodes[2 * j], nodes[2 * j + 1]) for j in mine]
+        pairs = [(nodes[2 * j], nodes[2 * j + 1]) for j in mine]
+        made = prover.join_all(pairs) if hasattr(prover, "join_all") else [prover.join(a, b) for a, b in pairs]
         per_rank = (n_join + world - 1) // world
         flat = [w for r in made for w in r] + [0] * (4 * (per_rank - len(made)))
         gathered = gather_roots(dist, flat, device)

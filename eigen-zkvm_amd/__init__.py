@@ -23,14 +23,14 @@ EXPORTS = [
     "zk_gl_ntt", "zk_gl_lde", "zk_gl_ntt_dev", "zk_gl_lde_dev", "zk_gl_ntt_passes",
     "zk_gl_poseidon", "zk_gl_linearhash", "zk_gl_linearhash_rows_dev",
     "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes", "zk_merkle_elements",
-    "zk_merkle_depth", "zk_merkle_group_proof", "zk_merkle_elements_dev", "zk_merkle_nodes_dev",
+    "zk_merkle_depth", "zk_merkle_group_proof", "zk_merkle_group_proofs", "zk_merkle_elements_dev", "zk_merkle_nodes_dev",
     "zk_merkle_free",
     "zk_transcript_new", "zk_transcript_put", "zk_transcript_put_dev", "zk_transcript_get_field",
     "zk_transcript_get_field_dev", "zk_transcript_get_fields1", "zk_transcript_get_permutations",
     "zk_transcript_free",
     "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
-    "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_run_rows_dev", "zk_program_free",
+    "zk_stream_new", "zk_stream_sync", "zk_stream_free", "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_run_rows_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_z_dev",
     "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
     "zk_msm_g1_bls12_381", "zk_msm_g1_bls12_381_dev", "zk_g1_bls12_381_mul_generator_dev",
@@ -38,15 +38,15 @@ EXPORTS = [
     "zk_msm_g2_bls12_381", "zk_msm_g2_bls12_381_dev", "zk_g2_bls12_381_mul_generator_dev",
     "zk_bn128_load_constants", "zk_bn128_poseidon", "zk_bn128_poseidon_dev", "zk_bn128_linearhash",
     "zk_bn128_merkle_n_nodes", "zk_bn128_merkelize", "zk_bn128_merkelize_dev", "zk_bn128_merkle_root", "zk_bn128_merkle_nodes",
-    "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_free",
+    "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_group_proofs", "zk_bn128_merkle_free",
     "zk_bn128_transcript_new", "zk_bn128_transcript_put", "zk_bn128_transcript_get_fields1", "zk_bn128_transcript_get_field",
     "zk_bn128_transcript_get_permutations", "zk_bn128_transcript_free",
     "zk_bls12381_load_constants", "zk_bls12381_poseidon", "zk_bls12381_poseidon_dev", "zk_bls12381_linearhash",
     "zk_bls12381_merkle_n_nodes", "zk_bls12381_merkelize", "zk_bls12381_merkelize_dev", "zk_bls12381_merkle_root", "zk_bls12381_merkle_nodes",
-    "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_free",
+    "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_group_proofs", "zk_bls12381_merkle_free",
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
-    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_string_free", "zk_stark_setup_free",
+    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_gen", "zk_stark_gen_dev", "zk_stark_gen_dev_on", "zk_string_free", "zk_stark_setup_free",
     "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
     "zk_c12_exec_new", "zk_c12_exec_dev", "zk_c12_exec_depth", "zk_c12_exec_free",
@@ -122,6 +122,7 @@ def _load():
         "zk_merkle_elements": (C.c_int, [vp, vp]),
         "zk_merkle_depth": (C.c_uint32, [vp]),
         "zk_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_merkle_group_proofs": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
         "zk_merkle_elements_dev": (vp, [vp]),
         "zk_merkle_nodes_dev": (vp, [vp]),
         "zk_merkle_free": (C.c_int, [vp]),
@@ -152,6 +153,7 @@ def _load():
         "zk_bn128_merkle_nodes": (C.c_int, [vp, vp]),
         "zk_bn128_merkle_depth": (C.c_uint32, [vp]),
         "zk_bn128_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_bn128_merkle_group_proofs": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
         "zk_bn128_merkle_free": (C.c_int, [vp]),
         "zk_bn128_transcript_new": (vp, []),
         "zk_bn128_transcript_put": (C.c_int, [vp, vp, C.c_size_t]),
@@ -170,6 +172,7 @@ def _load():
         "zk_bls12381_merkle_nodes": (C.c_int, [vp, vp]),
         "zk_bls12381_merkle_depth": (C.c_uint32, [vp]),
         "zk_bls12381_merkle_group_proof": (C.c_int, [vp, C.c_uint64, vp, vp]),
+        "zk_bls12381_merkle_group_proofs": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
         "zk_bls12381_merkle_free": (C.c_int, [vp]),
         "zk_bls12381_transcript_new": (vp, []),
         "zk_bls12381_transcript_put": (C.c_int, [vp, vp, C.c_size_t]),
@@ -183,6 +186,7 @@ def _load():
         "zk_stark_setup_set_prover_addr": (C.c_int, [vp, C.c_char_p]),
         "zk_stark_gen": (vp, [vp, vp, C.c_uint64]),
         "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
+        "zk_stark_gen_dev_on": (vp, [vp, vp, C.c_uint64, vp]),
         "zk_string_free": (None, [vp]),
         "zk_stark_setup_free": (C.c_int, [vp]),
         "zk_msm_g1_bn254_table_bytes": (C.c_size_t, [C.c_uint64]),
@@ -229,6 +233,7 @@ def _load():
         "zk_g2_bls12_381_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
+        "zk_stream_new": (vp, []), "zk_stream_sync": (C.c_int, [vp]), "zk_stream_free": (C.c_int, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
         "zk_program_run_rows_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, vp]),
         "zk_program_free": (C.c_int, [vp]),
@@ -348,9 +353,39 @@ class MerkleTreeGL:
         _check(lib().zk_merkle_group_proof(self._h, idx, _ptr(row), _ptr(path)))
         return row[:self.width], path[:4 * d].reshape(d, 4)
 
+    def get_group_proofs(self, idxs):
+        """every opening of a query list in one round trip: [(row, path)] in the order of idxs"""
+        d = lib().zk_merkle_depth(self._h); n = len(idxs)
+        ix = np.asarray(idxs, dtype=np.uint64)
+        rows = np.zeros(max(1, n * self.width), np.uint64); paths = np.zeros(max(1, n * d * 4), np.uint64)
+        _check(lib().zk_merkle_group_proofs(self._h, _ptr(ix), n, _ptr(rows), _ptr(paths)))
+        return [(rows[q * self.width:(q + 1) * self.width], paths[q * 4 * d:(q + 1) * 4 * d].reshape(d, 4)) for q in range(n)]
+
     def free(self):
         if self._h:
             lib().zk_merkle_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """a non-blocking HIP stream (zk_stream_new); `.handle` is what the `stream` arguments take"""
+
+    def __init__(self):
+        self.handle = lib().zk_stream_new()
+        if not self.handle:
+            raise ZkError(lib().zk_last_error().decode())
+
+    def sync(self):
+        _check(lib().zk_stream_sync(self.handle))
+
+    def free(self):
+        if self.handle:
+            _check(lib().zk_stream_free(self.handle)); self.handle = None
 
     def __del__(self):
         try:
@@ -588,6 +623,13 @@ class MerkleTreeBN128:
         row, path = np.zeros(max(1, self.width), np.uint64), np.zeros(max(1, depth) * 64, np.uint64)
         _check(_fr("merkle_group_proof", self.field)(self._h, idx, _ptr(row), _ptr(path)))
         return row[:self.width], path[:depth * 64].reshape(depth, 16, 4)
+
+    def get_group_proofs(self, idxs):
+        depth = _fr("merkle_depth", self.field)(self._h); n = len(idxs)
+        ix = np.asarray(idxs, dtype=np.uint64)
+        rows, paths = np.zeros(max(1, n * self.width), np.uint64), np.zeros(max(1, n * depth * 64), np.uint64)
+        _check(_fr("merkle_group_proofs", self.field)(self._h, _ptr(ix), n, _ptr(rows), _ptr(paths)))
+        return [(rows[q * self.width:(q + 1) * self.width], paths[q * 64 * depth:(q + 1) * 64 * depth].reshape(depth, 16, 4)) for q in range(n)]
 
     def free(self):
         if self._h:

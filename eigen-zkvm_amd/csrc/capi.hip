@@ -21,6 +21,8 @@ std::map<void*, Block> g_pool_blocks;       // every block handed out by pool_al
 std::vector<hipStream_t> g_streams{nullptr};  // streams the library has been asked to work on
 std::vector<hipEvent_t> g_event_cache;
 thread_local hipStream_t t_stream = nullptr;
+thread_local std::vector<hipStream_t> t_streams;   // non-null streams this host thread has issued on
+thread_local int t_depth = 0;                      // C-ABI calls in progress on this thread (the prover calls entry points itself)
 
 hipEvent_t event_get() {                     // g_pool_mu held
     if (!g_event_cache.empty()) { hipEvent_t e = g_event_cache.back(); g_event_cache.pop_back(); return e; }
@@ -30,14 +32,20 @@ hipEvent_t event_get() {                     // g_pool_mu held
 }
 }
 hipStream_t cur_stream() { return t_stream; }
-void reset_cur_stream() { t_stream = nullptr; }
+CallScope::CallScope() : saved(t_stream) { if (t_depth++ == 0) t_stream = nullptr; }   // a call from outside starts on the null stream,
+CallScope::~CallScope() { --t_depth; t_stream = saved; }                                // one made by the prover inherits the prover's
 hipStream_t on_stream(hipStream_t st) {
     t_stream = st;
     if (st) {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        bool known = false;
-        for (hipStream_t s : g_streams) known |= s == st;
-        if (!known) g_streams.push_back(st);
+        bool mine = false;
+        for (hipStream_t s : t_streams) mine |= s == st;
+        if (!mine) {
+            t_streams.push_back(st);
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            bool known = false;
+            for (hipStream_t s : g_streams) known |= s == st;
+            if (!known) g_streams.push_back(st);
+        }
     }
     return st;
 }
@@ -73,12 +81,17 @@ void pool_free(void* p) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     auto it = g_pool_blocks.find(p);
     if (it == g_pool_blocks.end()) { (void)hipFree(p); return; }
-    if (g_streams.size() > 1) {                                       // several streams in play: order the next user behind all of them
-        for (hipStream_t st : g_streams) {
+    if (g_streams.size() > 1) {
+        // several streams in play: the next user waits for the null stream and for every stream the FREEING thread has issued on
+        // (a buffer is released by the thread that owns it; work another thread did on it was ordered before this thread's by
+        // whoever handed it over).  Streams of other threads are left alone: concurrent provers must not wait for each other.
+        auto record = [&](hipStream_t st) {
             hipEvent_t e = event_get();
             if (hipEventRecord(e, st) == hipSuccess) it->second.pending.push_back(e);
             else { (void)hipGetLastError(); g_event_cache.push_back(e); }   // a destroyed stream has nothing in flight
-        }
+        };
+        record(nullptr);
+        for (hipStream_t st : t_streams) record(st);
     }
     g_pool_free.emplace(it->second.bytes, p);
 }
@@ -92,6 +105,8 @@ void pool_trim() {
     g_pool_free.clear();
 }
 void forget_stream(hipStream_t st) {                                  // before hipStreamDestroy
+    for (size_t i = 0; i < t_streams.size(); ++i)
+        if (t_streams[i] == st) { t_streams.erase(t_streams.begin() + i); break; }
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (size_t i = 1; i < g_streams.size(); ++i)
         if (g_streams[i] == st) { g_streams.erase(g_streams.begin() + i); break; }
@@ -104,7 +119,7 @@ DevBuf g_ws_a, g_ws_b, g_ws_c;  // grow-only staging for the host-pointer API
 
 template <class F>
 int guard(F&& f) {
-    reset_cur_stream();
+    CallScope scope;
     try { f(); return 0; }
     catch (const std::exception& e) { set_error(e.what()); return -1; }
     catch (...) { set_error("unknown error"); return -1; }
@@ -122,6 +137,39 @@ __global__ void gather_proof_kernel(const u64* __restrict__ elements, const u64*
             u64 next = (n - 1) / 2 + 1;
             off += next * 2; n = next; id >>= 1; ++d;
         }
+    }
+}
+
+// the same for n queries at once: block q serves idx[q], out + q * (width + 4 * depth)
+__global__ void gather_proofs_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width, u64 height,
+                                     u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs) {
+    const u32 t = threadIdx.x;
+    const u64 idx = idxs[blockIdx.x];
+    u64* __restrict__ out = outs + (u64)blockIdx.x * (width + 4 * depth);
+    for (u32 i = t; i < width; i += blockDim.x) out[i] = elements[idx * width + i];
+    if (t == 0) {
+        u64 n = height, off = 0, id = idx; u32 d = 0;
+        while (n > 1) {
+            const u64* sib = nodes + 4 * (off + (id ^ 1));
+            for (int k = 0; k < 4; ++k) out[width + 4 * d + k] = sib[k];
+            u64 next = (n - 1) / 2 + 1;
+            off += next * 2; n = next; id >>= 1; ++d;
+        }
+    }
+}
+// arity-16 trees of the scalar-field hashes (merklehash_bn128.rs:86-106): block q -> row + depth groups of 16 digests
+__global__ void fr_gather_proofs_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width, u64 height,
+                                        u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs) {
+    const u32 t = threadIdx.x;
+    const u64 idx = idxs[blockIdx.x];
+    u64* __restrict__ out = outs + (u64)blockIdx.x * (width + 64 * depth);
+    for (u32 i = t; i < width; i += blockDim.x) out[i] = elements[idx * width + i];
+    u64 n = height, off = 0, id = idx; u32 d = 0;
+    while (n > 1) {
+        const u64 si = id & ~(u64)15;
+        if (t < 64) out[width + 64 * d + t] = nodes[4 * (off + si) + t];
+        const u64 next = (n - 1) / 16 + 1;
+        off += next * 16; n = next; id >>= 4; ++d;
     }
 }
 
@@ -143,6 +191,7 @@ struct zk_merkle {
 struct zk_transcript {
     DevBuf state;  // TranscriptState (poseidon.hip)
     DevBuf io;     // staging for host-word put / get
+    hipStream_t stream = nullptr;  // where the state was last worked on: the host-word calls continue (and wait) there
 };
 
 static uint32_t tree_depth(uint64_t height) {
@@ -169,6 +218,20 @@ int zk_dev_trim(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); pool_
 int zk_dev_upload(void* d, const void* h, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); }); }
 int zk_dev_download(void* h, const void* d, size_t n) { return guard([&] { ZK_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); }); }
 int zk_dev_sync(void) { return guard([&] { ZK_HIP(hipDeviceSynchronize()); }); }
+void* zk_stream_new(void) {
+    hipStream_t st = nullptr;
+    if (guard([&] { ZK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }) != 0) return nullptr;
+    return st;
+}
+int zk_stream_sync(void* stream) { return guard([&] { ZK_HIP(hipStreamSynchronize((hipStream_t)stream)); }); }
+int zk_stream_free(void* stream) {
+    return guard([&] {
+        if (!stream) return;
+        ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        forget_stream((hipStream_t)stream);
+        ZK_HIP(hipStreamDestroy((hipStream_t)stream));
+    });
+}
 int zk_dev_memset(void* d, int value, size_t n) { return guard([&] { if (n) ZK_HIP(hipMemset(d, value, n)); }); }
 
 int zk_gl_ntt_passes(uint32_t nbits) { return ntt_num_passes(nbits); }
@@ -329,38 +392,69 @@ int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out,
     });
 }
 
+int zk_merkle_group_proofs(const zk_merkle_t* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out, uint64_t* paths_out) {
+    return guard([&] {
+        ZK_REQUIRE(t && (n == 0 || (idx && rows_out && (paths_out || t->depth == 0))), "zk_merkle_group_proofs: null");
+        if (n == 0) return;
+        for (uint32_t q = 0; q < n; ++q) ZK_REQUIRE(idx[q] < t->height, "MerkleTreeError: access invalid node");
+        const size_t per = (size_t)t->width + 4 * (size_t)t->depth;
+        on_stream(t->stream);
+        DevBuf d_idx, d_out; d_idx.reserve(n * 8); d_out.reserve(std::max<size_t>(1, per * n) * 8);
+        ZK_HIP(hipMemcpyAsync(d_idx.p, idx, n * 8, hipMemcpyHostToDevice, t->stream));
+        hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, t->stream, t->d_elements, t->nodes.u(), t->width, t->height,
+                           t->depth, d_idx.u(), d_out.u());
+        ZK_HIP(hipGetLastError());
+        std::vector<u64> h(std::max<size_t>(1, per * n));
+        ZK_HIP(hipMemcpyAsync(h.data(), d_out.p, per * n * 8, hipMemcpyDeviceToHost, t->stream));
+        ZK_HIP(hipStreamSynchronize(t->stream));
+        for (uint32_t q = 0; q < n; ++q) {
+            memcpy(rows_out + (size_t)q * t->width, h.data() + q * per, (size_t)t->width * 8);
+            if (t->depth) memcpy(paths_out + (size_t)q * 4 * t->depth, h.data() + q * per + t->width, (size_t)t->depth * 32);
+        }
+    });
+}
+
 // ---- transcript ------------------------------------------------------------------------------
+// the sponge state lives on one stream at a time: work moves to `st` after whatever was issued on the previous stream
+static hipStream_t transcript_stream(zk_transcript_t* t, hipStream_t st) {
+    if (t->stream != st) { ZK_HIP(hipStreamSynchronize(t->stream)); t->stream = st; }
+    return on_stream(st);
+}
 zk_transcript_t* zk_transcript_new(void) {
     zk_transcript_t* t = nullptr;
     int rc = guard([&] {
         t = new zk_transcript();
+        t->stream = cur_stream();                                       // the caller's (a prover's own stream, or the null stream)
         t->state.reserve(transcript_state_bytes());
         t->io.reserve(4096 * sizeof(u64));
-        transcript_init_dev(t->state.p, nullptr);
+        transcript_init_dev(t->state.p, t->stream);
     });
     if (rc != 0) { delete t; return nullptr; }
     return t;
 }
 int zk_transcript_put_dev(zk_transcript_t* t, const uint64_t* d_src, size_t n, void* stream) {
-    return guard([&] { ZK_REQUIRE(t, "transcript: null"); transcript_put_dev(t->state.p, (const u64*)d_src, n, on_stream((hipStream_t)stream)); });
+    return guard([&] { ZK_REQUIRE(t, "transcript: null"); transcript_put_dev(t->state.p, (const u64*)d_src, n, transcript_stream(t, (hipStream_t)stream)); });
 }
 int zk_transcript_put(zk_transcript_t* t, const uint64_t* src, size_t n) {
     return guard([&] {
         ZK_REQUIRE(t && (src || n == 0), "transcript: null");
         if (n == 0) return;
+        on_stream(t->stream);
         t->io.reserve(n * sizeof(u64));
+        ZK_HIP(hipStreamSynchronize(t->stream));                         // io may still be read by an earlier put
         ZK_HIP(hipMemcpy(t->io.p, src, n * sizeof(u64), hipMemcpyHostToDevice));
-        transcript_put_dev(t->state.p, t->io.u(), n, nullptr);
-        ZK_HIP(hipStreamSynchronize(nullptr));
+        transcript_put_dev(t->state.p, t->io.u(), n, on_stream(t->stream));
+        ZK_HIP(hipStreamSynchronize(t->stream));
     });
 }
 int zk_transcript_get_field_dev(zk_transcript_t* t, uint64_t* d_out3, void* stream) {
-    return guard([&] { ZK_REQUIRE(t && d_out3, "transcript: null"); transcript_get_dev(t->state.p, (u64*)d_out3, 3, on_stream((hipStream_t)stream)); });
+    return guard([&] { ZK_REQUIRE(t && d_out3, "transcript: null"); transcript_get_dev(t->state.p, (u64*)d_out3, 3, transcript_stream(t, (hipStream_t)stream)); });
 }
 static int transcript_get_host(zk_transcript_t* t, uint64_t* out, uint32_t n_words) {
     return guard([&] {
         ZK_REQUIRE(t && out, "transcript: null");
-        transcript_get_dev(t->state.p, t->io.u(), n_words, nullptr);
+        transcript_get_dev(t->state.p, t->io.u(), n_words, on_stream(t->stream));
+        ZK_HIP(hipStreamSynchronize(t->stream));
         ZK_HIP(hipMemcpy(out, t->io.p, n_words * sizeof(u64), hipMemcpyDeviceToHost));
     });
 }
@@ -369,8 +463,10 @@ int zk_transcript_get_fields1(zk_transcript_t* t, uint64_t* out) { return transc
 int zk_transcript_get_permutations(zk_transcript_t* t, uint32_t n, uint32_t nbits, uint64_t* out) {
     return guard([&] {
         ZK_REQUIRE(t && out, "transcript: null");
+        on_stream(t->stream);
         t->io.reserve((size_t)n * sizeof(u64) + 64);
-        transcript_permutations_dev(t->state.p, n, nbits, t->io.u(), nullptr);
+        transcript_permutations_dev(t->state.p, n, nbits, t->io.u(), t->stream);
+        ZK_HIP(hipStreamSynchronize(t->stream));
         ZK_HIP(hipMemcpy(out, t->io.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
     });
 }
@@ -547,6 +643,7 @@ void fr_mont_mul_host(const FrOps& F, const uint64_t a[4], const uint64_t b[4], 
 }
 void fr_tr_update(FrTranscript* t) {   // transcript_bn128.rs:22-31
     t->pending.resize(64, 0);
+    on_stream(nullptr);                         // the scalar-field sponges work on the null stream, whoever calls
     t->d_in.reserve(64 * 8); t->d_init.reserve(32); t->d_out.reserve(17 * 32);
     ZK_HIP(hipMemcpy(t->d_in.p, t->pending.data(), 64 * 8, hipMemcpyHostToDevice));
     ZK_HIP(hipMemcpy(t->d_init.p, t->state, 32, hipMemcpyHostToDevice));
@@ -573,6 +670,7 @@ int fr_poseidon(const FrOps& F, const uint64_t* inp, uint32_t n_in, const uint64
     return guard([&] {
         ZK_REQUIRE(inp && init_state && out, "poseidon: null buffer");
         ZK_REQUIRE(n_in >= 1 && n_in <= 16, "Wrong inputs length");
+        on_stream(nullptr);
         DevBuf d_in, d_init, d_out;
         d_in.reserve(n_in * 32); d_init.reserve(32); d_out.reserve(17 * 32);
         ZK_HIP(hipMemcpy(d_in.p, inp, n_in * 32, hipMemcpyHostToDevice));
@@ -585,6 +683,7 @@ int fr_poseidon(const FrOps& F, const uint64_t* inp, uint32_t n_in, const uint64
 int fr_linearhash(const FrOps& F, const uint64_t* v, size_t n, uint64_t* out) {
     return guard([&] {
         ZK_REQUIRE(out && (v || n == 0), "linearhash: null buffer");
+        on_stream(nullptr);
         DevBuf d_v, d_o; d_v.reserve(n * 8 + 8); d_o.reserve(32);
         if (n) ZK_HIP(hipMemcpy(d_v.p, v, n * 8, hipMemcpyHostToDevice));
         ZK_HIP(hipMemset(d_o.p, 0, 32));
@@ -603,6 +702,7 @@ T* fr_merkelize(const FrOps& F, const uint64_t* buff, bool on_device, uint32_t w
             t->F = &F;
             if (on_device) t->d_elements = (const u64*)buff;
             else {
+                on_stream(nullptr);
                 t->owned_elements.reserve((size_t)width * height * 8 + 8);
                 if (width) ZK_HIP(hipMemcpy(t->owned_elements.p, buff, (size_t)width * height * 8, hipMemcpyHostToDevice));
                 t->d_elements = t->owned_elements.u();
@@ -638,6 +738,27 @@ int fr_merkle_group_proof(const FrMerkle* t, uint64_t idx, uint64_t* row_out, ui
             ZK_HIP(hipMemcpy(path_out + (size_t)d * 64, t->nodes.u() + 4 * (off + si), 16 * 32, hipMemcpyDeviceToHost));
             const uint64_t next = (n - 1) / 16 + 1;
             off += next * 16; n = next; id >>= 4; ++d;
+        }
+    });
+}
+int fr_merkle_group_proofs(const FrMerkle* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out, uint64_t* paths_out) {
+    return guard([&] {
+        ZK_REQUIRE(t && (n == 0 || (idx && rows_out && paths_out)), "null argument");
+        if (n == 0) return;
+        for (uint32_t q = 0; q < n; ++q) ZK_REQUIRE(idx[q] < t->height, "MerkleTreeError: access invalid node");
+        ZK_HIP(hipDeviceSynchronize());                                   // (the tree does not remember the stream it was built on)
+        on_stream(nullptr);
+        const size_t per = (size_t)t->width + 64 * (size_t)t->depth;
+        DevBuf d_idx, d_out; d_idx.reserve(n * 8); d_out.reserve(std::max<size_t>(1, per * n) * 8);
+        ZK_HIP(hipMemcpy(d_idx.p, idx, n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(fr_gather_proofs_kernel, dim3(n), dim3(64), 0, nullptr, t->d_elements, t->nodes.u(), t->width, t->height,
+                           t->depth, d_idx.u(), d_out.u());
+        ZK_HIP(hipGetLastError());
+        std::vector<u64> h(std::max<size_t>(1, per * n));
+        ZK_HIP(hipMemcpy(h.data(), d_out.p, per * n * 8, hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < n; ++q) {
+            memcpy(rows_out + (size_t)q * t->width, h.data() + q * per, (size_t)t->width * 8);
+            if (t->depth) memcpy(paths_out + (size_t)q * 64 * t->depth, h.data() + q * per + t->width, (size_t)t->depth * 512);
         }
     });
 }
@@ -716,6 +837,10 @@ extern "C" {
     uint32_t zk_##P##_merkle_depth(const zk_##P##_merkle_t* t) { return t ? t->depth : 0; }                               \
     int zk_##P##_merkle_group_proof(const zk_##P##_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {    \
         return fr_merkle_group_proof(t, idx, row_out, path_out);                                                         \
+    }                                                                                                                    \
+    int zk_##P##_merkle_group_proofs(const zk_##P##_merkle_t* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out,     \
+                                     uint64_t* paths_out) {                                                              \
+        return fr_merkle_group_proofs(t, idx, n, rows_out, paths_out);                                                   \
     }                                                                                                                   \
     int zk_##P##_merkle_free(zk_##P##_merkle_t* t) { return guard([&] { delete t; }); }                                   \
     zk_##P##_transcript_t* zk_##P##_transcript_new(void) {                                                               \

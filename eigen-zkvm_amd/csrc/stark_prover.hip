@@ -75,6 +75,7 @@ struct FrApi {
     int (*root)(const void*, uint64_t*);
     uint32_t (*depth)(const void*);
     int (*group_proof)(const void*, uint64_t, uint64_t*, uint64_t*);
+    int (*group_proofs)(const void*, const uint64_t*, uint32_t, uint64_t*, uint64_t*);
     int (*tree_free)(void*);
     void* (*tr_new)(void);
     int (*tr_put)(void*, const uint64_t*, size_t);
@@ -88,6 +89,7 @@ struct FrApi {
      [](const void* t, uint64_t* o) { return zk_##P##_merkle_root((const zk_##P##_merkle_t*)t, o); },                           \
      [](const void* t) { return zk_##P##_merkle_depth((const zk_##P##_merkle_t*)t); },                                          \
      [](const void* t, uint64_t i, uint64_t* r, uint64_t* p) { return zk_##P##_merkle_group_proof((const zk_##P##_merkle_t*)t, i, r, p); }, \
+     [](const void* t, const uint64_t* i, uint32_t n, uint64_t* r, uint64_t* p) { return zk_##P##_merkle_group_proofs((const zk_##P##_merkle_t*)t, i, n, r, p); }, \
      [](void* t) { return zk_##P##_merkle_free((zk_##P##_merkle_t*)t); },                                                       \
      []() -> void* { return zk_##P##_transcript_new(); },                                                                       \
      [](void* t, const uint64_t* e, size_t n) { return zk_##P##_transcript_put((zk_##P##_transcript_t*)t, e, n); },             \
@@ -147,7 +149,7 @@ struct AnyTranscript {
 
 struct GroupProof { std::vector<u64> row; std::vector<u64> path; u32 depth; };
 
-void zero(DevBuf& b, size_t words) { if (words) ZK_HIP(hipMemset(b.p, 0, words * 8)); }
+void zero(DevBuf& b, size_t words, hipStream_t st) { if (words) ZK_HIP(hipMemsetAsync(b.p, 0, words * 8, st)); }
 
 }  // namespace
 
@@ -310,14 +312,19 @@ void put_path(std::ostringstream& o, const GroupProof& g, const FrApi* fr) {
     o << ']';
 }
 
-GroupProof group_proof(const AnyTree& t, u64 idx) {
-    GroupProof g; g.depth = t.depth();
-    const u32 lw = t.level_words();
-    g.row.resize(t.width ? t.width : 1); g.path.resize(g.depth ? (size_t)lw * g.depth : lw);
-    ck(t.gl ? zk_merkle_group_proof(t.gl, idx, M(g.row.data()), M(g.path.data()))
-            : t.F->group_proof(t.fr, idx, M(g.row.data()), M(g.path.data())));
-    g.row.resize(t.width);
-    return g;
+// the openings of one tree at every query index, one round trip (fri.rs:160-181)
+std::vector<GroupProof> group_proofs(const AnyTree& t, const std::vector<u64>& idx) {
+    const u32 n = (u32)idx.size(), depth = t.depth(), lw = t.level_words();
+    std::vector<u64> rows(std::max<size_t>(1, (size_t)n * t.width)), paths(std::max<size_t>(1, (size_t)n * lw * depth));
+    ck(t.gl ? zk_merkle_group_proofs(t.gl, C(idx.data()), n, M(rows.data()), M(paths.data()))
+            : t.F->group_proofs(t.fr, C(idx.data()), n, M(rows.data()), M(paths.data())));
+    std::vector<GroupProof> out(n);
+    for (u32 q = 0; q < n; ++q) {
+        out[q].depth = depth;
+        out[q].row.assign(rows.begin() + (size_t)q * t.width, rows.begin() + (size_t)(q + 1) * t.width);
+        out[q].path.assign(paths.begin() + (size_t)q * lw * depth, paths.begin() + (size_t)(q + 1) * lw * depth);
+    }
+    return out;
 }
 
 struct Key3 { u64 a, b, c; bool operator==(const Key3& o) const { return a == o.a && b == o.b && c == o.c; } };
@@ -419,23 +426,24 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
 }
 
 // cm_pols: host trace, or nullptr when d_cm (device-resident trace, borrowed) is given
-std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words) {
+std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words, hipStream_t st) {
     const JVal& I = S.info;
     const u32 nbits = S.nbits, nbits_ext = S.nbits_ext, ext = nbits_ext - nbits;
     const u64 N = 1ull << nbits, Next = 1ull << nbits_ext;
     const u64* sN = S.sN;
     ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
-    hipStream_t st = nullptr;
+    on_stream(st);                                        // everything below is issued on (or ordered against) the caller's stream
 
     // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
     DevBuf B[S_COUNT];
     u64* ptr[S_COUNT] = {};
     auto alloc = [&](int s, u64 words, bool zeroed = true) {
-        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words); ptr[s] = B[s].u();
+        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words, st); ptr[s] = B[s].u();
     };
     if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
     else {
         B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
+        ZK_HIP(hipStreamSynchronize(st));                 // the block's previous user is ordered before `st`, not before this copy
         if (n_words) ZK_HIP(hipMemcpy(ptr[S_CM1_N], cm_pols, n_words * 8, hipMemcpyHostToDevice));
     }
     for (int s : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(s, sN[s] * N);
@@ -449,11 +457,11 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     DevBuf x_n, x_2ns, zi, d_chal, d_evals, d_pub, xdiv, xdivw;                     // stark_gen.rs:231-249
     x_n.reserve(N * 8); x_2ns.reserve(Next * 8); zi.reserve((1ull << ext) * 8);
     x_table_dev(nbits, 1, x_n.u(), st); x_table_dev(nbits_ext, 49, x_2ns.u(), st); zh_inv_dev(nbits, ext, zi.u(), st);
-    d_chal.reserve(24 * 8); zero(d_chal, 24);                                        // challenge[8] (constant.rs:39-50)
+    d_chal.reserve(24 * 8); zero(d_chal, 24, st);                                        // challenge[8] (constant.rs:39-50)
     const u32 n_ev = (u32)I.at("ev_map").size();
     const u32 n_pub = (u32)I.at("publics").size();
-    d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3);
-    d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub));
+    d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3, st);
+    d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub), st);
 
     auto run = [&](const ProgramPtr& p, bool e, hipStream_t on = nullptr, u64 row0 = 0, u64 count = ~0ull) {
         if (!p) return;
@@ -493,6 +501,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             if (cm_pols) publics.push_back(cm_pols[pos]);
             else { u64 v; ZK_HIP(hipMemcpy(&v, d_cm + pos, 8, hipMemcpyDeviceToHost)); publics.push_back(v); }
         } else if (ty == "imP") {                                                  // calculate_exp_at_point :558-572
+            ZK_HIP(hipStreamSynchronize(st));                                      // (the clearing of d_pub is on `st`)
             if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
             ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
             ZK_REQUIRE(idx < N, "public out of range");
@@ -507,6 +516,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             publics.push_back(v[0]);
         } else throw Error("Invalid public type " + ty);
     }
+    ZK_HIP(hipStreamSynchronize(st));
     if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
     const FrApi* bn128 = S.fr;                            // non-null: a scalar-field hash type
     AnyTranscript tr(bn128);
@@ -556,7 +566,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     }
     TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
     challenge(2); challenge(3);                                                    // gamma, beta
-    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N);             // an output-only section starts from zero (stark_gen.rs:944-951)
+    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);         // an output-only section starts from zero (stark_gen.rs:944-951)
     run(S.step3prev, false);
     n_cm = S.n_cm1 + S.n_cm2;
     for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {                       // stark_gen.rs:329-353
@@ -569,7 +579,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             ZK_HIP(hipStreamSynchronize(st));
         }
     }
-    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N);
+    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);
     TreePtr tree3;
     if (stage3_early) {
         ZK_HIP(hipStreamWaitEvent(st, S.ev_stage3, 0));                            // cm3_n and its extension are ready
@@ -677,8 +687,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     std::vector<u64> ysi = ys;
     for (size_t si = 1; si < n_steps; ++si) {
         for (u64& y : ysi) y %= (1ull << steps[si]);
-        std::vector<GroupProof> gp;
-        for (u64 y : ysi) gp.push_back(group_proof(*fri_trees[si - 1], y));
+        const std::vector<GroupProof> gp = group_proofs(*fri_trees[si - 1], ysi);
         o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);
         o << ",\"s" << si << "_vals\":[";
         for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
@@ -690,8 +699,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         const AnyTree* trees0[5] = {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()};
         const char* names[5] = {"1", "2", "3", "4", "C"};
         std::vector<std::vector<GroupProof>> gp(5);
-        for (int j = 0; j < 5; ++j)
-            for (u64 y : ys) gp[j].push_back(group_proof(*trees0[j], y));
+        for (int j = 0; j < 5; ++j) gp[j] = group_proofs(*trees0[j], ys);
         for (int j = 0; j < 5; ++j) {
             o << ",\"s0_vals" << names[j] << "\":[";
             for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
@@ -706,6 +714,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     {
         const u64 n_last = 1ull << steps.back();
         std::vector<u64> last(3 * n_last);
+        ZK_HIP(hipStreamSynchronize(st));
         ZK_HIP(hipMemcpy(last.data(), d_pol, 24 * n_last, hipMemcpyDeviceToHost));
         o << ",\"finalPol\":[";
         for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, last.data() + 3 * i, 3); }
@@ -723,7 +732,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
 
 template <class F>
 int guard(F&& f) {
-    reset_cur_stream();
+    CallScope scope;
     try { f(); return 0; }
     catch (const std::exception& e) { set_error(e.what()); return -1; }
     catch (...) { set_error("unknown error"); return -1; }
@@ -753,7 +762,7 @@ char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_word
     if (guard([&] {
             ZK_REQUIRE(s, "zk_stark_gen: null setup");
             ZK_REQUIRE(cm_pols || n_words == 0, "zk_stark_gen: null trace");
-            const std::string z = stark_gen(*s, cm_pols, nullptr, n_words);
+            const std::string z = stark_gen(*s, cm_pols, nullptr, n_words, nullptr);
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);
@@ -762,10 +771,14 @@ char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_word
 }
 
 char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words) {
+    return zk_stark_gen_dev_on(s, d_cm_pols, n_words, nullptr);
+}
+
+char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words, void* stream) {
     char* out = nullptr;
     if (guard([&] {
             ZK_REQUIRE(s && d_cm_pols, "zk_stark_gen_dev: null argument");
-            const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words);
+            const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words, (hipStream_t)stream);
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);

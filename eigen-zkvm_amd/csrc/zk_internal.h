@@ -28,11 +28,12 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 // ---- device buffers ----
 // Size-keyed free list in front of hipMalloc/hipFree (capi.hip): a prover allocates the same
 // multi-GB sections for every proof, and hipFree/hipMalloc of such buffers costs hundreds of ms and
-// synchronises the device.  Reuse is ordered across streams: the library keeps the set of streams it has been
-// asked to work on (`on_stream`); pool_free records an event on each of them and pool_alloc makes the calling
-// thread's current stream wait for the events of the block it hands out, so a block freed with kernels still in
-// flight on stream A is never written early by stream B.  With a single stream in use (the common case) no event
-// is needed: reuse is stream ordered.
+// synchronises the device.  Reuse is ordered across streams: every host thread keeps the set of streams it has
+// issued on (`on_stream`); pool_free records an event on the null stream and on each stream of the freeing thread,
+// and pool_alloc makes the calling thread's current stream wait for the events of the block it hands out, so a
+// block freed with kernels still in flight on stream A is never written early by stream B -- while provers running
+// on different threads and streams never wait for each other.  With a single stream in use (the common case) no
+// event is needed: reuse is stream ordered.
 void* pool_alloc(size_t bytes);
 void pool_free(void* p);
 void pool_trim();  // hipFree everything cached
@@ -40,7 +41,9 @@ void pool_trim();  // hipFree everything cached
 // pool_alloc orders reuse against); returns st.  Every entry point that takes a stream goes through it.
 hipStream_t on_stream(hipStream_t st);
 hipStream_t cur_stream();
-void reset_cur_stream();  // back to the null stream (entry of every C-ABI call)
+// Scope of one C-ABI call: a call from outside the library starts on the null stream, a call the prover makes on its own
+// entry points inherits the prover's current stream; either way the caller's current stream is back when the call returns.
+struct CallScope { hipStream_t saved; CallScope(); ~CallScope(); CallScope(const CallScope&) = delete; CallScope& operator=(const CallScope&) = delete; };
 void forget_stream(hipStream_t st);  // call before destroying a registered stream
 
 struct DevBuf {

@@ -384,18 +384,24 @@ class NativeStarkSetup:
     def const_root(self):
         o = np.zeros(4, np.uint64); _check(lib().zk_stark_setup_const_root(self._h, _ptr(o))); return [int(v) for v in o]
 
-    def gen(self, cm_n):
-        """-> the proof as the zkin dict of serializer.rs:146-261; cm_n: host array or DevArray (HBM-resident trace)"""
+    def gen(self, cm_n, stream=None):
+        """-> the proof as the zkin dict of serializer.rs:146-261; cm_n: host array or DevArray (HBM-resident trace).
+        stream: a HIP stream handle (int) to prove on; setups on different streams may prove concurrently from different
+        host threads (zk_stark_gen_dev_on), one proof at a time per setup."""
+        return json.loads(self.gen_json(cm_n, stream))
+
+    def gen_json(self, cm_n, stream=None):
+        """the same proof as the JSON text the library wrote (what `zkit stark_prove --o` stores), unparsed"""
         import ctypes
         if isinstance(cm_n, DevArray):
-            p = lib().zk_stark_gen_dev(self._h, cm_n.ptr, cm_n.n)
+            p = lib().zk_stark_gen_dev_on(self._h, cm_n.ptr, cm_n.n, stream)
         else:
             c = _np(cm_n)
             p = lib().zk_stark_gen(self._h, _ptr(c), c.size)
         if not p:
             raise ZkError(lib().zk_last_error().decode())
         try:
-            return json.loads(ctypes.string_at(p).decode())
+            return ctypes.string_at(p).decode()
         finally:
             lib().zk_string_free(p)
 

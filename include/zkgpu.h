@@ -39,6 +39,12 @@ int zk_dev_trim(void);
 int zk_dev_upload(void* d_dst, const void* h_src, size_t bytes);
 int zk_dev_download(void* h_dst, const void* d_src, size_t bytes);
 int zk_dev_sync(void);
+/* A non-blocking HIP stream of the library's own making (any hipStream_t of the caller's serves as well) -- for hosts
+ * without a HIP binding of their own: one per concurrent prover thread.  zk_stream_free waits for the stream first;
+ * call it from the thread that used the stream. */
+void* zk_stream_new(void);
+int zk_stream_sync(void* stream);
+int zk_stream_free(void* stream);
 int zk_dev_memset(void* d_ptr, int value, size_t bytes);
 
 /* ---- NTT / LDE ---------------------------------------------------------------------------
@@ -88,6 +94,9 @@ uint32_t zk_merkle_depth(const zk_merkle_t* t);                     /* siblings 
 /* get_group_proof(idx) (merklehash.rs:430-438): row_out[width], path_out[depth*4];
  * idx >= height is an error, as the reference bails.                                          */
 int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out);
+/* n openings in one round trip (one launch, one copy): rows_out[n][width], paths_out[n][depth][4].  A proof opens every tree at
+ * every query index (fri.rs:160-181); asked one by one, the launch + wait + copy of each opening is most of a small proof.    */
+int zk_merkle_group_proofs(const zk_merkle_t* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out, uint64_t* paths_out);
 const uint64_t* zk_merkle_elements_dev(const zk_merkle_t* t);       /* device pointer of rows   */
 const uint64_t* zk_merkle_nodes_dev(const zk_merkle_t* t);          /* device pointer of nodes  */
 int zk_merkle_free(zk_merkle_t* t);
@@ -196,6 +205,8 @@ int zk_bn128_merkle_nodes(const zk_bn128_merkle_t* t, uint64_t* out);    /* all 
 uint32_t zk_bn128_merkle_depth(const zk_bn128_merkle_t* t);
 /* get_group_proof (:246-254): row_out[width], path_out[depth][16][4]; idx >= height is an error          */
 int zk_bn128_merkle_group_proof(const zk_bn128_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out);
+/* n openings at once: rows_out[n][width], paths_out[n][depth][16][4] */
+int zk_bn128_merkle_group_proofs(const zk_bn128_merkle_t* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out, uint64_t* paths_out);
 int zk_bn128_merkle_free(zk_bn128_merkle_t* t);
 /* TranscriptBN128 (transcript_bn128.rs:14-132): put takes one Goldilocks word (n = 1) or one digest (n = 4)       */
 typedef struct zk_bn128_transcript zk_bn128_transcript_t;
@@ -223,6 +234,7 @@ int zk_bls12381_merkle_root(const zk_bls12381_merkle_t* t, uint64_t out[4]);
 int zk_bls12381_merkle_nodes(const zk_bls12381_merkle_t* t, uint64_t* out);
 uint32_t zk_bls12381_merkle_depth(const zk_bls12381_merkle_t* t);
 int zk_bls12381_merkle_group_proof(const zk_bls12381_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out);
+int zk_bls12381_merkle_group_proofs(const zk_bls12381_merkle_t* t, const uint64_t* idx, uint32_t n, uint64_t* rows_out, uint64_t* paths_out);
 int zk_bls12381_merkle_free(zk_bls12381_merkle_t* t);
 zk_bls12381_transcript_t* zk_bls12381_transcript_new(void);
 int zk_bls12381_transcript_put(zk_bls12381_transcript_t* t, const uint64_t* e, size_t n);
@@ -260,6 +272,11 @@ char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_word
 /* same with the trace already resident in HBM (borrowed, not modified), e.g. written there by a device-side
  * witness generator or uploaded while the previous proof was running                                     */
 char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words);
+/* The same on a stream of the caller's.  Proofs of DIFFERENT setups may run at the same time from different host threads,
+ * each on its own (non-blocking) stream: small proofs are bound by the latency of their launch chain, not by the device
+ * (test/stark_aggregation.sh:70-73 runs its recursion tasks as parallel processes for the same reason).  One setup serves
+ * one proof at a time. */
+char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words, void* stream);
 void zk_string_free(char* s);
 int zk_stark_setup_free(zk_stark_setup_t* s);
 

@@ -29,7 +29,7 @@ int main(int argc, char **argv) {
                        (void *)zk_gl_poseidon, (void *)zk_gl_linearhash, (void *)zk_gl_merkelize, (void *)zk_merkle_root,
                        (void *)zk_merkle_group_proof, (void *)zk_merkle_free, (void *)zk_transcript_new, (void *)zk_fri_fold_dev,
                        (void *)zk_stark_calculate_z_dev, (void *)zk_msm_g1_bn254, (void *)zk_stark_setup_new, (void *)zk_stark_gen,
-                       (void *)zk_stark_gen_dev, (void *)zk_string_free, (void *)zk_stark_setup_free, (void *)zk_c12_exec_new,
+                       (void *)zk_stark_gen_dev, (void *)zk_stark_gen_dev_on, (void *)zk_program_run_rows_dev, (void *)zk_string_free, (void *)zk_stark_setup_free, (void *)zk_c12_exec_new,
                        (void *)zk_groth16_setup_new, (void *)zk_program_compile};
         unsigned n = 0;
         for (unsigned i = 0; i < sizeof fns / sizeof fns[0]; ++i) n += fns[i] != NULL;

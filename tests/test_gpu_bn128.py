@@ -92,6 +92,12 @@ def test_merkle_tree_matches_oracle(zk, orc, height, width):
             assert np.array_equal(h.root_from_proof(path, exp[idx]), t.root())
     with pytest.raises(zk.ZkError):
         t.get_group_proof(height)                                       # MerkleTreeError: access invalid node
+    qs = [int(v) for v in rng.integers(0, height, size=9)] + [height - 1, 0, 0]
+    for (row, path), idx in zip(t.get_group_proofs(qs), qs):           # the openings of a query list in one round trip
+        r1, p1 = t.get_group_proof(idx)
+        assert np.array_equal(row, r1) and np.array_equal(path, p1)
+    with pytest.raises(zk.ZkError):
+        t.get_group_proofs([0, height])
 
 
 def test_transcript_matches_oracle_sequence(zk, orc):

@@ -153,3 +153,11 @@ def test_merkle_nodes_and_proofs_match_oracle(zk, orc, height, width):
             assert np.array_equal(orc.root_from_proof(row, path.reshape(-1), idx), t.root())
     with pytest.raises(zk.ZkError, match="access invalid node"):     # merklehash.rs:431-433
         t.get_group_proof(height)
+    # every opening of a query list in one round trip (zk_merkle_group_proofs): the same answers, repeats and any order allowed
+    qs = [int(v) for v in rng.integers(0, height, size=11)] + [height - 1, 0, 0]
+    for (row, path), idx in zip(t.get_group_proofs(qs), qs):
+        r1, p1 = t.get_group_proof(idx)
+        assert np.array_equal(row, r1) and np.array_equal(path, p1)
+    assert t.get_group_proofs([]) == []
+    with pytest.raises(zk.ZkError, match="access invalid node"):
+        t.get_group_proofs([0, height])
