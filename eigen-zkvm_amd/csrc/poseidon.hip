@@ -299,6 +299,64 @@ __global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_rows_kernel(const
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = d[i];
 }
 
+// The same LinearHash with 16 lanes per row (coop_perm): lane l < 12 owns state word l, lanes 0..3 keep the batch digests.
+// For trees of few rows -- the FRI steps' trees: 2^3 ... 2^13 rows of up to 3 * 2^6 words, i.e. a sponge of up to 26
+// permutations per row -- the one-lane kernel is a single dependent chain of ~33 k instructions per permutation on a handful
+// of waves; spreading the state cuts the chain to a fifth.  Same control flow as linearhash_row (it depends on w only).
+__device__ __forceinline__ u64 coop_linearhash_row(const u64* __restrict__ row, u32 w, int l, const u64* __restrict__ tab) {
+    if (w <= 4) return (u32)l < w ? row[l] : 0;
+    u32 bs = (w + 3) / 4; if (bs < 8) bs = 8;
+    const u32 hsz = (w + bs - 1) / bs;
+    u64 hq[4] = {0, 0, 0, 0};                 // lane l < 4: word l of batch digest 0..3
+    u64 x = 0, cap = 0;                       // cap: lanes 8..11 carry the capacity into the next permutation
+    u32 b = 0, off = 0;
+    bool final_sponge = false, second = false;
+    for (;;) {
+        if (!final_sponge) {
+            const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
+            const u64* __restrict__ v = row + (u64)b * bs + off;
+            x = l < 8 ? (off + l < len ? v[l] : 0) : cap;
+        } else {
+            const u64 a = shfl64(second ? hq[2] : hq[0], l & 3), c = shfl64(second ? hq[3] : hq[1], l & 3);
+            x = l < 4 ? a : l < 8 ? c : cap;
+        }
+        x = coop_perm(x, tab);
+        if (!final_sponge) {
+            const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
+            off += 8;
+            if (off < len) { cap = shfl64(x, (l + 8) & 15); continue; }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) if ((u32)bb == b) hq[bb] = x;
+            ++b; off = 0;
+            if (b < hsz && w - b * bs <= 4) {   // short last batch: identity padding, no permutation
+                const u32 len2 = w - b * bs;
+                const u64 v = (u32)l < len2 ? row[(u64)b * bs + l] : 0;
+#pragma unroll
+                for (int bb = 1; bb < 4; ++bb) if ((u32)bb == b) hq[bb] = v;
+                ++b;
+            }
+            cap = 0;
+            if (b < hsz) continue;
+            if (hsz == 1) break;
+            final_sponge = true;
+        } else {
+            if (second || hsz <= 2) break;
+            second = true;
+            cap = shfl64(x, (l + 8) & 15);
+        }
+    }
+    return x;
+}
+__global__ __launch_bounds__(256) void linearhash_rows_coop_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    ZK_POSEIDON_LDS;
+    load_tables(tab);
+    const int l = threadIdx.x & 15;
+    const u64 r = (u64)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const u64 rc = r < height ? r : height - 1;                  // idle groups shadow the last row (no divergence)
+    const u64 x = coop_linearhash_row(rows + rc * width, width, l, tab);
+    if (r < height && l < 4) digests[4 * r + l] = x;
+}
+
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
 __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
     ZK_POSEIDON_LDS;
@@ -501,8 +559,13 @@ void poseidon_dev(const u64* d_in8, const u64* d_cap4, u64* d_out, int n_out, hi
 void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     ensure_constants();
     if (height == 0) return;
-    const u64 blocks = (height + 255) / 256;
-    hipLaunchKernelGGL(linearhash_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, d_rows, width, height, d_digests);
+    static const u64 coop_below = getenv("ZK_LH_COOP_BELOW") ? strtoull(getenv("ZK_LH_COOP_BELOW"), nullptr, 10) : 16384;
+    if (height < coop_below && width > 4) {    // few rows: latency-bound, 16 lanes per row
+        hipLaunchKernelGGL(linearhash_rows_coop_kernel, dim3((u32)((height + 15) / 16)), dim3(256), 0, st, d_rows, width, height, d_digests);
+    } else {
+        const u64 blocks = (height + 255) / 256;
+        hipLaunchKernelGGL(linearhash_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, d_rows, width, height, d_digests);
+    }
     ZK_HIP(hipGetLastError());
 }
 

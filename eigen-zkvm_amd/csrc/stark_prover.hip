@@ -562,8 +562,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         ZK_HIP(hipMemcpy(f.p, h1.data(), 24 * N, hipMemcpyHostToDevice));
         ZK_HIP(hipMemcpy(t.p, h2.data(), 24 * N, hipMemcpyHostToDevice));
         set_pol(S.cm_n.at(n_cm++), f.u()); set_pol(S.cm_n.at(n_cm++), t.u());
-        ZK_HIP(hipStreamSynchronize(st));
-    }
+    }                                                                              // (f, t go back to the pool: reuse is stream ordered)
     TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
     challenge(2); challenge(3);                                                    // gamma, beta
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);         // an output-only section starts from zero (stark_gen.rs:944-951)
@@ -576,7 +575,6 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             z.reserve(3 * N * 8);
             ck(zk_stark_calculate_z_dev(C(num.u()), C(den.u()), N, M(z.u()), st));
             set_pol(S.cm_n.at(n_cm++), z.u());
-            ZK_HIP(hipStreamSynchronize(st));
         }
     }
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);
@@ -659,8 +657,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             fri_transpose_dev(d_pol, 1ull << step_bits, nxt, tb.u(), st);
             fri_width[si] = (u32)(3 * group_size);
             fri_trees[si].reset(new AnyTree(bn128, tb.u(), fri_width[si], n_groups, st));
-            fri_trees[si]->root(fri_roots[si].data());
-            tr.put_root(*fri_trees[si], st);
+            tr.put_root(*fri_trees[si], st);                                           // (its words are read for the JSON below)
         } else {
             tr.put_words_dev(d_pol, 3ull << step_bits, st);                             // fri.rs:136-141
         }
@@ -673,6 +670,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     // ---- proof -> zkin JSON (serializer.rs:146-261)
     u64 r1[4], r2[4], r3[4], r4[4];
     tree1->root(r1); tree2->root(r2); tree3->root(r3); tree4->root(r4);
+    for (size_t si = 0; si + 1 < n_steps; ++si) fri_trees[si]->root(fri_roots[si].data());
     std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev));
     ZK_HIP(hipStreamSynchronize(st));
     if (n_ev) ZK_HIP(hipMemcpy(ev_host.data(), d_evals.p, 24 * (size_t)n_ev, hipMemcpyDeviceToHost));

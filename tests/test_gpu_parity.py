@@ -137,7 +137,8 @@ def test_merkle_root_kats(zk, golden):
 
 
 @pytest.mark.parametrize("height,width", [(1, 1), (1, 9), (2, 3), (3, 5), (33, 6), (255, 2), (256, 9), (1000, 19),
-                                          (4096, 12), (1 << 15, 18), (70001, 4), (2, 0), (1024, 0), (33, 0)])
+                                          (4096, 12), (1 << 15, 18), (70001, 4), (2, 0), (1024, 0), (33, 0),
+                                          (16383, 9), (16384, 9), (20000, 37), (300, 193), (8, 768)])   # leaf hashing: 16 lanes per row below 2^14 rows
 def test_merkle_nodes_and_proofs_match_oracle(zk, orc, height, width):
     rng = np.random.default_rng(height * 13 + width)
     buff = rng.integers(0, P, size=height * width, dtype=np.uint64)
