@@ -27,6 +27,8 @@ extern "C" {
     pub fn zk_gl_merkelize(buff: *const u64, width: u32, height: u64) -> *mut zk_merkle_t;
     pub fn zk_merkle_root(t: *const zk_merkle_t, out: *mut u64) -> c_int;
     pub fn zk_merkle_group_proof(t: *const zk_merkle_t, idx: u64, row_out: *mut u64, path_out: *mut u64) -> c_int;
+    /// every opening of a query list in one round trip: rows_out[n][width], paths_out[n][depth][4]
+    pub fn zk_merkle_group_proofs(t: *const zk_merkle_t, idx: *const u64, n: u32, rows_out: *mut u64, paths_out: *mut u64) -> c_int;
     pub fn zk_merkle_depth(t: *const zk_merkle_t) -> u32;
     pub fn zk_merkle_elements(t: *const zk_merkle_t, out: *mut u64) -> c_int;
     pub fn zk_merkle_free(t: *mut zk_merkle_t) -> c_int;
@@ -47,6 +49,12 @@ extern "C" {
     pub fn zk_stark_setup_const_root(s: *const zk_stark_setup_t, out: *mut u64) -> c_int;
     pub fn zk_stark_setup_set_prover_addr(s: *mut zk_stark_setup_t, prover_addr: *const c_char) -> c_int;
     pub fn zk_stark_gen(s: *mut zk_stark_setup_t, cm_pols: *const u64, n_words: u64) -> *mut c_char;
+    /// the trace already in HBM, on a stream of the caller's: setups on different streams prove side by side from
+    /// different host threads (one proof at a time per setup)
+    pub fn zk_stark_gen_dev_on(s: *mut zk_stark_setup_t, d_cm_pols: *const u64, n_words: u64, stream: *mut c_void) -> *mut c_char;
+    pub fn zk_stream_new() -> *mut c_void;
+    pub fn zk_stream_sync(stream: *mut c_void) -> c_int;
+    pub fn zk_stream_free(stream: *mut c_void) -> c_int;
     pub fn zk_string_free(s: *mut c_char);
     pub fn zk_stark_setup_free(s: *mut zk_stark_setup_t) -> c_int;
     pub fn zk_bn128_load_constants(path: *const c_char) -> c_int;
@@ -65,6 +73,28 @@ pub fn check(rc: c_int) -> anyhow::Result<()> {
 pub fn last_error() -> anyhow::Error {
     let msg = unsafe { CStr::from_ptr(zk_last_error()) }.to_string_lossy().into_owned();
     anyhow::anyhow!("libzkgpu: {msg}")
+}
+
+/// A non-blocking HIP stream of the library's making: one per prover thread (`zk_stark_gen_dev_on`).  Not `Send`: the
+/// library orders buffer reuse against the streams of the thread that frees, so a stream stays with the thread that made it.
+pub struct Stream(pub *mut c_void);
+impl Stream {
+    pub fn new() -> anyhow::Result<Self> {
+        let p = unsafe { zk_stream_new() };
+        if p.is_null() {
+            Err(last_error())
+        } else {
+            Ok(Stream(p))
+        }
+    }
+    pub fn sync(&self) -> anyhow::Result<()> {
+        check(unsafe { zk_stream_sync(self.0) })
+    }
+}
+impl Drop for Stream {
+    fn drop(&mut self) {
+        unsafe { zk_stream_free(self.0) };
+    }
 }
 
 #[allow(dead_code)]
