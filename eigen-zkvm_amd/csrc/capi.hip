@@ -868,6 +868,24 @@ int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset,
 int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const uint64_t* d_in3, void* stream) {
     return guard([&] { pol_set_dev((u64*)d_buf, width, offset, dim, n, (const u64*)d_in3, on_stream((hipStream_t)stream)); });
 }
+int zk_stark_calculate_h1h2_dev(const uint64_t* d_f3, const uint64_t* d_t3, uint64_t n, uint64_t* d_h1_3, uint64_t* d_h2_3, void* stream) {
+    return guard([&] {
+        ZK_REQUIRE(d_f3 && d_t3 && d_h1_3 && d_h2_3 && n >= 1, "calculate_H1H2: null or empty argument");
+        ZK_REQUIRE(n <= (1ull << 28), "calculate_H1H2: more than 2^28 rows");
+        hipStream_t st = on_stream((hipStream_t)stream);
+        DevBuf work; work.reserve(h1h2_work_words(n) * 8);
+        u64* d_missing = nullptr;
+        calculate_h1h2_dev((const u64*)d_f3, (const u64*)d_t3, n, (u64*)d_h1_3, (u64*)d_h2_3, work.u(), &d_missing, st);
+        u64 missing = 0;
+        ZK_HIP(hipStreamSynchronize(st));
+        ZK_HIP(hipMemcpy(&missing, d_missing, 8, hipMemcpyDeviceToHost));
+        if (missing != ~0ull) {                                          // stark_gen.rs:636-638, the first f that the table lacks
+            u64 e = 0;
+            ZK_HIP(hipMemcpy(&e, d_f3 + 3 * missing, 8, hipMemcpyDeviceToHost));
+            throw Error("Number not included: " + std::to_string(e));
+        }
+    });
+}
 int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream) {
     return guard([&] {
         ZK_REQUIRE(n >= 1, "calculate_Z: empty polynomial");

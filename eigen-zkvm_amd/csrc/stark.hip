@@ -418,6 +418,129 @@ void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_
     ZK_HIP(hipGetLastError());
 }
 
+
+// ---- calculate_H1H2 (stark_gen.rs:624-651) on the device ------------------------------------------------------------------
+// The reference maps every table row t[j] to its LAST index j (a hash map filled in order), looks every f[i] up, and sorts
+// the 2n pairs (index, value) stably by index with the table rows first: the sorted list is t[j] repeated 1 + c_j times for
+// j = 0, 1, ..., where c_j counts the f's that found index j; h1 and h2 are its even and odd entries.  Here:
+//   1. an open-addressing table over the indices of t (4n slots, linear probing; equal keys keep the larger index by atomicMax),
+//   2. one lookup per f[i] -> j, a histogram c_j (and the smallest i that finds nothing: the reference's error),
+//   3. an exclusive scan of 1 + c_j -> where index j starts in the sorted list,
+//   4. output position q belongs to the last j whose start is <= q (binary search): h1[i] = t[owner(2i)], h2[i] = t[owner(2i + 1)].
+namespace {
+__device__ __forceinline__ u64 h1h2_hash(const u64* __restrict__ e) {
+    u64 h = e[0] * 0x9E3779B97F4A7C15ull ^ (e[1] + 0x7F4A7C15ull) * 0xD1B54A32D192ED03ull ^ e[2] * 0x2545F4914F6CDD1Dull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return h;
+}
+__device__ __forceinline__ bool h1h2_eq(const u64* __restrict__ a, const u64* __restrict__ b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; }
+
+__global__ __launch_bounds__(256) void h1h2_insert_kernel(const u64* __restrict__ t, u64 n, u64* __restrict__ slots /* idx + 1, 0 = empty */, u64 mask) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64* e = t + 3 * i;
+    for (u64 s = h1h2_hash(e) & mask;; s = (s + 1) & mask) {
+        const u64 cur = atomicCAS((unsigned long long*)&slots[s], 0ull, (unsigned long long)(i + 1));
+        if (cur == 0) return;                                             // claimed an empty slot
+        if (h1h2_eq(t + 3 * (cur - 1), e)) { atomicMax((unsigned long long*)&slots[s], (unsigned long long)(i + 1)); return; }   // same value: the last index wins
+    }
+}
+__global__ __launch_bounds__(256) void h1h2_lookup_kernel(const u64* __restrict__ f, const u64* __restrict__ t, u64 n, const u64* __restrict__ slots,
+                                                          u64 mask, u64* __restrict__ count /* [n], starts at 1 */, u64* __restrict__ missing) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64* e = f + 3 * i;
+    for (u64 s = h1h2_hash(e) & mask;; s = (s + 1) & mask) {
+        const u64 cur = slots[s];
+        if (cur == 0) { atomicMin((unsigned long long*)missing, (unsigned long long)i); return; }
+        if (h1h2_eq(t + 3 * (cur - 1), e)) { atomicAdd((unsigned long long*)&count[cur - 1], 1ull); return; }
+    }
+}
+__global__ __launch_bounds__(256) void h1h2_fill_kernel(u64* __restrict__ p, u64 n, u64 v) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// exclusive scan of u64 counters, 4096 per block: block sums, a one-block scan of those (<= 2^16 of them for n <= 2^28), add back
+constexpr int SCAN_PER = 16;
+__global__ __launch_bounds__(256) void scan_block_kernel(const u64* __restrict__ in, u64 n, u64* __restrict__ out, u64* __restrict__ sums) {
+    __shared__ u64 sh[256];
+    const u64 base = ((u64)blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    u64 v[SCAN_PER], tot = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { v[k] = base + k < n ? in[base + k] : 0; tot += v[k]; }
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const u64 add = threadIdx.x >= (u32)d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    u64 run = sh[threadIdx.x] - tot;                                      // exclusive prefix of this lane inside the block
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) sums[blockIdx.x] = sh[255];
+}
+__global__ __launch_bounds__(1024) void scan_sums_kernel(u64* __restrict__ sums, u64 nb) {   // one block, in place, exclusive
+    __shared__ u64 sh[1024];
+    __shared__ u64 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < nb; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < nb ? sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const u64 add = threadIdx.x >= (u32)d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nb) sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(u64* __restrict__ out, u64 n, const u64* __restrict__ sums) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += sums[i / (256 * SCAN_PER)];
+}
+__global__ __launch_bounds__(256) void h1h2_emit_kernel(const u64* __restrict__ t, const u64* __restrict__ start /* [n] exclusive scan */, u64 n,
+                                                        u64* __restrict__ h1, u64* __restrict__ h2) {
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;          // position in the sorted list of 2n values
+    if (q >= 2 * n) return;
+    u64 lo = 0, hi = n;                                                   // last j with start[j] <= q
+    while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (start[mid] <= q) lo = mid; else hi = mid; }
+    u64* __restrict__ o = (q & 1 ? h2 : h1) + 3 * (q >> 1);
+    o[0] = t[3 * lo]; o[1] = t[3 * lo + 1]; o[2] = t[3 * lo + 2];
+}
+}  // namespace
+
+// d_work: 4*pow2ceil(n) + 2n + n/4096 + 8 words.  *d_missing (a word of d_work, see h1h2_missing_word) ends as the smallest i
+// whose f[i] is not in t, or ~0.
+uint64_t h1h2_work_words(uint64_t n) {
+    u64 m = 4; while (m < 4 * n) m <<= 1;
+    return m + 2 * n + (n + 4095) / 4096 + 8;
+}
+void calculate_h1h2_dev(const u64* d_f, const u64* d_t, uint64_t n, u64* d_h1, u64* d_h2, u64* d_work, u64** d_missing, hipStream_t st) {
+    u64 m = 4; while (m < 4 * n) m <<= 1;
+    u64* slots = d_work; u64* count = slots + m; u64* start = count + n; u64* sums = start + n; u64* missing = sums + (n + 4095) / 4096 + 1;
+    *d_missing = missing;
+    const u64 nsb = (n + 4095) / 4096;
+    ZK_HIP(hipMemsetAsync(slots, 0, m * 8, st));
+    ZK_HIP(hipMemsetAsync(missing, 0xFF, 8, st));
+    hipLaunchKernelGGL(h1h2_fill_kernel, grid1(n), dim3(256), 0, st, count, n, (u64)1);
+    hipLaunchKernelGGL(h1h2_insert_kernel, grid1(n), dim3(256), 0, st, d_t, n, slots, m - 1);
+    hipLaunchKernelGGL(h1h2_lookup_kernel, grid1(n), dim3(256), 0, st, d_f, d_t, n, slots, m - 1, count, missing);
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nsb), dim3(256), 0, st, count, n, start, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nsb);
+    hipLaunchKernelGGL(scan_add_kernel, grid1(n), dim3(256), 0, st, start, n, sums);
+    hipLaunchKernelGGL(h1h2_emit_kernel, grid1(2 * n), dim3(256), 0, st, d_t, start, n, d_h1, d_h2);
+    ZK_HIP(hipGetLastError());
+}
+
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st) {
     const u64 N = 1ull << nbits;
     const u64 shift_inv_n = gl::hpow(gl::hinv(49), N);

@@ -327,35 +327,6 @@ std::vector<GroupProof> group_proofs(const AnyTree& t, const std::vector<u64>& i
     return out;
 }
 
-struct Key3 { u64 a, b, c; bool operator==(const Key3& o) const { return a == o.a && b == o.b && c == o.c; } };
-struct Key3Hash { size_t operator()(const Key3& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull) * 0xD1B54A32D192ED03ull ^ k.c * 0x2545F4914F6CDD1Dull); } };
-
-// calculate_H1H2 (stark_gen.rs:624-651): hash-map lookup + stable sort by table index; rows are [n][3]
-void calculate_h1h2(const std::vector<u64>& f, const std::vector<u64>& t, u64 n, std::vector<u64>& h1, std::vector<u64>& h2) {
-    std::unordered_map<Key3, u64, Key3Hash> idx_t;
-    idx_t.reserve(n * 2);
-    std::vector<std::pair<u64, Key3>> s; s.reserve(2 * n);
-    for (u64 i = 0; i < n; ++i) {
-        Key3 e{t[3 * i], t[3 * i + 1], t[3 * i + 2]};
-        idx_t[e] = i;
-        s.emplace_back(i, e);
-    }
-    for (u64 i = 0; i < n; ++i) {
-        Key3 e{f[3 * i], f[3 * i + 1], f[3 * i + 2]};
-        auto it = idx_t.find(e);
-        if (it == idx_t.end()) throw Error("Number not included: " + dec(e.a));
-        s.emplace_back(it->second, e);
-    }
-    std::stable_sort(s.begin(), s.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-    h1.resize(3 * n); h2.resize(3 * n);
-    for (u64 i = 0; i < n; ++i) {
-        const Key3 &a = s[2 * i].second, &b = s[2 * i + 1].second;
-        h1[3 * i] = a.a; h1[3 * i + 1] = a.b; h1[3 * i + 2] = a.c;
-        h2[3 * i] = b.a; h2[3 * i + 1] = b.b; h2[3 * i + 2] = b.c;
-    }
-}
-
-
 zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t* const_pols, uint64_t n_words) {
     std::unique_ptr<zk_stark_setup> S(new zk_stark_setup);
     JVal root = JParser::parse(json);
@@ -552,17 +523,12 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     run(S.step2prev, false);
     u64 n_cm = S.n_cm1;
     for (const JVal& pu : I.at("pu_ctx").arr) {                                    // stark_gen.rs:300-308
-        DevBuf f, t;
+        DevBuf f, t, h1, h2;
         get_pol(e2p(pu.at("f_exp_id")), f); get_pol(e2p(pu.at("t_exp_id")), t);
-        std::vector<u64> hf(3 * N), ht(3 * N), h1, h2;
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_HIP(hipMemcpy(hf.data(), f.p, 24 * N, hipMemcpyDeviceToHost));
-        ZK_HIP(hipMemcpy(ht.data(), t.p, 24 * N, hipMemcpyDeviceToHost));
-        calculate_h1h2(hf, ht, N, h1, h2);
-        ZK_HIP(hipMemcpy(f.p, h1.data(), 24 * N, hipMemcpyHostToDevice));
-        ZK_HIP(hipMemcpy(t.p, h2.data(), 24 * N, hipMemcpyHostToDevice));
-        set_pol(S.cm_n.at(n_cm++), f.u()); set_pol(S.cm_n.at(n_cm++), t.u());
-    }                                                                              // (f, t go back to the pool: reuse is stream ordered)
+        h1.reserve(24 * N); h2.reserve(24 * N);
+        ck(zk_stark_calculate_h1h2_dev(C(f.u()), C(t.u()), N, M(h1.u()), M(h2.u()), st));
+        set_pol(S.cm_n.at(n_cm++), h1.u()); set_pol(S.cm_n.at(n_cm++), h2.u());
+    }
     TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
     challenge(2); challenge(3);                                                    // gamma, beta
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);         // an output-only section starts from zero (stark_gen.rs:944-951)

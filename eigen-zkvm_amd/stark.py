@@ -202,9 +202,9 @@ def stark_gen(cm_n, setup):
     e2p = lambda k: info["exp2pol"][k] if k in info["exp2pol"] else info["exp2pol"][str(k)]
     for pu in info["pu_ctx"]:                                                             # stark_gen.rs:300-308
         f, t = get_pol(e2p(pu["f_exp_id"])), get_pol(e2p(pu["t_exp_id"]))
-        h1, h2 = calculate_h1h2(f.to_host().reshape(-1, 3), t.to_host().reshape(-1, 3))
-        set_pol(info["cm_n"][n_cm], DevArray.from_host(h1)); n_cm += 1
-        set_pol(info["cm_n"][n_cm], DevArray.from_host(h2)); n_cm += 1
+        h1, h2 = calculate_h1h2_dev(f, t)
+        set_pol(info["cm_n"][n_cm], h1); n_cm += 1
+        set_pol(info["cm_n"][n_cm], h2); n_cm += 1
     tree2 = extend_and_merkelize("cm2"); put_root(tree2)
     challenge(2); challenge(3)                                                            # gamma, beta
     _zero(B["tmpexp_n"])                                  # an output-only section starts from zero (stark_gen.rs:944-951)
@@ -273,21 +273,11 @@ def _group_proof(tree, idx):
     return [int(v) for v in row], [[int(x) for x in lvl] for lvl in path]
 
 
-def calculate_h1h2(f, t):
-    """calculate_H1H2 (stark_gen.rs:624-651) on host rows [N][3]: hash-map lookup + stable sort by table index."""
-    idx_t = {}
-    s = []
-    for i, e in enumerate(map(tuple, t.tolist())):
-        idx_t[e] = i
-        s.append((e, i))
-    for e in map(tuple, f.tolist()):
-        if e not in idx_t:
-            raise ZkError("Number not included: %r" % (e,))
-        s.append((e, idx_t[e]))
-    s.sort(key=lambda a: a[1])
-    n = len(f)
-    h1 = np.array([s[2 * i][0] for i in range(n)], np.uint64).reshape(-1)
-    h2 = np.array([s[2 * i + 1][0] for i in range(n)], np.uint64).reshape(-1)
+def calculate_h1h2_dev(f, t):
+    """calculate_H1H2 (stark_gen.rs:624-651) on [N][3] device polynomials -> (h1, h2), device polynomials"""
+    n = f.n // 3
+    h1, h2 = DevArray(3 * n), DevArray(3 * n)
+    _check(lib().zk_stark_calculate_h1h2_dev(f.ptr, t.ptr, n, h1.ptr, h2.ptr, None))
     return h1, h2
 
 

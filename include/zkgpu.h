@@ -150,6 +150,10 @@ int zk_stark_get_pol_dev(const uint64_t* d_buf, uint64_t width, uint64_t offset,
                          uint64_t* d_out3, void* stream);
 int zk_stark_set_pol_dev(uint64_t* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n,
                          const uint64_t* d_in3, void* stream);
+/* calculate_H1H2 (:624-651) over [n][3] operands: the sorted merge of the looked-up values f and the table t, split into its even
+ * (h1) and odd (h2) entries.  A hash table over t on the device instead of the reference's HashMap + stable sort on the host;
+ * synchronises and fails with "Number not included: <value>" for the first f the table lacks (:636-638). */
+int zk_stark_calculate_h1h2_dev(const uint64_t* d_f3, const uint64_t* d_t3, uint64_t n, uint64_t* d_h1_3, uint64_t* d_h2_3, void* stream);
 /* calculate_Z (:653-666): z[0] = 1, z[i] = z[i-1]*num[i-1]/den[i-1] over [n][3] operands; synchronises
  * and fails ("z does not close") when z[n-1]*num[n-1]/den[n-1] != 1, as the reference asserts (:663-664) */
 int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uint64_t n, uint64_t* d_z3, void* stream);

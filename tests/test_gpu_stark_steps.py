@@ -1,7 +1,12 @@
 """Parity of the prover glue kernels (transcript, FRI fold/transposition, x/(x-xi), LEv, evals,
 Q split, domain tables) -- HIP through the C ABI vs the CPU oracle, bit exact."""
+import pathlib
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
@@ -122,3 +127,30 @@ def test_qsplit(zk, orc, nbits, ext, q_dim, q_deg):
     qq1 = rng.integers(0, P, size=(1 << (nbits + ext)) * q_dim, dtype=np.uint64)
     got = zk.qsplit(zk.DevArray.from_host(qq1), nbits, nbits + ext, q_dim, q_deg).to_host()
     assert np.array_equal(got, orc.qsplit(qq1, nbits, nbits + ext, q_dim, q_deg))
+
+
+@pytest.mark.parametrize("n,n_distinct", [(1, 1), (2, 1), (8, 3), (1000, 17), (1 << 12, 1 << 12), (1 << 16, 300), (100003, 5000)])
+def test_calculate_h1h2_matches_reference(zk, n, n_distinct):
+    """zk_stark_calculate_h1h2_dev against the restated calculate_H1H2 (stark_gen.rs:624-651; oracle/stark_prover.py): tables with
+    repeated rows (the LAST index of a value is its place), values looked up many times or never, dim-1 and dim-3 operands"""
+    import importlib
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import stark_prover as SP
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    zk.init(0)
+    rng = np.random.default_rng(n * 7 + n_distinct)
+    vals = rng.integers(0, P, size=(n_distinct, 3), dtype=np.uint64)
+    if n % 2 == 0:
+        vals[:, 1:] = 0                                                  # base-field operands as get_pol pads them
+    t = vals[rng.integers(0, n_distinct, size=n)]                        # table rows: repeats unless n_distinct >= n
+    f = t[rng.integers(0, n, size=n)]                                    # every looked-up value is in the table
+    if n > 4:
+        f[: n // 3] = t[0]                                               # one value carries a third of the lookups
+    h1, h2 = stark.calculate_h1h2_dev(zk.DevArray.from_host(f.reshape(-1)), zk.DevArray.from_host(t.reshape(-1)))
+    e1, e2 = SP.calculate_h1h2([tuple(int(v) for v in r) for r in f], [tuple(int(v) for v in r) for r in t])
+    assert np.array_equal(h1.to_host().reshape(-1, 3), np.array(e1, dtype=np.uint64).reshape(-1, 3))
+    assert np.array_equal(h2.to_host().reshape(-1, 3), np.array(e2, dtype=np.uint64).reshape(-1, 3))
+    if n >= 8:                                                           # the first missing value is the one reported
+        bad = f.copy(); bad[5] = [P - 1, P - 2, 7]; bad[n - 1] = [P - 3, 1, 1]
+        with pytest.raises(zk.ZkError, match="Number not included: %d" % (P - 1)):
+            stark.calculate_h1h2_dev(zk.DevArray.from_host(bad.reshape(-1)), zk.DevArray.from_host(t.reshape(-1)))
