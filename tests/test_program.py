@@ -189,3 +189,86 @@ def test_long_horner_chains_match_reference_interpreter(zk, orc, n_terms):
     interp.run(program, bufs, n, nxt, challenges=chal.reshape(8, 3).astype(object).tolist(), evals=evals.reshape(4, 3).astype(object).tolist(),
                xdiv=[int(v) for v in xd])
     assert [int(v) for v in d["q"].to_host()] == bufs["q"]
+
+
+def _random_program(rng, n_ops):
+    """A random straight-line step program over every operand kind the prover's segments use (A.9): temporaries of both
+    dimensions, primed and unprimed column reads, numbers, publics, challenges, evals, x, Zi, x/(x - xi) tables, Horner
+    chains on a challenge (the shape the translator keeps symbolic), read-back of its own column writes; it ends by
+    writing a dim-1 and a dim-3 column of cm3 and the dim-3 q."""
+    ch = lambda i: {"kind": "challenge", "id": i}
+    leaves1 = [lambda: M("cm1", int(rng.integers(0, 4)), 4, prime=bool(rng.integers(0, 2))),
+               lambda: M("const", int(rng.integers(0, 2)), 2, prime=bool(rng.integers(0, 2))),
+               lambda: N([0, 1, 2, 7, P - 1, 1 << 40, int(rng.integers(0, P, dtype=np.uint64))][int(rng.integers(0, 7))]),
+               lambda: {"kind": "public", "id": int(rng.integers(0, 2))},
+               lambda: {"kind": "x"}, lambda: {"kind": "Zi"}]
+    leaves3 = [lambda: ch(int(rng.integers(0, 8))), lambda: {"kind": "eval", "id": int(rng.integers(0, 4))},
+               lambda: M("cm1", 1, 4, dim=3, prime=bool(rng.integers(0, 2))),
+               lambda: {"kind": "xDivXSubXi"}, lambda: {"kind": "xDivXSubWXi"}]
+    prog, dims = [], []                                                # dims[i] = dimension of T(i)
+
+    def operand():
+        r = rng.random()
+        if dims and r < 0.5:
+            i = int(rng.integers(0, len(dims))); return T(i), dims[i]
+        if r < 0.85:
+            return leaves1[int(rng.integers(0, len(leaves1)))](), 1
+        return leaves3[int(rng.integers(0, len(leaves3)))](), 3
+
+    def emit(op, a, b):
+        d = max(a[1], b[1]) if b else a[1]
+        prog.append((op, T(len(dims)), a[0], b[0] if b else None)); dims.append(d)
+        return T(len(dims) - 1), d
+
+    while len(prog) < n_ops:
+        r = rng.random()
+        if r < 0.2:                                                      # acc <- v * acc + d, d a column, a (column - eval) or a temporary
+            v = ch(int(rng.integers(0, 8)))
+            acc = emit("mul", (v, 3), operand())
+            for _ in range(int(rng.integers(2, 40))):
+                if rng.random() < 0.3:
+                    d = emit("sub", (M("cm1", int(rng.integers(0, 4)), 4, prime=bool(rng.integers(0, 2))), 1), ({"kind": "eval", "id": int(rng.integers(0, 4))}, 3))
+                else:
+                    d = operand()
+                acc = emit("add", acc, d) if rng.random() < 0.8 else emit("sub", acc, d)
+                acc = emit("mul", (v, 3), acc) if rng.random() < 0.5 else emit("mul", acc, (v, 3))
+        elif r < 0.3:
+            emit("copy", operand(), None)
+        else:
+            emit(str(rng.choice(["add", "sub", "mul"])), operand(), operand())
+    one = [i for i, d in enumerate(dims) if d == 1]; three = [i for i, d in enumerate(dims) if d == 3]
+    if not one: emit("add", (leaves1[0](), 1), (N(3), 1)); one = [len(dims) - 1]
+    if not three: emit("mul", (ch(0), 3), (T(one[-1]), 1)); three = [len(dims) - 1]
+    prog.append(("copy", M("cm3", 0, 4), T(one[int(rng.integers(0, len(one)))]), None))
+    prog.append(("copy", M("cm3", 1, 4, dim=3), T(three[int(rng.integers(0, len(three)))]), None))
+    back = emit("mul", (M("cm3", 1, 4, dim=3), 3), (M("cm3", 0, 4), 1))                                  # read back own writes
+    last = emit("add", back, (T(three[-1]), 3))
+    prog.append(("mul", M("q", 0, 3, dim=3), last[0], {"kind": "Zi"}))
+    return prog
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_random_programs_match_reference_interpreter(zk, orc, seed):
+    import interp
+    zk.init(0)
+    rng = np.random.default_rng(1000 + seed)
+    nbits, ext = 4, 1
+    n = 1 << (nbits + ext); nxt = 1 << ext
+    program = _random_program(rng, int(rng.integers(5, 120)))
+    cm1 = rng.integers(0, P, size=4 * n, dtype=np.uint64); cm1[:6] = [0, P - 1, 1, P - 2, 0, 0]
+    const = rng.integers(0, P, size=2 * n, dtype=np.uint64)
+    chal = rng.integers(0, P, size=24, dtype=np.uint64); evals = rng.integers(0, P, size=12, dtype=np.uint64)
+    if seed % 3 == 0: chal[3:6] = [5, 0, 0]                                # a base-field valued challenge
+    pub = rng.integers(0, P, size=2, dtype=np.uint64)
+    xd, xdw = rng.integers(0, P, size=3 * n, dtype=np.uint64), rng.integers(0, P, size=3 * n, dtype=np.uint64)
+    zi = orc.zh_inv(nbits, ext); x = zk.x_table(nbits + ext, 49)
+    d = {"cm1": zk.DevArray.from_host(cm1), "const": zk.DevArray.from_host(const), "q": zk.DevArray(3 * n, zero=True), "cm3": zk.DevArray(4 * n, zero=True)}
+    _compile(zk, program).run({BUF[k]: v for k, v in d.items()}, nbits + ext, nxt, publics=zk.DevArray.from_host(pub), challenges=zk.DevArray.from_host(chal),
+                              evals=zk.DevArray.from_host(evals), x=x, zi=zk.DevArray.from_host(zi), xdiv=zk.DevArray.from_host(xd), xdivw=zk.DevArray.from_host(xdw))
+    bufs = {"cm1": [int(v) for v in cm1], "const": [int(v) for v in const], "q": [0] * (3 * n), "cm3": [0] * (4 * n)}
+    interp.run(program, bufs, n, nxt, publics=[int(v) for v in pub], challenges=chal.reshape(8, 3).astype(object).tolist(),
+               evals=evals.reshape(4, 3).astype(object).tolist(), x=[int(v) for v in x.to_host()], zi=[int(v) for v in zi],
+               xdiv=[int(v) for v in xd], xdivw=[int(v) for v in xdw])
+    assert [int(v) for v in d["cm3"].to_host()] == bufs["cm3"]
+    assert [int(v) for v in d["q"].to_host()] == bufs["q"]
