@@ -88,13 +88,12 @@ __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
             lo += (u64)lo32[j] * m;
             hi += (u64)hi32[j] * m;
         }
-        // value = lo + hi * 2^32, lo, hi < 2^42
-        const u64 l = lo + (hi << 32);
-        const u64 h = (hi >> 32) + (l < lo);          // < 2^11
-        // 2^64 = 2^32 - 1 (mod p)
-        const u64 t1 = (h << 32) - h;
-        u64 r = l + t1;
-        if (r < t1) r += GL_EPS;
+        // value = lo + hi * 2^32 with lo, hi < 2^42: words w0 = lo.lo, w1 = lo.hi + hi.lo (carry c), w2 = hi.hi + c < 2^11;
+        // w2 * 2^64 = w2 * (2^32 - 1) rides on one multiply-add whose carry-out selects the fix-up (gl::mad_eps_nc)
+        u32 c;
+        const u32 w1 = __builtin_addc((u32)(lo >> 32), (u32)hi, 0u, &c);
+        const u32 w2 = (u32)(hi >> 32) + c;
+        const u64 r = gl::mad_eps_nc(w2, gl::mk64((u32)lo, w1));
         st[i] = (CANON && r >= GL_P) ? r - GL_P : r;                      // inside the permutation any representative does
     }
 }
@@ -171,11 +170,10 @@ __device__ __forceinline__ u64 coop_mds(u64 x, int l) {
         alo += (u64)(u32)__shfl((int)lo, src, 16) * m;
         ahi += (u64)(u32)__shfl((int)hi, src, 16) * m;
     }
-    const u64 lw = alo + (ahi << 32);
-    const u64 hw = (ahi >> 32) + (lw < alo);
-    const u64 t1 = (hw << 32) - hw;
-    u64 r = lw + t1;
-    if (r < t1) r += GL_EPS;
+    u32 c;                                              // as in mds_small
+    const u32 w1 = __builtin_addc((u32)(alo >> 32), (u32)ahi, 0u, &c);
+    const u32 w2 = (u32)(ahi >> 32) + c;
+    const u64 r = gl::mad_eps_nc(w2, gl::mk64((u32)alo, w1));
     return r >= GL_P ? r - GL_P : r;
 }
 __device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12]) {
