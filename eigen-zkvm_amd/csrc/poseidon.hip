@@ -15,6 +15,7 @@
 //     per block, broadcast reads) -- as scalar loads their 288+ SGPRs spilled into VGPR lanes.
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
+#include <mutex>
 
 namespace zk {
 
@@ -502,9 +503,11 @@ __global__ __launch_bounds__(64) void tr_get_kernel(TranscriptState* t, u64* __r
 
 bool g_consts_loaded[64] = {};
 
+std::mutex g_consts_mu;
 void ensure_constants() {
     int dev; ZK_HIP(hipGetDevice(&dev));
     ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_consts_mu);          // provers on several host threads
     if (g_consts_loaded[dev]) return;
     // regroup C[118] by use (poseidon_opt.rs:98-199): initial add, post-S-box constants of the 8 full
     // rounds (C[12(R+1)+i] for R < 4, C[82+12(R-4)+i] for R = 4..6, none for the last), partial rounds
