@@ -609,8 +609,13 @@ def main():
 
     agg = None
     if not args.no_agg and not args.no_prove:                          # every rank takes part (N = 1: all 8 tasks on this GPU)
-        agg = aggregation_leg(GpuTaskProver(zk), dist, rank, world, dev)
-        if rank == 0:                                                  # the serial tail of the aggregation runs on rank 0
+        try:
+            agg = aggregation_leg(GpuTaskProver(zk), dist, rank, world, dev)
+        except Exception as e:                                         # at N = 1 the bench line survives a failing extra leg
+            if dist is not None:                                       # (with several ranks the others wait in a collective: fail loudly)
+                raise
+            agg = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0 and "error" not in agg:                           # the serial tail of the aggregation runs on rank 0
             try:
                 agg["final_wrap"] = final_wrap_leg(zk, join_root=agg["join_tree"]["root"])
             except Exception as e:                                     # never lose the bench line to the extra leg
@@ -643,18 +648,24 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "pass_bytes_gbs": round(pass_gbs, 1), "pass_hbm_frac": round(pass_gbs / HBM_PEAK_GBS, 4)},
         }
+        def leg(name, fn, *a):                                         # an extra leg that fails is reported, the line is not lost
+            try:
+                out[name] = fn(*a)
+            except Exception as e:
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("bench: leg %s FAILED: %s: %s" % (name, type(e).__name__, e), file=sys.stderr, flush=True)
         if not args.no_msm and world == 1:
-            out["msm_g1_bn254"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline)
-            out["msm_g1_bls12_381"] = msm_leg(zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
+            leg("msm_g1_bn254", msm_leg, zk, args.msm_logn, not args.no_cpu_baseline)
+            leg("msm_g1_bls12_381", msm_leg, zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
         if not args.no_poseidon and world == 1:
-            out["poseidon_merkle_gl"] = poseidon_leg(zk, 22, 19, not args.no_cpu_baseline)
+            leg("poseidon_merkle_gl", poseidon_leg, zk, 22, 19, not args.no_cpu_baseline)
         if not args.no_bn128 and world == 1:
-            out["merkle_bn128"] = bn128_merkle_leg(zk, 20, 12, not args.no_cpu_baseline)
+            leg("merkle_bn128", bn128_merkle_leg, zk, 20, 12, not args.no_cpu_baseline)
         if not args.no_groth16 and world == 1:
-            out["groth16_prove_bn128"] = groth16_leg(zk, "BN128", args.groth16_log_rows, not args.no_cpu_baseline)
-            out["groth16_prove_bls12381"] = groth16_leg(zk, "BLS12381", args.groth16_log_rows, False)
+            leg("groth16_prove_bn128", groth16_leg, zk, "BN128", args.groth16_log_rows, not args.no_cpu_baseline)
+            leg("groth16_prove_bls12381", groth16_leg, zk, "BLS12381", args.groth16_log_rows, False)
         if not args.no_prove and world == 1:
-            out["stark_prove"] = prove_leg(zk, args.prove_nbits)
+            leg("stark_prove", prove_leg, zk, args.prove_nbits)
         if agg is not None:
             out["aggregation"] = agg
         if not args.no_cpu_baseline and world == 1:                   # a reported baseline of the N = 1 line only
