@@ -474,7 +474,8 @@ void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u6
     if (width) FH_FN(linearhash_rows_dev)(d_rows, width, height, d_nodes, st);
     uint64_t n = height, next = (n - 1) / 16 + 1, p_in = 0, p_out = next * 16;
     while (n > 1) {
-        if (next <= 4096)  // latency-bound: 32 lanes per parent
+        static const u64 coop_upto = getenv("ZK_FR_LEVEL_COOP") ? strtoull(getenv("ZK_FR_LEVEL_COOP"), nullptr, 10) : 16384;
+        if (next <= coop_upto)  // latency-bound: 32 lanes per parent
             hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)((next + 1) / 2)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else
             hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
