@@ -123,6 +123,9 @@ def test_native_driver_bn128_zkin_equals_oracle_zkin(zk, orc, name):
     assert list(got.keys()) == list(exp.keys())
     for k in exp:
         assert got[k] == exp[k], k
+    st = zk.Stream()                                                         # the same proof from an HBM-resident trace on a stream of the caller's
+    assert ns.gen(zk.DevArray.from_host(np.fromfile(D / cm_f, dtype="<u8")), stream=st.handle) == got
+    st.free()
 
 
 @pytest.mark.parametrize("name", ["fibonacci", "plookup"])
