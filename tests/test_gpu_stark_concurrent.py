@@ -21,17 +21,21 @@ def test_concurrent_proofs_equal_sequential_proofs(zk):
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     assert zk.lib().zk_device_count() >= 1
     zk.init(0)
-    W, ROUNDS = 4, 3
+    import poseidong as PG
+    W, ROUNDS = 6, 3
     circ = AW.Circuit(AW.STRUCTS["c12"]["nBits"])
-    consts = {"fib": AW.fib_consts(), "c12": circ.consts}
+    consts = {"fib": AW.fib_consts(), "c12": circ.consts, "pg": PG.consts(10)}
+    programs = {"fib": AW.program("fib"), "c12": AW.program("c12"), "pg": PG.program(10)}   # pg: stage 3 runs early on the setup's side stream
+    structs = {"fib": AW.STRUCTS["fib"], "c12": AW.STRUCTS["c12"], "pg": PG.stark_struct(10)}
+    trace = {"fib": lambda k: AW.fib_trace(k), "c12": lambda k: circ.witness(k), "pg": lambda k: PG.trace(10, None, PG.FIRST_COUNT, seed=k)}
     workers = []
     for w in range(W):
-        kind = "fib" if w % 2 == 0 else "c12"
-        su = stark.NativeStarkSetup(consts[kind], json.dumps(AW.program(kind)), json.dumps(AW.STRUCTS[kind]))
-        cms = [zk.DevArray.from_host(AW.fib_trace(10 * w + r) if kind == "fib" else circ.witness(10 * w + r)) for r in range(ROUNDS)]
+        kind = ("fib", "c12", "pg")[w % 3]
+        su = stark.NativeStarkSetup(consts[kind], json.dumps(programs[kind]), json.dumps(structs[kind]))
+        cms = [zk.DevArray.from_host(trace[kind](10 * w + r)) for r in range(ROUNDS)]
         workers.append((su, cms))
     alone = [[su.gen(cm) for cm in cms] for su, cms in workers]            # default stream, one at a time
-    assert len({json.dumps(z, sort_keys=True) for zs in alone for z in zs}) == W * ROUNDS   # all different
+    assert len({json.dumps(z, sort_keys=True) for zs in alone for z in zs}) >= W * ROUNDS - 2   # (the Fibonacci inputs repeat every 8 tasks)
     got = [[None] * ROUNDS for _ in range(W)]
     errors = []
     streams = [zk.Stream() for _ in range(W)]
