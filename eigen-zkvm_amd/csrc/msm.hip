@@ -66,9 +66,31 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {  // 2R mod q
     constexpr u32 y[8] = {0x8b1e1b3au, 0xa6ba871bu, 0xeb8e167bu, 0x14f1d651u, 0xf0f28c58u, 0xccdd46deu, 0x340fbe5eu, 0x1c14ef83u};
     return y[i];
 }
+}  // namespace g1
+namespace g1half {   // the same group with 128-bit scalars (8 windows, 4 words apart): the sum behind the endomorphism split of g1
+using g1::GEN_X; using g1::GEN_Y;
+#define MSM_N_WIN 8
+#define MSM_SC_WORDS 4
 namespace {
 #include "msm_impl.cuh"
 }
+}  // namespace g1half
+namespace g1 {
+// phi(x, y) = (beta x, y) = [lambda](x, y) on y^2 = x^3 + 3: beta = 2203960485148121921418603742825762020974279258880205651966 (beta^3 = 1 in
+// Fq), lambda = 4407920970296243842393367215006156084916469457145843978461; lattice basis a1 = b2 = 9931322734385697763,
+// -b1 = 147946756881789319000765030803803410728, a2 = 147946756881789319010696353538189108491 (tools/glv_constants.py derives and checks them)
+#define GLV_BETA_STD 0xd782e155u, 0x71930c11u, 0xffbe3323u, 0xa6bb947cu, 0xd4741444u, 0xaa303344u, 0x26594943u, 0x2c3b3f0du
+#define GLV_G1 0xc7e0b3d7u, 0xd91d232eu, 0x00000002u
+#define GLV_G2 0x391eb18du, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u
+#define GLV_A1 0x94d213e3u, 0x89d32568u
+#define GLV_A2 0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u
+#define GLV_NB1 0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u
+#define GLV_B2 0x94d213e3u, 0x89d32568u
+#define MSM_GLV g1half
+namespace {
+#include "msm_impl.cuh"
+}
+#undef MSM_GLV
 }  // namespace g1
 namespace g2 {   // the twist y^2 = x^3 + 3/(9 + u) over Fq2 = Fq[u]/(u^2 + 1); generator of EIP-197, x = c0 + c1 u
 __host__ __device__ constexpr u32 GEN_X(int i) {

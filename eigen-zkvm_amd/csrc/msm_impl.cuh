@@ -186,13 +186,19 @@ __device__ void pt_to_std(const xyzz& p, u32* x, u32* y) {   // CW_STD words eac
     cf_to_std(cf_mul(p.X, izz), x); cf_to_std(cf_mul(p.Y, izzz), y);
 }
 
-constexpr int C_BITS = 16, N_WIN = 16, N_BUCKET = 1 << C_BITS;  // 254-bit scalars: 16 windows of 16 bits
+#ifndef MSM_N_WIN
+#define MSM_N_WIN 16      /* 254-bit scalars: 16 windows of 16 bits */
+#endif
+#ifndef MSM_SC_WORDS
+#define MSM_SC_WORDS 8    /* 32-bit words between two scalars of the input array */
+#endif
+constexpr int C_BITS = 16, N_WIN = MSM_N_WIN, N_BUCKET = 1 << C_BITS;
 
 __global__ __launch_bounds__(256) void msm_count_kernel(const u32* __restrict__ scalars, u64 n, u32* __restrict__ counts) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;  // one lane per (point, window)
     if (t >= n * N_WIN) return;
     const u64 i = t / N_WIN; const u32 w = t % N_WIN;
-    const u32 word = scalars[i * 8 + (w >> 1)];
+    const u32 word = scalars[i * MSM_SC_WORDS + (w >> 1)];
     const u32 d = (w & 1) ? word >> 16 : word & 0xFFFF;
     if (d) atomicAdd(&counts[w * N_BUCKET + d], 1u);
 }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const u32* __restrict_
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * N_WIN) return;
     const u64 i = t / N_WIN; const u32 w = t % N_WIN;
-    const u32 word = scalars[i * 8 + (w >> 1)];
+    const u32 word = scalars[i * MSM_SC_WORDS + (w >> 1)];
     const u32 d = (w & 1) ? word >> 16 : word & 0xFFFF;
     if (!d) return;
     const u32 key = w * N_BUCKET + d;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void scan_add_kernel(u32* __restrict__ out, co
 constexpr int SORT_PTS = 8192;        // points per block in pass 1
 constexpr int N_COARSE = N_WIN * 256;  // 4096
 __device__ __forceinline__ u32 digit_of(const u32* __restrict__ scalars, u64 i, u32 w) {
-    const u32 word = scalars[i * 8 + (w >> 1)];
+    const u32 word = scalars[i * MSM_SC_WORDS + (w >> 1)];
     return (w & 1) ? word >> 16 : word & 0xFFFF;
 }
 __global__ __launch_bounds__(256) void sort_hist_kernel(const u32* __restrict__ scalars, u64 n, u32 n_blocks, u32* __restrict__ hist /* [N_COARSE][n_blocks] */) {
@@ -266,7 +272,8 @@ __global__ __launch_bounds__(256) void sort_hist_kernel(const u32* __restrict__ 
     for (u32 t = threadIdx.x; t < SORT_PTS; t += 256) {   // one point per trip: its 16 digits are independent work
         const u64 i = base + t;
         if (i >= n) break;
-        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[2 * i], hi = reinterpret_cast<const uint4*>(scalars)[2 * i + 1];
+        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[(MSM_SC_WORDS / 4) * i];
+        const uint4 hi = MSM_SC_WORDS > 4 ? reinterpret_cast<const uint4*>(scalars)[(MSM_SC_WORDS / 4) * i + 1] : uint4{0, 0, 0, 0};
         const u32 wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
         for (int w = 0; w < N_WIN; ++w) {
@@ -286,7 +293,8 @@ __global__ __launch_bounds__(256) void sort_coarse_kernel(const u32* __restrict_
     for (u32 t = threadIdx.x; t < SORT_PTS; t += 256) {
         const u64 i = base + t;
         if (i >= n) break;
-        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[2 * i], hi = reinterpret_cast<const uint4*>(scalars)[2 * i + 1];
+        const uint4 lo = reinterpret_cast<const uint4*>(scalars)[(MSM_SC_WORDS / 4) * i];
+        const uint4 hi = MSM_SC_WORDS > 4 ? reinterpret_cast<const uint4*>(scalars)[(MSM_SC_WORDS / 4) * i + 1] : uint4{0, 0, 0, 0};
         const u32 wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         u32 pos[N_WIN];
 #pragma unroll
@@ -596,17 +604,19 @@ void msm_fixed_prepare_dev(const void* d_bases, uint64_t n, void* d_table, hipSt
 
 // d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag).  d_table != nullptr: the sum runs over the n points
 // [base_off, base_off + n) of a window table built for table_n points; d_bases is ignored
-static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
+// d_preconv != nullptr: n points already in the internal layout (PTW words each); d_bases is ignored
+static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st,
+                     const void* d_preconv = nullptr) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
     ZK_REQUIRE(!d_table || (n < (1ull << 24) && base_off + n <= table_n && table_n < (1ull << 24)), "msm table: range out of bounds");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;
     DevBuf counts, offsets, cursors, tops, idx, buckets, S0, A0, S1, A1, conv;
-    if (!d_table) {
+    if (!d_table && !d_preconv) {
         conv.reserve((size_t)n * PTW * 4);
         hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, n, (u32*)conv.p);
         ZK_HIP(hipGetLastError());
     }
-    const u32* points = d_table ? (const u32*)d_table : (const u32*)conv.p;
+    const u32* points = d_table ? (const u32*)d_table : d_preconv ? (const u32*)d_preconv : (const u32*)conv.p;
     counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
     idx.reserve((size_t)n * N_WIN * 4);
     buckets.reserve(n_keys * sizeof(xyzz));
@@ -686,9 +696,82 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     ZK_HIP(hipGetLastError());
     ZK_HIP(hipStreamSynchronize(st));  // the pooled scratch above is released at scope exit
 }
+void msm_preconv_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points); }
+#ifdef MSM_GLV
+// ---- the curve's endomorphism phi(x, y) = (beta x, y) = [lambda](x, y): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128, so a sum
+// over n points with 254-bit scalars becomes a sum over 2n points with 128-bit scalars: the same number of bucket additions, half
+// the windows -- half the bucket hierarchy and half of the doublings of the final Horner walk, the two serial tails of a sum.
+// (k1, k2) = k - c1 (a1, b1) - c2 (a2, b2) with c1 = floor(k g1 / 2^256), c2 = floor(k g2 / 2^256), g1 = floor(2^256 b2 / r),
+// g2 = floor(-2^256 b1 / r) for the short basis (a1, b1), (a2, b2) of {(x, y): x + y lambda = 0 mod r}; any integers c1, c2 give
+// a correct split, these keep both halves below 2^128 (checked over the edge scalars and 2 * 10^5 random ones when the constants
+// were derived, tools/glv_constants.py).  One kernel splits the scalar, converts the base and writes (+-P, |k1|), (+-phi(P), |k2|).
+template <int NA, int NB, int NO>
+__device__ __forceinline__ void glv_mul(const u32 (&a)[NA], const u32 (&b)[NB], u32 (&out)[NO], int from) {   // words [from, from + NO) of a * b
+    u64 acc = 0;
+    u32 carry_hi = 0;
+    for (int k = 0; k < from + NO; ++k) {       // column k; (acc, carry_hi) is a 96-bit running sum
+        for (int i = 0; i < NA; ++i) {
+            const int j = k - i;
+            if (j < 0 || j >= NB) continue;
+            const u64 p = (u64)a[i] * b[j];
+            acc += p;
+            carry_hi += acc < p;
+        }
+        if (k >= from) out[k - from] = (u32)acc;
+        acc = (acc >> 32) | ((u64)carry_hi << 32);
+        carry_hi = 0;
+    }
+}
+__global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ bases, const u32* __restrict__ scalars, u64 n,
+                                                        u32* __restrict__ conv2 /* 2n points */, u32* __restrict__ sc2 /* 2n x 4 words */) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 G1[3] = {GLV_G1}, G2[5] = {GLV_G2}, A1[2] = {GLV_A1}, A2[4] = {GLV_A2}, NB1[4] = {GLV_NB1}, B2[2] = {GLV_B2}, BETA[NL] = {GLV_BETA_STD};
+    u32 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = scalars[i * 8 + j];
+    u32 c1[3], c2[5];
+    glv_mul<8, 3, 3>(k, G1, c1, 8);
+    glv_mul<8, 5, 5>(k, G2, c2, 8);
+    u32 t1[8], t2[8], k1[8], k2[8];
+    glv_mul<3, 2, 8>(c1, A1, t1, 0); glv_mul<5, 4, 8>(c2, A2, t2, 0);          // k1 = k - c1 a1 - c2 a2  (mod 2^256, two's complement)
+    u64 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const u64 d = (u64)k[j] - t1[j] - t2[j] - br; k1[j] = (u32)d; br = (0 - (d >> 32)) & 3; }
+    glv_mul<3, 4, 8>(c1, NB1, t1, 0); glv_mul<5, 2, 8>(c2, B2, t2, 0);         // k2 = c1 |b1| - c2 b2
+    br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const u64 d = (u64)t1[j] - t2[j] - br; k2[j] = (u32)d; br = (0 - (d >> 32)) & 1; }
+    const bool n1 = k1[7] >> 31, n2 = k2[7] >> 31;
+    if (n1) { u64 c = 1; for (int j = 0; j < 8; ++j) { c += (u32)~k1[j]; k1[j] = (u32)c; c >>= 32; } }
+    if (n2) { u64 c = 1; for (int j = 0; j < 8; ++j) { c += (u32)~k2[j]; k2[j] = (u32)c; c >>= 32; } }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc2[(2 * i) * 4 + j] = k1[j]; sc2[(2 * i + 1) * 4 + j] = k2[j]; }
+    u32 w[2 * CW_STD];
+    const uint4* p = (const uint4*)(bases + i * (2 * CW_STD));
+#pragma unroll
+    for (int q = 0; q < 2 * CW_STD / 4; ++q) { const uint4 v = p[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    const cf x = cf_from_std(w), y = cf_from_std(w + CW_STD), ny = cf_sub<2>(cf_zero(), y);
+    const cf bx = cf_mul(x, cf_from_std(BETA));
+    u32* o = conv2 + (2 * i) * PTW;
+    cf_store_int(x, o); cf_store_int(n1 ? ny : y, o + CW_INT);
+    cf_store_int(bx, o + PTW); cf_store_int(n2 ? ny : y, o + PTW + CW_INT);
+}
+void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
+    static const bool off = getenv("ZK_MSM_NO_GLV") != nullptr;
+    if (off || n < 4096 || n >= (1ull << 27)) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); return; }
+    DevBuf conv2, sc2;
+    conv2.reserve((size_t)2 * n * PTW * 4); sc2.reserve((size_t)2 * n * 16);
+    hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
+    ZK_HIP(hipGetLastError());
+    MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);     // (synchronises: the buffers go back to the pool after it)
+}
+#else
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); }
+#endif
 void msm_fixed_dev(const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     ZK_REQUIRE(d_table, "msm table: null table");
     msm_core(nullptr, d_table, table_n, base_off, d_scalars, n, d_out, st);
 }
-
+#undef MSM_N_WIN
+#undef MSM_SC_WORDS

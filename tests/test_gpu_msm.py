@@ -52,6 +52,33 @@ def test_msm_edge_scalars(zk, orc):
     assert inf == einf and np.array_equal(got, exp)
 
 
+def test_msm_endomorphism_split_edge_scalars(zk, orc):
+    """Sums of >= 4096 points go through k P = k1 P + k2 phi(P) (csrc/msm_impl.cuh, glv_split_kernel): scalars at the edges of the
+    split -- 0, 1, r - 1, lambda and its neighbours, 2^127, 2^128 and neighbours, the lattice vectors, values whose halves
+    change sign -- among random ones, against the closed form and against the oracle's Pippenger."""
+    LAM = 4407920970296243842393367215006156084916469457145843978461
+    A2, NB1, B2 = 147946756881789319010696353538189108491, 147946756881789319000765030803803410728, 9931322734385697763
+    edge = [0, 1, 2, R - 1, R - 2, LAM, LAM - 1, LAM + 1, R - LAM, (LAM * LAM) % R, 1 << 127, (1 << 127) - 1, 1 << 128, (1 << 128) - 1, (1 << 128) + 1,
+            A2, NB1, B2, A2 + 1, NB1 - 1, R // 2, R // 2 + 1, R // 3, (1 << 253), (1 << 253) - 1, 0xFFFF << 112, 0xFFFF << 128, (B2 * LAM) % R, (A2 * LAM) % R]
+    n = 4096
+    rng = np.random.default_rng(77)
+    vals = edge + [int.from_bytes(rng.bytes(32), "little") % R for _ in range(n - len(edge))]
+    bases = orc.bn254_make_bases(n, 7, 11)
+    scal = np.concatenate([words(v) for v in vals])
+    got, inf = zk.msm_g1_bn254(bases, scal)
+    k = sum(v * (7 + 11 * i) for i, v in enumerate(vals)) % R
+    exp, einf = orc.bn254_scalar_mul(orc.bn254_generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+    exp2, einf2 = orc.bn254_msm(bases, scal, 8)
+    assert inf == einf2 and np.array_equal(got, exp2)
+    # s P + (r - s) P = 0 whatever the signs of the four halves: the second half of the sum repeats the bases of the first
+    half = n // 2
+    b = bases.reshape(n, -1).copy(); b[half:] = b[:half]
+    sc = np.concatenate([words(v) for v in vals[:half]] + [words((R - v) % R) for v in vals[:half]])
+    _, inf0 = zk.msm_g1_bn254(b.reshape(-1), sc)
+    assert inf0
+
+
 def test_msm_all_zero_scalars_is_infinity(zk, orc):
     bases = orc.bn254_make_bases(100, 1, 1)
     _, inf = zk.msm_g1_bn254(bases, np.zeros(400, np.uint64))
