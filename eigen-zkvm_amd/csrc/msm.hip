@@ -91,6 +91,13 @@ namespace {
 #include "msm_impl.cuh"
 }
 #undef MSM_GLV
+#undef GLV_BETA_STD
+#undef GLV_G1
+#undef GLV_G2
+#undef GLV_A1
+#undef GLV_A2
+#undef GLV_NB1
+#undef GLV_B2
 }  // namespace g1
 namespace g2 {   // the twist y^2 = x^3 + 3/(9 + u) over Fq2 = Fq[u]/(u^2 + 1); generator of EIP-197, x = c0 + c1 u
 __host__ __device__ constexpr u32 GEN_X(int i) {
@@ -175,9 +182,32 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
                            0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
     return y[i];
 }
+}  // namespace g1
+namespace g1half {   // 128-bit scalars, 8 windows: the sum behind the endomorphism split of g1
+using g1::GEN_X; using g1::GEN_Y;
+#define MSM_N_WIN 8
+#define MSM_SC_WORDS 4
 namespace {
 #include "msm_impl.cuh"
 }
+}  // namespace g1half
+namespace g1 {
+// phi(x, y) = (beta x, y) = [lambda](x, y) on y^2 = x^3 + 4 with lambda = z^2 - 1 = 0xac45a4010001a40200000000ffffffff (z the curve parameter):
+// lambda^2 + lambda + 1 = 0 mod r, so k = k1 + k2 lambda by division; beta =
+// 4002409555221667392624310435006688643935503118305586438271171395842971157480381377015405980053539358417135540939436
+#define GLV_BETA_STD 0x8671f071u, 0xcd03c9e4u, 0x1fcda5d2u, 0x5dab2246u, 0xd3851b95u, 0x587042afu, 0x01bacb9eu, 0x8eb60ebeu, 0x83d050d2u, 0x03f97d6eu, 0x54638741u, 0x18f02065u
+#define GLV_LAMBDA 0xffffffffu, 0x00000000u, 0x0001a402u, 0xac45a401u
+#define GLV_G 0xf6cfee30u, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u
+#define GLV_R 0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u
+#define MSM_GLV g1half
+namespace {
+#include "msm_impl.cuh"
+}
+#undef MSM_GLV
+#undef GLV_BETA_STD
+#undef GLV_LAMBDA
+#undef GLV_G
+#undef GLV_R
 }  // namespace g1
 namespace g2 {   // the twist y^2 = x^3 + 4(1 + u) over Fq2 = Fq[u]/(u^2 + 1); G2 generator of the BLS12-381 specification
 __host__ __device__ constexpr u32 GEN_X(int i) {

@@ -726,14 +726,46 @@ __global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ 
                                                         u32* __restrict__ conv2 /* 2n points */, u32* __restrict__ sc2 /* 2n x 4 words */) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u32 G1[3] = {GLV_G1}, G2[5] = {GLV_G2}, A1[2] = {GLV_A1}, A2[4] = {GLV_A2}, NB1[4] = {GLV_NB1}, B2[2] = {GLV_B2}, BETA[NL] = {GLV_BETA_STD};
-    u32 k[8];
+    const u32 BETA[NL] = {GLV_BETA_STD};
+    u32 k[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) k[j] = scalars[i * 8 + j];
+    bool n1 = false, n2 = false;
+#ifdef GLV_LAMBDA
+    // lambda^2 + lambda + 1 = 0 (mod r) with lambda < 2^128: k = k1 + k2 lambda by plain division, both halves non-negative.  A scalar
+    // is brought below r first (k2 <= lambda + 1 needs it); the quotient from the reciprocal g = floor(2^256 / lambda) is at most
+    // one short, made up by one conditional step
+    const u32 LAMBDA[4] = {GLV_LAMBDA}, GG[5] = {GLV_G}, RMOD[8] = {GLV_R};
+    for (int rep = 0; rep < 2; ++rep) {
+        u32 t[8]; u64 br = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u64 d = (u64)k[j] - RMOD[j] - br; t[j] = (u32)d; br = (d >> 32) & 1; }
+        if (!br) { for (int j = 0; j < 8; ++j) k[j] = t[j]; }
+    }
+    u32 c[5], t8[8];
+    glv_mul<8, 5, 5>(k, GG, c, 8);
+    glv_mul<5, 4, 8>(c, LAMBDA, t8, 0);
+    u64 br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const u64 d = (u64)k[j] - t8[j] - br; k1[j] = (u32)d; br = (d >> 32) & 1; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k2[j] = j < 5 ? c[j] : 0;
+    {   // k1 >= lambda: one more lambda goes to k2
+        u32 t[8]; u64 b2 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u64 d = (u64)k1[j] - (j < 4 ? LAMBDA[j] : 0u) - b2; t[j] = (u32)d; b2 = (d >> 32) & 1; }
+        if (!b2) {
+            for (int j = 0; j < 8; ++j) k1[j] = t[j];
+            u64 cy = 1;
+            for (int j = 0; j < 8; ++j) { cy += k2[j]; k2[j] = (u32)cy; cy >>= 32; }
+        }
+    }
+#else
+    const u32 G1[3] = {GLV_G1}, G2[5] = {GLV_G2}, A1[2] = {GLV_A1}, A2[4] = {GLV_A2}, NB1[4] = {GLV_NB1}, B2[2] = {GLV_B2};
     u32 c1[3], c2[5];
     glv_mul<8, 3, 3>(k, G1, c1, 8);
     glv_mul<8, 5, 5>(k, G2, c2, 8);
-    u32 t1[8], t2[8], k1[8], k2[8];
+    u32 t1[8], t2[8];
     glv_mul<3, 2, 8>(c1, A1, t1, 0); glv_mul<5, 4, 8>(c2, A2, t2, 0);          // k1 = k - c1 a1 - c2 a2  (mod 2^256, two's complement)
     u64 br = 0;
 #pragma unroll
@@ -742,9 +774,10 @@ __global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ 
     br = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const u64 d = (u64)t1[j] - t2[j] - br; k2[j] = (u32)d; br = (0 - (d >> 32)) & 1; }
-    const bool n1 = k1[7] >> 31, n2 = k2[7] >> 31;
+    n1 = k1[7] >> 31; n2 = k2[7] >> 31;
     if (n1) { u64 c = 1; for (int j = 0; j < 8; ++j) { c += (u32)~k1[j]; k1[j] = (u32)c; c >>= 32; } }
     if (n2) { u64 c = 1; for (int j = 0; j < 8; ++j) { c += (u32)~k2[j]; k2[j] = (u32)c; c >>= 32; } }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sc2[(2 * i) * 4 + j] = k1[j]; sc2[(2 * i + 1) * 4 + j] = k2[j]; }
     u32 w[2 * CW_STD];

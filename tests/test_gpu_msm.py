@@ -216,6 +216,32 @@ def test_bls_msm_edge_scalars_and_cancellation(zk, orc):
     assert inf == einf and np.array_equal(got, exp)
 
 
+def test_bls_msm_endomorphism_split_edge_scalars(zk, orc):
+    """BLS12-381 G1 sums of >= 4096 points: k = k1 + k2 lambda by division (lambda = z^2 - 1).  Scalars around multiples of lambda,
+    around r, and above r (brought below it before the split) among random ones; closed form, the oracle, and s P + (r - s) P = 0."""
+    cv = orc.curve("bls12_381")
+    LAM = 0xac45a4010001a40200000000ffffffff
+    edge = [0, 1, LAM - 1, LAM, LAM + 1, 2 * LAM - 1, 2 * LAM, LAM * LAM, LAM * LAM + LAM, R_BLS - 1, R_BLS - 2, R_BLS - LAM, R_BLS // 2,
+            (1 << 128) - 1, 1 << 128, (1 << 128) + 1, 1 << 127, (LAM + 1) * LAM - 1, 0xFFFF << 112, 0xFFFF << 128, (1 << 254) - 1,
+            R_BLS, R_BLS + 1, R_BLS + LAM, (1 << 256) - 1, 2 * R_BLS, 2 * R_BLS + 5]                       # the last six are not canonical
+    n = 4096
+    rng = np.random.default_rng(381)
+    vals = edge + [int.from_bytes(rng.bytes(32), "little") % R_BLS for _ in range(n - len(edge))]
+    bases = cv.make_bases(n, 7, 11)
+    scal = np.concatenate([words(v) for v in vals])
+    got, inf = zk.msm_g1(bases, scal, "bls12_381")
+    k = sum(v * (7 + 11 * i) for i, v in enumerate(vals)) % R_BLS
+    exp, einf = cv.scalar_mul(cv.generator(), words(k))
+    assert inf == einf and np.array_equal(got, exp)
+    canon = np.concatenate([words(v % R_BLS) for v in vals])
+    exp2, einf2 = cv.msm(bases, canon, 8)
+    assert inf == einf2 and np.array_equal(got, exp2)
+    half = n // 2
+    b = bases.reshape(n, -1).copy(); b[half:] = b[:half]
+    sc = np.concatenate([words(v % R_BLS) for v in vals[:half]] + [words((R_BLS - v) % R_BLS) for v in vals[:half]])
+    assert zk.msm_g1(b.reshape(-1), sc, "bls12_381")[1]
+
+
 def test_bls_generator_multiples_match_oracle(zk, orc):
     cv = orc.curve("bls12_381")
     rng = np.random.default_rng(4)

@@ -2,7 +2,9 @@
 beta (a cube root of unity in Fq) and lambda (in Fr) with (beta x, y) = [lambda](x, y); a short basis (a1, b1), (a2, b2) of the
 lattice {(x, y): x + y lambda = 0 mod r} by the extended Euclid walk of Gallant-Lambert-Vanstone; g1 = floor(2^256 b2 / r),
 g2 = floor(-2^256 b1 / r); the bound |k1|, |k2| < 2^128 of the split the device computes with them.  Prints the 32-bit words
-the header of bn254::g1 in msm.hip carries.  python tools/glv_constants.py"""
+the header of bn254::g1 in msm.hip carries.  (BLS12-381 G1 needs no lattice: lambda = z^2 - 1 < 2^128 and lambda^2 + lambda + 1 = 0
+mod r, so k = k1 + k2 lambda is a plain division; its beta is x([lambda]G) / x(G), checked the same way when it was derived.)
+python tools/glv_constants.py"""
 import math
 import random
 
