@@ -486,10 +486,11 @@ def msm_leg(zk, logn, cpu_baseline, curve="bn254"):
         out = zk.msm_g1_dev(d_bases, d_scal, n, curve)
         zk.lib().zk_dev_sync()
         times.append(time.perf_counter() - t0)
-    res = {"workload": "BASELINE config 4: %s G1 Pippenger MSM, n=2^%d, c=16, HBM-resident" % (curve, logn),
+    res = {"workload": "BASELINE config 4: %s G1 Pippenger MSM, n=2^%d, c=16 (2n points x 8 windows behind the curve's endomorphism), HBM-resident" % (curve, logn),
            "value": round(n / min(times) / 1e6, 2), "unit": "Mpts/s", "ms": round(min(times) * 1e3, 2)}
-    # integer-ALU roofline: 16 windows x n mixed additions into buckets + 16 x 2^17 in the bucket
-    # reduction, PADD_PRODUCTS Fq products each, against the multiply-add issue ceiling
+    # integer-ALU roofline: 16 n mixed additions into buckets (16 windows x n points, or 8 x 2n behind the
+    # endomorphism) + 16 x 2^17 in the bucket reduction (an upper figure with 8 windows), PADD_PRODUCTS Fq products each, against
+    # the multiply-add issue ceiling
     products = (16 * n + 16 * (1 << 17)) * PADD_PRODUCTS
     peak = VALU_MAD_PER_S / FQ_MADS[curve]
     res["roofline"] = {"bound": "int-alu", "kernel": "msm_accumulate_kernel (+ sort, bucket reduction)", "achieved": round(products / min(times) / 1e9, 1),
