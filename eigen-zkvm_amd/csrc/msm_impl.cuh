@@ -724,9 +724,11 @@ __device__ __forceinline__ void glv_mul(const u32 (&a)[NA], const u32 (&b)[NB], 
 }
 __global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ bases, const u32* __restrict__ scalars, u64 n,
                                                         u32* __restrict__ conv2 /* 2n points */, u32* __restrict__ sc2 /* 2n x 4 words */) {
+    __shared__ cf beta_s;                                              // beta in the internal form, converted once per block
+    if (threadIdx.x == 0) { const u32 BETA[NL] = {GLV_BETA_STD}; beta_s = cf_from_std(BETA); }
+    __syncthreads();
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const u32 BETA[NL] = {GLV_BETA_STD};
     u32 k[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) k[j] = scalars[i * 8 + j];
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 2 * CW_STD / 4; ++q) { const uint4 v = p[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
     const cf x = cf_from_std(w), y = cf_from_std(w + CW_STD), ny = cf_sub<2>(cf_zero(), y);
-    const cf bx = cf_mul(x, cf_from_std(BETA));
+    const cf bx = cf_mul(x, beta_s);
     u32* o = conv2 + (2 * i) * PTW;
     cf_store_int(x, o); cf_store_int(n1 ? ny : y, o + CW_INT);
     cf_store_int(bx, o + PTW); cf_store_int(n2 ? ny : y, o + PTW + CW_INT);
