@@ -611,7 +611,8 @@ def main():
     agg = None
     if not args.no_agg and not args.no_prove:                          # every rank takes part (N = 1: all 8 tasks on this GPU)
         try:
-            agg = aggregation_leg(GpuTaskProver(zk), dist, rank, world, dev)
+            n_workers = int(os.environ.get("ZK_BENCH_WORKERS", max(1, min(4, (8 + world - 1) // world))))   # no more provers than a rank has tasks
+            agg = aggregation_leg(GpuTaskProver(zk, workers=n_workers), dist, rank, world, dev)
         except Exception as e:                                         # at N = 1 the bench line survives a failing extra leg
             if dist is not None:                                       # (with several ranks the others wait in a collective: fail loudly)
                 raise
