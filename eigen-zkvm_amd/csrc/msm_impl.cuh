@@ -180,6 +180,88 @@ __device__ __forceinline__ xyzz pt_neg(const xyzz& p) {
     r.Y = cf_sub<4>(cf_zero(), p.Y);                                        // 4q - Y <= 4q
     return r;
 }
+// ---- four lanes per point operation -------------------------------------------------------------------------------------------
+// The tails of a sum -- the bucket hierarchy and the final walk over the windows -- are chains of a few hundred dependent point
+// operations on a handful of lanes: latency, not throughput.  A doubling is 9 field products in 3 dependent stages, a full addition
+// 14 in 4; here the lanes of a quad hold the same point and lane q computes the q-th product of each stage, the results travel by
+// DPP quad broadcasts (a move per limb, no LDS).  The same formulas, the same operands, the same bounds: bit-identical results, in
+// a third of the dependent products.  Called by all four lanes of a quad with identical arguments.
+__device__ __forceinline__ u32 quad_word(u32 v, int k) {            // lane k's value in every lane of the quad (k is uniform)
+    switch (k) {
+        case 0: return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xF, 0xF, false);
+        case 1: return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xF, 0xF, false);
+        case 2: return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xF, 0xF, false);
+        default: return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xF, 0xF, false);
+    }
+}
+__device__ __forceinline__ fe quad_fe(const fe& v, int k) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = quad_word(v.l[i], k);
+    return r;
+}
+__device__ __forceinline__ fe pick_fe(int q, const fe& a0, const fe& a1, const fe& a2, const fe& a3) {
+    // by masks, not by `?:` -- the compiler turns a select between structures into four branches under EXEC, each with its own
+    // copy of the product that follows, and the four lanes then take their turns
+    u32 m0 = q == 0 ? ~0u : 0u, m1 = q == 1 ? ~0u : 0u, m2 = q == 2 ? ~0u : 0u, m3 = q == 3 ? ~0u : 0u;
+    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+    fe r;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r.l[i] = (a0.l[i] & m0) | (a1.l[i] & m1) | (a2.l[i] & m2) | (a3.l[i] & m3);
+    return r;
+}
+__device__ __forceinline__ void fe_opaque(fe& v) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) asm volatile("" : "+v"(v.l[i]));
+}
+#ifndef MSM_G2
+__device__ __forceinline__ void cf_opaque(cf& v) { fe_opaque(v); }
+__device__ __forceinline__ cf quad_cf(const cf& v, int k) { return quad_fe(v, k); }
+__device__ __forceinline__ cf pick_cf(int q, const cf& a0, const cf& a1, const cf& a2, const cf& a3) { return pick_fe(q, a0, a1, a2, a3); }
+#else
+__device__ __forceinline__ void cf_opaque(cf& v) { fe_opaque(v.c0); fe_opaque(v.c1); }
+__device__ __forceinline__ cf quad_cf(const cf& v, int k) { cf r; r.c0 = quad_fe(v.c0, k); r.c1 = quad_fe(v.c1, k); return r; }
+__device__ __forceinline__ cf pick_cf(int q, const cf& a0, const cf& a1, const cf& a2, const cf& a3) {
+    cf r; r.c0 = pick_fe(q, a0.c0, a1.c0, a2.c0, a3.c0); r.c1 = pick_fe(q, a0.c1, a1.c1, a2.c1, a3.c1); return r;
+}
+#endif
+// one stage: lane q multiplies (a_q, b_q); out[k] = the product of lane k, in every lane
+__device__ PT_COLD_ATTR void quad_stage(const cf& a0, const cf& b0, const cf& a1, const cf& b1, const cf& a2, const cf& b2, const cf& a3, const cf& b3,
+                                        cf& o0, cf& o1, cf& o2, cf& o3) {
+    const int q = threadIdx.x & 3;
+    cf prod = cf_mul(pick_cf(q, a0, a1, a2, a3), pick_cf(q, b0, b1, b2, b3));
+    cf_opaque(prod);                                                       // (the broadcasts read exactly this value)
+    o0 = quad_cf(prod, 0); o1 = quad_cf(prod, 1); o2 = quad_cf(prod, 2); o3 = quad_cf(prod, 3);
+    cf_opaque(o0); cf_opaque(o1); cf_opaque(o2); cf_opaque(o3);
+}
+__device__ PT_COLD_ATTR xyzz pt_dbl4(const xyzz& p) {   // pt_dbl, three stages
+    if (pt_is_inf(p)) return p;
+    const cf U = cf_dbl(p.Y);
+    cf V, xx, W, S, MM, t1, t2, d0, d1;
+    quad_stage(U, U, p.X, p.X, U, U, U, U, V, xx, d0, d1);                      // V = U^2, xx = X^2
+    const cf M = cf_add(cf_dbl(xx), xx);
+    quad_stage(U, V, p.X, V, M, M, U, V, W, S, MM, d0);                          // W = U V, S = X V, M^2
+    xyzz r;
+    r.X = cf_sub<4>(MM, cf_dbl(S));
+    quad_stage(cf_sub<8>(S, r.X), M, W, p.Y, V, p.ZZ, W, p.ZZZ, t1, t2, r.ZZ, r.ZZZ);
+    r.Y = cf_sub<2>(t1, t2);
+    return r;
+}
+__device__ PT_COLD_ATTR xyzz pt_add4(const xyzz& p, const xyzz& q) {   // pt_add, four stages
+    if (pt_is_inf(p)) return q;
+    if (pt_is_inf(q)) return p;
+    cf U1, U2, S1, S2, PP, RR, ZZ12, ZZZ12, PPP, Q, t1, t2, d0;
+    quad_stage(p.X, q.ZZ, q.X, p.ZZ, p.Y, q.ZZZ, q.Y, p.ZZZ, U1, U2, S1, S2);
+    const cf P = cf_sub<2>(U2, U1), Rr = cf_sub<2>(S2, S1);                      // < 4q
+    quad_stage(P, P, Rr, Rr, p.ZZ, q.ZZ, p.ZZZ, q.ZZZ, PP, RR, ZZ12, ZZZ12);
+    if (cf_is_zero_m(PP)) return cf_is_zero_m(RR) ? pt_dbl4(p) : pt_inf();
+    xyzz r;
+    quad_stage(P, PP, U1, PP, ZZ12, PP, P, PP, PPP, Q, r.ZZ, d0);
+    r.X = cf_sub<4>(cf_sub<2>(RR, PPP), cf_dbl(Q));
+    quad_stage(cf_sub<8>(Q, r.X), Rr, S1, PPP, ZZZ12, PPP, S1, PPP, t1, t2, r.ZZZ, d0);
+    r.Y = cf_sub<2>(t1, t2);
+    return r;
+}
 // affine (external layout) of a finite point: x = X/ZZ, y = Y/ZZZ; 1/ZZ = (ZZ/ZZZ)^2 because ZZ^3 = ZZZ^2
 __device__ void pt_to_std(const xyzz& p, u32* x, u32* y) {   // CW_STD words each
     const cf izzz = cf_inv(p.ZZZ), t = cf_mul(p.ZZ, izzz), izz = cf_sqr(t);
@@ -434,31 +516,35 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restric
 // 16/RLOG levels the one item left per window holds A = sum_k k*B_k.  The tail of a sum is the serial chain of
 // these levels: 3R - 1 + RLOG*level point operations each -- 212 in all for R = 16 (first version), 144 for R = 4.
 constexpr int RED_RLOG = 2;
-template <int RLOG>
+// QUAD: four lanes per item (pt_add4 / pt_dbl4) -- for the upper levels, where a few hundred items leave the device idle and
+// the serial chain of a lane is all that counts; the wide lower levels keep one lane per item (a quad does 1.7 x the work)
+template <int RLOG, bool QUAD>
 __global__ __launch_bounds__(64) void msm_reduce_level_kernel(const xyzz* __restrict__ S_in, const xyzz* __restrict__ A_in,
                                                               xyzz* __restrict__ S_out, xyzz* __restrict__ A_out,
                                                               u32 n_out, int level) {
     constexpr int R = 1 << RLOG;
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 g = (blockIdx.x * blockDim.x + threadIdx.x) >> (QUAD ? 2 : 0);
     if (g >= n_out) return;
+    auto add = [](const xyzz& a, const xyzz& b) { return QUAD ? pt_add4(a, b) : pt_add(a, b); };
     const xyzz* s = S_in + (u64)g * R;
     xyzz run = pt_inf(), acc = pt_inf();
-    for (int j = R - 1; j >= 1; --j) { run = pt_add(run, s[j]); acc = pt_add(acc, run); }
-    run = pt_add(run, s[0]);
+    for (int j = R - 1; j >= 1; --j) { run = add(run, s[j]); acc = add(acc, run); }
+    run = add(run, s[0]);
     if (level > 0) {
-        for (int k = 0; k < RLOG * level; ++k) acc = pt_dbl(acc);
+        for (int k = 0; k < RLOG * level; ++k) acc = QUAD ? pt_dbl4(acc) : pt_dbl(acc);
         const xyzz* a = A_in + (u64)g * R;
-        for (int j = 0; j < R; ++j) acc = pt_add(acc, a[j]);
+        for (int j = 0; j < R; ++j) acc = add(acc, a[j]);
     }
-    S_out[g] = run; A_out[g] = acc;
+    if (!QUAD || (threadIdx.x & 3) == 0) { S_out[g] = run; A_out[g] = acc; }
 }
 __global__ __launch_bounds__(64) void msm_final_kernel(const xyzz* __restrict__ win, u32* __restrict__ out /* 2*CW_STD words + flag */, int weighted) {
-    if (threadIdx.x | blockIdx.x) return;
+    if (blockIdx.x || threadIdx.x >= 4) return;                            // one quad walks the windows
     xyzz acc = pt_inf();
     for (int w = N_WIN - 1; w >= 0; --w) {
-        if (!weighted) for (int k = 0; k < C_BITS; ++k) acc = pt_dbl(acc);   // weighted: the table already holds 2^(16 w) P
-        acc = pt_add(acc, win[w]);
+        if (!weighted) for (int k = 0; k < C_BITS; ++k) acc = pt_dbl4(acc);   // weighted: the table already holds 2^(16 w) P
+        acc = pt_add4(acc, win[w]);
     }
+    if (threadIdx.x) return;
     if (pt_is_inf(acc)) { for (int i = 0; i < 2 * CW_STD; ++i) out[i] = 0; out[2 * CW_STD] = 1; return; }
     u32 x[CW_STD], y[CW_STD];
     pt_to_std(acc, x, y);
@@ -683,12 +769,23 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         ZK_HIP(hipStreamSynchronize(st));
         return;
     }
+    // four lanes per item from the level with this many items up (measured: G1 gains from 2^15 items on; over Fq2 the selects and
+    // broadcasts of a stage cost what the shorter chain saves, only the final walk keeps its quad)
+#ifdef MSM_G2
+    constexpr u32 quad_default = 0;
+#else
+    constexpr u32 quad_default = 32768;
+#endif
+    static const u32 quad_below = getenv("ZK_MSM_QUAD_BELOW") ? (u32)atoi(getenv("ZK_MSM_QUAD_BELOW")) : quad_default;
     // reduction hierarchy: ping-pong (S, A) arrays of n_keys / R and n_keys / R^2 items
     const xyzz* s_in = (const xyzz*)buckets.p; const xyzz* a_in = nullptr;
     u32 n_out = (u32)(n_keys >> RED_RLOG);
     for (int level = 0; level < C_BITS / RED_RLOG; ++level, n_out >>= RED_RLOG) {
         xyzz* s_out = (xyzz*)(level & 1 ? S1.p : S0.p); xyzz* a_out = (xyzz*)(level & 1 ? A1.p : A0.p);
-        hipLaunchKernelGGL(msm_reduce_level_kernel<RED_RLOG>, dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
+        if (n_out <= quad_below)
+            hipLaunchKernelGGL((msm_reduce_level_kernel<RED_RLOG, true>), dim3((4 * n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
+        else
+            hipLaunchKernelGGL((msm_reduce_level_kernel<RED_RLOG, false>), dim3((n_out + 63) / 64), dim3(64), 0, st, s_in, a_in, s_out, a_out, n_out, level);
         s_in = s_out; a_in = a_out;
     }
     ZK_HIP(hipGetLastError());
