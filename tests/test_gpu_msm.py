@@ -253,7 +253,7 @@ def test_bls_generator_multiples_match_oracle(zk, orc):
         assert np.array_equal(bases[i], exp) and cv.on_curve(bases[i])
 
 
-@pytest.mark.parametrize("logn", [16, 20])
+@pytest.mark.parametrize("logn", [16, 20, 22])
 def test_bls_msm_large_closed_form(zk, orc, logn):
     cv = orc.curve("bls12_381")
     n = 1 << logn
