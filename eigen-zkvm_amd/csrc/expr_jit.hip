@@ -18,6 +18,7 @@
 #include <hip/hiprtc.h>
 #include <map>
 #include <sstream>
+#include <tuple>
 #include <vector>
 
 namespace zk {
@@ -33,6 +34,28 @@ struct EvalCtx {
     const u64* x; const u64* zi; u64 zi_mask; const u64* xdiv; const u64* xdivw;
 };
 DEV f3 ld3(const u64* p) { return f3{{p[0], p[1], p[2]}}; }
+// Section rows are staged through LDS one chunk of W columns at a time (W <= 19, LDS rows of W|1 words: odd, so the
+// lanes' 8-byte reads of one column fall in distinct banks).  A wave moves the chunk of its 64 rows with consecutive lanes
+// on consecutive words -- rows of 64 x W x 8 bytes in runs of W words -- instead of 64 lanes each walking its own row;
+// row numbers wrap at the end of the domain (the primed rows of the last wave), rows past the launch's range are read
+// all the same (they exist).  One wave, one buffer: LDS instructions of a wave execute in order, the fences only keep the
+// compiler from moving them.  Stores stay per lane: a lane writes its row's cells back to back at the end of the kernel
+// and L2 merges them into whole lines; staging them measured slower (DESIGN.md 3.3).
+DEV void stage_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int W, int S>
+DEV void stage_in(u64* __restrict__ wl, const u64* __restrict__ buf, unsigned rbase, unsigned mask, unsigned c0, unsigned lane) {
+    constexpr unsigned WP = W | 1;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const unsigned w = lane + 64u * k, r = w / (unsigned)W, cc = w - r * (unsigned)W;
+        wl[r * WP + cc] = buf[(u64)((rbase + r) & mask) * S + c0 + cc];
+    }
+    stage_sync();
+}
 DEV f3 add31(f3 a, u64 b) { return f3{{gl::add(a.v[0], b), a.v[1], a.v[2]}}; }               // f3g.rs:338-341
 DEV f3 add13(u64 a, f3 b) { return f3{{gl::add(b.v[0], a), b.v[1], b.v[2]}}; }               // f3g.rs:346-349
 DEV f3 sub31(f3 a, u64 b) { return f3{{gl::sub(a.v[0], b), a.v[1], a.v[2]}}; }               // f3g.rs:381-384
@@ -87,7 +110,18 @@ struct Val {
 struct ChainConst { int ch; std::vector<CTerm> cterms; };   // sum of a chain's uniform terms: computed once per launch
 
 struct Gen {
+    // Kernel text = prologue (every section read) + body (arithmetic) + epilogue (every section write).  A lane reads the
+    // cells of its own rows only, and what it reads after writing comes from fwd, so all reads can be issued before the
+    // first store and all stores after the last operation: nothing aliases a store any more, a row's cache lines are
+    // fetched and written within a short window instead of once per use, and the reads of wide sections can go through
+    // LDS (stage_in).  PoseidonG, 2^22 rows, kernels alone: 7.1 ms with reads and writes where the program has them,
+    // 5.0 ms hoisted, 4.3 ms hoisted and staged.
     std::ostringstream body;
+    // rows of at least this many words go through LDS (below that neighbouring lanes already share cache lines); 0 = never
+    const uint32_t stage_min = getenv("ZK_JIT_STAGE_MIN") ? (uint32_t)atoi(getenv("ZK_JIT_STAGE_MIN")) : 8;
+    struct Cell { uint32_t buf, id, dim, stride; bool prime; std::string name; };
+    std::vector<Cell> reads, writes;    // in program order; name = the SSA value read into / written from
+    static constexpr uint32_t CHUNK = 19;   // columns per staged chunk: 64 x 19 x 8 B per wave, four blocks of four waves per CU
     std::map<uint32_t, Val> tmp;                                   // tmp id -> current SSA value
     std::map<std::pair<uint32_t, uint32_t>, Val> fwd, fwd_prime;   // (buf, column) -> value this lane wrote at row i / i+next
     // Rows are evaluated concurrently (one lane per row), the reference evaluates them in order inside a chunk
@@ -98,8 +132,9 @@ struct Gen {
     // -- the same expression evaluated at the same row -- whichever lane lands last.
     struct Access { uint32_t buf, id, dim; bool prime; };
     std::vector<Access> mem_reads, mem_writes;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t, bool>, Val> loaded;   // cells already read in the prologue
+    static bool overlap(const Access& a, const Access& b) { return a.buf == b.buf && a.id < b.id + b.dim && b.id < a.id + a.dim; }
     void check_row_hazards() const {
-        auto overlap = [](const Access& a, const Access& b) { return a.buf == b.buf && a.id < b.id + b.dim && b.id < a.id + a.dim; };
         for (const Access& w : mem_writes) {
             for (const Access& r : mem_reads)
                 ZK_REQUIRE(!(overlap(w, r) && w.prime != r.prime), "eval program: a column is written at one row and read at the next row in the same step");
@@ -148,7 +183,6 @@ struct Gen {
     }
     Val load(const zk_operand& o, bool keep_lazy = false) {
         ZK_REQUIRE(o.dim == 1 || o.dim == 3, "eval program: operand dim must be 1 or 3");
-        std::ostringstream e;
         switch (o.kind) {
             case ZK_OPND_TMP: {
                 auto it = tmp.find(o.id);
@@ -166,11 +200,18 @@ struct Gen {
                     auto it = fwd_prime.find(key);   // this lane computed the next-row value itself (e.g. t' of a plookup)
                     if (it != fwd_prime.end() && it->second.dim == o.dim) return it->second;
                 }
-                mem_reads.push_back(Access{(uint32_t)o.buf, o.id, (uint32_t)o.dim, o.prime != 0});
-                e << "c.bufs[" << (int)o.buf << "] + " << (o.prime ? "ip" : "i") << " * " << o.stride << "ull + " << o.id;
+                const Access acc{(uint32_t)o.buf, o.id, (uint32_t)o.dim, o.prime != 0};
+                // the read is issued before this lane's stores: it must not need one of them (a store of another shape
+                // over the same words; exact matches were served from fwd above)
+                for (const Access& w : mem_writes)
+                    ZK_REQUIRE(!(overlap(w, acc) && w.prime == acc.prime), "eval program: a read partially overlaps an earlier write of the same row");
+                auto lkey = std::make_tuple(acc.buf, acc.id, acc.dim, acc.prime);
+                auto lit = loaded.find(lkey);
+                if (lit != loaded.end()) return lit->second;
+                mem_reads.push_back(acc);
                 Val v{fresh(), o.dim};
-                if (o.dim == 1) body << "    const u64 " << v.name << " = (" << e.str() << ")[0];\n";
-                else            body << "    const f3 " << v.name << " = ld3(" << e.str() << ");\n";
+                reads.push_back(Cell{acc.buf, acc.id, acc.dim, o.stride, acc.prime, v.name});
+                loaded[lkey] = v;
                 return v;
             }
             case ZK_OPND_NUMBER: {
@@ -196,15 +237,77 @@ struct Gen {
         ZK_REQUIRE(d.kind == ZK_OPND_MEM && d.buf < 16, "eval program: destination must be tmp or a section cell");
         // A primed destination (set_ref -> eval_map with prime, interpreter.rs:331-345) stores the value of row
         // i+next into row i+next's cell; the lane of that row stores the same field element there.
-        std::ostringstream e;
-        e << "(c.bufs[" << (int)d.buf << "] + " << (d.prime ? "ip" : "i") << " * " << d.stride << "ull + " << d.id << ")";
-        if (v.dim == 1) body << "    " << e.str() << "[0] = " << v.name << ";\n";   // interpreter.rs:149-152
-        else body << "    { u64* p = " << e.str() << "; p[0] = " << v.name << ".v[0]; p[1] = " << v.name << ".v[1]; p[2] = "
-                  << v.name << ".v[2]; }\n";                                          // interpreter.rs:153-159
+        writes.push_back(Cell{(uint32_t)d.buf, d.id, (uint32_t)v.dim, d.stride, d.prime != 0, v.name});   // interpreter.rs:149-159
         auto key = std::make_pair((uint32_t)d.buf, d.id);
-        mem_writes.push_back(Access{(uint32_t)d.buf, d.id, (uint32_t)v.dim, d.prime != 0});
-        if (d.prime) { fwd_prime[key] = v; return; }
-        fwd[key] = v;
+        const Access acc{(uint32_t)d.buf, d.id, (uint32_t)v.dim, d.prime != 0};
+        mem_writes.push_back(acc);
+        auto& f = d.prime ? fwd_prime : fwd;
+        for (auto it = f.begin(); it != f.end();) {     // an older value of other words of this store is no longer what the cells hold
+            const Access old{it->first.first, it->first.second, (uint32_t)it->second.dim, acc.prime};
+            if (it->first != key && overlap(old, acc)) it = f.erase(it); else ++it;
+        }
+        f[key] = v;
+    }
+
+    // one (section, row offset) group of cells, cut into chunks of at most CHUNK columns
+    struct Group { uint32_t buf, stride; bool prime; std::vector<const Cell*> cells; };
+    static std::vector<Group> groups_of(const std::vector<Cell>& cells) {
+        std::vector<Group> g;
+        for (const Cell& c : cells) {
+            size_t k = 0;
+            while (k < g.size() && !(g[k].buf == c.buf && g[k].prime == c.prime)) ++k;
+            if (k == g.size()) g.push_back(Group{c.buf, c.stride, c.prime, {}});
+            ZK_REQUIRE(g[k].stride == c.stride, "eval program: one section addressed with two row sizes");
+            g[k].cells.push_back(&c);
+        }
+        return g;
+    }
+    static std::string word_of(const Cell& c, uint32_t j) { return c.dim == 1 ? c.name : c.name + ".v[" + std::to_string(j) + "]"; }
+    uint32_t lds_words = 0;             // per wave
+    std::string prologue() {
+        std::ostringstream o;
+        for (uint32_t dim : {1u, 3u}) {
+            std::string names;
+            for (const Cell& c : reads) if (c.dim == dim) names += (names.empty() ? "" : ", ") + c.name;
+            if (!names.empty()) o << (dim == 1 ? "    u64 " : "    f3 ") << names << ";\n";
+        }
+        for (const Group& g : groups_of(reads)) {
+            const uint32_t S = g.stride, n_chunks = (S + CHUNK - 1) / CHUNK, W0 = (S + n_chunks - 1) / n_chunks;
+            const std::string row = g.prime ? "ip" : "i", rbase = g.prime ? "i0 + (unsigned)next" : "i0";
+            for (uint32_t c0 = 0; c0 < S; c0 += W0) {
+                const uint32_t W = std::min(W0, S - c0);
+                uint32_t used = 0;
+                for (uint32_t col = c0; col < c0 + W; ++col) {
+                    bool u = false;
+                    for (const Cell* c : g.cells) u = u || (c->id <= col && col < c->id + c->dim);
+                    used += u;
+                }
+                if (!used) continue;
+                const bool staged = stage_min && S >= stage_min && 2 * used >= W;
+                if (staged) {
+                    lds_words = std::max(lds_words, 64 * (W | 1));
+                    o << "    stage_in<" << W << ", " << S << ">(wl, c.bufs[" << g.buf << "], " << rbase << ", (unsigned)(n - 1), " << c0 << ", lane);\n";
+                }
+                for (const Cell* c : g.cells)
+                    for (uint32_t j = 0; j < c->dim; ++j) {
+                        const uint32_t col = c->id + j;
+                        if (col < c0 || col >= c0 + W) continue;
+                        if (staged) o << "    " << word_of(*c, j) << " = wl[lane * " << (W | 1) << " + " << col - c0 << "];\n";
+                        else o << "    " << word_of(*c, j) << " = c.bufs[" << g.buf << "][" << row << " * " << S << "ull + " << col << "];\n";
+                    }
+                if (staged) o << "    stage_sync();\n";
+            }
+        }
+        return o.str();
+    }
+    std::string epilogue() {
+        std::ostringstream o;
+        o << "    if (live) {\n";
+        for (const Cell& c : writes)          // program order: a later store of the same word wins
+            for (uint32_t j = 0; j < c.dim; ++j)
+                o << "        c.bufs[" << c.buf << "][" << (c.prime ? "ip" : "i") << " * " << c.stride << "ull + " << c.id + j << "] = " << word_of(c, j) << ";\n";
+        o << "    }\n";
+        return o.str();
     }
 
     void instr(const zk_instr& in) {
@@ -311,14 +414,19 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
             powk << "    }\n";
         }
         ZK_REQUIRE(lane <= 64, "eval program: too many challenges with Horner chains");
+        std::string pro_src = g.prologue(), epi_src = g.epilogue();
+        if (g.lds_words) pro_src = "    __shared__ u64 zk_stage[4][" + std::to_string(g.lds_words) + "];\n    u64* const wl = zk_stage[wave];\n" + pro_src;
         p->pow_entries = (pow_words + 3 * (uint32_t)g.chain_consts.size() + 5) / 6;
         src << "extern \"C\" __global__ __launch_bounds__(64) void zk_pow_kernel(const EvalCtx c, u64* __restrict__ pw) {\n" << powk.str() << "}\n"
             << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw, const u64 row0, const u64 count) {\n"
-            << "    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;\n"
-            << "    if (k >= count) return;\n"
-            << "    const u64 i = row0 + k;\n"
+            << "    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
+            << "    const u64 k0 = (u64)blockIdx.x * blockDim.x + wave * 64u;\n"
+            << "    if (k0 >= count) return;                                  // whole wave past the range\n"
+            << "    const unsigned i0 = (unsigned)(row0 + k0);                    // first row of this wave (the domain has at most 2^32 rows)\n"
+            << "    const bool live = k0 + lane < count;                        // lanes past the range compute on rows that exist and store nothing\n"
+            << "    const u64 i = (u64)((i0 + lane) & (unsigned)(n - 1));\n"
             << "    const u64 ip = (i + next) & (n - 1);\n"
-            << g.body.str() << "}\n";
+            << pro_src << g.body.str() << epi_src << "}\n";
         p->source = src.str();
 
         hiprtcProgram prog;

@@ -272,3 +272,64 @@ def test_random_programs_match_reference_interpreter(zk, orc, seed):
                xdiv=[int(v) for v in xd], xdivw=[int(v) for v in xdw])
     assert [int(v) for v in d["cm3"].to_host()] == bufs["cm3"]
     assert [int(v) for v in d["q"].to_host()] == bufs["q"]
+
+
+def _wide_program(rng, w_cm1, w_const):
+    """Reads nearly every column of two wide sections -- base-field cells and cubic-extension cells that straddle the
+    chunks the translator stages through LDS, at row i and at row i+next -- and a few columns of a third one (too few
+    for staging); writes a dim-1 and a dim-3 column of cm3 and q."""
+    prog, t = [], 0
+    prog.append(("mul", T(0), M("cm1", 0, w_cm1), M("const", 0, w_const, prime=True)))
+    for col in range(1, w_cm1):
+        src = M("cm1", col, w_cm1, prime=bool(rng.integers(0, 2)))
+        prog.append((str(rng.choice(["add", "sub", "mul"])), T(t + 1), T(t), src)); t += 1
+    for col in range(1, w_const):
+        prog.append((str(rng.choice(["add", "sub"])), T(t + 1), T(t), M("const", col, w_const, prime=bool(rng.integers(0, 2))))); t += 1
+    d1 = t
+    for col in sorted({1, 12, 13, 14, 17, 18, 19, w_cm1 - 3}):                # cubic-extension cells across chunk boundaries
+        if col + 3 > w_cm1: continue
+        prog.append(("mul", T(t + 1), M("cm1", col, w_cm1, dim=3, prime=bool(rng.integers(0, 2))), T(t))); t += 1
+    prog.append(("add", T(t + 1), T(t), M("wide", 5, 64)));  t += 1            # 2 of 64 columns: read directly
+    prog.append(("add", T(t + 1), T(t), M("wide", 40, 64, dim=3, prime=True)));  t += 1
+    prog.append(("copy", M("cm3", 0, 4), T(d1), None))
+    prog.append(("copy", M("cm3", 1, 4, dim=3), T(t), None))
+    prog.append(("mul", M("q", 0, 3, dim=3), T(t), {"kind": "x"}))
+    return prog
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w_cm1,w_const,nbits", [(19, 18, 9), (40, 9, 8), (36, 8, 7), (73, 20, 8)])
+def test_wide_sections_match_reference_interpreter(zk, orc, w_cm1, w_const, nbits):
+    """Sections of 8 and more columns are read through LDS in chunks of at most 19 columns (csrc/expr_jit.hip stage_in):
+    whole domain (several waves and blocks, the primed rows of the last wave wrapping to row 0) and a row range that
+    starts and ends inside a wave."""
+    import interp
+    assert zk.lib().zk_device_count() >= 1
+    zk.init(0)
+    BUF["wide"] = 4
+    rng = np.random.default_rng(w_cm1 * 100 + w_const)
+    ext = 1
+    n = 1 << (nbits + ext); nxt = 1 << ext
+    program = _wide_program(rng, w_cm1, w_const)
+    host = {"cm1": rng.integers(0, P, size=w_cm1 * n, dtype=np.uint64), "const": rng.integers(0, P, size=w_const * n, dtype=np.uint64),
+            "wide": rng.integers(0, P, size=64 * n, dtype=np.uint64)}
+    chal = rng.integers(0, P, size=24, dtype=np.uint64)
+    x = zk.x_table(nbits + ext, 49); zi = orc.zh_inv(nbits, ext)
+    prog = _compile(zk, program)
+    assert "stage_in<" in prog.source and "c.bufs[4][" in prog.source
+    def go(rows):
+        d = {k: zk.DevArray.from_host(v) for k, v in host.items()}
+        d["q"] = zk.DevArray.from_host(np.full(3 * n, 7, dtype=np.uint64)); d["cm3"] = zk.DevArray.from_host(np.full(4 * n, 7, dtype=np.uint64))
+        prog.run({BUF[k]: v for k, v in d.items()}, nbits + ext, nxt, challenges=zk.DevArray.from_host(chal), x=x, zi=zk.DevArray.from_host(zi), rows=rows)
+        return d["q"].to_host().reshape(n, 3), d["cm3"].to_host().reshape(n, 4)
+    bufs = {k: [int(v) for v in a] for k, a in host.items()}
+    bufs["q"] = [0] * (3 * n); bufs["cm3"] = [0] * (4 * n)
+    interp.run(program, bufs, n, nxt, challenges=chal.reshape(8, 3).astype(object).tolist(), x=[int(v) for v in x.to_host()], zi=[int(v) for v in zi])
+    q_ref = np.array(bufs["q"], dtype=np.uint64).reshape(n, 3); c_ref = np.array(bufs["cm3"], dtype=np.uint64).reshape(n, 4)
+    q, c = go(None)
+    assert (q == q_ref).all() and (c == c_ref).all()
+    for row0, count in [(n - 70, 70), (37, 300 if n > 400 else 100), (5, 1)]:
+        q, c = go((row0, count))
+        inside = np.zeros(n, dtype=bool); inside[row0:row0 + count] = True
+        assert (q[inside] == q_ref[inside]).all() and (q[~inside] == 7).all()
+        assert (c[inside] == c_ref[inside]).all() and (c[~inside] == 7).all()
