@@ -17,6 +17,7 @@
 #include "gl_jit_src.h"
 #include <hip/hiprtc.h>
 #include <map>
+#include <set>
 #include <sstream>
 #include <tuple>
 #include <vector>
@@ -119,6 +120,11 @@ struct Gen {
     std::ostringstream body;
     // rows of at least this many words go through LDS (below that neighbouring lanes already share cache lines); 0 = never
     const uint32_t stage_min = getenv("ZK_JIT_STAGE_MIN") ? (uint32_t)atoi(getenv("ZK_JIT_STAGE_MIN")) : 8;
+    // The prologue holds every word it reads in registers until its use: past HOIST_MAX words (PoseidonG's widest step
+    // reads 93 and sits at the 256-register limit) the reads stay where the program has them and the compiler schedules them
+    // -- still ahead of every store, which all sit in the epilogue.
+    static constexpr uint32_t HOIST_MAX = 112;
+    bool hoist_reads = true;
     struct Cell { uint32_t buf, id, dim, stride; bool prime; std::string name; };
     std::vector<Cell> reads, writes;    // in program order; name = the SSA value read into / written from
     static constexpr uint32_t CHUNK = 19;   // columns per staged chunk: 64 x 19 x 8 B per wave, four blocks of four waves per CU
@@ -210,6 +216,13 @@ struct Gen {
                 if (lit != loaded.end()) return lit->second;
                 mem_reads.push_back(acc);
                 Val v{fresh(), o.dim};
+                if (!hoist_reads) {    // too many cells to hold from the top of the kernel: read at first use (still before every store)
+                    const std::string at = "c.bufs[" + std::to_string(acc.buf) + "] + " + (acc.prime ? "ip" : "i") + " * " + std::to_string(o.stride) + "ull + " + std::to_string(acc.id);
+                    if (o.dim == 1) body << "    const u64 " << v.name << " = (" << at << ")[0];\n";
+                    else            body << "    const f3 " << v.name << " = ld3(" << at << ");\n";
+                    loaded[lkey] = v;
+                    return v;
+                }
                 reads.push_back(Cell{acc.buf, acc.id, acc.dim, o.stride, acc.prime, v.name});
                 loaded[lkey] = v;
                 return v;
@@ -389,6 +402,13 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
         p = new zk_program();
         p->n_instr = n_instr;
         Gen g;
+        {   // words the program reads from sections (an upper bound: reads of cells it wrote itself never reach memory)
+            std::set<std::tuple<uint32_t, uint32_t, bool>> words;
+            for (uint32_t k = 0; k < n_instr; ++k)
+                for (const zk_operand& o : code[k].src)
+                    if (o.kind == ZK_OPND_MEM) for (uint32_t j = 0; j < o.dim && j < 3; ++j) words.insert(std::make_tuple((uint32_t)o.buf, o.id + j, o.prime != 0));
+            g.hoist_reads = words.size() <= Gen::HOIST_MAX;
+        }
         for (uint32_t k = 0; k < n_instr; ++k) g.instr(code[k]);
         g.check_row_hazards();
         std::ostringstream src, powk;
