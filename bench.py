@@ -342,6 +342,9 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     prover.sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
+    lat = None
+    if inputs:                                                          # one task alone: the floor of the job once every rank holds one task
+        t1 = time.perf_counter(); prover.prove(inputs[0]); prover.sync(); lat = time.perf_counter() - t1
     per_rank = (n_tasks + world - 1) // world
     flat = [w for task_roots in roots for r in task_roots for w in r]
     flat += [0] * (per_rank * 12 - len(flat))                           # ranks with one task fewer pad their slot
@@ -353,6 +356,7 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     out = {"workload": "BASELINE config 5 (sharded part): %d recursion tasks, task u on rank u mod %d, each = %s; "
                        "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
            "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
+           "task_latency_s": None if lat is None else round(lat, 4),
            "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
            "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
     out["join_tree"] = join_tree(prover, dist, rank, world, device, [by_task[u][2] for u in sorted(by_task)])

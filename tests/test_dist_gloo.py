@@ -45,8 +45,9 @@ def test_aggregation_leg_control_flow_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # each rank proves its own tasks once after one warm-up of its first task, nobody else's
-    assert res[0][1] == [0, 0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5]
+    # each rank proves its own tasks once after one warm-up of its first task, nobody else's; then its first task alone (task_latency_s)
+    assert res[0][1] == [0, 0, 2, 4, 6, 0] and res[1][1] == [1, 1, 3, 5, 1]
+    assert all(r[2]["task_latency_s"] is not None for r in res)
     # the join tree over 7 leaves: 3 + 2 + 1 joins in 3 levels, shared between the ranks, same root everywhere and equal
     # to the tree computed in one process
     st = StubProver()
@@ -69,7 +70,7 @@ def test_aggregation_leg_single_rank():
     import bench
     pr = StubProver()
     out = bench.aggregation_leg(pr, None, 0, 1, torch.device("cpu"))
-    assert pr.proved == [0] + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+    assert pr.proved == [0] + list(range(8)) + [0] and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
     assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 7)
 
 
