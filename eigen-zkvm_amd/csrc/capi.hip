@@ -414,6 +414,16 @@ int zk_merkle_group_proofs(const zk_merkle_t* t, const uint64_t* idx, uint32_t n
     });
 }
 
+}  // extern "C"
+namespace zk {
+void merkle_group_proofs_async(const zk_merkle* t, const u64* d_idx, uint32_t n, u64* d_out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, st, t->d_elements, t->nodes.u(), t->width, t->height, t->depth, d_idx, d_out);
+    ZK_HIP(hipGetLastError());
+}
+}  // namespace zk
+extern "C" {
+
 // ---- transcript ------------------------------------------------------------------------------
 // the sponge state lives on one stream at a time: work moves to `st` after whatever was issued on the previous stream
 static hipStream_t transcript_stream(zk_transcript_t* t, hipStream_t st) {

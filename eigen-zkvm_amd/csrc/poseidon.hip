@@ -384,6 +384,27 @@ __global__ __launch_bounds__(256) void merkle_level_coop_kernel(const u64* __res
     if (i < n_ops && l < 4) out[4 * i + l] = x;
 }
 
+// The top of a tree in ONE launch: from n <= 64 children to the root, one group of 16 lanes per parent, a block barrier
+// between the levels.  Each of these levels is one permutation deep whatever runs it; as launches of their own they cost
+// a dependent-launch gap each (six per tree, and a small proof builds seven trees or more): 2^15-row proof 6.79 -> 6.69 ms.
+__global__ __launch_bounds__(1024) void merkle_top_coop_kernel(u64* nodes, u64 n, u64 p_in) {
+    ZK_POSEIDON_LDS;
+    load_tables(tab);
+    const int l = threadIdx.x & 15;
+    const u64 g = threadIdx.x >> 4;
+    while (n > 1) {                                                // merklehash.rs:331-343
+        const u64 next = (n - 1) / 2 + 1, p_out = p_in + 2 * next;
+        if ((g & ~(u64)3) < next) {                                // a wave whose four groups are all idle only waits
+            const u64 gc = g < next ? g : next - 1;                // idle groups of a busy wave shadow the last parent (no divergence)
+            u64 x = l < 8 ? nodes[4 * p_in + 8 * gc + l] : 0;
+            x = coop_perm(x, tab);
+            if (g < next && l < 4) nodes[4 * p_out + 4 * g + l] = x;
+        }
+        __syncthreads();                                           // the level is in memory before the block reads it back
+        n = next; p_in = p_out;
+    }
+}
+
 // A tree over zero-width rows (tree2 / tree3 of a PIL without plookups or grand products,
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
@@ -612,6 +633,12 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
     linearhash_rows_dev(d_rows, width, height, d_nodes, st);
     uint64_t n64 = height, next = (n64 - 1) / 2 + 1, p_in = 0, p_out = next * 2;
     while (n64 > 1) {  // merklehash.rs:331-343
+        if (n64 <= 64) {      // the last six levels: one block, one launch (from 128 children the block's 16 waves crowd one CU: slower)
+            const unsigned threads = (unsigned)std::min<uint64_t>(1024, std::max<uint64_t>(64, ((n64 + 1) / 2) * 16));
+            hipLaunchKernelGGL(merkle_top_coop_kernel, dim3(1), dim3(threads), 0, st, d_nodes, n64, p_in);
+            ZK_HIP(hipGetLastError());
+            break;
+        }
         if (next <= 32768) {  // few parents: latency-bound, 16 lanes per permutation
             hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((u32)((next + 15) / 16)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         } else {

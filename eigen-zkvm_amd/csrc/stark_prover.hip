@@ -110,6 +110,7 @@ struct AnyTree {
     AnyTree(const AnyTree&) = delete; AnyTree& operator=(const AnyTree&) = delete;
     ~AnyTree() { if (gl) zk_merkle_free(gl); if (fr) F->tree_free(fr); }
     void root(u64* out) const { ck(gl ? zk_merkle_root(gl, M(out)) : F->root(fr, M(out))); }
+    const u64* root_dev() const { return gl ? K(zk_merkle_nodes_dev(gl)) + 4 * (zk_merkle_n_nodes(height) - 1) : nullptr; }   // last node (merklehash.rs:455-457)
     u32 depth() const { return gl ? zk_merkle_depth(gl) : F->depth(fr); }
     u32 level_words() const { return gl ? 4 : 64; }   // one sibling digest, or the 16 digests of the group
 };
@@ -327,6 +328,66 @@ std::vector<GroupProof> group_proofs(const AnyTree& t, const std::vector<u64>& i
     return out;
 }
 
+// Device words the host needs for the proof's JSON (roots, evaluations, the last FRI polynomial): collected in one device
+// block with asynchronous copies and fetched with ONE copy -- each of them on its own was a blocking round trip, and a
+// small proof is a chain of those.
+struct ReadBack {
+    DevBuf stage; std::vector<u64> host; size_t words = 0, cap = 0; hipStream_t st;
+    ReadBack(size_t capacity, hipStream_t s) : cap(std::max<size_t>(1, capacity)), st(s) { stage.reserve(cap * 8); }
+    size_t add(const u64* d_src, size_t n) {
+        ZK_REQUIRE(words + n <= cap, "ReadBack: capacity");
+        if (n) ZK_HIP(hipMemcpyAsync(stage.u() + words, d_src, n * 8, hipMemcpyDeviceToDevice, st));
+        const size_t off = words; words += n; return off;
+    }
+    u64* reserve(size_t n) { ZK_REQUIRE(words + n <= cap, "ReadBack: capacity"); u64* p = stage.u() + words; words += n; return p; }
+    void fetch() {
+        host.resize(std::max<size_t>(1, words));
+        if (words) ZK_HIP(hipMemcpyAsync(host.data(), stage.p, words * 8, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+    }
+    const u64* at(size_t off) const { return host.data() + off; }
+};
+
+// the openings of several trees, tree j at the indices idx[j]: for GL trees one upload of the indices, one gather launch per
+// tree and one copy back for all of them (fri.rs:160-181, stark_gen.rs:525-557)
+std::vector<std::vector<GroupProof>> group_proofs_all(const std::vector<const AnyTree*>& trees, const std::vector<const std::vector<u64>*>& idx, hipStream_t st) {
+    std::vector<std::vector<GroupProof>> out(trees.size());
+    size_t n_idx = 0, n_out = 0;
+    for (size_t j = 0; j < trees.size(); ++j) {
+        if (!trees[j]->gl) { out[j] = group_proofs(*trees[j], *idx[j]); continue; }     // scalar-field trees: one round trip each
+        for (u64 y : *idx[j]) ZK_REQUIRE(y < trees[j]->height, "MerkleTreeError: access invalid node");
+        n_idx += idx[j]->size(); n_out += idx[j]->size() * ((size_t)trees[j]->width + 4 * (size_t)trees[j]->depth());
+    }
+    if (n_idx == 0) return out;
+    std::vector<u64> h_idx; h_idx.reserve(n_idx);
+    for (size_t j = 0; j < trees.size(); ++j) if (trees[j]->gl) h_idx.insert(h_idx.end(), idx[j]->begin(), idx[j]->end());
+    DevBuf d_idx; d_idx.reserve(n_idx * 8);
+    ZK_HIP(hipMemcpyAsync(d_idx.p, h_idx.data(), n_idx * 8, hipMemcpyHostToDevice, st));
+    ReadBack rb(n_out, st);
+    std::vector<size_t> offs(trees.size(), 0);
+    size_t i0 = 0;
+    for (size_t j = 0; j < trees.size(); ++j) {
+        if (!trees[j]->gl) continue;
+        const u32 n = (u32)idx[j]->size();
+        const size_t per = (size_t)trees[j]->width + 4 * (size_t)trees[j]->depth();
+        offs[j] = rb.words;
+        merkle_group_proofs_async(trees[j]->gl, d_idx.u() + i0, n, rb.reserve(per * n), st);
+        i0 += n;
+    }
+    rb.fetch();                                          // also orders the upload of h_idx before it goes out of scope
+    for (size_t j = 0; j < trees.size(); ++j) {
+        if (!trees[j]->gl) continue;
+        const u32 n = (u32)idx[j]->size(), depth = trees[j]->depth(), w = trees[j]->width;
+        const size_t per = (size_t)w + 4 * (size_t)depth;
+        out[j].resize(n);
+        for (u32 q = 0; q < n; ++q) {
+            const u64* p = rb.at(offs[j] + q * per);
+            out[j][q].depth = depth; out[j][q].row.assign(p, p + w); out[j][q].path.assign(p + w, p + per);
+        }
+    }
+    return out;
+}
+
 zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t* const_pols, uint64_t n_words) {
     std::unique_ptr<zk_stark_setup> S(new zk_stark_setup);
     JVal root = JParser::parse(json);
@@ -462,7 +523,28 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
 
     // publics (stark_gen.rs:256-270) and their absorption (:272-277)
     std::vector<u64> publics;
-    for (u32 i = 0; i < n_pub; ++i) {
+    DevBuf d_pub_ext;                                     // words 1 and 2 of every computed public: checked to be zero at the end
+    const bool pub_on_device = d_cm != nullptr;           // device-resident trace: no host round trip per public
+    if (pub_on_device) {
+        d_pub_ext.reserve(std::max<u32>(1, n_pub) * 16); zero(d_pub_ext, 2 * (size_t)std::max<u32>(1, n_pub), st);
+        for (u32 i = 0; i < n_pub; ++i) {
+            const JVal& pe = I.at("publics").at(i);
+            const std::string& ty = pe.at("polType").str();
+            const u64 idx = pe.at("idx").u64();
+            if (ty == "cmP") {
+                const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
+                ZK_REQUIRE(pos < n_words, "public out of range");
+                ZK_HIP(hipMemcpyAsync(d_pub.u() + i, d_cm + pos, 8, hipMemcpyDeviceToDevice, st));
+            } else if (ty == "imP") {                                              // calculate_exp_at_point :558-572
+                ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
+                ZK_REQUIRE(idx < N, "public out of range");
+                run(S.public_programs[i], false, nullptr, idx, 1);                 // its one row; reads the publics before it from d_pub
+                ZK_HIP(hipMemcpyAsync(d_pub.u() + i, ptr[S_SCRATCH] + 3 * idx, 8, hipMemcpyDeviceToDevice, st));
+                ZK_HIP(hipMemcpyAsync(d_pub_ext.u() + 2 * i, ptr[S_SCRATCH] + 3 * idx + 1, 16, hipMemcpyDeviceToDevice, st));
+            } else throw Error("Invalid public type " + ty);
+        }
+    }
+    for (u32 i = 0; i < n_pub && !pub_on_device; ++i) {
         const JVal& pe = I.at("publics").at(i);
         const std::string& ty = pe.at("polType").str();
         const u64 idx = pe.at("idx").u64();
@@ -487,11 +569,13 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             publics.push_back(v[0]);
         } else throw Error("Invalid public type " + ty);
     }
-    ZK_HIP(hipStreamSynchronize(st));
-    if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
+    if (!pub_on_device) {
+        ZK_HIP(hipStreamSynchronize(st));
+        if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
+    }
     const FrApi* bn128 = S.fr;                            // non-null: a scalar-field hash type
     AnyTranscript tr(bn128);
-    tr.put_words_dev(d_pub.u(), publics.size(), st);
+    tr.put_words_dev(d_pub.u(), n_pub, st);
 
     std::vector<std::unique_ptr<DevBuf>> keep;                                     // workspaces alive until the end
     auto extend_and_merkelize = [&](int sec_n, int sec_2ns) {                     // stark_gen.rs:709-732
@@ -635,11 +719,40 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
 
     // ---- proof -> zkin JSON (serializer.rs:146-261)
     u64 r1[4], r2[4], r3[4], r4[4];
-    tree1->root(r1); tree2->root(r2); tree3->root(r3); tree4->root(r4);
-    for (size_t si = 0; si + 1 < n_steps; ++si) fri_trees[si]->root(fri_roots[si].data());
-    std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev));
-    ZK_HIP(hipStreamSynchronize(st));
-    if (n_ev) ZK_HIP(hipMemcpy(ev_host.data(), d_evals.p, 24 * (size_t)n_ev, hipMemcpyDeviceToHost));
+    const u64 n_last = 1ull << steps.back();
+    std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev)), last(3 * n_last);
+    {   // roots, evaluations and the last polynomial in one copy (Goldilocks trees: their roots are device words)
+        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub, st);
+        const AnyTree* t4[4] = {tree1.get(), tree2.get(), tree3.get(), tree4.get()};
+        u64* r4p[4] = {r1, r2, r3, r4};
+        size_t off_r[4] = {}, off_ev = 0, off_last = 0;
+        std::vector<size_t> off_fri(n_steps, 0);
+        if (!bn128) {
+            for (int j = 0; j < 4; ++j) off_r[j] = rb.add(t4[j]->root_dev(), 4);
+            for (size_t si = 0; si + 1 < n_steps; ++si) off_fri[si] = rb.add(fri_trees[si]->root_dev(), 4);
+        }
+        off_ev = rb.add(d_evals.u(), 3 * (size_t)n_ev);
+        off_last = rb.add(d_pol, 3 * n_last);
+        const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
+        rb.fetch();
+        if (pub_on_device) {
+            publics.assign(rb.at(off_pub), rb.at(off_pub) + n_pub);
+            // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value; a
+            // computed public with extension words means a malformed program (see the host-trace path above)
+            for (u32 i = 0; i < n_pub; ++i)
+                ZK_REQUIRE(rb.at(off_ext)[2 * i] == 0 && rb.at(off_ext)[2 * i + 1] == 0,
+                           "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
+        }
+        if (!bn128) {
+            for (int j = 0; j < 4; ++j) memcpy(r4p[j], rb.at(off_r[j]), 32);
+            for (size_t si = 0; si + 1 < n_steps; ++si) memcpy(fri_roots[si].data(), rb.at(off_fri[si]), 32);
+        } else {
+            for (int j = 0; j < 4; ++j) t4[j]->root(r4p[j]);
+            for (size_t si = 0; si + 1 < n_steps; ++si) fri_trees[si]->root(fri_roots[si].data());
+        }
+        if (n_ev) memcpy(ev_host.data(), rb.at(off_ev), 24 * (size_t)n_ev);
+        memcpy(last.data(), rb.at(off_last), 24 * n_last);
+    }
     std::ostringstream o;
     o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
     o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
@@ -648,10 +761,16 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
     o << ']';
     // queries of the later steps: group proofs of the folded polynomials (fri.rs:160-181)
-    std::vector<u64> ysi = ys;
+    // every opening of the proof in one batch: the folded polynomials' trees at the reduced indices, the five trees at ys
+    std::vector<std::vector<u64>> ysi(n_steps, ys);
+    for (size_t si = 1; si < n_steps; ++si)
+        for (size_t q = 0; q < ys.size(); ++q) ysi[si][q] = ysi[si - 1][q] % (1ull << steps[si]);
+    std::vector<const AnyTree*> all_trees; std::vector<const std::vector<u64>*> all_idx;
+    for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(fri_trees[si - 1].get()); all_idx.push_back(&ysi[si]); }
+    for (const AnyTree* t : {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()}) { all_trees.push_back(t); all_idx.push_back(&ys); }
+    const std::vector<std::vector<GroupProof>> all_gp = group_proofs_all(all_trees, all_idx, st);
     for (size_t si = 1; si < n_steps; ++si) {
-        for (u64& y : ysi) y %= (1ull << steps[si]);
-        const std::vector<GroupProof> gp = group_proofs(*fri_trees[si - 1], ysi);
+        const std::vector<GroupProof>& gp = all_gp[si - 1];
         o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);
         o << ",\"s" << si << "_vals\":[";
         for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
@@ -660,10 +779,8 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         o << ']';
     }
     {   // step 0: openings of the five trees at the query indices
-        const AnyTree* trees0[5] = {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()};
         const char* names[5] = {"1", "2", "3", "4", "C"};
-        std::vector<std::vector<GroupProof>> gp(5);
-        for (int j = 0; j < 5; ++j) gp[j] = group_proofs(*trees0[j], ys);
+        const std::vector<GroupProof>* gp = all_gp.data() + (n_steps - 1);
         for (int j = 0; j < 5; ++j) {
             o << ",\"s0_vals" << names[j] << "\":[";
             for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
@@ -676,10 +793,6 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         }
     }
     {
-        const u64 n_last = 1ull << steps.back();
-        std::vector<u64> last(3 * n_last);
-        ZK_HIP(hipStreamSynchronize(st));
-        ZK_HIP(hipMemcpy(last.data(), d_pol, 24 * n_last, hipMemcpyDeviceToHost));
         o << ",\"finalPol\":[";
         for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, last.data() + 3 * i, 3); }
         o << ']';

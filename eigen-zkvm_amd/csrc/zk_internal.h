@@ -8,6 +8,7 @@
 #include <vector>
 #include "gl.cuh"
 
+struct zk_merkle;
 namespace zk {
 
 // ---- error handling: C ABI returns int status, message kept per thread (include/zkgpu.h) ----
@@ -95,6 +96,9 @@ void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp
 void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv, u64* d_out, hipStream_t st);
 void pol_get_dev(const u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, u64* d_out, hipStream_t st);
 void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const u64* d_in, hipStream_t st);
+// openings of a GL tree at n device-resident (already range-checked) indices, written to device memory as
+// n x (width + 4 * depth) words: no host round trip (capi.hip; the prover batches the openings of all its trees)
+void merkle_group_proofs_async(const struct ::zk_merkle* t, const u64* d_idx, uint32_t n, u64* d_out, hipStream_t st);
 uint64_t h1h2_work_words(uint64_t n);
 void calculate_h1h2_dev(const u64* d_f, const u64* d_t, uint64_t n, u64* d_h1, u64* d_h2, u64* d_work, u64** d_missing, hipStream_t st);
 void calculate_z_dev(const u64* d_num, const u64* d_den, uint64_t n, u64* d_z, u64* d_work, u64* d_check, hipStream_t st);
