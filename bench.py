@@ -266,6 +266,7 @@ class GpuTaskProver:
         mk = lambda k: stark.NativeStarkSetup(consts[k], json.dumps(AW.program(k)), json.dumps(AW.STRUCTS[k]))
         self.sets = [{k: mk(k) for k in ("fib", "c12", "r1")} for _ in range(self.workers)]
         self.streams = [zk.Stream() for _ in range(self.workers)]
+        self.join_exec_s, self.join_prove_s = [0.0] * self.workers, [0.0] * self.workers   # per worker: host exec step / proof, summed over its joins
         self.setups = self.sets[0]
         self.sizes = {k: AW.STRUCTS[k]["nBits"] for k in self.setups}
 
@@ -310,8 +311,13 @@ class GpuTaskProver:
         """One recursive2 step of the aggregation (test/stark_aggregation.sh:80-128: join_zkin + compressor12_exec +
         stark_prove with r1.starkStruct.json, 2^18 rows): the joined circuit's primary inputs are the two child roots."""
         primary = [int(w) for w in root_a] + [int(w) for w in root_b] + [0] * 8
+        t0 = time.perf_counter()
         cm = self.circ["r1"].witness(primary=primary)                         # the exec step (host), then the proof
-        return self._root1(self.sets[worker]["r1"].gen_json(self.zk.DevArray.from_host(cm), self.streams[worker].handle))
+        d_cm = self.zk.DevArray.from_host(cm)
+        t1 = time.perf_counter()
+        root = self._root1(self.sets[worker]["r1"].gen_json(d_cm, self.streams[worker].handle))
+        self.join_exec_s[worker] += t1 - t0; self.join_prove_s[worker] += time.perf_counter() - t1
+        return root
 
     def join_all(self, pairs):
         """the joins of one tree level: independent of each other"""
@@ -363,6 +369,15 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     return out
 
 
+def shard_all_joins(n_leaves, rank, world):
+    """(level, join) pairs of the join tree that fall on this rank"""
+    n, level = n_leaves, 0
+    while n > 1:
+        for j in shard_units(n // 2, rank, world):
+            yield level, j
+        n, level = n // 2 + n % 2, level + 1
+
+
 def join_tree(prover, dist, rank, world, device, leaves):
     """The join phase as a tree instead of the reference's chain (test/stark_aggregation.sh:76-156 joins proof
     k+1 into the running aggregate: NUM_PROOF - 1 sequential recursive2 proofs).  Level l joins neighbours pairwise, join j
@@ -390,7 +405,11 @@ def join_tree(prover, dist, rank, world, device, leaves):
     prover.sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
-    return {"levels": levels, "joins": joins, "chain_depth_of_the_reference": max(0, len(leaves) - 1), "s": round(dt, 4), "root": [int(w) for w in nodes[0]]}
+    out = {"levels": levels, "joins": joins, "chain_depth_of_the_reference": max(0, len(leaves) - 1), "s": round(dt, 4), "root": [int(w) for w in nodes[0]]}
+    if hasattr(prover, "join_exec_s") and joins:      # where a join's time goes on this rank: the host exec step (witness of the joined circuit) and the proof
+        out["per_join_ms"] = {"exec_host": round(1e3 * sum(prover.join_exec_s) / max(1, sum(1 for _ in shard_all_joins(len(leaves), rank, world))), 1),
+                              "prove": round(1e3 * sum(prover.join_prove_s) / max(1, sum(1 for _ in shard_all_joins(len(leaves), rank, world))), 1)}
+    return out
 
 
 def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
