@@ -30,7 +30,8 @@ constexpr int T_PC = T_FC + 96;      // [22] partial-round constants (+2 pad)
 constexpr int T_SC = T_PC + 24;      // [22][11]: S[23r + 12 .. 23r + 22], the column applied to st[1..11]
 constexpr int T_PT = T_SC + 242;     // [12 i][12 j] split: P[j][i]
 constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
-constexpr int T_WORDS = T_SR + 528;  // 1190 words = 9.3 KB
+constexpr int T_SRR = T_SR + 528;    // [22][16] whole words: S[23r + l] for lane l < 12 of a cooperative permutation, 0 for its four idle lanes
+constexpr int T_WORDS = T_SRR + 352; // 1542 words = 12 KB
 static_assert(T_PT % 2 == 0 && T_SR % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
@@ -184,6 +185,45 @@ __device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12])
         x1[j] = (u32)__shfl((int)(u32)(x >> 32), j, 16);
     }
 }
+// Partial rounds without the LDS crossbar.  A group is one 16-lane DPP row: lane 0's S-box output reaches the row by
+// three DPP moves, every lane multiplies its own word by its entry of the sparse row (idle lanes: entry 0), and the
+// twelve 128-bit products are summed towards lane 0 by four shifted row additions on five 32-bit limbs -- instead of
+// every lane gathering all twelve words (24 ds_bpermute) and computing the whole dot product itself (72 multiply-adds).
+__device__ __forceinline__ u32 dpp_opaque(u32 v) { asm volatile("" : "+v"(v)); return v; }   // keeps the DPP moves where they are written (section 3.9)
+__device__ __forceinline__ u32 row_bcast0(u32 v) {
+    v = dpp_opaque(v);
+    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x00, 0xF, 0xF, false);     // quad_perm [0,0,0,0]
+    v = dpp_opaque(v);
+    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0x2, false);    // row_shr:4, lanes 4..7 only
+    v = dpp_opaque(v);
+    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xC, false);    // row_shr:8, lanes 8..15 only
+    return dpp_opaque(v);
+}
+template <int N>
+__device__ __forceinline__ void row_add_shl(u32 (&s)[5]) {            // s[lane] += s[lane + N] within the row (nothing beyond lane 15)
+    u32 q[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) q[k] = dpp_opaque((u32)__builtin_amdgcn_update_dpp(0, (int)dpp_opaque(s[k]), 0x100 + N, 0xF, 0xF, true));
+    u32 c = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = __builtin_addc(s[k], q[k], c, &c);
+}
+// sum over the row of coef * a, as an nc word; meaningful in lane 0 of the row
+__device__ __forceinline__ u64 row_dot(u64 coef, u64 a) {
+    GL_OPAQUE(coef); GL_OPAQUE(a);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)coef, b1 = (u32)(coef >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    u32 s[5] = {(u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32), 0u};
+    row_add_shl<8>(s); row_add_shl<4>(s); row_add_shl<2>(s); row_add_shl<1>(s);
+    // s0 + s1 2^32 + s2 2^64 + s3 2^96 + s4 2^128, and 2^128 = -2^32 (mod p): reduce four limbs, take s4 2^32 off
+    const u64 t = gl::reduce_words_nc(s[0], s[1], s[2], s[3]), b = (u64)s[4] << 32;
+    const u64 d = t - b;
+    return t < b ? d - GL_EPS : d;                                     // wrapped below zero: + p = - (2^32 - 1) mod 2^64, cannot wrap again
+}
+
 // x = this lane's state word (lanes 12..15 of a group carry garbage and only serve the shuffles)
 __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
     const int l = threadIdx.x & 15, lc = l < 12 ? l : 11;
@@ -199,10 +239,9 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
         }
 #pragma unroll 1
         for (int r = 0; r < 22; ++r) {
-            const u64 st0 = shfl64(pow7_add(x, tab[T_PC + r]), 0);  // lane 0's S-box, broadcast
-            u32 x0[12], x1[12];
-            coop_gather(l == 0 ? st0 : x, x0, x1);
-            const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);           // every lane computes the same s0
+            const u64 t = pow7_add(x, tab[T_PC + r]);
+            const u64 st0 = gl::mk64(row_bcast0((u32)t), row_bcast0((u32)(t >> 32)));   // lane 0's S-box, to its row
+            const u64 s0 = row_dot(tab[T_SRR + 16 * r + l], l == 0 ? st0 : x);         // lane 0: the new st[0]
             const u64 rest = gl::mul_add_nc(tab[T_SC + 11 * r + (lc > 0 ? lc - 1 : 0)], st0, x);
             x = l == 0 ? s0 : rest;
         }
@@ -544,6 +583,7 @@ void ensure_constants() {
     for (int r = 0; r < 22; ++r) {
         for (int j = 0; j < 12; ++j) split(T_SR + 2 * (12 * r + j), ZK_POSEIDON_S[23 * r + j]);
         for (int k = 1; k < 12; ++k) tab[T_SC + 11 * r + k - 1] = ZK_POSEIDON_S[23 * r + 11 + k];
+        for (int j = 0; j < 12; ++j) tab[T_SRR + 16 * r + j] = ZK_POSEIDON_S[23 * r + j];
     }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
     g_consts_loaded[dev] = true;
