@@ -199,15 +199,16 @@ __device__ __forceinline__ u32 row_bcast0(u32 v) {
     v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xC, false);    // row_shr:8, lanes 8..15 only
     return dpp_opaque(v);
 }
-template <int N>
-__device__ __forceinline__ void row_add_shl(u32 (&s)[5]) {            // s[lane] += s[lane + N] within the row (nothing beyond lane 15)
-    u32 q[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) q[k] = dpp_opaque((u32)__builtin_amdgcn_update_dpp(0, (int)dpp_opaque(s[k]), 0x100 + N, 0xF, 0xF, true));
-    u32 c = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) s[k] = __builtin_addc(s[k], q[k], c, &c);
-}
+// s[lane] += s[lane + N] within the row (nothing beyond lane 15), five limbs with carry: the shifted operand rides on the
+// additions' DPP modifier.  A DPP operand written by the instruction just before needs two wait states: the leading s_nop.
+#define ZK_ROW_ADD_SHL(N)                                                                                      \
+    asm volatile("s_nop 1\n\t"                                                                                 \
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"       \
+                 : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]) : : "vcc")
 // sum over the row of coef * a, as an nc word; meaningful in lane 0 of the row
 __device__ __forceinline__ u64 row_dot(u64 coef, u64 a) {
     GL_OPAQUE(coef); GL_OPAQUE(a);
@@ -217,7 +218,7 @@ __device__ __forceinline__ u64 row_dot(u64 coef, u64 a) {
     const u64 p2 = (u64)a1 * b0 + (u32)p1;
     const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
     u32 s[5] = {(u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32), 0u};
-    row_add_shl<8>(s); row_add_shl<4>(s); row_add_shl<2>(s); row_add_shl<1>(s);
+    ZK_ROW_ADD_SHL(8); ZK_ROW_ADD_SHL(4); ZK_ROW_ADD_SHL(2); ZK_ROW_ADD_SHL(1);
     // s0 + s1 2^32 + s2 2^64 + s3 2^96 + s4 2^128, and 2^128 = -2^32 (mod p): reduce four limbs, take s4 2^32 off
     const u64 t = gl::reduce_words_nc(s[0], s[1], s[2], s[3]), b = (u64)s[4] << 32;
     const u64 d = t - b;
