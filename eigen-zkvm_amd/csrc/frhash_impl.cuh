@@ -272,8 +272,55 @@ __device__ fe coop_matmul(const fe* __restrict__ mat, const fe& x, u32* xs, int 
     const u32 lc = (u32)l < t ? l : 0;
     return dot_products(mat + lc, t, [&](u32 j) { return coop_get(xs, j); }, t, DOT_DENSE);
 }
+// Partial rounds exchange nothing through LDS.  A block is one wave holding two groups of 32 lanes (two DPP rows each): lane 0's
+// S-box output reaches its group through v_readlane; the t products S[j] st[j] are summed towards lane 0 by shifted row
+// additions (limbs are 29 bits wide: four summands fit a word, then a carry pass) and one v_readlane across the two rows --
+// instead of seventeen LDS round trips walked by lane 0 alone while the other lanes wait, with four barriers a round.
+__device__ __forceinline__ fe fe_pick(bool c, const fe& a, const fe& b) {        // limb-wise: a ?: on the structs becomes branches
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r.l[k] = c ? a.l[k] : b.l[k];
+    return r;
+}
+__device__ __forceinline__ fe group_bcast0(const fe& v, int g) {                 // lane 0 of each 32-lane group -> its group
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)v.l[k], 0), hi = (u32)__builtin_amdgcn_readlane((int)v.l[k], 32);
+        r.l[k] = g ? hi : lo;
+    }
+    return r;
+}
+static_assert(NR == 9, "the row additions below name nine limbs");
+#define ZK_FR_ROW_ADD_SHL(N)                                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                                 \
+                 "v_add_u32_dpp %0, %0, %0 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %2, %2, %2 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %3, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %4, %4, %4 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %5, %5, %5 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %6, %6, %6 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %7, %7, %7 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
+                 "v_add_u32_dpp %8, %8, %8 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                    \
+                 : "+v"(v.l[0]), "+v"(v.l[1]), "+v"(v.l[2]), "+v"(v.l[3]), "+v"(v.l[4]), "+v"(v.l[5]), "+v"(v.l[6]), "+v"(v.l[7]), "+v"(v.l[8]))
+// sum of v over the 32 lanes of the group (values < 2r, normalised limbs), valid in lane 0 of the group, < 64r
+__device__ __forceinline__ fe group_sum32(fe v, int g) {
+    ZK_FR_ROW_ADD_SHL(1); ZK_FR_ROW_ADD_SHL(2);      // four summands per limb: < 2^31
+    fe_norm_u(v);
+    ZK_FR_ROW_ADD_SHL(4); ZK_FR_ROW_ADD_SHL(8);      // lanes 0 and 16 of the group: the sums of their rows
+    fe_norm_u(v);
+    fe o;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)v.l[k], 16), hi = (u32)__builtin_amdgcn_readlane((int)v.l[k], 48);
+        o.l[k] = g ? hi : lo;
+    }
+    return fe_add(v, o);
+}
+#undef ZK_FR_ROW_ADD_SHL
 __device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
-    const int l = threadIdx.x & 31;
+    const int l = threadIdx.x & 31, g = (threadIdx.x >> 5) & 1;
     const u32 lc = (u32)l < t ? l : 0;
     const Params P = g_prm[t - 2];
     x = fe_add(x, P.c[lc]);
@@ -283,29 +330,20 @@ __device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
     }
     pow5(x); x = fe_add(x, P.c[4 * t + lc]);
     x = coop_matmul(P.p, x, xs, l, t);
+    const fe one = fe_one(), zero = fe_zero();
     for (u32 r = 0; r < P.n_rp; ++r) {
         const fe* __restrict__ S = P.s + (size_t)(2 * t - 1) * r;
         fe y = x;
-        pow5(y); y = fe_add(y, P.c[5 * t + r]);                 // only lane 0's result is used
-        if (l == 0) x = y;
-        __syncthreads();
-        if (l == 0) coop_put(xs, 0, t, x);                      // broadcast the new st[0]
-        __syncthreads();
-        const fe st0 = coop_get(xs, 0);
-        const fe prod = fe_mul(S[lc], x);                       // S[j] * st[j]
-        __syncthreads();
-        coop_put(xs, l, t, prod);
-        __syncthreads();
-        if (l == 0) {
-            fe s0 = coop_get(xs, 0);
-            for (u32 j = 1; j < t; ++j) s0 = fe_add(s0, coop_get(xs, j));   // < 34r
-            x = fe_renorm(s0);
-        } else {
-            x = fe_add(x, fe_mul(S[t + (lc > 0 ? lc : 1) - 1], st0));
-            if (r % PR_RENORM == PR_RENORM - 1) x = fe_renorm(x);
-        }
+        pow5(y); y = fe_add(y, P.c[5 * t + r]);                 // only lane 0's result is used: the new st[0]
+        const fe st0 = group_bcast0(y, g);
+        const fe prod = fe_pick((u32)l < t, fe_mul(S[lc], fe_pick(l == 0, st0, x)), zero);   // S[j] * st[j]; idle lanes add nothing
+        const fe s0 = group_sum32(prod, g);                     // lane 0: < 34r
+        // one multiplication serves both sides: lane 0 brings its sum back below 2r (x 1), lane k adds S[t + k - 1] * st[0]
+        const fe m = fe_mul(fe_pick(l == 0, s0, S[t + (lc > 0 ? lc : 1) - 1]), fe_pick(l == 0, one, st0));
+        x = fe_pick(l == 0, m, fe_add(x, m));
+        if (r % PR_RENORM == PR_RENORM - 1) x = fe_pick(l == 0, x, fe_renorm(x));
     }
-    if (l != 0) x = fe_renorm(x);
+    x = fe_pick(l == 0, x, fe_renorm(x));
     for (u32 r = 0; r < 3; ++r) {
         pow5(x); x = fe_add(x, P.c[5 * t + P.n_rp + r * t + lc]);
         x = coop_matmul(P.m, x, xs, l, t);
