@@ -73,6 +73,8 @@ def test_native_driver_zkin_equals_oracle_zkin(zk, orc, name):
     assert got == exp
     got2 = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))                       # a setup serves many proofs
     assert got2 == exp
+    # trace resident in HBM: publics (read from columns, or computed at their row) never visit the host before the proof's one read-back
+    assert ns.gen(zk.DevArray.from_host(np.fromfile(D / cm_f, dtype="<u8"))) == exp
 
 
 def test_native_driver_rejects_bad_input(zk):
