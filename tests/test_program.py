@@ -73,6 +73,28 @@ def test_program_compiles_without_gpu(zk):
     assert "void zk_pow_kernel" in src
 
 
+def test_translator_lays_reads_first_and_stages_wide_sections(zk):
+    """the kernel text (no GPU needed): every section read sits in the prologue, ahead of the arithmetic and of the stores;
+    rows of 8 words and more come through stage_in, narrow ones and sparsely used ones are read directly; a program
+    that reads more words than the prologue may hold keeps its reads where it uses them"""
+    BUF["wide"] = 4
+    rng = np.random.default_rng(3)
+    src = _compile(zk, _wide_program(rng, 40, 9)).source
+    body = src[src.index("void zk_eval_kernel"):]
+    assert "stage_in<14, 40>" in body and "stage_in<12, 40>" in body                        # 40 columns: chunks of 14 + 14 + 12
+    assert "stage_in<9, 9>" in body and "stage_in<16, 64>" not in body and "c.bufs[4][" in body
+    first_store = body.index("if (live) {")
+    assert body.rindex("stage_in<") < body.index("gl::") < first_store                    # reads, then arithmetic, then stores
+    assert all(body.index(s) > first_store for s in ("c.bufs[3][i * 4ull + 0] =", "c.bufs[2][i * 3ull + 0] ="))
+    narrow = _compile(zk, _fib_like_program()).source
+    assert "stage_in<" not in narrow[narrow.index("void zk_eval_kernel"):]                # 2-column sections: direct reads
+    big = _compile(zk, _wide_program(rng, 300, 20)).source
+    assert "stage_in<" not in big[big.index("void zk_eval_kernel"):] and "zk_stage" not in big
+    # a read that would need one of this lane's stores of another shape cannot be issued first: rejected
+    with pytest.raises(zk.ZkError, match="partially overlaps an earlier write"):
+        _compile(zk, [("copy", T(0), {"kind": "challenge", "id": 4}, None), ("copy", M("cm3", 0, 4, dim=3), T(0), None), ("copy", T(1), M("cm3", 1, 4), None)])
+
+
 def test_program_rejects_bad_code(zk):
     with pytest.raises(zk.ZkError, match="tmp read before write"):
         _compile(zk, [("add", T(1), T(0), N(1))])
