@@ -224,6 +224,7 @@ __device__ __forceinline__ u64 row_dot(u64 coef, u64 a) {
     const u64 d = t - b;
     return t < b ? d - GL_EPS : d;                                     // wrapped below zero: + p = - (2^32 - 1) mod 2^64, cannot wrap again
 }
+#undef ZK_ROW_ADD_SHL
 
 // x = this lane's state word (lanes 12..15 of a group carry garbage and only serve the shuffles)
 __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
