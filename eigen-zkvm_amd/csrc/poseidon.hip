@@ -707,8 +707,9 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
     ensure_constants();
     ZK_REQUIRE(height >= 1, "merkelize: height must be >= 1");
     const uint64_t nn = merkle_n_nodes(height);
-    // absent right siblings on odd levels are the all-zero digest (merklehash.rs:307)
-    ZK_HIP(hipMemsetAsync(d_nodes, 0, nn * 32, st));
+    // absent right siblings on odd levels are the all-zero digest (merklehash.rs:307); a power-of-two height has no odd level and
+    // every node is written below (a zero-width tree keeps its all-zero leaves from the clearing)
+    if (width == 0 || height < 2 || (height & (height - 1))) ZK_HIP(hipMemsetAsync(d_nodes, 0, nn * 32, st));
     if (width == 0 && (height & (height - 1)) == 0 && height > 1) {  // all-zero leaves, full binary tree
         uint32_t levels = 0;
         while ((1ull << levels) < height) ++levels;
