@@ -65,6 +65,43 @@ def test_aggregation_leg_control_flow_two_ranks():
         assert out["tasks"] == 7 and out["proofs_per_s"] == round(3 * out["tasks_per_s"], 3) or abs(out["proofs_per_s"] - 3 * out["tasks_per_s"]) < 0.01
 
 
+def _agg8_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pr = StubProver()
+    out = bench.aggregation_leg(pr, dist, rank, world, torch.device("cpu"), n_tasks=8)
+    dist.barrier()
+    q.put((rank, pr.proved, out, getattr(pr, "joined", 0)))
+    dist.destroy_process_group()
+
+
+def test_aggregation_leg_eight_ranks_one_task_each():
+    """the driver's 8-GPU shape: every rank holds one task; the joins of the tree thin out over the ranks (4 + 2 + 1), ranks
+    without a join at a level pad the gather, and every rank ends with the root a single process computes"""
+    world, port = 8, 29547
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agg8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[k, k, k] for k in range(8)]           # warm-up, the timed proof, the latency probe: its own task only
+    assert [r[3] for r in res] == [3, 2, 1, 1, 0, 0, 0, 0]                # join j of a level on rank j
+    st = StubProver()
+    lvl = [st.prove(u)[2] for u in range(8)]
+    while len(lvl) > 1:
+        lvl = [st.join(lvl[2 * j], lvl[2 * j + 1]) for j in range(len(lvl) // 2)]
+    for r in res:
+        out = r[2]
+        assert out["join_tree"]["root"] == lvl[0] and (out["join_tree"]["levels"], out["join_tree"]["joins"]) == (3, 7)
+        assert out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8 and out["n_gpus"] == 8
+
+
 def test_aggregation_leg_single_rank():
     sys.path.insert(0, str(ROOT))
     import bench
