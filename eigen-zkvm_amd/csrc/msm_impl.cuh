@@ -728,7 +728,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         hipLaunchKernelGGL(sort_fine_kernel2, dim3(N_COARSE), dim3(256), 0, st, (const u32*)coarse.p, (const u32*)hist_scanned.p, n_blocks, (const u32*)tops.p,
                            (u32*)counts.p, (u32*)offsets.p, (u32*)idx.p, d_table ? (u32)table_n : 0u, d_table ? (u32)base_off : 0u);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipStreamSynchronize(st));  // hist/coarse go back to the pool at scope exit
+        // hist / coarse go back to the pool at scope exit: the pool orders their next use behind this stream (capi.hip pool_free)
     } else {
         ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
         ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
@@ -766,7 +766,6 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         }
         hipLaunchKernelGGL(msm_final_bits_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)pa, (u32*)d_out);
         ZK_HIP(hipGetLastError());
-        ZK_HIP(hipStreamSynchronize(st));
         return;
     }
     // four lanes per item from the level with this many items up (measured: G1 gains from 2^15 items on; over Fq2 the selects and
@@ -791,8 +790,8 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     ZK_HIP(hipGetLastError());
     hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(64), 0, st, a_in, (u32*)d_out, d_table ? 1 : 0);
     ZK_HIP(hipGetLastError());
-    ZK_HIP(hipStreamSynchronize(st));  // the pooled scratch above is released at scope exit
-}
+}   // the pooled scratch above is released here, stream-ordered: the sum is asynchronous on `st` like every other _dev entry point
+
 void msm_preconv_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points); }
 #ifdef MSM_GLV
 // ---- the curve's endomorphism phi(x, y) = (beta x, y) = [lambda](x, y): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128, so a sum

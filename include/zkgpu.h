@@ -163,7 +163,8 @@ int zk_stark_calculate_z_dev(const uint64_t* d_num3, const uint64_t* d_den3, uin
  * multiexp, the seam bellperson occupies under `--features cuda` (groth16.rs:45-57).  Layout as
  * bellman keeps it: bases n x 64 B affine (x || y), Fq in Montgomery form (R = 2^256), little-endian
  * limbs; scalars n x 32 B canonical little-endian (FrRepr); out 64 B affine Montgomery, *is_infinity
- * set when the sum is the point at infinity.  `_dev` takes device pointers (d_out: 68 bytes).       */
+ * set when the sum is the point at infinity.  `_dev` takes device pointers (d_out: 68 bytes) and, as
+ * every `_dev` entry point, returns once the work is queued on `stream`.                              */
 int zk_msm_g1_bn254(const void* bases, const void* scalars, uint64_t n, void* out, int* is_infinity);
 int zk_msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, void* stream);
 /* the same on BLS12-381 G1 (zkit --curve BLS12381; pairing_ce bls12_381): Fq = 12 x 32-bit limbs, Montgomery
