@@ -136,6 +136,21 @@ def test_merkle_root_kats(zk, golden):
         assert [int(v) for v in t.root()] == k["root"]
 
 
+def test_merkle_shapes_around_every_kernel_switch(zk, orc):
+    """node for node against the oracle across the heights where the builder changes kernels -- the one-launch tree top (64 children),
+    the 16-lanes-per-permutation levels, 16 lanes per leaf row below 2^14 rows, batches of a row side by side up to 2^18 rows -- and
+    the widths where LinearHash changes shape (one batch, a short last batch, two sponge steps of digests)"""
+    rng = np.random.default_rng(7)
+    for height in [2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 4095, 16383, 16385, 65537, 262144, 262145]:
+        for width in [1, 4, 5, 8, 9, 16, 17, 33, 37, 100]:
+            if height * width > 12_000_000:
+                continue
+            buff = rng.integers(0, P, size=height * width, dtype=np.uint64)
+            t = zk.MerkleTreeGL(); t.merkelize(buff, width, height)
+            assert np.array_equal(t.nodes(), orc.merkelize(buff, width, height)), (height, width)
+            t.free()
+
+
 @pytest.mark.parametrize("height,width", [(1, 1), (1, 9), (2, 3), (3, 5), (33, 6), (255, 2), (256, 9), (1000, 19),
                                           (4096, 12), (1 << 15, 18), (70001, 4), (2, 0), (1024, 0), (33, 0),
                                           (16383, 9), (16384, 9), (20000, 37), (300, 193), (8, 768)])   # leaf hashing: 16 lanes per row below 2^14 rows
