@@ -165,6 +165,12 @@ __device__ __forceinline__ u64 reduce_words_nc(u32 w0, u32 w1, u32 r2, u32 r3) {
     t1 = __builtin_subc(t1, 0u, e0, &e1);
     return mad_eps_nc(r2, mk64(t0, t1));
 }
+// acc + x for a 32-bit word x as ONE multiply-add (x * 1 + acc) instead of a zero-extending move and a 64-bit addition
+__device__ __forceinline__ u64 add_word(u64 acc, u32 x) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry) : "v"(x), "v"(acc));
+    return d;
+}
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {                // any u64 in, nc out
     GL_OPAQUE(a); GL_OPAQUE(b);
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);

@@ -15,6 +15,7 @@
 //     per block, broadcast reads) -- as scalar loads their 288+ SGPRs spilled into VGPR lanes.
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
+#include "ntt_reg.cuh"   // static_for
 #include <mutex>
 
 namespace zk {
@@ -31,8 +32,11 @@ constexpr int T_SC = T_PC + 24;      // [22][11]: S[23r + 12 .. 23r + 22], the c
 constexpr int T_PT = T_SC + 242;     // [12 i][12 j] split: P[j][i]
 constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
 constexpr int T_SRR = T_SR + 528;    // [22][16] whole words: S[23r + l] for lane l < 12 of a cooperative permutation, 0 for its four idle lanes
-constexpr int T_WORDS = T_SRR + 352; // 1542 words = 12 KB
-static_assert(T_PT % 2 == 0 && T_SR % 2 == 0, "split constants are read as 16-byte pairs");
+constexpr int T_DD = T_SRR + 352;    // [2 blocks][m (m - 1) / 2 + i] split: D[r][r0 + i], r = r0 + m (partial rounds, below)
+constexpr int T_SCS = T_DD + 220;    // [2 blocks][11 k][11 m] split: S[23 (r0 + m) + 12 + k], the column entries regrouped by state word
+constexpr int T_WORDS = T_SCS + 484; // 2246 words = 18 KB
+constexpr int PR_B = 11;             // partial rounds per block
+static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
 
@@ -41,26 +45,88 @@ __device__ __forceinline__ void load_tables(u64* __restrict__ tab) {
     __syncthreads();
 }
 
-// sum_j c_j * x_j mod p for 12 split constants (c points at 12 x 2 words in LDS) and 12 state words given
-// as 32-bit halves.  Six 64-bit accumulators take the 22x32-bit partial products straight from
-// v_mad_u64_u32 (12 * 2^54 < 2^58: no carries); one 128-bit recombination and ONE reduction per dot
-// product instead of twelve multiplications with a reduction each.
-__device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[12], const u32 (&x1)[12]) {
-    typedef unsigned __int128 u128;
-    u64 A00 = 0, A10 = 0, A20 = 0, A01 = 0, A11 = 0, A21 = 0;
+// Batched dot products: sum_j c_j * x_j mod p with the constants c_j split in three limbs of 22/22/20 bits (two LDS words
+// each) and the state words x_j given as 32-bit halves.  Six 64-bit accumulators take the 22x32-bit partial products straight
+// from v_mad_u64_u32 (n * 2^54 < 2^64 for n <= 512: no carries); ONE recombination and ONE reduction per dot product instead
+// of a multiplication with a reduction per term.
+struct Acc6 { u64 a00, a10, a20, a01, a11, a21; };   // a[i][h]: limb i of the constants x half h of the words
+__device__ __forceinline__ void acc_zero(Acc6& A) { A.a00 = A.a10 = A.a20 = A.a01 = A.a11 = A.a21 = 0; }
+__device__ __forceinline__ void acc_word(Acc6& A, u64 s) { A.a00 = (u32)s; A.a01 = s >> 32; A.a10 = A.a20 = A.a11 = A.a21 = 0; }   // 1 * s
+__device__ __forceinline__ void acc_mac(Acc6& A, const u64* __restrict__ c /* LDS, 2 words */, u32 x0, u32 x1) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(c);
+    const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;
+    A.a00 += (u64)l0 * x0; A.a10 += (u64)l1 * x0; A.a20 += (u64)l2 * x0;
+    A.a01 += (u64)l0 * x1; A.a11 += (u64)l1 * x1; A.a21 += (u64)l2 * x1;
+}
+// a * b + c as ONE v_mad_u64_u32, whatever a, b, c are: written as C, a product by a power of two becomes a 64-bit shift, an
+// and-mask and an addition, and "c + (x >> 32)" a zero-extending move and a 64-bit addition.
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul32(u32 a, u32 b) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b));
+    return d;
+}
+using gl::add_word;
+// V = sum_{i,h} a[i][h] 2^(22 i + 32 h).  The six accumulators sit at bit offsets 0, 22, 44 = 32 + 12, 32, 54 = 32 + 22 and
+// 76 = 64 + 12: their 32-bit halves, shifted by 22 or 12 bits, are accumulated by multiply-adds into four 64-bit columns
+// Z0..Z3 spaced 32 bits apart (every column < 2^61), three more multiply-adds carry each column's high word into the next,
+// and with t = 2^32, t^2 = t - 1, t^3 = -1:  V = (w0 + w1 t) + w2 (2^32 - 1) - Y3  -- 11 multiply-adds and one reduction
+// where the 128-bit shifts and additions of the first version took 56 instructions.  Any u64 in, nc out.
+__device__ __forceinline__ u64 acc_finish(const Acc6& A) {
+    constexpr u32 S22 = 1u << 22, S12 = 1u << 12;
+    const u64 Z0 = mad32((u32)A.a10, S22, A.a00);
+    u64 Z1 = mad32((u32)(A.a10 >> 32), S22, A.a01);
+    Z1 = mad32((u32)A.a11, S22, Z1);
+    Z1 = mad32((u32)A.a20, S12, Z1);
+    u64 Z2 = mul32((u32)(A.a11 >> 32), S22);
+    Z2 = mad32((u32)(A.a20 >> 32), S12, Z2);
+    Z2 = mad32((u32)A.a21, S12, Z2);
+    const u64 Z3 = mul32((u32)(A.a21 >> 32), S12);
+    const u64 Y1 = add_word(Z1, (u32)(Z0 >> 32));
+    const u64 Y2 = add_word(Z2, (u32)(Y1 >> 32));
+    const u64 Y3 = add_word(Z3, (u32)(Y2 >> 32));                     // < 2^42: the words above 2^96 are subtracted as one number
+    u32 b0, b1, e0, e1;
+    u32 t0 = __builtin_subc((u32)Z0, (u32)Y3, 0u, &b0);               // t = (w0 + w1 t) - Y3
+    u32 t1 = __builtin_subc((u32)Y1, (u32)(Y3 >> 32), b0, &b1);
+    const u32 mb = 0u - b1;                                           // borrowed: t -= 2^32 - 1 (t >= 2^64 - 2^42: cannot borrow again)
+    t0 = __builtin_subc(t0, mb, 0u, &e0);
+    t1 = __builtin_subc(t1, 0u, e0, &e1);
+    return gl::mad_eps_nc((u32)Y2, gl::mk64(t0, t1));
+}
+// N terms: constants c[2 j], c[2 j + 1] (LDS), word j's halves from x(j).  The constants of four terms are requested together and one
+// group ahead of the multiply-adds that use them (a read per term, waited for at once, left the LDS latency in the open 300 times
+// per permutation).
+template <int N, class X>
+__device__ __forceinline__ void acc_dot(Acc6& A, const u64* __restrict__ c, X&& x) {
+    constexpr int G = 4, NG = (N + G - 1) / G;
+    ulonglong2 buf[2][G];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const ulonglong2 v = reinterpret_cast<const ulonglong2*>(c)[j];
-        const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;
-        A00 += (u64)l0 * x0[j]; A10 += (u64)l1 * x0[j]; A20 += (u64)l2 * x0[j];
-        A01 += (u64)l0 * x1[j]; A11 += (u64)l1 * x1[j]; A21 += (u64)l2 * x1[j];
-    }
-    // V = X0 + X1 * 2^32, X = A0 + A1 * 2^22 + A2 * 2^44 < 2^103;  X1 * 2^32 = X1l * 2^32 + X1h * 2^96 = X1l * 2^32 - X1h
-    const u128 X0 = (u128)A00 + ((u128)A10 << 22) + ((u128)A20 << 44);
-    const u128 X1 = (u128)A01 + ((u128)A11 << 22) + ((u128)A21 << 44);
-    const u64 X1l = (u64)X1, X1h = (u64)(X1 >> 64);                       // X1h < 2^39
-    const u128 W = X0 + ((u128)X1l << 32) + (u128)(GL_P - X1h);            // < 2^104, congruent to V
-    return gl::reduce_words_nc((u32)W, (u32)(W >> 32), (u32)(W >> 64), (u32)(W >> 96));
+    for (int j = 0; j < G && j < N; ++j) buf[0][j] = reinterpret_cast<const ulonglong2*>(c)[j];
+    static_for<0, NG>([&](auto GI) {
+        constexpr int g = decltype(GI)::value;
+        if constexpr (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < G && (g + 1) * G + j < N; ++j) buf[(g + 1) & 1][j] = reinterpret_cast<const ulonglong2*>(c)[(g + 1) * G + j];
+        }
+#pragma unroll
+        for (int j = 0; j < G && g * G + j < N; ++j) {
+            const ulonglong2 v = buf[g & 1][j];
+            u32 x0, x1;
+            x(g * G + j, x0, x1);
+            const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;
+            A.a00 += (u64)l0 * x0; A.a10 += (u64)l1 * x0; A.a20 += (u64)l2 * x0;
+            A.a01 += (u64)l0 * x1; A.a11 += (u64)l1 * x1; A.a21 += (u64)l2 * x1;
+        }
+    });
+}
+__device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[12], const u32 (&x1)[12]) {
+    Acc6 A; acc_zero(A);
+    acc_dot<12>(A, c, [&](int j, u32& a, u32& b) { a = x0[j]; b = x1[j]; });
+    return acc_finish(A);
 }
 
 // Inside a permutation every word is "nc" (gl.cuh: some u64 congruent to the value); the dense MDS product and the
@@ -115,6 +181,42 @@ __device__ __forceinline__ void mat_full(const u64* __restrict__ PT /* LDS */, u
     }
 }
 
+// The 22 partial rounds (poseidon_opt.rs:140-163) in two blocks of 11 without a reduction per state word and round.
+// In round r only st[0] passes the S-box: u_r = st[0]^7 + c_r, st[0] <- S_r[0] u_r + sum_k S_r[k] st[k], st[k] += SC_r[k] u_r.
+// The words k >= 1 are linear in the u's, so inside a block that starts at round r0 with words s_k
+//     st[0] after round r  =  S_r[0] u_r + sum_k S_r[k] s_k + sum_{r0 <= i < r} D[r][i] u_i,   D[r][i] = sum_k S_r[k] SC_i[k]
+// (D precomputed on the host), one batched dot product of 12 + (r - r0) terms, and at the end of the block
+//     s_k <- s_k + sum_i SC_i[k] u_i,
+// eleven batched dot products of 11 terms: 44 reductions per permutation where the round-by-round form has 22 + 242.
+// Blocks of 11 minimise multiply-adds + reductions (616 terms; one block of 22 would need 737, four of 5-6 have 66 reductions).
+__device__ __forceinline__ void partial_rounds(u64 (&st)[12], const u64* __restrict__ tab) {
+#pragma unroll 1
+    for (int b = 0; b < 22 / PR_B; ++b) {
+        const u64* __restrict__ SR = tab + T_SR + 24 * PR_B * b;
+        const u64* __restrict__ DD = tab + T_DD + 2 * (PR_B * (PR_B - 1) / 2) * b;
+        const u64* __restrict__ SCS = tab + T_SCS + 2 * 11 * PR_B * b;
+        const u64* __restrict__ PC = tab + T_PC + PR_B * b;
+        u32 u0[PR_B], u1[PR_B];
+        u64 s0 = st[0];
+        static_for<0, PR_B>([&](auto MI) {
+            constexpr int m = decltype(MI)::value;
+            const u64 u = pow7_add(s0, PC[m]);
+            u0[m] = (u32)u; u1[m] = (u32)(u >> 32);
+            Acc6 A; acc_zero(A);
+            acc_dot<12>(A, SR + 24 * m, [&](int k, u32& a, u32& c) { a = k ? (u32)st[k] : u0[m]; c = k ? (u32)(st[k] >> 32) : u1[m]; });
+            if constexpr (m > 0) acc_dot<m>(A, DD + 2 * (m * (m - 1) / 2), [&](int i, u32& a, u32& c) { a = u0[i]; c = u1[i]; });
+            s0 = acc_finish(A);
+        });
+        st[0] = s0;
+#pragma unroll
+        for (int k = 1; k < 12; ++k) {
+            Acc6 A; acc_word(A, st[k]);
+            acc_dot<PR_B>(A, SCS + 2 * (PR_B * (k - 1)), [&](int m, u32& a, u32& c) { a = u0[m]; c = u1[m]; });
+            st[k] = acc_finish(A);
+        }
+    }
+}
+
 // in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables
 __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab) {
 #pragma unroll
@@ -126,18 +228,7 @@ __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restri
         if (R == 7) { mds_small<true>(st); continue; }                    // the permutation's output: canonical words
         if (R != 3) { mds_small<false>(st); continue; }
         mat_full(tab + T_PT, st);
-#pragma unroll 1
-        for (int r = 0; r < 22; ++r) {
-            const u64* __restrict__ SC = tab + T_SC + 11 * r;
-            st[0] = pow7_add(st[0], tab[T_PC + r]);
-            u32 x0[12], x1[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
-            const u64 s0 = dot12(tab + T_SR + 24 * r, x0, x1);
-#pragma unroll
-            for (int k = 1; k < 12; ++k) st[k] = gl::mul_add_nc(SC[k - 1], st[0], st[k]);
-            st[0] = s0;
-        }
+        partial_rounds(st, tab);
     }
 }
 
@@ -641,6 +732,19 @@ void ensure_constants() {
         for (int k = 1; k < 12; ++k) tab[T_SC + 11 * r + k - 1] = ZK_POSEIDON_S[23 * r + 11 + k];
         for (int j = 0; j < 12; ++j) tab[T_SRR + 16 * r + j] = ZK_POSEIDON_S[23 * r + j];
     }
+    for (int b = 0; b < 22 / PR_B; ++b)                  // tables of partial_rounds()
+        for (int m = 0; m < PR_B; ++m) {
+            const int r = PR_B * b + m;
+            for (int i = 0; i < m; ++i) {                // D[r][r0 + i] = sum_k S_r[k] SC_{r0 + i}[k]
+                u64 d = 0;
+                for (int k = 1; k < 12; ++k) {
+                    const u64 t = gl::hmul(ZK_POSEIDON_S[23 * r + k], ZK_POSEIDON_S[23 * (PR_B * b + i) + 11 + k]);
+                    d = d + t >= GL_P || d + t < d ? d + t - GL_P : d + t;
+                }
+                split(T_DD + 2 * ((PR_B * (PR_B - 1) / 2) * b + m * (m - 1) / 2 + i), d);
+            }
+            for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
+        }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
     g_consts_loaded[dev] = true;
 }
