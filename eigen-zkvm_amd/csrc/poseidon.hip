@@ -419,6 +419,9 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 #ifndef ZK_LH_WAVES
 #define ZK_LH_WAVES 4
 #endif
+#ifndef ZK_LH_ROWS_WAVES
+#define ZK_LH_ROWS_WAVES 3
+#endif
 // The same digest in two launches for trees of middling height: one lane per (row, batch) hashes its batch, then one lane per
 // row sponges the batch digests.  A row of 37 words is 4 batches of 2 permutations and a final sponge of 2: four
 // permutations deep instead of ten -- what counts while there are too few rows to fill the chip (2^15-row proof 5.47 -> 5.36 ms,
@@ -473,7 +476,8 @@ __global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_final_kernel(cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = st[i];
 }
-__global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+// (three waves per SIMD: 168 registers keep the block-lazy partial rounds out of the private segment; four spill, 2-4 % slower)
+__global__ __launch_bounds__(256, ZK_LH_ROWS_WAVES) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
     ZK_POSEIDON_LDS;
     load_tables(tab);
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
