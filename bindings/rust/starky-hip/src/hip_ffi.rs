@@ -34,7 +34,7 @@ extern "C" {
     pub fn zk_merkle_free(t: *mut zk_merkle_t) -> c_int;
 
     pub fn zk_transcript_new() -> *mut zk_transcript_t;
-    pub fn zk_transcript_put(t: *mut zk_transcript_t, words: *const u64, n: u64) -> c_int;
+    pub fn zk_transcript_put(t: *mut zk_transcript_t, words: *const u64, n: usize) -> c_int;
     pub fn zk_transcript_get_field(t: *mut zk_transcript_t, out3: *mut u64) -> c_int;
     pub fn zk_transcript_get_fields1(t: *mut zk_transcript_t, out: *mut u64) -> c_int;
     pub fn zk_transcript_get_permutations(t: *mut zk_transcript_t, n: u32, nbits: u32, out: *mut u64) -> c_int;

@@ -44,14 +44,14 @@ pub fn stark_prove(
     let circom_w = File::create(circom_file)?;
     let zkin_w = File::create(zkin)?;
     match ss.verificationHashType.as_str() {
-        "GL" => prove::<FGL, MerkleTreeGL, _>(&mut pil, const_pol, cm_pol, &ss, agg_stage, norm_stage, skip_main, circom_w, zkin_w, prover_addr),
+        "GL" => prove::<FGL, MerkleTreeGL, _, _>(&mut pil, const_pol, cm_pol, &ss, agg_stage, norm_stage, skip_main, circom_w, zkin_w, prover_addr),
         "BN128" => {
             load_tables("bn128")?;
-            prove::<starky::field_bn128::Fr, MerkleTreeBN128, _>(&mut pil, const_pol, cm_pol, &ss, false, norm_stage, skip_main, circom_w, zkin_w, prover_addr)
+            prove::<starky::field_bn128::Fr, MerkleTreeBN128, _, _>(&mut pil, const_pol, cm_pol, &ss, false, norm_stage, skip_main, circom_w, zkin_w, prover_addr)
         }
         "BLS12381" => {
             load_tables("bls12381")?;
-            prove::<starky::field_bls12381::Fr, MerkleTreeBLS12381, _>(&mut pil, const_pol, cm_pol, &ss, false, norm_stage, skip_main, circom_w, zkin_w, prover_addr)
+            prove::<starky::field_bls12381::Fr, MerkleTreeBLS12381, _, _>(&mut pil, const_pol, cm_pol, &ss, false, norm_stage, skip_main, circom_w, zkin_w, prover_addr)
         }
         other => panic!("Invalid hashtype {other}"),             // prove.rs:89
     }
@@ -72,7 +72,7 @@ fn load_tables(field: &str) -> Result<()> {
 }
 
 #[allow(clippy::too_many_arguments)]
-fn prove<F, M, W>(
+fn prove<F, M, W1, W2>(
     pil: &mut PIL,
     const_pol: PolsArray,
     cm_pol: PolsArray,
@@ -80,14 +80,15 @@ fn prove<F, M, W>(
     agg_stage: bool,
     norm_stage: bool,
     skip_main: bool,
-    mut circom_file_writer: W,
-    mut zkin_writer: W,
+    mut circom_file_writer: W1,
+    mut zkin_writer: W2,
     prover_addr: &str,
 ) -> Result<()>
 where
     F: ff::PrimeField + Default,
     M: MerkleTree<MTNode = starky::ElementDigest<4, F>> + Default,
-    W: Write,
+    W1: Write,
+    W2: Write,
 {
     // host: code generation (and, for now, the reference's own constant tree) -- prove.rs:108
     let mut setup = StarkSetup::<M>::new(&const_pol, pil, stark_struct, None)?;

@@ -40,7 +40,7 @@ impl Transcript for TranscriptHipGL {
     /// transcript.rs:16-33: `es` is flattened, one word per element
     fn put(&mut self, es: &[Vec<FGL>]) -> Result<()> {
         let words: Vec<u64> = es.iter().flatten().map(|e| e.as_int()).collect();
-        ffi::check(unsafe { ffi::zk_transcript_put(self.handle, words.as_ptr(), words.len() as u64) })
+        ffi::check(unsafe { ffi::zk_transcript_put(self.handle, words.as_ptr(), words.len()) })
     }
 
     fn get_permutations(&mut self, n: usize, nbits: usize) -> Result<Vec<usize>> {

@@ -24,10 +24,10 @@ thread_local hipStream_t t_stream = nullptr;
 thread_local std::vector<hipStream_t> t_streams;   // non-null streams this host thread has issued on
 thread_local int t_depth = 0;                      // C-ABI calls in progress on this thread (the prover calls entry points itself)
 
-hipEvent_t event_get() {                     // g_pool_mu held
+hipEvent_t event_get() {                     // g_pool_mu held; never throws (DevBuf destructors end up here): nullptr = no event to be had
     if (!g_event_cache.empty()) { hipEvent_t e = g_event_cache.back(); g_event_cache.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return e;
 }
 }
@@ -44,12 +44,18 @@ hipStream_t on_stream(hipStream_t st) {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             bool known = false;
             for (hipStream_t s : g_streams) known |= s == st;
-            if (!known) g_streams.push_back(st);
+            if (!known) {
+                // While the null stream was the only one in use, blocks went back to the pool without an event (pool_free):
+                // work queued there may still be running on them, and a non-blocking stream does not wait for the null stream.
+                // Drain once, at the moment a second stream appears; from here on every free records its events.
+                if (g_streams.size() == 1) (void)hipDeviceSynchronize();
+                g_streams.push_back(st);
+            }
         }
     }
     return st;
 }
-void* pool_alloc(size_t bytes) {
+void* pool_alloc(size_t bytes, bool host_wait) {
     if (bytes == 0) bytes = 8;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -57,8 +63,9 @@ void* pool_alloc(size_t bytes) {
         if (it != g_pool_free.end()) {
             void* p = it->second; g_pool_free.erase(it);
             Block& b = g_pool_blocks[p];
-            for (hipEvent_t e : b.pending) {                          // whoever used the block last finishes first
-                (void)hipStreamWaitEvent(t_stream, e, 0);
+            for (hipEvent_t e : b.pending) {                          // whoever used the block last finishes first:
+                if (host_wait) (void)hipEventSynchronize(e);          // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
+                else (void)hipStreamWaitEvent(t_stream, e, 0);        // the library's own buffers -> the stream it is working on waits
                 g_event_cache.push_back(e);
             }
             b.pending.clear();
@@ -87,6 +94,7 @@ void pool_free(void* p) {
         // whoever handed it over).  Streams of other threads are left alone: concurrent provers must not wait for each other.
         auto record = [&](hipStream_t st) {
             hipEvent_t e = event_get();
+            if (!e) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); return; }   // no event to be had: wait here instead
             if (hipEventRecord(e, st) == hipSuccess) it->second.pending.push_back(e);
             else { (void)hipGetLastError(); g_event_cache.push_back(e); }   // a destroyed stream has nothing in flight
         };
@@ -94,6 +102,19 @@ void pool_free(void* p) {
         for (hipStream_t st : t_streams) record(st);
     }
     g_pool_free.emplace(it->second.bytes, p);
+}
+// Host <-> device copies of the library's own pooled buffers: on the stream this thread is working on (the one whose
+// queue was ordered behind the buffer's previous user by pool_alloc), then waited for -- a plain hipMemcpy runs on the
+// null stream, which a non-blocking stream does not synchronise with.
+void h2d_sync(void* d, const void* h, size_t n) {
+    if (!n) return;
+    ZK_HIP(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, t_stream));
+    ZK_HIP(hipStreamSynchronize(t_stream));
+}
+void d2h_sync(void* h, const void* d, size_t n) {
+    if (!n) return;
+    ZK_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, t_stream));
+    ZK_HIP(hipStreamSynchronize(t_stream));
 }
 void pool_trim() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -210,7 +231,8 @@ uint64_t zk_gl_root_of_unity(uint32_t k) { return k <= 32 ? gl::hroot(k) : 0; }
 
 void* zk_dev_alloc(size_t bytes) {
     void* p = nullptr;
-    if (guard([&] { p = pool_alloc(bytes); }) != 0) return nullptr;
+    // handed to the caller, who may write it on any stream: reuse is ordered on the host, not on the null stream of this call
+    if (guard([&] { p = pool_alloc(bytes, /*host_wait=*/true); }) != 0) return nullptr;
     return p;
 }
 int zk_dev_free(void* p) { return guard([&] { pool_free(p); }); }

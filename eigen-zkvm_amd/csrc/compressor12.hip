@@ -114,8 +114,8 @@ C12Exec* c12_exec_new(const char* exec_json, size_t len, uint64_t n_witness) {
         sm[k] = (u32)m[k];
     }
     E->ops.reserve(std::max<size_t>(sorted.size(), 1) * sizeof(AddOp)); E->s_map.reserve(std::max<size_t>(sm.size(), 1) * 4);
-    if (!sorted.empty()) ZK_HIP(hipMemcpy(E->ops.p, sorted.data(), sorted.size() * sizeof(AddOp), hipMemcpyHostToDevice));
-    if (!sm.empty()) ZK_HIP(hipMemcpy(E->s_map.p, sm.data(), sm.size() * 4, hipMemcpyHostToDevice));
+    if (!sorted.empty()) h2d_sync(E->ops.p, sorted.data(), sorted.size() * sizeof(AddOp));
+    if (!sm.empty()) h2d_sync(E->s_map.p, sm.data(), sm.size() * 4);
     return E.release();
 }
 void c12_exec_free(C12Exec* e) { delete e; }

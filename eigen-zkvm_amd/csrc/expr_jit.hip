@@ -16,6 +16,12 @@
 #include "../../include/zkgpu.h"
 #include "gl_jit_src.h"
 #include <hip/hiprtc.h>
+#include "sha256.h"
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <map>
 #include <set>
 #include <sstream>
@@ -378,14 +384,90 @@ std::string hiprtc_log(hiprtcProgram prog) {
     return log;
 }
 
+
+// ---- code objects of the generated kernels: compiled once per text ---------------------------------------------------------
+// hipRTC takes seconds per step program (PoseidonG's five: most of a setup), and the text is a pure function of the PIL, the
+// StarkStruct and this file.  Code objects are therefore kept (a) in the process, keyed by sha256(compiler version | options |
+// text) -- the worker setups of one process compile each program once -- and (b) on disk under $ZK_JIT_CACHE (default
+// $XDG_CACHE_HOME/zkgpu or ~/.cache/zkgpu; "off" disables), one file per key, written to a temporary name and renamed.
+std::mutex g_jit_mu;
+std::map<std::string, std::shared_ptr<const std::vector<char>>> g_jit_mem;
+JitStats g_jit_stats;
+
+std::string jit_cache_dir() {
+    const char* e = getenv("ZK_JIT_CACHE");
+    if (e && (!strcmp(e, "off") || !strcmp(e, "0") || !*e)) return "";
+    if (e) return e;
+    if (const char* x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/zkgpu";
+    if (const char* h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/zkgpu";
+    return "";
+}
+void mkdirs(const std::string& d) {
+    for (size_t i = 1; i <= d.size(); ++i)
+        if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0700);
+}
+
+std::shared_ptr<const std::vector<char>> compile_cached(const std::string& source) {
+    static const char* const opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    int maj = 0, min = 0; (void)hiprtcVersion(&maj, &min);
+    std::string keyed = "hiprtc " + std::to_string(maj) + "." + std::to_string(min);
+    for (const char* o : opts) { keyed += ' '; keyed += o; }
+    keyed += '\n'; keyed += source;
+    const std::string key = sha256_hex(keyed.data(), keyed.size());
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    std::lock_guard<std::mutex> lk(g_jit_mu);            // one compilation at a time: a second setup of the same circuit waits and then hits
+    auto it = g_jit_mem.find(key);
+    if (it != g_jit_mem.end()) { g_jit_stats.mem_hits++; return it->second; }
+    const std::string dir = jit_cache_dir(), path = dir.empty() ? "" : dir + "/" + key + ".co";
+    if (!path.empty()) {
+        if (FILE* f = fopen(path.c_str(), "rb")) {
+            std::vector<char> buf;
+            char tmp[65536]; size_t n;
+            while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+            fclose(f);
+            if (buf.size() > 16 && !memcmp(buf.data(), "\x7f" "ELF", 4)) {     // a truncated or foreign file is recompiled and replaced
+                auto sp = std::make_shared<const std::vector<char>>(std::move(buf));
+                g_jit_mem[key] = sp; g_jit_stats.disk_hits++; g_jit_stats.ms += ms_since();
+                return sp;
+            }
+        }
+    }
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "zk_eval.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        throw Error("hiprtcCreateProgram failed");
+    hiprtcResult rc = hiprtcCompileProgram(prog, 3, const_cast<const char**>(opts));
+    if (rc != HIPRTC_SUCCESS) {
+        std::string log = hiprtc_log(prog);
+        hiprtcDestroyProgram(&prog);
+        throw Error("hiprtc compile failed: " + log.substr(0, 2000));
+    }
+    size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
+    std::vector<char> code(sz);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    if (!path.empty()) {                                  // best effort: a read-only or missing cache directory costs nothing but the next compile
+        mkdirs(dir);
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+            const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+            if (fclose(f) == 0 && ok) { if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str()); }
+            else (void)remove(tmp.c_str());
+        }
+    }
+    auto sp = std::make_shared<const std::vector<char>>(std::move(code));
+    g_jit_mem[key] = sp; g_jit_stats.compiled++; g_jit_stats.ms += ms_since();
+    return sp;
+}
 }  // namespace
+JitStats jit_stats() { std::lock_guard<std::mutex> lk(g_jit_mu); return g_jit_stats; }
 }  // namespace zk
 
 using namespace zk;
 
 struct zk_program {
     std::string source;
-    std::vector<char> code;
+    std::shared_ptr<const std::vector<char>> code;   // the code object, shared by every program of this process with the same text
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr, fn_pow = nullptr;
     uint32_t n_instr = 0;
@@ -449,20 +531,7 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
             << pro_src << g.body.str() << epi_src << "}\n";
         p->source = src.str();
 
-        hiprtcProgram prog;
-        if (hiprtcCreateProgram(&prog, p->source.c_str(), "zk_eval.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-            throw Error("hiprtcCreateProgram failed");
-        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-        hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
-        if (rc != HIPRTC_SUCCESS) {
-            std::string log = hiprtc_log(prog);
-            hiprtcDestroyProgram(&prog);
-            throw Error("hiprtc compile failed: " + log.substr(0, 2000));
-        }
-        size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
-        p->code.resize(sz);
-        hiprtcGetCode(prog, p->code.data());
-        hiprtcDestroyProgram(&prog);
+        p->code = compile_cached(p->source);
         return p;
     } catch (const std::exception& e) { set_error(e.what()); delete p; return nullptr; }
 }
@@ -481,7 +550,7 @@ int zk_program_run_rows_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nb
         ZK_REQUIRE(row0 <= (1ull << nbits_domain) && count <= (1ull << nbits_domain) - row0, "zk_program_run_rows_dev: rows outside the domain");
         if (count == 0) return 0;
         if (!p->module) {  // load lazily: compiling needs no GPU, running does
-            ZK_HIP(hipModuleLoadData(&p->module, p->code.data()));
+            ZK_HIP(hipModuleLoadData(&p->module, p->code->data()));
             ZK_HIP(hipModuleGetFunction(&p->fn, p->module, "zk_eval_kernel"));
             ZK_HIP(hipModuleGetFunction(&p->fn_pow, p->module, "zk_pow_kernel"));
             if (p->pow_entries) ZK_HIP(hipMalloc(&p->d_pow, (size_t)p->pow_entries * 48));

@@ -66,11 +66,11 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
                 ptr.push_back(cols.size());
             }
             rp[w].reserve(ptr.size() * 8); cl[w].reserve(cols.size() * 4 + 4); cf[w].reserve(cols.size() * NR * 4 + 4);
-            ZK_HIP(hipMemcpy(rp[w].p, ptr.data(), ptr.size() * 8, hipMemcpyHostToDevice));
+            h2d_sync(rp[w].p, ptr.data(), ptr.size() * 8);
             if (!cols.empty()) {
-                ZK_HIP(hipMemcpy(cl[w].p, cols.data(), cols.size() * 4, hipMemcpyHostToDevice));
+                h2d_sync(cl[w].p, cols.data(), cols.size() * 4);
                 DevBuf raw; raw.reserve(coef.size() * 4);
-                ZK_HIP(hipMemcpy(raw.p, coef.data(), coef.size() * 4, hipMemcpyHostToDevice));
+                h2d_sync(raw.p, coef.data(), coef.size() * 4);
                 hipLaunchKernelGGL(frn_canon_to_fe_kernel, dim3(frn_blocks(cols.size())), dim3(256), 0, st, (const u32*)raw.p, (u32*)cf[w].p, (u64)cols.size());
                 ZK_HIP(hipGetLastError());
                 ZK_HIP(hipStreamSynchronize(st));
@@ -91,7 +91,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
         for (uint32_t j = 0; j < n_aux; ++j) li.push_back(pk.l.inf[j] ? -1 : (int)(ni + j));
         auto upload_idx = [&](DevBuf& d, const std::vector<int>& v) {
             d.reserve(v.size() * 4 + 4);
-            if (!v.empty()) ZK_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            if (!v.empty()) h2d_sync(d.p, v.data(), v.size() * 4);
         };
         upload_idx(a_idx, ai); upload_idx(b_idx, bi); upload_idx(l_idx, li);
         // bases: canonical coordinates -> Montgomery on the device; a point at infinity (only `l` may hold one: a wire
@@ -107,7 +107,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
                     ZK_REQUIRE(allow_inf, std::string("groth16: key element `") + what + "` is the point at infinity");
                     std::copy(pk.vk[0].w.begin(), pk.vk[0].w.begin() + P1, tmp.begin() + i * pw);   // stand-in (G1 only), zero scalar via l_idx
                 }
-            ZK_HIP(hipMemcpy((u32*)d.p + at * pw, tmp.data(), count * pw * 4, hipMemcpyHostToDevice));
+            h2d_sync((u32*)d.p + at * pw, tmp.data(), count * pw * 4);
         };
         put(g1b, 0, pk.h, P1, nh, false, "h");
         put(g1b, off_l, pk.l, P1, n_aux, true, "l");
@@ -231,7 +231,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
             std::vector<u32> all(2 * P1 + P2);
             std::memcpy(all.data(), A.data(), P1 * 4); std::memcpy(all.data() + P1, B.data(), P2 * 4); std::memcpy(all.data() + P1 + P2, Cc.data(), P1 * 4);
             DevBuf d; d.reserve(all.size() * 4);
-            ZK_HIP(hipMemcpy(d.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+            h2d_sync(d.p, all.data(), all.size() * 4);
             G16_FQ_TO_CANON(d.p, all.size() / G16_CW, st);
             ZK_HIP(hipStreamSynchronize(st));
             ZK_HIP(hipMemcpy(all.data(), d.p, all.size() * 4, hipMemcpyDeviceToHost));

@@ -895,7 +895,7 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
     conv2.reserve((size_t)2 * n * PTW * 4); sc2.reserve((size_t)2 * n * 16);
     hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
     ZK_HIP(hipGetLastError());
-    MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);     // (synchronises: the buffers go back to the pool after it)
+    MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);     // asynchronous: conv2 / sc2 go back to the pool with the sum still in flight; pool_free's events order their reuse
 }
 #else
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); }

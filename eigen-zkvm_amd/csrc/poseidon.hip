@@ -824,14 +824,20 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
         // digest of an all-zero subtree of every height up to 2^32: a property of the hash, not of the proof --
         // computed once per device (33 serial permutations, 3 ms) and kept
         static u64* g_zero_chain[64] = {};
+        static std::mutex g_zero_chain_mu;
         int dev; ZK_HIP(hipGetDevice(&dev));
         ZK_REQUIRE(levels <= 32, "merkelize: tree too tall");
-        if (!g_zero_chain[dev]) {
-            u64* d = nullptr;
-            ZK_HIP(hipMalloc((void**)&d, 33 * 32));
-            hipLaunchKernelGGL(zero_tree_chain_kernel, dim3(1), dim3(64), 0, st, 32u, d);
-            ZK_HIP(hipGetLastError());
-            g_zero_chain[dev] = d;
+        {   // provers on several host threads, each on its own stream: the chain is built once, under the lock, and is in memory
+            // before its address is published (a second prover's fill kernels run on another stream and would not wait for this one)
+            std::lock_guard<std::mutex> lk(g_zero_chain_mu);
+            if (!g_zero_chain[dev]) {
+                u64* d = nullptr;
+                ZK_HIP(hipMalloc((void**)&d, 33 * 32));
+                hipLaunchKernelGGL(zero_tree_chain_kernel, dim3(1), dim3(64), 0, st, 32u, d);
+                ZK_HIP(hipGetLastError());
+                ZK_HIP(hipStreamSynchronize(st));
+                g_zero_chain[dev] = d;
+            }
         }
         const u64* d_h = g_zero_chain[dev];
         uint64_t n = height, off = 0;

@@ -13,6 +13,8 @@
 #include "../../include/zkgpu.h"
 #include "json_min.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <array>
 #include <cstring>
 #include <map>
@@ -152,6 +154,48 @@ struct GroupProof { std::vector<u64> row; std::vector<u64> path; u32 depth; };
 
 void zero(DevBuf& b, size_t words, hipStream_t st) { if (words) ZK_HIP(hipMemsetAsync(b.p, 0, words * 8, st)); }
 
+// Per-stage device time of one proof, opt-in (ZK_STARK_TIMING=1): the reference's `#[time_profiler]` spans
+// (stark_gen.rs:192,624,709,734,785, fri.rs:83) as HIP-event intervals on the proof's stream.  mark(name) closes the
+// interval that began at the previous mark and gives it `name`; intervals of the same name add up.  Off: no events, no cost.
+struct StageTimer {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    std::chrono::steady_clock::time_point t0;
+    StageTimer(hipStream_t s) : st(s) {
+        static const bool env = getenv("ZK_STARK_TIMING") && *getenv("ZK_STARK_TIMING") && strcmp(getenv("ZK_STARK_TIMING"), "0");
+        on = env;
+        if (on) { t0 = std::chrono::steady_clock::now(); mark("begin"); }
+    }
+    ~StageTimer() { for (auto& m : marks) (void)hipEventDestroy(m.second); }
+    void mark(const char* name) {
+        if (!on) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); on = false; return; }
+        (void)hipEventRecord(e, st);
+        marks.emplace_back(name, e);
+    }
+    // JSON object {"stage": ms, ..., "total_gpu_ms": .., "wall_ms": ..}; one line of it on stderr
+    std::string finish(u32 nbits) {
+        if (!on || marks.size() < 2) return "";
+        (void)hipEventSynchronize(marks.back().second);
+        std::vector<std::pair<std::string, double>> acc;
+        for (size_t i = 1; i < marks.size(); ++i) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+            bool found = false;
+            for (auto& a : acc) if (a.first == marks[i].first) { a.second += ms; found = true; }
+            if (!found) acc.emplace_back(marks[i].first, ms);
+        }
+        float total = 0; (void)hipEventElapsedTime(&total, marks.front().second, marks.back().second);
+        std::ostringstream o; o.setf(std::ios::fixed); o.precision(3);
+        o << "{\"nBits\":" << nbits;
+        for (auto& a : acc) o << ",\"" << a.first << "\":" << a.second;
+        o << ",\"total_gpu_ms\":" << total << ",\"wall_ms\":" << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << "}";
+        fprintf(stderr, "[zkgpu stark_gen] %s\n", o.str().c_str());
+        return o.str();
+    }
+};
+
 }  // namespace
 
 struct zk_stark_setup {
@@ -175,6 +219,8 @@ struct zk_stark_setup {
     bool early_stage3 = false;
     hipStream_t side_stream = nullptr;     // memory-bound stage-3 work beside the ALU-bound hashing of tree 1
     hipEvent_t ev_inputs = nullptr, ev_stage3 = nullptr;
+    std::string setup_timing;              // JSON: where StarkSetup::new's time went (zk_stark_setup_timing)
+    std::string last_timing;               // JSON: the stages of the last proof, HIP-event milliseconds (ZK_STARK_TIMING=1)
     ~zk_stark_setup() {
         if (side_stream) { forget_stream(side_stream); (void)hipStreamDestroy(side_stream); }
         if (ev_inputs) (void)hipEventDestroy(ev_inputs);
@@ -390,6 +436,9 @@ std::vector<std::vector<GroupProof>> group_proofs_all(const std::vector<const An
 
 zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t* const_pols, uint64_t n_words) {
     std::unique_ptr<zk_stark_setup> S(new zk_stark_setup);
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const clk::time_point t_begin = clk::now();
     JVal root = JParser::parse(json);
     S->info = root.at("starkinfo"); S->prog = root.at("program");
     S->ss = JParser::parse(ss_json);
@@ -419,15 +468,18 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
 
     const u64 N = 1ull << S->nbits, Next = 1ull << S->nbits_ext, nc = S->n_constants;
     ZK_REQUIRE(n_words == nc * N, "const trace size mismatch");
+    const clk::time_point t_parsed = clk::now();
     S->const_n.reserve(std::max<u64>(1, nc * N) * 8); S->const_2ns.reserve(std::max<u64>(1, nc * Next) * 8);
     if (nc) {
-        ZK_HIP(hipMemcpy(S->const_n.p, const_pols, nc * N * 8, hipMemcpyHostToDevice));
+        h2d_sync(S->const_n.p, const_pols, nc * N * 8);
         DevBuf tmp; tmp.reserve(nc * Next * 8);
         lde_dev(S->const_n.u(), S->const_2ns.u(), tmp.u(), (u32)nc, S->nbits, S->nbits_ext, nullptr);
         ZK_HIP(hipStreamSynchronize(nullptr));
     }
     S->const_tree.reset(new AnyTree(S->fr, S->const_2ns.u(), (u32)nc, Next, nullptr));
-    S->const_tree->root(S->const_root);
+    S->const_tree->root(S->const_root);                    // (copies the root back: the tree is built when this returns)
+    const clk::time_point t_tree = clk::now();
+    const JitStats j0 = jit_stats();
     const JVal& P = S->prog;
     S->step2prev = S->compile_segment(P.at("step2prev"), false, false);
     S->step3prev = S->compile_segment(P.at("step3prev"), false, false);
@@ -435,6 +487,17 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     S->step42ns = S->compile_segment(P.at("step42ns"), true, false);
     S->step52ns = S->compile_segment(P.at("step52ns"), true, false);
     for (const JVal& seg : P.at("publics_code").arr) S->public_programs.push_back(S->compile_segment(seg, false, true));
+    {   // where the time went (stark_setup.rs:26 `#[time_profiler("stark_setup")]` has one number; a caller deciding whether to keep a
+        // setup alive wants the split): JSON parsing, upload + extension + tree of the constants, kernel generation / compilation
+        const clk::time_point t_jit = clk::now();
+        const JitStats j1 = jit_stats();
+        std::ostringstream o; o.setf(std::ios::fixed); o.precision(3);
+        o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_tree, t_jit)
+          << ",\"hiprtc_compiled\":" << (j1.compiled - j0.compiled) << ",\"code_cache_disk_hits\":" << (j1.disk_hits - j0.disk_hits)
+          << ",\"code_cache_mem_hits\":" << (j1.mem_hits - j0.mem_hits) << ",\"total_ms\":" << ms(t_begin, t_jit) << "}";
+        S->setup_timing = o.str();
+        if (getenv("ZK_STARK_TIMING") && strcmp(getenv("ZK_STARK_TIMING"), "0")) fprintf(stderr, "[zkgpu stark_setup] %s\n", S->setup_timing.c_str());
+    }
     {
         bool indep = S->n_cm2 == 0 && I.at("pu_ctx").size() == 0 && I.at("pe_ctx").size() == 0 && I.at("ci_ctx").size() == 0 &&
                      S->sN[S_CM3_N] > 0 && getenv("ZK_STARK_NO_OVERLAP") == nullptr;
@@ -465,6 +528,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     const u64* sN = S.sN;
     ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
     on_stream(st);                                        // everything below is issued on (or ordered against) the caller's stream
+    StageTimer T(st);
 
     // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
     DevBuf B[S_COUNT];
@@ -476,7 +540,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     else {
         B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
         ZK_HIP(hipStreamSynchronize(st));                 // the block's previous user is ordered before `st`, not before this copy
-        if (n_words) ZK_HIP(hipMemcpy(ptr[S_CM1_N], cm_pols, n_words * 8, hipMemcpyHostToDevice));
+        if (n_words) h2d_sync(ptr[S_CM1_N], cm_pols, n_words * 8);
     }
     for (int s : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(s, sN[s] * N);
     // sections that a kernel writes in full before anything reads them are not cleared: the extended sections (LDE
@@ -576,6 +640,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     const FrApi* bn128 = S.fr;                            // non-null: a scalar-field hash type
     AnyTranscript tr(bn128);
     tr.put_words_dev(d_pub.u(), n_pub, st);
+    T.mark("inputs_publics");
 
     std::vector<std::unique_ptr<DevBuf>> keep;                                     // workspaces alive until the end
     auto extend_and_merkelize = [&](int sec_n, int sec_2ns) {                     // stark_gen.rs:709-732
@@ -584,7 +649,10 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             keep.emplace_back(new DevBuf); keep.back()->reserve(width * Next * 8);
             lde_dev(ptr[sec_n], ptr[sec_2ns], keep.back()->u(), (u32)width, nbits, nbits_ext, st);
         }
-        return TreePtr(new AnyTree(bn128, ptr[sec_2ns], (u32)width, Next, st));
+        T.mark("extend");                                                          // the two halves of extend_and_merkelize (:709, :734)
+        TreePtr t(new AnyTree(bn128, ptr[sec_2ns], (u32)width, Next, st));
+        T.mark("merkelize");
+        return t;
     };
     auto challenge = [&](int i) { tr.get_field_dev(d_chal.u() + 3 * i, st); };
     auto put_root = [&](const TreePtr& t, u64) { tr.put_root(*t, st); };
@@ -604,7 +672,9 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     }
     TreePtr tree1 = extend_and_merkelize(S_CM1_N, S_CM1_2NS); put_root(tree1, Next);
     challenge(0); challenge(1);                                                    // u, defVal
+    T.mark("transcript");
     run(S.step2prev, false);
+    T.mark("calculate_exps_parallel");
     u64 n_cm = S.n_cm1;
     for (const JVal& pu : I.at("pu_ctx").arr) {                                    // stark_gen.rs:300-308
         DevBuf f, t, h1, h2;
@@ -612,11 +682,14 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         h1.reserve(24 * N); h2.reserve(24 * N);
         ck(zk_stark_calculate_h1h2_dev(C(f.u()), C(t.u()), N, M(h1.u()), M(h2.u()), st));
         set_pol(S.cm_n.at(n_cm++), h1.u()); set_pol(S.cm_n.at(n_cm++), h2.u());
+        T.mark("calculate_H1H2");
     }
     TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
     challenge(2); challenge(3);                                                    // gamma, beta
+    T.mark("transcript");
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);         // an output-only section starts from zero (stark_gen.rs:944-951)
     run(S.step3prev, false);
+    T.mark("calculate_exps_parallel");
     n_cm = S.n_cm1 + S.n_cm2;
     for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {                       // stark_gen.rs:329-353
         for (const JVal& o : I.at(ctx).arr) {
@@ -625,20 +698,26 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             z.reserve(3 * N * 8);
             ck(zk_stark_calculate_z_dev(C(num.u()), C(den.u()), N, M(z.u()), st));
             set_pol(S.cm_n.at(n_cm++), z.u());
+            T.mark("calculate_Z");
         }
     }
     zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);
     TreePtr tree3;
     if (stage3_early) {
         ZK_HIP(hipStreamWaitEvent(st, S.ev_stage3, 0));                            // cm3_n and its extension are ready
+        T.mark("wait_side_stream");
         tree3.reset(new AnyTree(bn128, ptr[S_CM3_2NS], (u32)sN[S_CM3_N], Next, st));
+        T.mark("merkelize");
     } else {
         run(S.step3, false);
+        T.mark("calculate_exps_parallel");
         tree3 = extend_and_merkelize(S_CM3_N, S_CM3_2NS);
     }
     put_root(tree3, Next);
     challenge(4);                                                                  // vc
+    T.mark("transcript");
     run(S.step42ns, true);
+    T.mark("calculate_exps_parallel");
     {   // Q split (stark_gen.rs:375-396)
         const u32 q_dim = S.q_dim, q_deg = S.q_deg;
         keep.emplace_back(new DevBuf); DevBuf& qq1 = *keep.back(); qq1.reserve(q_dim * Next * 8);
@@ -652,9 +731,12 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
         }
     }
+    T.mark("q_split_ntt");
     TreePtr tree4(new AnyTree(bn128, ptr[S_CM4_2NS], (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
+    T.mark("merkelize");
     put_root(tree4, Next);
     challenge(7);                                                                  // xi
+    T.mark("transcript");
     const u64* d_xi = d_chal.u() + 3 * 7;
     DevBuf LEv, LpEv, lt1, lt2;                                                     // stark_gen.rs:416-430
     LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
@@ -676,11 +758,15 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         evals_dev(descs.data(), n_ev, nbits, ext, LEv.u(), LpEv.u(), d_evals.u(), st);
         tr.put_words_dev(d_evals.u(), 3 * (size_t)n_ev, st);                          // stark_gen.rs:469-472
     }
+    T.mark("evals");
     challenge(5); challenge(6);                                                    // v1, v2
+    T.mark("transcript");
     xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);                        // stark_gen.rs:481-522
     xdivxsub_dev(d_xi, 1, nbits_ext, xdiv.u(), st);
     xdivxsub_dev(d_xi, gl::hroot(nbits), nbits_ext, xdivw.u(), st);
+    T.mark("xDivXSubXi");
     run(S.step52ns, true);
+    T.mark("calculate_exps_parallel");
 
     // ---- FRI::prove (fri.rs:84-184)
     const std::vector<u32>& steps = S.steps;
@@ -714,8 +800,10 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         for (u32 k = 0; k < pol_bits - step_bits; ++k) shift_inv = gl::hmul(shift_inv, shift_inv);
         pol_bits = step_bits;
     }
+    T.mark("fri_prove");
     std::vector<u64> ys(S.n_queries);
     tr.get_permutations(S.n_queries, steps[0], ys.data());                             // fri.rs:158
+    T.mark("fri_query_indices");
 
     // ---- proof -> zkin JSON (serializer.rs:146-261)
     u64 r1[4], r2[4], r3[4], r4[4];
@@ -769,6 +857,8 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(fri_trees[si - 1].get()); all_idx.push_back(&ysi[si]); }
     for (const AnyTree* t : {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()}) { all_trees.push_back(t); all_idx.push_back(&ys); }
     const std::vector<std::vector<GroupProof>> all_gp = group_proofs_all(all_trees, all_idx, st);
+    T.mark("openings_readback");
+    S.last_timing = T.finish(nbits);
     for (size_t si = 1; si < n_steps; ++si) {
         const std::vector<GroupProof>& gp = all_gp[si - 1];
         o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);
@@ -862,6 +952,9 @@ char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64
         }) != 0) return nullptr;
     return out;
 }
+
+const char* zk_stark_setup_timing(const zk_stark_setup_t* s) { return s ? s->setup_timing.c_str() : ""; }
+const char* zk_stark_last_timing(const zk_stark_setup_t* s) { return s ? s->last_timing.c_str() : ""; }
 
 int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr) {
     return guard([&] { ZK_REQUIRE(s && prover_addr, "null argument"); s->prover_addr = prover_addr; });

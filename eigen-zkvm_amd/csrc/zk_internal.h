@@ -35,7 +35,9 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 // block freed with kernels still in flight on stream A is never written early by stream B -- while provers running
 // on different threads and streams never wait for each other.  With a single stream in use (the common case) no
 // event is needed: reuse is stream ordered.
-void* pool_alloc(size_t bytes);
+void* pool_alloc(size_t bytes, bool host_wait = false);   // host_wait: drain the previous users on the host (the block leaves the library)
+void h2d_sync(void* d, const void* h, size_t n);            // copies of pooled buffers, ordered on the current stream and waited for
+void d2h_sync(void* h, const void* d, size_t n);
 void pool_free(void* p);
 void pool_trim();  // hipFree everything cached
 // registers `st` as a stream the library works on and makes it the calling thread's current stream (the one
@@ -60,6 +62,10 @@ struct DevBuf {
     u64* u() const { return (u64*)p; }
     void release() { if (p) { pool_free(p); p = nullptr; bytes = 0; } }
 };
+
+// ---- run-time compiled kernels (expr_jit.hip): what the code-object cache did so far in this process ----
+struct JitStats { uint64_t compiled = 0, disk_hits = 0, mem_hits = 0; double ms = 0; };
+JitStats jit_stats();
 
 // ---- NTT (ntt.hip) ----
 // natural-order batched NTT over a row-major [1<<nbits][n_pols] device matrix; dst != src.

@@ -374,6 +374,16 @@ class NativeStarkSetup:
     def const_root(self):
         o = np.zeros(4, np.uint64); _check(lib().zk_stark_setup_const_root(self._h, _ptr(o))); return [int(v) for v in o]
 
+    def setup_timing(self):
+        """where StarkSetup::new's time went: {json_parse_ms, const_lde_merkle_ms, programs_ms, hiprtc_compiled, code_cache_*_hits, total_ms}"""
+        t = lib().zk_stark_setup_timing(self._h)
+        return json.loads(t.decode()) if t else {}
+
+    def last_timing(self):
+        """per-stage HIP-event milliseconds of the last proof (reference span names); {} unless ZK_STARK_TIMING=1 was set"""
+        t = lib().zk_stark_last_timing(self._h)
+        return json.loads(t.decode()) if t else {}
+
     def gen(self, cm_n, stream=None):
         """-> the proof as the zkin dict of serializer.rs:146-261; cm_n: host array or DevArray (HBM-resident trace).
         stream: a HIP stream handle (int) to prove on; setups on different streams may prove concurrently from different
@@ -386,6 +396,8 @@ class NativeStarkSetup:
         if isinstance(cm_n, DevArray):
             p = lib().zk_stark_gen_dev_on(self._h, cm_n.ptr, cm_n.n, stream)
         else:
+            if stream:
+                raise ZkError("gen: a stream needs an HBM-resident trace (DevArray); zk_stark_gen takes host traces on the null stream only")
             c = _np(cm_n)
             p = lib().zk_stark_gen(self._h, _ptr(c), c.size)
         if not p:

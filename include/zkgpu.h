@@ -273,6 +273,15 @@ zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const c
 int zk_stark_setup_const_root(const zk_stark_setup_t* s, uint64_t out[4]);   /* StarkSetup.const_root */
 /* stark_gen's `prover_addr` argument (stark_gen.rs:201): echoed as "proverAddr" by non-GL proofs (serializer.rs:255-262) */
 int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr);
+/* Where the time went, as JSON text owned by the setup (valid until the next call on it / its release).
+ * zk_stark_setup_timing: StarkSetup::new (stark_setup.rs:26-66, one `#[time_profiler("stark_setup")]` span there) split into
+ *   json_parse_ms, const_lde_merkle_ms, programs_ms (+ how many step programs hipRTC compiled and how many came from the
+ *   code-object cache: $ZK_JIT_CACHE, default ~/.cache/zkgpu, "off" disables).
+ * zk_stark_last_timing: the stages of the last proof of this setup in HIP-event milliseconds, named after the reference's
+ *   spans (stark_gen.rs:192,624,709,734,785; fri.rs:83): extend, merkelize, calculate_exps_parallel, calculate_H1H2,
+ *   calculate_Z, fri_prove, ...  Collected only when the environment has ZK_STARK_TIMING=1 (also logged to stderr); "" otherwise. */
+const char* zk_stark_setup_timing(const zk_stark_setup_t* s);
+const char* zk_stark_last_timing(const zk_stark_setup_t* s);
 char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_words);
 /* same with the trace already resident in HBM (borrowed, not modified), e.g. written there by a device-side
  * witness generator or uploaded while the previous proof was running                                     */
