@@ -60,3 +60,53 @@ def test_exec_errors(zk, dev):
     with pytest.raises(zk.ZkError, match="not a Goldilocks field element"):
         E.run(np.array(bad, dtype=np.uint64), 4)
     E.free()
+
+
+@pytest.mark.parametrize("nbits,layer_bits", [(8, 4), (12, 8), (16, 12)])
+def test_join_circuit_exec_matches_oracle_and_host_walk(zk, dev, nbits, layer_bits):
+    """The aggregation's join circuit (tools/aggregation_workload.py JoinCircuit: the recursive2 stand-in of
+    test/stark_aggregation.sh:80-156 whose witness compressor12 exec can compute): the device exec of its .exec file gives the
+    oracle's .cm matrix (oracle/compressor12.py, up to 2^12 rows: it is a Python loop) and the trace the host walk over the
+    gates gives (tools/tracegen.c c12s_witness), which satisfies every identity of the PIL (the proof below is accepted)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import aggregation_workload as AW
+    J = AW.JoinCircuit(nbits, layer_bits)
+    text = J.exec_text()
+    E = dev.Compressor12Exec(text, AW.JoinCircuit.N_WITNESS)
+    assert 1 <= E.depth <= (1 << nbits) >> layer_bits                 # at most one level of additions per layer
+    for seed in (0, 1):
+        primary = np.random.default_rng(seed).integers(0, P, 16, dtype=np.uint64)
+        if seed == 0: primary[:3] = [0, P - 1, 1]
+        w = J.witness_vector(primary)
+        cm = E.run(w, 1 << nbits).to_host()
+        assert np.array_equal(cm, J.witness(primary))
+        if nbits <= 12:
+            assert np.array_equal(cm.reshape(-1, 12), C12.exec_cm(text.decode(), [int(x) for x in w], 1 << nbits))
+    E.free()
+
+
+def test_join_proof_from_device_exec_verifies(zk, dev, orc):
+    """exec on the device -> zk_stark_gen_dev on the trace it left in HBM -> the restated verifier accepts, the publics are
+    the first three primary inputs, and the proof equals the one made from the host-walk trace"""
+    import json
+    sys.path.insert(0, str(ROOT / "tools"))
+    import aggregation_workload as AW
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    import stark_prover as SP, starkinfo as SI                         # oracle/: the checker
+    nbits = 10
+    ss = {"nBits": nbits, "nBitsExt": nbits + 1, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": nbits + 1}, {"nBits": 7}, {"nBits": 3}]}
+    J = AW.JoinCircuit(nbits, 6)
+    import poseidong
+    prog = poseidong.native_program(AW.c12_pil(nbits), ss)
+    S = stark.NativeStarkSetup(J.consts, json.dumps(prog), json.dumps(ss))
+    E = dev.Compressor12Exec(J.exec_text(), AW.JoinCircuit.N_WITNESS)
+    primary = np.arange(100, 116, dtype=np.uint64)
+    d_cm = E.run(J.witness_vector(primary), 1 << nbits)
+    proof = S.gen(d_cm)
+    assert [int(x) for x in proof["publics"]] == [100, 101, 102]
+    assert proof == S.gen(J.witness(primary))
+    p = SP.from_zkin(proof)
+    assert [int(v) for v in p["rootC"]] == S.const_root()
+    info, oprog, _ = SI.generate(AW.c12_pil(nbits), ss)
+    assert SP.stark_verify(p, p["rootC"], info, oprog, ss, orc)
+    E.free(); S.free()

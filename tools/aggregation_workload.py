@@ -19,6 +19,7 @@ STRUCTS = {                                                              # stark
     "c12": {"nBits": 15, "nBitsExt": 16, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 16}, {"nBits": 11}, {"nBits": 7}, {"nBits": 4}]},
     "r1": {"nBits": 18, "nBitsExt": 19, "nQueries": 6, "verificationHashType": "GL", "steps": [{"nBits": 19}, {"nBits": 13}, {"nBits": 8}, {"nBits": 4}]},
 }
+STRUCTS["r2"] = STRUCTS["r1"]            # the joins prove recursive2 under r1.starkStruct.json too (stark_aggregation.sh:118-126)
 P = 0xFFFFFFFF00000001
 
 
@@ -53,7 +54,7 @@ def fib_pil():
 
 
 def program(kind):
-    """{"starkinfo", "program"} for "fib" | "c12" | "r1" from the product's code generator"""
+    """{"starkinfo", "program"} for "fib" | "c12" | "r1" | "r2" from the product's code generator"""
     import poseidong
     return poseidong.native_program(fib_pil() if kind == "fib" else c12_pil(STRUCTS[kind]["nBits"]), STRUCTS[kind])
 
@@ -74,6 +75,40 @@ class Circuit:
             primary = np.random.default_rng(1000 + task).integers(0, P, size=16, dtype=np.uint64)
         primary = np.ascontiguousarray(np.asarray(primary, dtype=np.uint64) % np.uint64(P))
         assert primary.size == 16
+        cm = np.zeros((1 << self.nbits) * 12, np.uint64)
+        _lib().c12s_witness(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), _vp(primary), _vp(cm))
+        return cm
+
+
+class JoinCircuit:
+    """The join circuit of the aggregation (recursive2, test/stark_aggregation.sh:80-156) as a stand-in whose witness compressor12
+    exec can compute: same PIL shape as Circuit, linear gates in layers (tools/tracegen.c c12l_*).  `.exec_text()` is its
+    .exec file, `.witness_vector(primary)` what the circom calculator would hand to exec: [1, 16 primary inputs]."""
+    N_WITNESS = 17
+
+    def __init__(self, nbits, layer_bits=12, seed=13):
+        self.nbits, self.layer_bits = nbits, min(layer_bits, nbits)
+        N = 1 << nbits
+        self.consts = np.zeros(N * 26, np.uint64)
+        self.wires = np.zeros(N * 8, np.uint32)
+        _lib().c12l_circuit(C.c_uint(nbits), C.c_uint(self.layer_bits), C.c_uint64(seed), C.c_uint64(gl_root(nbits)), _vp(self.consts), _vp(self.wires))
+
+    def exec_text(self):
+        f = _lib().c12l_exec_text
+        f.restype = C.c_uint64
+        n = f(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), None, C.c_uint64(0))
+        buf = C.create_string_buffer(n + 1)
+        assert f(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), buf, C.c_uint64(n)) == n
+        return buf.raw[:n]
+
+    @staticmethod
+    def witness_vector(primary):
+        v = np.zeros(17, np.uint64); v[0] = 1; v[1:] = np.asarray(primary, dtype=np.uint64) % np.uint64(P)
+        return v
+
+    def witness(self, primary):
+        """the same trace by the host walk over the gates (tools/tracegen.c c12s_witness): what the exec must reproduce"""
+        primary = np.ascontiguousarray(np.asarray(primary, dtype=np.uint64) % np.uint64(P))
         cm = np.zeros((1 << self.nbits) * 12, np.uint64)
         _lib().c12s_witness(C.c_uint(self.nbits), _vp(self.consts), _vp(self.wires), _vp(primary), _vp(cm))
         return cm

@@ -4,6 +4,8 @@
  * Build: gcc -O2 -shared -fPIC tools/tracegen.c -o tools/libtracegen.so */
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
 #define P 0xFFFFFFFF00000001ULL
 static inline uint64_t addp(uint64_t a, uint64_t b) { unsigned __int128 s = (unsigned __int128)a + b; if (s >= P) s -= P; return (uint64_t)s; }
 /* first row a_k = seed + k + 1, b_k = 2k + 3: every seed is a different valid witness (sub-proof input) */
@@ -158,6 +160,80 @@ void c12s_witness(unsigned nbits, const uint64_t *consts, const uint32_t *wires,
         }
     }
     free(val);
+}
+/* ---- the join circuit of the aggregation (recursive2 in test/stark_aggregation.sh:80-156): same PIL shape, LINEAR gates in layers ----
+ * The real recursive2 witness is what its circom calculator writes, followed by compressor12 exec: PlonkAdd sums + the s_map
+ * gather (compressor12_exec.rs:58-103).  This stand-in keeps only what exec can compute, so that a join needs no host walk:
+ * every gate is out = C0 x + C1 y (C3 = C4 = 0, C2 = -1), i.e. ONE PlonkAdd, and the inputs of a row in layer l (rows
+ * [l 2^layer_bits, (l + 1) 2^layer_bits)) are drawn from the wires of earlier layers only (layer 0: the primary inputs), so the
+ * additions form a DAG of N / 2^layer_bits levels.  Witness vector of the exec: w[0] = 1 (circom's constant signal), w[1..16] = the
+ * primary inputs, add k = gate (row k / 4, k mod 4) -> w[17 + k].  Same constants layout and wiring format as c12s_circuit. */
+void c12l_circuit(unsigned nbits, unsigned layer_bits, uint64_t seed, uint64_t root_of_unity, uint64_t *consts, uint32_t *wires) {
+    const uint64_t N = (uint64_t)1 << nbits, K = 12275445934081160404ULL, n_wires = C12S_PRIMARY + 4 * N;
+    uint64_t ks[12]; ks[0] = 1; for (int i = 1; i < 12; ++i) ks[i] = mulp(ks[i - 1], K);
+    int64_t *first = (int64_t *)malloc(n_wires * sizeof(int64_t)), *last = (int64_t *)malloc(n_wires * sizeof(int64_t));
+    int64_t *sigma = (int64_t *)malloc(12 * N * sizeof(int64_t));
+    uint64_t *wpow = (uint64_t *)malloc(N * sizeof(uint64_t));
+    for (uint64_t w = 0; w < n_wires; ++w) first[w] = last[w] = -1;
+    wpow[0] = 1; for (uint64_t i = 1; i < N; ++i) wpow[i] = mulp(wpow[i - 1], root_of_unity);
+    uint64_t ctr = 0;
+    for (uint64_t r = 0; r < N; ++r) {
+        uint64_t *o = consts + r * 26;
+        for (int j = 0; j < 26; ++j) o[j] = 0;
+        o[0] = r == 0; o[25] = 1;
+        uint64_t *C = o + 13;
+        C[0] = pg_splitmix(seed, ctr++); C[1] = pg_splitmix(seed, ctr++); C[2] = P - 1;
+        C[6] = pg_splitmix(seed, ctr++); C[7] = pg_splitmix(seed, ctr++); C[8] = P - 1;
+        const uint64_t avail = C12S_PRIMARY + 4 * ((r >> layer_bits) << layer_bits);   /* wires of earlier layers */
+        for (int g = 0; g < 12; ++g) {
+            uint64_t w;
+            int is_out = -1;
+            for (int k = 0; k < 4; ++k) if (C12S_OUT[k] == g) is_out = k;
+            if (is_out >= 0) w = C12S_PRIMARY + 4 * r + is_out;
+            else {
+                int slot = 0; for (int k = 0; k < 8; ++k) if (C12S_IN[k] == g) slot = k;
+                if (r == 0) w = slot;                                                /* the publics: a0, a1, a3 of row 0 */
+                else { uint64_t x = pg_splitmix(seed ^ 0xC12E, ctr++); w = (x & 1) ? avail - 1 - (x >> 1) % (avail < 4096 ? avail : 4096) : (x >> 1) % avail; }
+                wires[r * 8 + slot] = (uint32_t)w;
+            }
+            const int64_t cell = 12 * (int64_t)r + g;
+            if (first[w] < 0) first[w] = cell; else sigma[last[w]] = cell;
+            last[w] = cell;
+        }
+    }
+    for (uint64_t w = 0; w < n_wires; ++w) if (first[w] >= 0) sigma[last[w]] = first[w];
+    #pragma omp parallel for schedule(static)
+    for (uint64_t r = 0; r < N; ++r)
+        for (int g = 0; g < 12; ++g) { const int64_t t = sigma[12 * r + g]; consts[r * 26 + 1 + g] = mulp(ks[t % 12], wpow[t / 12]); }
+    free(first); free(last); free(sigma); free(wpow);
+}
+/* The circuit's .exec file (compressor12_setup.rs:51-83): [adds_len, s_map_column_len, adds (a, b, raw ca, raw cb), s_map row by row];
+ * coefficients as the raw words of an FGL, value * 2^64 mod p (field_gl.rs:503-507).  Returns the text length (without the
+ * terminating zero); writes at most cap bytes -- call with cap = 0 for the size. */
+uint64_t c12l_exec_text(unsigned nbits, const uint64_t *consts, const uint32_t *wires, char *buf, uint64_t cap) {
+    const uint64_t N = (uint64_t)1 << nbits, R64 = 0xFFFFFFFFULL;                    /* 2^64 mod p */
+    uint64_t len = 0;
+    char tmp[32];
+    #define EMIT_U64(v) do { int n_ = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)(v)); if (len + n_ <= cap) memcpy(buf + len, tmp, n_); len += n_; } while (0)
+    #define EMIT_CH(c) do { if (len + 1 <= cap) buf[len] = (c); len += 1; } while (0)
+    EMIT_CH('['); EMIT_U64(4 * N); EMIT_CH(','); EMIT_U64(N);
+    for (uint64_t r = 0; r < N; ++r)
+        for (int g = 0; g < 4; ++g) {
+            const uint64_t *c = consts + r * 26 + 13 + (g < 2 ? 0 : 6);
+            EMIT_CH(','); EMIT_U64(1 + wires[r * 8 + 2 * g]); EMIT_CH(','); EMIT_U64(1 + wires[r * 8 + 2 * g + 1]);
+            EMIT_CH(','); EMIT_U64(mulp(c[0], R64)); EMIT_CH(','); EMIT_U64(mulp(c[1], R64));
+        }
+    for (uint64_t r = 0; r < N; ++r)
+        for (int col = 0; col < 12; ++col) {
+            uint64_t w;
+            if (col % 3 == 2) w = C12S_PRIMARY + 4 * r + col / 3;                      /* a gate output: its add */
+            else w = wires[r * 8 + 2 * (col / 3) + col % 3];
+            EMIT_CH(','); EMIT_U64(1 + w);
+        }
+    EMIT_CH(']');
+    #undef EMIT_U64
+    #undef EMIT_CH
+    return len;
 }
 /* the starkjs Fibonacci circuit of the first STARK of a task (fibonacci.js:8-27): const [N][2] = L1, LLAST; cm [N][2] = l1, l2 */
 void fib_consts(unsigned nbits, uint64_t *out) {
