@@ -283,15 +283,33 @@ class GpuTaskProver:
     @staticmethod
     def _root1(zkin_json):
         """root1 of a proof's JSON text without parsing the megabytes of openings after it (serializer.rs:146-152: rootC, root1, ...)"""
-        i = zkin_json.index('"root1":') + 8
-        j = zkin_json.index(']', i) + 1 if zkin_json[i] == '[' else zkin_json.index(',', i)
+        i = zkin_json.index(b'"root1":') + 8
+        j = zkin_json.index(b']', i) + 1 if zkin_json[i:i + 1] == b'[' else zkin_json.index(b',', i)
         r = json.loads(zkin_json[i:j])
         return [int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])]
 
     def prove(self, inputs, worker=0):
         """-> the root of the committed trace of each of the task's three proofs, [[4 words]] * 3"""
         st = self.streams[worker].handle
-        return [self._root1(self.sets[worker][kind].gen_json(d_cm, st)) for kind, d_cm in inputs]
+        return [self._root1(self.sets[worker][kind].gen_bytes(d_cm, st)) for kind, d_cm in inputs]
+
+    def task_stage_times(self, inputs, worker=0):
+        """one task with ZK_STARK_TIMING on: per proof, HIP-event time on the proof's stream against the wall time of the call, and
+        the three largest stages (reference span names) -- where a task's latency goes: device work or waiting between launches"""
+        old = os.environ.get("ZK_STARK_TIMING")
+        os.environ["ZK_STARK_TIMING"] = "quiet"
+        try:
+            out, st = {}, self.streams[worker].handle
+            for kind, d_cm in inputs:
+                t0 = time.perf_counter(); self.sets[worker][kind].gen_bytes(d_cm, st); call_ms = (time.perf_counter() - t0) * 1e3
+                t = self.sets[worker][kind].last_timing()
+                stages = sorted(((k, v) for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms")), key=lambda kv: -kv[1])
+                out[kind] = {"call_ms": round(call_ms, 2), "gpu_event_ms": t.get("total_gpu_ms"), "host_after_last_launch_ms": round(call_ms - t.get("total_gpu_ms", 0), 2),
+                             "top_stages_ms": {k: round(v, 2) for k, v in stages[:4]}}
+            return out
+        finally:
+            if old is None: os.environ.pop("ZK_STARK_TIMING", None)
+            else: os.environ["ZK_STARK_TIMING"] = old
 
     def _spread(self, jobs, fn):
         """jobs[i] -> fn(jobs[i], worker) on worker i mod workers, the workers side by side; results in job order"""
@@ -323,7 +341,7 @@ class GpuTaskProver:
         t1 = time.perf_counter()
         d_cm = self.join_exec.run(d_w, 1 << self.sizes["r2"], st)                         # PlonkAdds + s_map gather: the trace is born in HBM
         t2 = time.perf_counter()
-        root = self._root1(self.sets[worker]["r2"].gen_json(d_cm, st))
+        root = self._root1(self.sets[worker]["r2"].gen_bytes(d_cm, st))
         self.join_exec_s[worker] += t1 - t0; self.join_exec_dev_s[worker] += t2 - t1; self.join_prove_s[worker] += time.perf_counter() - t2
         return root
 
@@ -362,9 +380,11 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
     prover.sync()
     dt = time.perf_counter() - t0
     (dt,) = max_over_ranks(dist, [dt], device)
-    lat = None
+    lat, lat_split = None, None
     if inputs:                                                          # one task alone: the floor of the job once every rank holds one task
         t1 = time.perf_counter(); prover.prove(inputs[0]); prover.sync(); lat = time.perf_counter() - t1
+        if hasattr(prover, "task_stage_times"):                          # the same task once more with the library's stage timers on
+            lat_split = prover.task_stage_times(inputs[0])
     per_rank = (n_tasks + world - 1) // world
     flat = [w for task_roots in roots for r in task_roots for w in r]
     flat += [0] * (per_rank * 12 - len(flat))                           # ranks with one task fewer pad their slot
@@ -377,6 +397,9 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
                        "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
            "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
            "task_latency_s": None if lat is None else round(lat, 4),
+           # what 8 GPUs can make of this job at best: every rank holds one task, so the job cannot finish before one task does
+           "scaling_ceiling": None if not lat else round(dt / lat, 2),
+           "task_latency_split": lat_split,
            "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
            "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
     out["join_tree"] = join_tree(prover, dist, rank, world, device, [by_task[u][2] for u in sorted(by_task)])

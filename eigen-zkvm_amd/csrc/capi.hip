@@ -163,9 +163,9 @@ __global__ void gather_proof_kernel(const u64* __restrict__ elements, const u64*
 
 // the same for n queries at once: block q serves idx[q], out + q * (width + 4 * depth)
 __global__ void gather_proofs_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width, u64 height,
-                                     u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs) {
+                                     u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs, u64 mask) {
     const u32 t = threadIdx.x;
-    const u64 idx = idxs[blockIdx.x];
+    const u64 idx = idxs[blockIdx.x] & mask;             // mask: the query index reduced to a later FRI step's domain (fri.rs:166-168)
     u64* __restrict__ out = outs + (u64)blockIdx.x * (width + 4 * depth);
     for (u32 i = t; i < width; i += blockDim.x) out[i] = elements[idx * width + i];
     if (t == 0) {
@@ -424,7 +424,7 @@ int zk_merkle_group_proofs(const zk_merkle_t* t, const uint64_t* idx, uint32_t n
         DevBuf d_idx, d_out; d_idx.reserve(n * 8); d_out.reserve(std::max<size_t>(1, per * n) * 8);
         ZK_HIP(hipMemcpyAsync(d_idx.p, idx, n * 8, hipMemcpyHostToDevice, t->stream));
         hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, t->stream, t->d_elements, t->nodes.u(), t->width, t->height,
-                           t->depth, d_idx.u(), d_out.u());
+                           t->depth, d_idx.u(), d_out.u(), ~0ull);
         ZK_HIP(hipGetLastError());
         std::vector<u64> h(std::max<size_t>(1, per * n));
         ZK_HIP(hipMemcpyAsync(h.data(), d_out.p, per * n * 8, hipMemcpyDeviceToHost, t->stream));
@@ -440,8 +440,20 @@ int zk_merkle_group_proofs(const zk_merkle_t* t, const uint64_t* idx, uint32_t n
 namespace zk {
 void merkle_group_proofs_async(const zk_merkle* t, const u64* d_idx, uint32_t n, u64* d_out, hipStream_t st) {
     if (n == 0) return;
-    hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, st, t->d_elements, t->nodes.u(), t->width, t->height, t->depth, d_idx, d_out);
+    hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, st, t->d_elements, t->nodes.u(), t->width, t->height, t->depth, d_idx, d_out, ~0ull);
     ZK_HIP(hipGetLastError());
+}
+// the same at the indices d_idx[q] & mask (mask + 1 = the tree's height, a power of two): the query indices stay on the device
+void merkle_group_proofs_masked_async(const zk_merkle* t, const u64* d_idx, u64 mask, uint32_t n, u64* d_out, hipStream_t st) {
+    if (n == 0) return;
+    ZK_REQUIRE(mask < t->height, "MerkleTreeError: access invalid node");
+    hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, st, t->d_elements, t->nodes.u(), t->width, t->height, t->depth, d_idx, d_out, mask);
+    ZK_HIP(hipGetLastError());
+}
+// get_permutations (transcript.rs:73-102) into device memory, on `st`: the indices feed the gather kernels without visiting the host
+void transcript_permutations_async(zk_transcript* t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st) {
+    t->stream = st;
+    transcript_permutations_dev(t->state.p, n, nbits, d_dst, st);
 }
 }  // namespace zk
 extern "C" {

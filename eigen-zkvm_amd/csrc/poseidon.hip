@@ -857,7 +857,8 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
             ZK_HIP(hipGetLastError());
             break;
         }
-        if (next <= 32768) {  // few parents: latency-bound, 16 lanes per permutation
+        static const u64 coop_upto = getenv("ZK_MERKLE_COOP_UPTO") ? strtoull(getenv("ZK_MERKLE_COOP_UPTO"), nullptr, 10) : 32768;
+        if (next <= coop_upto) {  // few parents: latency-bound, 16 lanes per permutation
             hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((u32)((next + 15) / 16)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         } else {
             const u64 blocks = (next + 255) / 256;

@@ -145,6 +145,10 @@ struct AnyTranscript {
         ck(F->tr_get_field(fr, M(f)));
         ZK_HIP(hipMemcpy(d_out3, f, 24, hipMemcpyHostToDevice));
     }
+    void get_permutations_dev(u32 n, u32 nbits, u64* d_out, hipStream_t st) {   // Goldilocks transcript only: the indices stay in HBM
+        ZK_REQUIRE(gl != nullptr, "get_permutations_dev: scalar-field transcripts keep their sponge on the host");
+        transcript_permutations_async(gl, n, nbits, d_out, st);
+    }
     void get_permutations(u32 n, u32 nbits, u64* out) {
         ck(gl ? zk_transcript_get_permutations(gl, n, nbits, M(out)) : F->tr_get_permutations(fr, n, nbits, M(out)));
     }
@@ -158,13 +162,14 @@ void zero(DevBuf& b, size_t words, hipStream_t st) { if (words) ZK_HIP(hipMemset
 // (stark_gen.rs:192,624,709,734,785, fri.rs:83) as HIP-event intervals on the proof's stream.  mark(name) closes the
 // interval that began at the previous mark and gives it `name`; intervals of the same name add up.  Off: no events, no cost.
 struct StageTimer {
-    bool on = false;
+    bool on = false, quiet = false;
     hipStream_t st = nullptr;
     std::vector<std::pair<std::string, hipEvent_t>> marks;
     std::chrono::steady_clock::time_point t0;
     StageTimer(hipStream_t s) : st(s) {
-        static const bool env = getenv("ZK_STARK_TIMING") && *getenv("ZK_STARK_TIMING") && strcmp(getenv("ZK_STARK_TIMING"), "0");
-        on = env;
+        const char* env = getenv("ZK_STARK_TIMING");      // read per proof: a caller may switch it on for one proof ("quiet": no stderr line)
+        on = env && *env && strcmp(env, "0");
+        quiet = on && !strcmp(env, "quiet");
         if (on) { t0 = std::chrono::steady_clock::now(); mark("begin"); }
     }
     ~StageTimer() { for (auto& m : marks) (void)hipEventDestroy(m.second); }
@@ -191,7 +196,7 @@ struct StageTimer {
         o << "{\"nBits\":" << nbits;
         for (auto& a : acc) o << ",\"" << a.first << "\":" << a.second;
         o << ",\"total_gpu_ms\":" << total << ",\"wall_ms\":" << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << "}";
-        fprintf(stderr, "[zkgpu stark_gen] %s\n", o.str().c_str());
+        if (!quiet) fprintf(stderr, "[zkgpu stark_gen] %s\n", o.str().c_str());
         return o.str();
     }
 };
@@ -301,7 +306,25 @@ std::vector<u64> u64_list(const JVal& a) {
     return v;
 }
 
-std::string dec(u64 v) { return std::to_string(v); }
+// The proof's JSON text is thousands of decimal words (every opening): written straight into one growing string --
+// an ostringstream with a temporary std::string per number cost several hundred microseconds of a small proof.
+struct Dec { u64 v; };
+inline Dec dec(u64 v) { return Dec{v}; }
+struct JOut {
+    std::string s;
+    JOut() { s.reserve(1 << 16); }
+    JOut& operator<<(char c) { s.push_back(c); return *this; }
+    JOut& operator<<(const char* t) { s.append(t); return *this; }
+    JOut& operator<<(const std::string& t) { s.append(t); return *this; }
+    JOut& operator<<(Dec d) {
+        char buf[20]; int n = 0; u64 v = d.v;
+        do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) s.push_back(buf[--n]);
+        return *this;
+    }
+    JOut& operator<<(size_t v) { return *this << Dec{(u64)v}; }
+    std::string str() { return std::move(s); }
+};
 // a BN128 digest holds the raw Montgomery limbs of an Fr; JSON carries its canonical value in decimal
 // (digest.rs:91-94 -> helper::fr_to_biguint)
 std::string fr_raw_to_dec(const FrApi& F, const u64* raw) {
@@ -337,17 +360,17 @@ std::string fr_raw_to_dec(const FrApi& F, const u64* raw) {
     }
     return out.empty() ? "0" : out;
 }
-void put_digest(std::ostringstream& o, const u64* d, const FrApi* fr) {  // digest.rs:84-112
+void put_digest(JOut& o, const u64* d, const FrApi* fr) {  // digest.rs:84-112
     if (fr) { o << '"' << fr_raw_to_dec(*fr, d) << '"'; return; }
     if (d[1] == 0 && d[2] == 0 && d[3] == 0) { o << '"' << dec(d[0]) << '"'; return; }
     o << "[\"" << dec(d[0]) << "\",\"" << dec(d[1]) << "\",\"" << dec(d[2]) << "\",\"" << dec(d[3]) << "\"]";
 }
-void put_list(std::ostringstream& o, const u64* v, size_t n) {
+void put_list(JOut& o, const u64* v, size_t n) {
     o << '[';
     for (size_t i = 0; i < n; ++i) { if (i) o << ','; o << '"' << dec(v[i]) << '"'; }
     o << ']';
 }
-void put_path(std::ostringstream& o, const GroupProof& g, const FrApi* fr) {
+void put_path(JOut& o, const GroupProof& g, const FrApi* fr) {
     o << '[';
     for (u32 l = 0; l < g.depth; ++l) {
         if (l) o << ',';
@@ -801,20 +824,33 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         pol_bits = step_bits;
     }
     T.mark("fri_prove");
+    // ---- queries (fri.rs:158-181) and the proof's words
+    // Goldilocks hashing: the query indices are squeezed into HBM, every tree is opened there at (index mod its height) and ONE copy
+    // brings back roots, evaluations, the last polynomial, the publics, the indices and all openings -- one host round trip where
+    // the indices, the proof's words and the openings used to be three.  Scalar-field hashing keeps its host-side sponge and trees.
     std::vector<u64> ys(S.n_queries);
-    tr.get_permutations(S.n_queries, steps[0], ys.data());                             // fri.rs:158
+    DevBuf d_ys;
+    if (!bn128) { d_ys.reserve(std::max<u32>(1, S.n_queries) * 8); tr.get_permutations_dev(S.n_queries, steps[0], d_ys.u(), st); }
+    else tr.get_permutations(S.n_queries, steps[0], ys.data());
     T.mark("fri_query_indices");
 
     // ---- proof -> zkin JSON (serializer.rs:146-261)
     u64 r1[4], r2[4], r3[4], r4[4];
     const u64 n_last = 1ull << steps.back();
     std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev)), last(3 * n_last);
-    {   // roots, evaluations and the last polynomial in one copy (Goldilocks trees: their roots are device words)
-        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub, st);
+    // the trees a proof opens: the folded polynomials' trees at the reduced indices, then the five trees at ys
+    std::vector<const AnyTree*> all_trees; std::vector<u64> all_mask;
+    for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(fri_trees[si - 1].get()); all_mask.push_back((1ull << steps[si]) - 1); }
+    for (const AnyTree* t : {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()}) { all_trees.push_back(t); all_mask.push_back((1ull << steps[0]) - 1); }
+    std::vector<std::vector<GroupProof>> all_gp;
+    {
+        size_t open_words = 0;
+        if (!bn128) for (const AnyTree* t : all_trees) open_words += (size_t)S.n_queries * ((size_t)t->width + 4 * (size_t)t->depth());
+        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub + S.n_queries + open_words, st);
         const AnyTree* t4[4] = {tree1.get(), tree2.get(), tree3.get(), tree4.get()};
         u64* r4p[4] = {r1, r2, r3, r4};
-        size_t off_r[4] = {}, off_ev = 0, off_last = 0;
-        std::vector<size_t> off_fri(n_steps, 0);
+        size_t off_r[4] = {}, off_ev = 0, off_last = 0, off_ys = 0;
+        std::vector<size_t> off_fri(n_steps, 0), off_open(all_trees.size(), 0);
         if (!bn128) {
             for (int j = 0; j < 4; ++j) off_r[j] = rb.add(t4[j]->root_dev(), 4);
             for (size_t si = 0; si + 1 < n_steps; ++si) off_fri[si] = rb.add(fri_trees[si]->root_dev(), 4);
@@ -822,6 +858,14 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         off_ev = rb.add(d_evals.u(), 3 * (size_t)n_ev);
         off_last = rb.add(d_pol, 3 * n_last);
         const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
+        if (!bn128) {
+            off_ys = rb.add(d_ys.u(), S.n_queries);
+            for (size_t j = 0; j < all_trees.size(); ++j) {
+                const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
+                off_open[j] = rb.words;
+                merkle_group_proofs_masked_async(all_trees[j]->gl, d_ys.u(), all_mask[j], S.n_queries, rb.reserve(per * S.n_queries), st);
+            }
+        }
         rb.fetch();
         if (pub_on_device) {
             publics.assign(rb.at(off_pub), rb.at(off_pub) + n_pub);
@@ -834,6 +878,17 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         if (!bn128) {
             for (int j = 0; j < 4; ++j) memcpy(r4p[j], rb.at(off_r[j]), 32);
             for (size_t si = 0; si + 1 < n_steps; ++si) memcpy(fri_roots[si].data(), rb.at(off_fri[si]), 32);
+            if (S.n_queries) memcpy(ys.data(), rb.at(off_ys), 8 * (size_t)S.n_queries);
+            all_gp.resize(all_trees.size());
+            for (size_t j = 0; j < all_trees.size(); ++j) {
+                const u32 depth = all_trees[j]->depth(), w = all_trees[j]->width;
+                const size_t per = (size_t)w + 4 * (size_t)depth;
+                all_gp[j].resize(S.n_queries);
+                for (u32 q = 0; q < S.n_queries; ++q) {
+                    const u64* p = rb.at(off_open[j] + q * per);
+                    all_gp[j][q].depth = depth; all_gp[j][q].row.assign(p, p + w); all_gp[j][q].path.assign(p + w, p + per);
+                }
+            }
         } else {
             for (int j = 0; j < 4; ++j) t4[j]->root(r4p[j]);
             for (size_t si = 0; si + 1 < n_steps; ++si) fri_trees[si]->root(fri_roots[si].data());
@@ -841,7 +896,15 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         if (n_ev) memcpy(ev_host.data(), rb.at(off_ev), 24 * (size_t)n_ev);
         memcpy(last.data(), rb.at(off_last), 24 * n_last);
     }
-    std::ostringstream o;
+    if (bn128) {   // scalar-field trees: the reduced indices on the host, one round trip per tree
+        std::vector<std::vector<u64>> ysi(all_trees.size(), ys);
+        std::vector<const std::vector<u64>*> all_idx;
+        for (size_t j = 0; j < all_trees.size(); ++j) { for (u64& y : ysi[j]) y &= all_mask[j]; all_idx.push_back(&ysi[j]); }
+        all_gp = group_proofs_all(all_trees, all_idx, st);
+    }
+    T.mark("openings_readback");
+    S.last_timing = T.finish(nbits);
+    JOut o;
     o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
     o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
     o << ",\"root3\":"; put_digest(o, r3, bn128); o << ",\"root4\":"; put_digest(o, r4, bn128);
@@ -849,16 +912,6 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
     o << ']';
     // queries of the later steps: group proofs of the folded polynomials (fri.rs:160-181)
-    // every opening of the proof in one batch: the folded polynomials' trees at the reduced indices, the five trees at ys
-    std::vector<std::vector<u64>> ysi(n_steps, ys);
-    for (size_t si = 1; si < n_steps; ++si)
-        for (size_t q = 0; q < ys.size(); ++q) ysi[si][q] = ysi[si - 1][q] % (1ull << steps[si]);
-    std::vector<const AnyTree*> all_trees; std::vector<const std::vector<u64>*> all_idx;
-    for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(fri_trees[si - 1].get()); all_idx.push_back(&ysi[si]); }
-    for (const AnyTree* t : {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()}) { all_trees.push_back(t); all_idx.push_back(&ys); }
-    const std::vector<std::vector<GroupProof>> all_gp = group_proofs_all(all_trees, all_idx, st);
-    T.mark("openings_readback");
-    S.last_timing = T.finish(nbits);
     for (size_t si = 1; si < n_steps; ++si) {
         const std::vector<GroupProof>& gp = all_gp[si - 1];
         o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);

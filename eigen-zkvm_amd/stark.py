@@ -392,6 +392,10 @@ class NativeStarkSetup:
 
     def gen_json(self, cm_n, stream=None):
         """the same proof as the JSON text the library wrote (what `zkit stark_prove --o` stores), unparsed"""
+        return self.gen_bytes(cm_n, stream).decode()
+
+    def gen_bytes(self, cm_n, stream=None):
+        """the proof's JSON text as bytes (no decoding: a caller that stores it or picks a root out of it needs none)"""
         import ctypes
         if isinstance(cm_n, DevArray):
             p = lib().zk_stark_gen_dev_on(self._h, cm_n.ptr, cm_n.n, stream)
@@ -403,7 +407,7 @@ class NativeStarkSetup:
         if not p:
             raise ZkError(lib().zk_last_error().decode())
         try:
-            return ctypes.string_at(p).decode()
+            return ctypes.string_at(p)
         finally:
             lib().zk_string_free(p)
 
