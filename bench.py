@@ -136,6 +136,13 @@ def prove_leg(zk, nbits, verify=True):
            "ms": round(min(times[1:]), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
            "poseidon_perms_per_proof": perms, "root1": proof["root1"],
            "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2), "stand_in": False}
+    out["setup_split"] = setup.setup_timing()                             # StarkSetup::new: JSON / constants / step programs (code-object cache)
+    # The proof is four fifths Poseidon permutations (the three trees over the extended sections): rated as a whole against
+    # the same integer-ALU ceiling as the Merkle leg -- every millisecond that is not hashing lowers the fraction.
+    rate = perms / (min(times[1:]) * 1e-3)
+    out["roofline"] = {"bound": "int-alu", "kernel": "linearhash_rows_kernel + merkle_level_kernel inside stark_gen", "achieved": round(rate / 1e9, 3),
+                       "peak": round(VALU_MAD_PER_S / POSEIDON_MADS / 1e9, 3), "unit": "Gperm/s", "frac": round(rate / (VALU_MAD_PER_S / POSEIDON_MADS), 4),
+                       "model": "the proof's %d permutations / its whole time, against %d v_mad_u64_u32 per permutation at the measured issue rate" % (perms, POSEIDON_MADS)}
     if verify:                                                              # the checker, after the clock has stopped
         sys.path.insert(0, str(ROOT / "oracle"))
         import oracle_lib, stark_prover as SP, starkinfo as SI
@@ -231,6 +238,16 @@ def final_wrap_leg(zk, nbits=18, log_rows=18, join_root=None):
     setup.gen(d_cm)
     t0 = time.perf_counter(); z = setup.gen(d_cm); out["final_stark_bls12381_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     out["final_stark_root1"] = z["root1"]
+    try:   # after the clock: the restated verifier (oracle/, stark_verify.rs:20-136 with MerkleTreeBLS12381 / TranscriptBLS12381) on the zkin text
+        sys.path.insert(0, str(ROOT / "oracle")); sys.path.insert(0, str(ROOT / "tests"))
+        import stark_prover as SP, starkinfo as SI, oracle_lib
+        b = SP.BN128Backend(oracle_lib.load(), "bls12381")
+        vinfo, vprog, _ = SI.generate(AW.c12_pil(16), ss)
+        pz = SP.from_zkin_bn128(z, b)
+        croot = [int(v) for v in setup.const_root()]                  # the setup's own root of the constants (raw limbs), not the proof's copy
+        out["final_stark_verified"] = bool(SP.stark_verify(pz, croot, vinfo, vprog, ss, b)) and z["publics"][:3] == [str(v) for v in primary[:3]]
+    except Exception as e:                                              # the checker failing must not lose the measured line
+        out["final_stark_verified"] = "error: %s: %s" % (type(e).__name__, e)
     setup.free()
     # 3. Groth16 wrap on BLS12-381
     rb, wit, ni, n_wires = GB.make_circuit(GB.FR["BLS12381"], log_rows)
@@ -475,6 +492,17 @@ def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
     res = {"workload": "MerkleTreeBN128, 2^%d rows x %d Goldilocks columns, HBM-resident" % (log_height, width),
            "ms": round(min(times[1:]) * 1e3, 2), "rows_per_s": round(h / min(times[1:]), 1),
            "permutations": {"leaf_t%d" % (nb + 1): h * ((nb + 15) // 16), "node_t17": nodes}}
+    # Fr products of a Poseidon-BN128 permutation of width t (poseidon_bn128_opt.rs:98-224): 8 full rounds of t S-boxes (x^5: 3 products)
+    # and a dense t x t matrix, the pre-sparse matrix, N_P(t) partial rounds of one S-box and a sparse row + column (2t - 1 products)
+    n_p = [56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68]
+    fr_products = lambda t: 8 * (3 * t + t * t) + t * t + n_p[t - 2] * (3 + 2 * t - 1)
+    t_leaf = min(nb, 16) + 1
+    products = h * ((nb + 15) // 16) * fr_products(t_leaf) + nodes * fr_products(17)
+    peak = VALU_MAD_PER_S / FQ_MADS["bn254"]
+    res["roofline"] = {"bound": "int-alu", "kernel": "bn128_leaf_reg_kernel + bn128 node kernels", "achieved": round(products / min(times[1:]) / 1e9, 1),
+                       "peak": round(peak / 1e9, 1), "unit": "G Fr products/s", "frac": round(products / min(times[1:]) / peak, 4),
+                       "model": "%d Fr products per tree (t = %d leaves: %d each, t = 17 nodes: %d each), %d v_mad_u64_u32 per product in 29-bit limbs at the measured issue rate"
+                                % (products, t_leaf, fr_products(t_leaf), fr_products(17), FQ_MADS["bn254"])}
     if cpu_baseline:
         import oracle_lib
         ob = oracle_lib.load().bn128()
@@ -511,6 +539,19 @@ def groth16_leg(zk, curve, log_rows, cpu_baseline):
         t0 = time.perf_counter(); S.prove(wit, 5, 7); th.append(time.perf_counter() - t0)
     res = {"workload": "Groth16 %s proof, synthetic circuit of 2^%d rows, %d wires; quotient (7 Fr transforms) + 3 multi-scalar sums" % (curve, log_rows, n_wires),
            "ms": round(min(ts) * 1e3, 2), "ms_from_host_witness": round(min(th) * 1e3, 2), "value": round((1 << log_rows) / min(ts) / 1e6, 2), "unit": "Mrows/s"}
+    # Fq products of the three multi-scalar sums over the window tables: one mixed addition (11 products) per (point, 16-bit window)
+    # pair -- g_a over the A query, g_c over h, l and the B query in G1 -- and the same over Fq2 for g_b in G2 (three Fq products per
+    # Fq2 product); the seven Fr transforms and the sorts come on top, so the fraction is a lower bound of the arithmetic done.
+    cn = "bn254" if curve == "BN128" else "bls12_381"
+    na, nbq = GB.density(rb, ni, n_wires)
+    n_win = 16
+    pts_g1 = na + ((1 << log_rows) - 1) + (n_wires - ni) + nbq
+    products = 11 * n_win * pts_g1 + 3 * 11 * n_win * nbq
+    peak = VALU_MAD_PER_S / FQ_MADS[cn]
+    res["roofline"] = {"bound": "int-alu", "kernel": "msm_accumulate_kernel over the key's window tables (G1 and G2)", "achieved": round(products / min(ts) / 1e9, 1),
+                       "peak": round(peak / 1e9, 1), "unit": "G Fq products/s", "frac": round(products / min(ts) / peak, 4),
+                       "model": "%d Fq products (11 per table addition, %d G1 points and %d G2 points x %d windows; an Fq2 product counted as 3), %d v_mad_u64_u32 per product"
+                                % (products, pts_g1, nbq, n_win, FQ_MADS[cn])}
     if cpu_baseline:
         import oracle_lib
         sys.path.insert(0, str(ROOT / "oracle"))

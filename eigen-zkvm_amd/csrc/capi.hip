@@ -64,8 +64,11 @@ void* pool_alloc(size_t bytes, bool host_wait) {
             void* p = it->second; g_pool_free.erase(it);
             Block& b = g_pool_blocks[p];
             for (hipEvent_t e : b.pending) {                          // whoever used the block last finishes first:
-                if (host_wait) (void)hipEventSynchronize(e);          // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
-                else (void)hipStreamWaitEvent(t_stream, e, 0);        // the library's own buffers -> the stream it is working on waits
+                const hipError_t rc = host_wait ? hipEventSynchronize(e)               // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
+                                                : hipStreamWaitEvent(t_stream, e, 0);  // the library's own buffers -> the stream it is working on waits
+                // an event whose stream has been destroyed since (a released setup's side stream: drained before it went) reports an
+                // error here; its work is done, and the error must not surface at some later hipGetLastError()
+                if (rc != hipSuccess) (void)hipGetLastError();
                 g_event_cache.push_back(e);
             }
             b.pending.clear();
@@ -161,6 +164,15 @@ __global__ void gather_proof_kernel(const u64* __restrict__ elements, const u64*
     }
 }
 
+// synthetic words for benchmarks and size tests: word i = splitmix64(seed + i) folded below p (one conditional subtraction)
+__global__ void fill_splitmix_kernel(u64* __restrict__ out, u64 n, u64 seed) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 z = seed + i + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31;
+    out[i] = z >= GL_P ? z - GL_P : z;
+}
+
 // the same for n queries at once: block q serves idx[q], out + q * (width + 4 * depth)
 __global__ void gather_proofs_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width, u64 height,
                                      u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs, u64 mask) {
@@ -252,6 +264,15 @@ int zk_stream_free(void* stream) {
         ZK_HIP(hipStreamSynchronize((hipStream_t)stream));
         forget_stream((hipStream_t)stream);
         ZK_HIP(hipStreamDestroy((hipStream_t)stream));
+    });
+}
+int zk_dev_fill_splitmix(uint64_t* d, uint64_t n_words, uint64_t seed, void* stream) {
+    return guard([&] {
+        if (!n_words) return;
+        ZK_REQUIRE(d != nullptr, "zk_dev_fill_splitmix: null buffer");
+        ZK_REQUIRE((n_words + 255) / 256 < (1ull << 31), "zk_dev_fill_splitmix: too many words for one launch");
+        hipLaunchKernelGGL(fill_splitmix_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, on_stream((hipStream_t)stream), (u64*)d, n_words, seed);
+        ZK_HIP(hipGetLastError());
     });
 }
 int zk_dev_memset(void* d, int value, size_t n) { return guard([&] { if (n) ZK_HIP(hipMemset(d, value, n)); }); }

@@ -116,7 +116,7 @@ struct AnyTree {
     u32 depth() const { return gl ? zk_merkle_depth(gl) : F->depth(fr); }
     u32 level_words() const { return gl ? 4 : 64; }   // one sibling digest, or the 16 digests of the group
 };
-using TreePtr = std::unique_ptr<AnyTree>;
+using TreePtr = std::shared_ptr<AnyTree>;       // shared: a setup lends its all-zero tree to every proof
 struct AnyTranscript {
     zk_transcript_t* gl = nullptr; const FrApi* F = nullptr; void* fr = nullptr;
     explicit AnyTranscript(const FrApi* f) : F(f) {
@@ -215,6 +215,8 @@ struct zk_stark_setup {
     const FrApi* fr = nullptr;             // verificationHashType "BN128" / "BLS12381"; nullptr = "GL"
     std::string prover_addr;               // StarkProof.prover_addr (serializer.rs:255-262), non-GL proofs only
     TreePtr const_tree;
+    TreePtr zero_tree;                     // the tree over a zero-width section (tree2 / tree3 of a PIL without such columns): the same in every proof
+    DevBuf x_n, x_2ns, zi;                 // x over the domain and the extended coset, 1 / Z_H on the coset (stark_gen.rs:231-249): functions of the sizes only
     u64 const_root[4] = {};
     ProgramPtr step2prev, step3prev, step3, step42ns, step52ns;
     std::vector<ProgramPtr> public_programs;
@@ -226,6 +228,7 @@ struct zk_stark_setup {
     hipEvent_t ev_inputs = nullptr, ev_stage3 = nullptr;
     std::string setup_timing;              // JSON: where StarkSetup::new's time went (zk_stark_setup_timing)
     std::string last_timing;               // JSON: the stages of the last proof, HIP-event milliseconds (ZK_STARK_TIMING=1)
+    std::chrono::steady_clock::time_point t_json_begin, t_json_end;   // host time of the last proof's serialisation (timing runs only)
     ~zk_stark_setup() {
         if (side_stream) { forget_stream(side_stream); (void)hipStreamDestroy(side_stream); }
         if (ev_inputs) (void)hipEventDestroy(ev_inputs);
@@ -501,6 +504,15 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     }
     S->const_tree.reset(new AnyTree(S->fr, S->const_2ns.u(), (u32)nc, Next, nullptr));
     S->const_tree->root(S->const_root);                    // (copies the root back: the tree is built when this returns)
+    {   // what every proof of this setup would otherwise rebuild: the two x tables, 1 / Z_H, and the tree of an empty section
+        const u32 ext = S->nbits_ext - S->nbits;
+        S->x_n.reserve(N * 8); S->x_2ns.reserve(Next * 8); S->zi.reserve((1ull << ext) * 8);
+        x_table_dev(S->nbits, 1, S->x_n.u(), nullptr); x_table_dev(S->nbits_ext, 49, S->x_2ns.u(), nullptr); zh_inv_dev(S->nbits, ext, S->zi.u(), nullptr);
+        bool any_empty = false;
+        for (int sec : {S_CM1_N, S_CM2_N, S_CM3_N}) any_empty |= S->sN[sec] == 0;
+        if (any_empty) S->zero_tree.reset(new AnyTree(S->fr, nullptr, 0, Next, nullptr));
+        ZK_HIP(hipStreamSynchronize(nullptr));
+    }
     const clk::time_point t_tree = clk::now();
     const JitStats j0 = jit_stats();
     const JVal& P = S->prog;
@@ -573,9 +585,8 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     alloc(S_Q_2NS, S.q_dim * Next, false); alloc(S_F_2NS, 3 * Next, false); alloc(S_SCRATCH, 3 * Next);
     ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
 
-    DevBuf x_n, x_2ns, zi, d_chal, d_evals, d_pub, xdiv, xdivw;                     // stark_gen.rs:231-249
-    x_n.reserve(N * 8); x_2ns.reserve(Next * 8); zi.reserve((1ull << ext) * 8);
-    x_table_dev(nbits, 1, x_n.u(), st); x_table_dev(nbits_ext, 49, x_2ns.u(), st); zh_inv_dev(nbits, ext, zi.u(), st);
+    DevBuf d_chal, d_evals, d_pub, xdiv, xdivw;                                      // stark_gen.rs:231-249 (x, Zi: the setup's tables)
+    const DevBuf &x_n = S.x_n, &x_2ns = S.x_2ns, &zi = S.zi;
     d_chal.reserve(24 * 8); zero(d_chal, 24, st);                                        // challenge[8] (constant.rs:39-50)
     const u32 n_ev = (u32)I.at("ev_map").size();
     const u32 n_pub = (u32)I.at("publics").size();
@@ -673,6 +684,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             lde_dev(ptr[sec_n], ptr[sec_2ns], keep.back()->u(), (u32)width, nbits, nbits_ext, st);
         }
         T.mark("extend");                                                          // the two halves of extend_and_merkelize (:709, :734)
+        if (!width && S.zero_tree) return S.zero_tree;                            // an empty section: every node is the all-zero digest of its level
         TreePtr t(new AnyTree(bn128, ptr[sec_2ns], (u32)width, Next, st));
         T.mark("merkelize");
         return t;
@@ -904,6 +916,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     }
     T.mark("openings_readback");
     S.last_timing = T.finish(nbits);
+    S.t_json_begin = std::chrono::steady_clock::now();
     JOut o;
     o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
     o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
@@ -947,6 +960,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         o << '"';
     }
     o << '}';
+    S.t_json_end = std::chrono::steady_clock::now();
     return o.str();
 }
 
@@ -998,10 +1012,19 @@ char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64
     char* out = nullptr;
     if (guard([&] {
             ZK_REQUIRE(s && d_cm_pols, "zk_stark_gen_dev: null argument");
+            const auto t0 = std::chrono::steady_clock::now();
             const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words, (hipStream_t)stream);
+            const auto t1 = std::chrono::steady_clock::now();          // stark_gen's buffers, trees and events are released by now
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);
+            if (!s->last_timing.empty() && s->last_timing.back() == '}') {   // a timing run: where the host time after the last launch went
+                auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                char buf[256];
+                snprintf(buf, sizeof buf, ",\"host_json_ms\":%.3f,\"host_release_ms\":%.3f,\"host_copy_ms\":%.3f,\"call_ms\":%.3f,\"zkin_bytes\":%zu}",
+                         ms(s->t_json_begin, s->t_json_end), ms(s->t_json_end, t1), ms(t1, std::chrono::steady_clock::now()), ms(t0, std::chrono::steady_clock::now()), z.size());
+                s->last_timing.pop_back(); s->last_timing += buf;
+            }
         }) != 0) return nullptr;
     return out;
 }

@@ -46,6 +46,9 @@ void* zk_stream_new(void);
 int zk_stream_sync(void* stream);
 int zk_stream_free(void* stream);
 int zk_dev_memset(void* d_ptr, int value, size_t bytes);
+/* Synthetic field elements for benchmarks and size tests, generated where they are used: word i = splitmix64(seed + i), minus p
+ * when that is >= p (the reference's benches fill their inputs with random field elements the same way, the files under starky/benches). */
+int zk_dev_fill_splitmix(uint64_t* d, uint64_t n_words, uint64_t seed, void* stream);
 
 /* ---- NTT / LDE ---------------------------------------------------------------------------
  * replaces fft_p::fft / fft_p::ifft (starky/src/fft_p.rs:242-253):

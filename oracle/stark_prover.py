@@ -417,6 +417,24 @@ def from_zkin(z):
             "fri_proof": {"queries": queries, "last": [[int(v) for v in e] for e in z["finalPol"]]}}
 
 
+def from_zkin_bn128(z, backend):
+    """inverse of to_zkin_bn128 (serializer.rs:146-262 with MerkleTreeBN128 / MerkleTreeBLS12381): decimal Fr digests back to
+    the raw Montgomery limbs of ElementDigest<4, Fr>, 16 siblings per level -- so that the restated verifier can check a
+    scalar-field-hashed proof that only exists as zkin text (the final STARK of an aggregation)"""
+    dg = lambda d: [int(v) for v in backend._h.to_mont(int(d))]
+    n_steps = 1 + sum(1 for k in z if k.startswith("s") and k.endswith("_root"))
+    path = lambda p: [dg(p[l][k]) for l in range(len(p)) for k in range(16)]      # depth * 16 rows of 4 limbs
+    n_q = len(z["s0_vals1"])
+    queries = [{"root": None, "pol_queries": [[([int(v) for v in z["s0_vals" + nm][q]], path(z["s0_siblings" + nm][q]))
+                                                for nm in ("1", "2", "3", "4", "C")] for q in range(n_q)]}]
+    for i in range(1, n_steps):
+        queries.append({"root": dg(z["s%d_root" % i]),
+                        "pol_queries": [[([int(v) for v in z["s%d_vals" % i][q]], path(z["s%d_siblings" % i][q]))] for q in range(n_q)]})
+    return {"rootC": dg(z["rootC"]), "root1": dg(z["root1"]), "root2": dg(z["root2"]), "root3": dg(z["root3"]), "root4": dg(z["root4"]),
+            "evals": [[int(v) for v in e] for e in z["evals"]], "publics": [int(v) for v in z["publics"]],
+            "fri_proof": {"queries": queries, "last": [[int(v) for v in e] for e in z["finalPol"]]}}
+
+
 def f3(v):
     return tuple(int(x) for x in v)
 
