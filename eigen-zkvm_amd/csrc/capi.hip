@@ -14,7 +14,9 @@ void set_error(const std::string& msg) { t_err = msg; }
 
 // ---- caching device allocator -------------------------------------------------------------------
 namespace {
-struct Block { size_t bytes = 0; std::vector<hipEvent_t> pending; };   // events recorded when the block was freed
+// An event recorded when blocks were freed; shared by all blocks freed in one burst (pool_defer_*), recycled by the last of them
+struct Ev { hipEvent_t e = nullptr; int refs = 0; };
+struct Block { size_t bytes = 0; std::vector<Ev*> pending; };
 std::mutex g_pool_mu;
 std::multimap<size_t, void*> g_pool_free;   // size -> idle block
 std::map<void*, Block> g_pool_blocks;       // every block handed out by pool_alloc
@@ -23,6 +25,9 @@ std::vector<hipEvent_t> g_event_cache;
 thread_local hipStream_t t_stream = nullptr;
 thread_local std::vector<hipStream_t> t_streams;   // non-null streams this host thread has issued on
 thread_local int t_depth = 0;                      // C-ABI calls in progress on this thread (the prover calls entry points itself)
+thread_local bool t_defer = false;                 // pool_defer_begin(): frees are collected ...
+thread_local std::vector<void*> t_deferred;        // ... here, and stamped with ONE set of events by pool_defer_flush()
+void ev_release(Ev* v) { if (--v->refs == 0) { g_event_cache.push_back(v->e); delete v; } }   // g_pool_mu held
 
 hipEvent_t event_get() {                     // g_pool_mu held; never throws (DevBuf destructors end up here): nullptr = no event to be had
     if (!g_event_cache.empty()) { hipEvent_t e = g_event_cache.back(); g_event_cache.pop_back(); return e; }
@@ -63,13 +68,13 @@ void* pool_alloc(size_t bytes, bool host_wait) {
         if (it != g_pool_free.end()) {
             void* p = it->second; g_pool_free.erase(it);
             Block& b = g_pool_blocks[p];
-            for (hipEvent_t e : b.pending) {                          // whoever used the block last finishes first:
-                const hipError_t rc = host_wait ? hipEventSynchronize(e)               // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
-                                                : hipStreamWaitEvent(t_stream, e, 0);  // the library's own buffers -> the stream it is working on waits
+            for (Ev* v : b.pending) {                                 // whoever used the block last finishes first:
+                const hipError_t rc = host_wait ? hipEventSynchronize(v->e)               // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
+                                                : hipStreamWaitEvent(t_stream, v->e, 0);  // the library's own buffers -> the stream it is working on waits
                 // an event whose stream has been destroyed since (a released setup's side stream: drained before it went) reports an
                 // error here; its work is done, and the error must not surface at some later hipGetLastError()
                 if (rc != hipSuccess) (void)hipGetLastError();
-                g_event_cache.push_back(e);
+                ev_release(v);
             }
             b.pending.clear();
             return p;
@@ -86,25 +91,49 @@ void* pool_alloc(size_t bytes, bool host_wait) {
     g_pool_blocks[p].bytes = bytes;
     return p;
 }
-void pool_free(void* p) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
+namespace {
+// events for blocks freed now: the null stream and every stream the FREEING thread has issued on (a buffer is released by the
+// thread that owns it; work another thread did on it was ordered before this thread's by whoever handed it over).  Streams of
+// other threads are left alone: concurrent provers must not wait for each other.  g_pool_mu held.
+std::vector<Ev*> stamp_now() {
+    std::vector<Ev*> out;
+    if (g_streams.size() <= 1) return out;               // a single stream in use: reuse is stream ordered (on_stream drains at the second)
+    auto record = [&](hipStream_t st) {
+        hipEvent_t e = event_get();
+        if (!e) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); return; }   // no event to be had: wait here instead
+        if (hipEventRecord(e, st) == hipSuccess) out.push_back(new Ev{e, 0});
+        else { (void)hipGetLastError(); g_event_cache.push_back(e); }   // a destroyed stream has nothing in flight
+    };
+    record(nullptr);
+    for (hipStream_t st : t_streams) record(st);
+    return out;
+}
+void release_stamped(void* p, const std::vector<Ev*>& evs) {   // g_pool_mu held
     auto it = g_pool_blocks.find(p);
     if (it == g_pool_blocks.end()) { (void)hipFree(p); return; }
-    if (g_streams.size() > 1) {
-        // several streams in play: the next user waits for the null stream and for every stream the FREEING thread has issued on
-        // (a buffer is released by the thread that owns it; work another thread did on it was ordered before this thread's by
-        // whoever handed it over).  Streams of other threads are left alone: concurrent provers must not wait for each other.
-        auto record = [&](hipStream_t st) {
-            hipEvent_t e = event_get();
-            if (!e) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); return; }   // no event to be had: wait here instead
-            if (hipEventRecord(e, st) == hipSuccess) it->second.pending.push_back(e);
-            else { (void)hipGetLastError(); g_event_cache.push_back(e); }   // a destroyed stream has nothing in flight
-        };
-        record(nullptr);
-        for (hipStream_t st : t_streams) record(st);
-    }
+    for (Ev* v : evs) { ++v->refs; it->second.pending.push_back(v); }
     g_pool_free.emplace(it->second.bytes, p);
+}
+}  // namespace
+void pool_free(void* p) {
+    if (!p) return;
+    if (t_defer) { t_deferred.push_back(p); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    const std::vector<Ev*> evs = stamp_now();
+    release_stamped(p, evs);
+    for (Ev* v : evs) if (v->refs == 0) { g_event_cache.push_back(v->e); delete v; }   // the block was not the pool's
+}
+// A burst of frees with no launch in between (the end of a proof: ~70 buffers and trees go at once) shares one set of events
+// instead of recording two per block: pool_defer_begin() after the last launch, pool_defer_flush() once the destructors have run.
+void pool_defer_begin() { t_defer = true; }
+void pool_defer_flush() {
+    t_defer = false;
+    if (t_deferred.empty()) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    const std::vector<Ev*> evs = stamp_now();
+    for (void* p : t_deferred) release_stamped(p, evs);
+    for (Ev* v : evs) if (v->refs == 0) { g_event_cache.push_back(v->e); delete v; }
+    t_deferred.clear();
 }
 // Host <-> device copies of the library's own pooled buffers: on the stream this thread is working on (the one whose
 // queue was ordered behind the buffer's previous user by pool_alloc), then waited for -- a plain hipMemcpy runs on the
@@ -123,7 +152,7 @@ void pool_trim() {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto& kv : g_pool_free) {
         Block& b = g_pool_blocks[kv.second];
-        for (hipEvent_t e : b.pending) { (void)hipEventSynchronize(e); g_event_cache.push_back(e); }
+        for (Ev* v : b.pending) { if (hipEventSynchronize(v->e) != hipSuccess) (void)hipGetLastError(); ev_release(v); }
         (void)hipFree(kv.second); g_pool_blocks.erase(kv.second);
     }
     g_pool_free.clear();

@@ -961,12 +961,16 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     }
     o << '}';
     S.t_json_end = std::chrono::steady_clock::now();
+    pool_defer_begin();                                   // nothing is launched from here on: the buffers and trees go back as one burst
     return o.str();
 }
+
+struct DeferFlush { ~DeferFlush() { pool_defer_flush(); } };   // after stark_gen's locals are gone (also when it throws)
 
 template <class F>
 int guard(F&& f) {
     CallScope scope;
+    DeferFlush flush;
     try { f(); return 0; }
     catch (const std::exception& e) { set_error(e.what()); return -1; }
     catch (...) { set_error("unknown error"); return -1; }

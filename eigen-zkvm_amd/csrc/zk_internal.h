@@ -40,6 +40,8 @@ void* pool_alloc(size_t bytes, bool host_wait = false);   // host_wait: drain th
 void h2d_sync(void* d, const void* h, size_t n);            // copies of pooled buffers, ordered on the current stream and waited for
 void d2h_sync(void* h, const void* d, size_t n);
 void pool_free(void* p);
+void pool_defer_begin();   // frees of this thread are collected until pool_defer_flush() stamps them with one set of events
+void pool_defer_flush();
 void pool_trim();  // hipFree everything cached
 // registers `st` as a stream the library works on and makes it the calling thread's current stream (the one
 // pool_alloc orders reuse against); returns st.  Every entry point that takes a stream goes through it.
