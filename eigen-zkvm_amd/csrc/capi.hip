@@ -584,7 +584,7 @@ int zk_stark_xdivxsub_dev(const uint64_t* d_xi, uint64_t mulw, uint32_t nbits_ex
     return guard([&] { ZK_REQUIRE(nbits_ext <= 32, "xdivxsub: nbits_ext > 32"); xdivxsub_dev((const u64*)d_xi, mulw, nbits_ext, (u64*)d_out, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_lev_dev(const uint64_t* d_xi, uint32_t nbits, int prime, uint64_t* d_out, uint64_t* d_tmp, uint64_t* d_tmp2, void* stream) {
-    return guard([&] { lev_dev((const u64*)d_xi, nbits, prime != 0, (u64*)d_out, (u64*)d_tmp, (u64*)d_tmp2, on_stream((hipStream_t)stream)); });
+    return guard([&] { lev_dev((const u64*)d_xi, nbits, prime != 0, 49, (u64*)d_out, (u64*)d_tmp, (u64*)d_tmp2, on_stream((hipStream_t)stream)); });
 }
 int zk_stark_evals_dev(const zk_eval_desc* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const uint64_t* d_LEv,
                        const uint64_t* d_LpEv, uint64_t* d_out, void* stream) {

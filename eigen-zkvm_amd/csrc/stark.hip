@@ -8,6 +8,10 @@
 //   :416-430 (LEv/LpEv), :432-466 (evals), :481-522 (xDivXSubXi via sequential batch_inverse,
 //   polutils.rs:35-53 -- here every point is inverted independently: same field elements).
 #include "zk_internal.h"
+#include "acc6.cuh"
+#include <vector>
+#include <cstring>
+#include <algorithm>
 #include "ntt_reg.cuh"
 
 namespace zk {
@@ -174,29 +178,72 @@ __global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi
 
 // ---- evals (stark_gen.rs:432-466) ----------------------------------------------------------
 struct EvalDesc { const u64* buf; u64 width; u64 offset; u32 dim; u32 prime; };
+// the descriptor the kernel sees: which weight table (LEv / LpEv of the caller), and the row stride of the section as a shift
+struct EvalDescK { const u64* buf; const u64* L; u64 width; u64 offset; u32 dim; u32 rshift; };
 constexpr int EV_BLOCKS = 4096;  // blocks along the row axis: the row loop is latency-bound, more waves in flight = more loads in flight
                                  // (512 blocks: 7.1 ms per 2^24-row proof, 2048: 5.5 ms)
 constexpr int EV_LANES = 32;     // evaluations per block: consecutive descriptors sit in consecutive lanes
+struct EvalBatch { EvalDescK d[EV_LANES]; u32 out[EV_LANES]; };   // 32 base-field columns (+ their partial-sum slots) travel as a kernel argument: no upload, no wait for one
+constexpr int EV_UNROLL = 4;     // rows per lane and trip, all loads issued before the first product
+constexpr int EV_FLUSH = 256;    // terms an Acc6 may take before it is folded (acc6.cuh: n * 2^54 < 2^64)
 
-// One block = 8 rows x 32 evaluations per trip: the 32 lanes of a row read neighbouring columns of the same
-// section row (ev_map lists a section's columns one after the other), so a trip reads whole row segments
-// instead of one word per 128-byte line; L[k] is shared by the lanes of a row.
-__global__ __launch_bounds__(256) void evals_partial_kernel(const EvalDesc* __restrict__ descs, u32 n_ev, u32 nbits, u32 ext,
-                                                            const u64* __restrict__ LEv, const u64* __restrict__ LpEv,
-                                                            u64* __restrict__ partial /* [n_ev][EV_BLOCKS][3] */) {
-    const u32 lane = threadIdx.x % EV_LANES, rowl = threadIdx.x / EV_LANES;   // 8 rows per trip
-    const u32 e = blockIdx.y * EV_LANES + lane;
-    const bool live = e < n_ev;
-    EvalDesc d = descs[live ? e : 0];
+// One block = 8 x EV_UNROLL rows x 32 columns per trip: the 32 lanes of a row read neighbouring columns of the same section row
+// (ev_map lists a section's columns one after the other), so a trip reads whole row segments; L[k] is shared by the lanes of a row.
+// slot = sum_k section[(k << rshift)][offset] * L[k] over k < N, a base-field column against extension-field weights.
+// Measured (rocprofv3, 2^24 rows): the first version -- a modular product and a modular addition per limb of L[k], ~100
+// instructions per (column, row) -- took 1.7 ms per 32 columns whatever the loads did, and an extension column, alone in a launch
+// of its own kind, 3.3 ms: the kernel is bound by wave-instructions.  Now a column word is split in 22/22/20-bit limbs once per row
+// and the three limbs of L[k] accumulate carry-free (18 multiply-adds per row, one fold per EV_FLUSH rows), and an extension column
+// is three base-field columns (the product by L[k] is linear in the column: c L = c0 L + x (c1 L) + x^2 (c2 L), combined at the end).
+__global__ __launch_bounds__(256) void evals_partial_kernel(const EvalBatch B, u32 n_live, u32 nbits, u32 n_row_blocks,
+                                                            u64* __restrict__ partial /* [slots][n_row_blocks][3] */) {
+    const u32 lane = threadIdx.x % EV_LANES, rowl = threadIdx.x / EV_LANES;   // 8 rows per trip and unroll step
+    const bool live = lane < n_live;
+    const EvalDescK d = B.d[live ? lane : 0];
     const u64 N = 1ull << nbits;
-    const u64* __restrict__ L = d.prime ? LpEv : LEv;
+    const u64* __restrict__ L = d.L;
+    const u64 stride = (u64)gridDim.x * 8;
     f3 acc{{0, 0, 0}};
-    if (live)
-        for (u64 k = (u64)blockIdx.x * 8 + rowl; k < N; k += (u64)gridDim.x * 8) {
-            const u64* c = d.buf + (k << ext) * d.width + d.offset;
-            const f3 l = ld3(L + 3 * k);
-            acc = gl::f3_add(acc, d.dim == 1 ? gl::f3_muls(l, c[0]) : gl::f3_mul(ld3(c), l));
+    Acc6 A[3];
+    acc_zero(A[0]); acc_zero(A[1]); acc_zero(A[2]);
+    u32 pending = 0;
+    auto term = [&](u64 c, const f3& l) {
+        const u32 c0 = (u32)c & 0x3FFFFFu, c1 = (u32)(c >> 22) & 0x3FFFFFu, c2 = (u32)(c >> 44);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const u32 x0 = (u32)l.v[i], x1 = (u32)(l.v[i] >> 32);
+            A[i].a00 += (u64)c0 * x0; A[i].a10 += (u64)c1 * x0; A[i].a20 += (u64)c2 * x0;
+            A[i].a01 += (u64)c0 * x1; A[i].a11 += (u64)c1 * x1; A[i].a21 += (u64)c2 * x1;
         }
+    };
+    auto fold = [&] {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u64 r = acc_finish(A[i]);
+            r = r >= GL_P ? r - GL_P : r;
+            acc.v[i] = gl::add(acc.v[i], r);
+            acc_zero(A[i]);
+        }
+        pending = 0;
+    };
+    if (live) {
+        u64 k = (u64)blockIdx.x * 8 + rowl;
+        for (; k + (EV_UNROLL - 1) * stride < N; k += EV_UNROLL * stride) {
+            f3 l[EV_UNROLL]; u64 c[EV_UNROLL];
+#pragma unroll
+            for (int j = 0; j < EV_UNROLL; ++j) {
+                const u64 kk = k + j * stride;
+                l[j] = ld3(L + 3 * kk);
+                c[j] = d.buf[(kk << d.rshift) * d.width + d.offset];
+            }
+#pragma unroll
+            for (int j = 0; j < EV_UNROLL; ++j) term(c[j], l[j]);
+            pending += EV_UNROLL;
+            if (pending >= (u32)EV_FLUSH) fold();
+        }
+        for (; k < N; k += stride) { term(d.buf[(k << d.rshift) * d.width + d.offset], ld3(L + 3 * k)); if (++pending >= (u32)EV_FLUSH) fold(); }
+        fold();
+    }
     __shared__ u64 red[256 * 3];
     st3(red + threadIdx.x * 3, acc);
     __syncthreads();
@@ -204,20 +251,30 @@ __global__ __launch_bounds__(256) void evals_partial_kernel(const EvalDesc* __re
         if ((int)rowl < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s * EV_LANES) * 3)));
         __syncthreads();
     }
-    if (rowl == 0 && live) st3(partial + ((u64)e * gridDim.x + blockIdx.x) * 3, ld3(red + lane * 3));
+    if (rowl == 0 && live) st3(partial + ((u64)B.out[lane] * n_row_blocks + blockIdx.x) * 3, ld3(red + lane * 3));
 }
-__global__ __launch_bounds__(64) void evals_final_kernel(const u64* __restrict__ partial, u32 n_ev, u32 nblk, u64* __restrict__ out) {
-    const u32 e = blockIdx.x;                          // one wave per evaluation: lanes stride over the row blocks
-    f3 acc{{0, 0, 0}};
-    for (u32 b = threadIdx.x; b < nblk; b += 64) acc = gl::f3_add(acc, ld3(partial + ((u64)e * nblk + b) * 3));
+// out[e] = the sum of slot s over the row blocks for a base-field column, s + x (s + 1) + x^2 (s + 2) for an extension column
+// (x (a0, a1, a2) = (a2, a0 + a2, a1) in GF(p)[x] / (x^3 - x - 1)).  One wave per evaluation; 64 evaluations per launch.
+struct EvalFinalBatch { u32 slot[64]; u32 dim[64]; };
+__global__ __launch_bounds__(64) void evals_final_kernel(const u64* __restrict__ partial, const EvalFinalBatch F, u32 e0, u32 nblk, u64* __restrict__ out) {
+    const u32 e = blockIdx.x;
     __shared__ u64 red[64 * 3];
-    st3(red + threadIdx.x * 3, acc);
-    __syncthreads();
-    for (int s = 32; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s) * 3)));
+    f3 res{{0, 0, 0}};
+    for (u32 j = 0; j < F.dim[e]; ++j) {
+        f3 acc{{0, 0, 0}};
+        for (u32 b = threadIdx.x; b < nblk; b += 64) acc = gl::f3_add(acc, ld3(partial + ((u64)(F.slot[e] + j) * nblk + b) * 3));
+        st3(red + threadIdx.x * 3, acc);
         __syncthreads();
+        for (int s = 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) st3(red + threadIdx.x * 3, gl::f3_add(ld3(red + threadIdx.x * 3), ld3(red + (threadIdx.x + s) * 3)));
+            __syncthreads();
+        }
+        f3 t = ld3(red);
+        __syncthreads();
+        for (u32 m = 0; m < j; ++m) t = f3{{t.v[2], gl::add(t.v[0], t.v[2]), t.v[1]}};     // times x, j times
+        res = gl::f3_add(res, t);
     }
-    if (threadIdx.x == 0) st3(out + 3 * e, ld3(red));
+    if (threadIdx.x == 0) st3(out + 3 * (e0 + e), res);
 }
 
 // ---- Q split (stark_gen.rs:375-391) ---------------------------------------------------------
@@ -393,29 +450,61 @@ void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hip
     ZK_HIP(hipGetLastError());
 }
 
-void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp, u64* d_tmp2, hipStream_t st) {
+// LEv / LpEv (stark_gen.rs:416-430): d_pow <- powers of xi / shift (prime: xi w / shift), d_out <- their inverse transform.
+// shift = 49 gives the reference's tables (weights of the rows k 2^ext of an extended section); shift = 1 the weights of the
+// rows of the section itself, and d_pow then holds the powers of xi (the weights of a polynomial's coefficients).
+void lev_pow_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_pow, hipStream_t st) {   // (xi / shift)^k or (xi w / shift)^k, k < 2^nbits
     const u64 n = 1ull << nbits;
-    u64 c = gl::hinv(49);
+    u64 c = gl::hinv(shift);
     if (prime) c = gl::hmul(c, gl::hroot(nbits));
-    hipLaunchKernelGGL(lev_pow_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, c, n, d_tmp);
+    hipLaunchKernelGGL(lev_pow_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, c, n, d_pow);
     ZK_HIP(hipGetLastError());
-    ntt_dev(d_tmp, d_out, d_tmp2, 3, nbits, true, st);  // FFT::ifft over F3G == per-limb iNTT (base-field roots)
+}
+void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_out, u64* d_pow, u64* d_tmp2, hipStream_t st) {
+    lev_pow_dev(d_xi, nbits, prime, shift, d_pow, st);
+    ntt_dev(d_pow, d_out, d_tmp2, 3, nbits, true, st);  // FFT::ifft over F3G == per-limb iNTT (base-field roots)
 }
 
+// evaluations at xi (stark_gen.rs:432-466): out[e] = sum_k section_e[k << rshift_e] * L_e[k], k < 2^nbits
+void evals_k_dev(const EvalDescKHost* descs, uint32_t n_ev, uint32_t nbits, u64* d_out, hipStream_t st) {
+    if (n_ev == 0) return;
+    static_assert(sizeof(EvalDescKHost) == sizeof(EvalDescK), "descriptor layout");
+    u32 n_slots = 0;
+    for (u32 e = 0; e < n_ev; ++e) { ZK_REQUIRE(descs[e].dim == 1 || descs[e].dim == 3, "evals: dim must be 1 or 3"); n_slots += descs[e].dim; }
+    DevBuf partial;  // pooled block; returned to the pool at scope exit, reuse is stream ordered
+    partial.reserve((size_t)n_slots * EV_BLOCKS * 24);
+    EvalBatch B; memset(&B, 0, sizeof B);
+    u32 n = 0, slot = 0;
+    auto flush = [&] {
+        if (!n) return;
+        hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS), dim3(256), 0, st, B, n, nbits, (u32)EV_BLOCKS, partial.u());
+        n = 0;
+    };
+    std::vector<u32> slot0(n_ev);
+    for (u32 e = 0; e < n_ev; ++e) {
+        slot0[e] = slot;
+        for (u32 j = 0; j < descs[e].dim; ++j) {              // an extension column = three base-field columns
+            memcpy(&B.d[n], descs + e, sizeof(EvalDescK));
+            B.d[n].offset += j; B.d[n].dim = 1; B.out[n] = slot++;
+            if (++n == (u32)EV_LANES) flush();
+        }
+    }
+    flush();
+    ZK_HIP(hipGetLastError());
+    for (u32 e0 = 0; e0 < n_ev; e0 += 64) {
+        EvalFinalBatch F; memset(&F, 0, sizeof F);
+        const u32 m = std::min<u32>(64, n_ev - e0);
+        for (u32 i = 0; i < m; ++i) { F.slot[i] = slot0[e0 + i]; F.dim[i] = descs[e0 + i].dim; }
+        hipLaunchKernelGGL(evals_final_kernel, dim3(m), dim3(64), 0, st, (const u64*)partial.u(), F, e0, (u32)EV_BLOCKS, d_out);
+    }
+    ZK_HIP(hipGetLastError());
+}
+// the reference's form: every section extended, rows k 2^ext, LEv / LpEv built with shift 49
 void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv,
                u64* d_out, hipStream_t st) {
-    if (n_ev == 0) return;
-    static_assert(sizeof(EvalDescHost) == sizeof(EvalDesc), "descriptor layout");
-    DevBuf desc, partial;  // pooled blocks; returned to the pool at scope exit, reuse is stream ordered
-    desc.reserve(n_ev * sizeof(EvalDesc));
-    partial.reserve((size_t)n_ev * EV_BLOCKS * 24);
-    ZK_HIP(hipMemcpyAsync(desc.p, descs, n_ev * sizeof(EvalDesc), hipMemcpyHostToDevice, st));
-    ZK_HIP(hipStreamSynchronize(st));  // `descs` is caller-owned pageable memory
-    hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS, (n_ev + EV_LANES - 1) / EV_LANES), dim3(256), 0, st, (const EvalDesc*)desc.p, n_ev, nbits, ext,
-                       d_LEv, d_LpEv, partial.u());
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(evals_final_kernel, dim3(n_ev), dim3(64), 0, st, partial.u(), n_ev, (u32)EV_BLOCKS, d_out);
-    ZK_HIP(hipGetLastError());
+    std::vector<EvalDescKHost> k(n_ev);
+    for (u32 e = 0; e < n_ev; ++e) k[e] = EvalDescKHost{descs[e].buf, descs[e].prime ? d_LpEv : d_LEv, descs[e].width, descs[e].offset, descs[e].dim, ext};
+    evals_k_dev(k.data(), n_ev, nbits, d_out, st);
 }
 
 

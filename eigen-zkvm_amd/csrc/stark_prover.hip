@@ -753,6 +753,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     T.mark("transcript");
     run(S.step42ns, true);
     T.mark("calculate_exps_parallel");
+    const u64* d_qq2 = nullptr;                           // the split quotient's coefficients [N][q_dim q_deg] (kept for the evaluations)
     {   // Q split (stark_gen.rs:375-396)
         const u32 q_dim = S.q_dim, q_deg = S.q_deg;
         keep.emplace_back(new DevBuf); DevBuf& qq1 = *keep.back(); qq1.reserve(q_dim * Next * 8);
@@ -762,6 +763,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             keep.emplace_back(new DevBuf); DevBuf& qq2 = *keep.back(); qq2.reserve((u64)q_dim * q_deg * Next * 8);
             ZK_HIP(hipMemsetAsync(qq2.p, 0, (u64)q_dim * q_deg * Next * 8, st));
             qsplit_dev(qq1.u(), nbits, q_dim, q_deg, qq2.u(), st);
+            d_qq2 = qq2.u();
             keep.emplace_back(new DevBuf); DevBuf& tmp4 = *keep.back(); tmp4.reserve((u64)q_dim * q_deg * Next * 8);
             ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
         }
@@ -773,24 +775,45 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     challenge(7);                                                                  // xi
     T.mark("transcript");
     const u64* d_xi = d_chal.u() + 3 * 7;
-    DevBuf LEv, LpEv, lt1, lt2;                                                     // stark_gen.rs:416-430
+    // Evaluations at xi and xi w (stark_gen.rs:416-466).  The reference weighs the rows k 2^ext of the EXTENDED sections with
+    // LEv = ifft(powers of xi / shift).  The same values come from the sections themselves -- p(xi) = sum_k p(w^k) L'[k] with
+    // L' = ifft(powers of xi), the shift-1 instance of the same identity -- and, for the quotient's pieces (which only exist
+    // extended), from their coefficients qq2 and the powers of xi: every read is a contiguous row of an N-row buffer instead of
+    // every other row of a 2N-row one, half the bytes.  Field arithmetic is exact: the evaluations, hence the proof, are the same words.
+    // (cm4_2ns is the plain transform of qq2, i.e. the coset values of the polynomial with coefficients qq2_i / shift^i: its value at
+    // xi is sum_i qq2_i (xi / shift)^i -- the weights of the coefficients are the powers the reference feeds its ifft.)
+    DevBuf LEv, LpEv, pw, pwp, lt1, lt2;
     LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
-    lev_dev(d_xi, nbits, false, LEv.u(), lt1.u(), lt2.u(), st);
-    lev_dev(d_xi, nbits, true, LpEv.u(), lt1.u(), lt2.u(), st);
-    if (n_ev) {                                                                    // stark_gen.rs:432-466
-        std::vector<EvalDescHost> descs;
+    lev_dev(d_xi, nbits, false, 1, LEv.u(), lt1.u(), lt2.u(), st);
+    lev_dev(d_xi, nbits, true, 1, LpEv.u(), lt1.u(), lt2.u(), st);
+    bool q_plain = false, q_prime = false;                // which openings of the quotient's pieces exist
+    for (const JVal& ev : I.at("ev_map").arr)
+        if (ev.at("type_").str() == "cm" && S.pol(S.cm_2ns.at(ev.at("id").u64())).slot == S_CM4_2NS) (ev.at("prime").boolean() ? q_prime : q_plain) = true;
+    if (d_qq2 && q_plain) { pw.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, false, 49, pw.u(), st); }
+    if (d_qq2 && q_prime) { pwp.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, true, 49, pwp.u(), st); }
+    if (n_ev) {
+        std::vector<EvalDescKHost> descs;
         for (const JVal& ev : I.at("ev_map").arr) {
             const std::string& ty = ev.at("type_").str();
-            EvalDescHost d;
-            d.prime = ev.at("prime").boolean() ? 1 : 0;
-            if (ty == "const") { d.buf = ptr[S_CONST_2NS]; d.width = S.n_constants; d.offset = ev.at("id").u64(); d.dim = 1; }
+            const bool prime = ev.at("prime").boolean();
+            EvalDescKHost d; d.rshift = 0; d.L = prime ? LpEv.u() : LEv.u();
+            if (ty == "const") { d.buf = ptr[S_CONST_N]; d.width = S.n_constants; d.offset = ev.at("id").u64(); d.dim = 1; }
             else if (ty == "cm") {
-                const PolRef p = S.pol(S.cm_2ns.at(ev.at("id").u64()));
-                d.buf = ptr[p.slot]; d.width = p.width; d.offset = p.pos; d.dim = p.dim;
+                const u64 id = ev.at("id").u64();
+                const PolRef p2 = S.pol(S.cm_2ns.at(id));
+                if (p2.slot == S_CM4_2NS) {                                        // a piece of the quotient: its coefficients (Q split above)
+                    ZK_REQUIRE(d_qq2 != nullptr, "evaluation of a quotient piece without a split quotient");
+                    d.buf = d_qq2; d.width = p2.width; d.offset = p2.pos; d.dim = p2.dim; d.L = prime ? pwp.u() : pw.u();
+                } else {
+                    ZK_REQUIRE(id < S.cm_n.size(), "ev_map: cm id out of range");
+                    const PolRef p = S.pol(S.cm_n.at(id));                         // the same column before its extension
+                    ZK_REQUIRE(p.dim == p2.dim, "ev_map: section mismatch");
+                    d.buf = ptr[p.slot]; d.width = p.width; d.offset = p.pos; d.dim = p.dim;
+                }
             } else throw Error("Invalid ev type: " + ty);
             descs.push_back(d);
         }
-        evals_dev(descs.data(), n_ev, nbits, ext, LEv.u(), LpEv.u(), d_evals.u(), st);
+        evals_k_dev(descs.data(), n_ev, nbits, d_evals.u(), st);
         tr.put_words_dev(d_evals.u(), 3 * (size_t)n_ev, st);                          // stark_gen.rs:469-472
     }
     T.mark("evals");

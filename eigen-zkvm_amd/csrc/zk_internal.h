@@ -101,7 +101,10 @@ void fri_transpose_dev(const u64* d_pol, uint64_t n, uint32_t tbits, u64* d_out,
 void x_table_dev(uint32_t nbits, u64 shift, u64* d_out, hipStream_t st);
 void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st);
 void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st);
-void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64* d_out, u64* d_tmp, u64* d_tmp2, hipStream_t st);
+struct EvalDescKHost { const u64* buf; const u64* L; uint64_t width; uint64_t offset; uint32_t dim; uint32_t rshift; };   // L: weights per row; rows k << rshift
+void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_out, u64* d_pow, u64* d_tmp2, hipStream_t st);
+void lev_pow_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_pow, hipStream_t st);
+void evals_k_dev(const EvalDescKHost* descs, uint32_t n_ev, uint32_t nbits, u64* d_out, hipStream_t st);
 void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv, u64* d_out, hipStream_t st);
 void pol_get_dev(const u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, u64* d_out, hipStream_t st);
 void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, const u64* d_in, hipStream_t st);
