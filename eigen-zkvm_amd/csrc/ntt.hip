@@ -55,6 +55,8 @@ struct PassParams {
     u32 np;
     u32 log_s;
     u32 has_tw;        // L > R (not the last pass)
+    u32 out_mul;       // last pass only: output row r lands in row r * out_mul + out_off (1, 0 = plain; 2, b = coset b of an extension)
+    u32 out_off;
 };
 
 __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e) {
@@ -157,7 +159,12 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
         if (u >= P.inner) return;
 
         u64* __restrict__ outp = P.out + p * R * P.s_np + rem;
-        const u64 row_q = P.sc_lo ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
+        u64 kstride = P.s_np;                          // words between the outputs kappa and kappa + 1 of a lane
+        const u64 row_q = (P.sc_lo || P.out_mul > 1) ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
+        if (P.out_mul > 1) {                           // rows interleaved with another transform's: row r -> r * out_mul + out_off
+            outp = P.out + ((row_q * P.out_mul + P.out_off) * P.np + (rem - row_q * P.np));
+            kstride = P.s_np * P.out_mul;
+        }
         if (P.tw_mid) {
 #pragma unroll
             for (int g = 0; g < GB; ++g) {
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
 #ifndef ZK_NTT_NOMATH
                     v = gl::mul(v, tw[g][kb]);
 #endif
-                    outp[(u64)(RA * kb + ka) * P.s_np] = v;
+                    outp[(u64)(RA * kb + ka) * kstride] = v;
                 }
             }
             return;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
                     v = gl::mul(v, f);
                     if (kb + 1 < RB) f = gl::mul(f, fstep);
                 }
-                outp[(u64)(RA * kb + ka) * P.s_np] = v;
+                outp[(u64)(RA * kb + ka) * kstride] = v;
             }
         }
     }
@@ -218,7 +225,7 @@ struct ScaleTables { u64 *lo = nullptr, *hi = nullptr; };
 
 std::mutex g_mu;
 std::map<std::pair<int, std::pair<u32, int>>, Tables> g_tables;      // (device,(nbits,inverse))
-std::map<std::pair<int, std::pair<u32, u32>>, ScaleTables> g_scales;  // (device,(nbits,g))
+std::map<std::pair<int, std::pair<u32, u64>>, ScaleTables> g_scales;  // (device,(nbits,g))
 
 u64* upload(const std::vector<u64>& v) {
     u64* d = nullptr;
@@ -273,7 +280,7 @@ Tables get_tables(u32 nbits, bool inverse) {
 ScaleTables get_scale(u32 nbits, u64 g, u64 cst) {  // cst * g^k, k < 2^nbits
     int dev; ZK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    auto key = std::make_pair(dev, std::make_pair(nbits, (u32)g));
+    auto key = std::make_pair(dev, std::make_pair(nbits, g));
     auto it = g_scales.find(key);
     if (it != g_scales.end()) return it->second;
     std::vector<u64> lo, hi;
@@ -325,8 +332,12 @@ std::vector<int> plan(u32 nbits) {
 // bufs.back() = output.  scale: optional (g, cst) output scaling cst*g^row; out_scale: constant.
 struct Scale { bool on = false; u64 g = 1, cst = 1; };
 
+// first_pass / n_run: run only passes [first_pass, first_pass + n_run) of the plan (n_run < 0: all of them); `in` is then the
+// input of pass first_pass and the passes write a / b alternately so that the LAST pass run lands in `a`.  out_mul / out_off:
+// the transform's last pass interleaves its output rows (PassParams).
 void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land in `a` */
-                   u32 n_pols, u32 nbits, u64 valid_rows, bool inverse, Scale sc, u64 out_scale, hipStream_t st) {
+                   u32 n_pols, u32 nbits, u64 valid_rows, bool inverse, Scale sc, u64 out_scale, hipStream_t st,
+                   int first_pass = 0, int n_run = -1, u32 out_mul = 1, u32 out_off = 0) {
     const u64 n = 1ull << nbits;
     if (nbits < 4) {
         u64 w = gl::hroot(nbits);
@@ -346,9 +357,12 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
     if (sc.on) S = get_scale(nbits, sc.g, sc.cst);
     u32 log_s = 0;
     const u64* cur = in;
-    for (int i = 0; i < np; ++i) {
+    const int end_pass = n_run < 0 ? np : first_pass + n_run;
+    ZK_REQUIRE(first_pass >= 0 && end_pass <= np && first_pass <= end_pass, "ntt: pass range");
+    for (int i = 0; i < first_pass; ++i) log_s += radices[i];
+    for (int i = first_pass; i < end_pass; ++i) {
         const int logr = radices[i];
-        u64* dstbuf = ((np - 1 - i) % 2 == 0) ? a : b;
+        u64* dstbuf = ((end_pass - 1 - i) % 2 == 0) ? a : b;
         const bool last = (i == np - 1);
         PassParams P{};
         P.in = cur; P.out = dstbuf;
@@ -369,6 +383,7 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
         P.np = n_pols;
         P.log_s = log_s;
         P.has_tw = last ? 0 : 1;
+        P.out_mul = last ? out_mul : 1; P.out_off = last ? out_off : 0;
         P.dshift = T.dshift;
         P.tw_mid = (!last && log_s >= T.dshift) ? T.mid : nullptr;  // L = N >> log_s <= 2^16
         const bool kmode = P.s_np < 16;
@@ -397,6 +412,40 @@ void lde_dev(const u64* d_src, u64* d_dst, u64* d_tmp, uint32_t n_pols, uint32_t
     if (n_pols == 0) return;  // fft_p.rs:262-264
     ZK_REQUIRE(d_src != d_dst, "lde: dst may not alias src");
     const u64 n = 1ull << nbits;
+    static const bool coset = getenv("ZK_LDE_COSET") != nullptr;
+    if (nbits_ext == nbits + 1 && nbits >= 9 && coset) {
+        // NOT the default -- measured slower (round 3, 2^24 -> 2^25: 18.7 vs 15.2 ms for 19 columns, 32.3 vs 28.5 ms for 36; bit-exact,
+        // tests/test_gpu_parity.py passes with ZK_LDE_COSET=1): the duplicated inverse pass and two 24-level transforms are 80
+        // N-levels of butterflies against the 74 of the plan below, and a pass costs what its butterflies cost.  Kept as the record.
+        // Blow-up 2 (every StarkStruct of the reference): the extension's even rows are the size-N transform of the coefficients
+        // scaled by 49^k, its odd rows the one of the coefficients scaled by (49 w_ext)^k -- the two cosets 49 <w> and 49 w_ext <w>
+        // of 49 <w_ext>.  Two N-point transforms (3 passes at 2^24, the 8-bit kernel) instead of one 2N-point transform over a
+        // half-zero input (4 passes of 6-7 bits over twice the rows): 10 N-pass-equivalents instead of 11, no butterfly on zeros.
+        //   inverse: its last pass runs twice, with the scale tables of g = 49 and g = 49 w_ext  -> c0, c1
+        //   forward: c0 and c1 separately; the last passes write rows 2k and 2k + 1 of dst.
+        // Buffers (N n_pols words each): dst = [D0 | D1], tmp = [T0 | T1].  With m = passes - 1: m even -> c0, c1 live in T0, T1 and
+        // ping-pong with D0, D1 (an even number of steps ends where it began); m odd -> they live in D0, D1 and end in T0, T1.
+        // Either way the last forward passes read tmp and write dst, and the inverse's earlier passes use the other pair.
+        const int np = ntt_num_passes(nbits), m = np - 1;
+        const u64 half = n * n_pols;
+        u64 *D0 = d_dst, *D1 = d_dst + half, *T0 = d_tmp, *T1 = d_tmp + half;
+        u64 *C0 = (m % 2 == 0) ? T0 : D0, *C1 = (m % 2 == 0) ? T1 : D1;          // where the coefficients go
+        u64 *P0 = (m % 2 == 0) ? D0 : T0, *P1 = (m % 2 == 0) ? D1 : T1;          // the other pair
+        const u64 ninv = gl::hinv(n % GL_P), w_ext = gl::hroot(nbits_ext);
+        Scale s0; s0.on = true; s0.g = 49; s0.cst = ninv;
+        Scale s1; s1.on = true; s1.g = gl::hmul(49, w_ext); s1.cst = ninv;
+        const u64* last_in = d_src;
+        if (m > 0) { run_transform(d_src, P0, P1, n_pols, nbits, n, true, Scale{}, 1, st, 0, m); last_in = P0; }   // lands in P0
+        run_transform(last_in, C0, nullptr, n_pols, nbits, n, true, s0, 1, st, m, 1);
+        run_transform(last_in, C1, nullptr, n_pols, nbits, n, true, s1, 1, st, m, 1);
+        if (m > 0) {
+            run_transform(C0, (m % 2 == 0) ? C0 : P0, (m % 2 == 0) ? P0 : C0, n_pols, nbits, n, false, Scale{}, 1, st, 0, m);   // ends in tmp
+            run_transform(C1, (m % 2 == 0) ? C1 : P1, (m % 2 == 0) ? P1 : C1, n_pols, nbits, n, false, Scale{}, 1, st, 0, m);
+        }
+        run_transform(T0, d_dst, nullptr, n_pols, nbits, n, false, Scale{}, 1, st, m, 1, 2, 0);
+        run_transform(T1, d_dst, nullptr, n_pols, nbits, n, false, Scale{}, 1, st, m, 1, 2, 1);
+        return;
+    }
     // coefficients * 49^i / N  (fft_p.rs:144-172): the inverse transform's last pass applies it.
     Scale sc; sc.on = true; sc.g = 49; sc.cst = gl::hinv(n % GL_P);
     const int fwd_passes = ntt_num_passes(nbits_ext);
