@@ -244,6 +244,15 @@ namespace {
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     bn254::g1::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
 }
+#ifdef ZK_MSM_UBENCH
+}  // namespace zk
+// variant builds only (tools/build_variant.sh ... "-DZK_MSM_UBENCH"): msm_impl.cuh's cost probe of batched-affine additions
+extern "C" int zk_msm_ubench_affine(const void* d_bases_std, uint64_t n_lanes, uint32_t K, int mode) {
+    try { zk::bn254::g1half::ubench_affine_dev(d_bases_std, n_lanes, K, mode, nullptr); return 0; }
+    catch (const std::exception& e) { fprintf(stderr, "ubench: %s\n", e.what()); return -1; }
+}
+namespace zk {
+#endif
 void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
     bn254::g1::g1_mul_generator_dev(d_k, n, d_bases, st);
 }

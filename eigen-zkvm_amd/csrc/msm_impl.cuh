@@ -792,6 +792,76 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     ZK_HIP(hipGetLastError());
 }   // the pooled scratch above is released here, stream-ordered: the sum is asynchronous on `st` like every other _dev entry point
 
+#if defined(ZK_MSM_UBENCH) && !defined(MSM_G2) && !defined(MSM_GLV)
+// ---- micro-benchmark (variant builds only, tools/msm_affine_ubench.py): what would batched-affine bucket additions cost?
+// A: the shipped accumulation -- a lane adds K resident affine points into one XYZZ accumulator (pt_madd, 10 products each).
+// B: K independent affine additions P_i + Q_i per lane with ONE inversion for all of them (Montgomery's trick inside the lane):
+//    sweep 1: d_i = x(Q_i) - x(P_i), prefix products kept in a global scratch row; Fermat inversion of the lane's product;
+//    sweep 2, backwards: 1/d_i from the running inverse and the stored prefix, lambda, x3, y3 (2 products + 1 square) --
+//    6 products per addition + 300 / K for the inversion + 36 B written and read per addition for the prefix.
+// Both read their points from a [lane][K] array (the same words), so the loads are the same.  No special cases (the inputs are
+// distinct multiples of G): this measures the arithmetic and the scratch traffic, not a usable kernel.
+__global__ __launch_bounds__(64) void ubench_madd_kernel(const u32* __restrict__ pts, u32 K, xyzz* __restrict__ out) {
+    const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    xyzz acc = pt_inf();
+    for (u32 k = 0; k < K; ++k) acc = pt_madd(acc, load_aff(pts, (u32)(lane * K + k)));
+    out[lane] = acc;
+}
+__global__ __launch_bounds__(64) void ubench_affine_kernel(const u32* __restrict__ pts, u32 K, u32* __restrict__ scratch /* [lanes][K][NR] */,
+                                                           u32* __restrict__ out /* [lanes][K/2][PTW] */) {
+    const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 m = K / 2;                                                  // pairs (2 i, 2 i + 1) of the lane's points
+    u32* __restrict__ sc = scratch + lane * (u64)m * NR;
+    cf run = cf_one();
+    for (u32 i = 0; i < m; ++i) {
+        const aff P = load_aff(pts, (u32)(lane * K + 2 * i)), Q = load_aff(pts, (u32)(lane * K + 2 * i + 1));
+        run = cf_mul(run, cf_sub<2>(Q.x, P.x));
+#pragma unroll
+        for (int l = 0; l < NR; ++l) sc[(u64)i * NR + l] = run.l[l];
+    }
+    cf inv = cf_inv(run);
+    for (u32 i = m; i-- > 0;) {
+        const aff P = load_aff(pts, (u32)(lane * K + 2 * i)), Q = load_aff(pts, (u32)(lane * K + 2 * i + 1));
+        cf pre = cf_one();
+        if (i) {
+#pragma unroll
+            for (int l = 0; l < NR; ++l) pre.l[l] = sc[(u64)(i - 1) * NR + l];
+        }
+        const cf d = cf_sub<2>(Q.x, P.x);
+        const cf inv_d = cf_mul(inv, pre);
+        inv = cf_mul(inv, d);
+        const cf lam = cf_mul(cf_sub<2>(Q.y, P.y), inv_d);
+        const cf x3 = cf_sub<2>(cf_sub<2>(cf_sqr(lam), P.x), Q.x);         // < 6q
+        const cf y3 = cf_sub<2>(cf_mul(lam, cf_sub<8>(P.x, x3)), P.y);      // < 4q
+        u32* o = out + (lane * (u64)m + i) * PTW;
+#pragma unroll
+        for (int l = 0; l < NR; ++l) { o[l] = x3.l[l]; o[NR + l] = y3.l[l]; }
+    }
+}
+// both on `st`; returns nothing: the caller times it.  pts: n_lanes * K converted points (msm_convert_kernel's layout)
+void ubench_affine_dev(const void* d_bases_std, uint64_t n_lanes, uint32_t K, int mode, hipStream_t st) {
+    DevBuf conv, scratch, out;
+    const u64 n = n_lanes * K;
+    conv.reserve((size_t)n * PTW * 4);
+    hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases_std, n, (u32*)conv.p);
+    ZK_HIP(hipStreamSynchronize(st));
+    hipEvent_t a, b; ZK_HIP(hipEventCreate(&a)); ZK_HIP(hipEventCreate(&b));
+    float best = 1e30f;
+    if (mode == 0) out.reserve(n_lanes * sizeof(xyzz));
+    else { scratch.reserve((size_t)n_lanes * (K / 2) * NR * 4); out.reserve((size_t)n_lanes * (K / 2) * PTW * 4); }
+    for (int rep = 0; rep < 3; ++rep) {
+        ZK_HIP(hipEventRecord(a, st));
+        if (mode == 0) hipLaunchKernelGGL(ubench_madd_kernel, dim3((unsigned)(n_lanes / 64)), dim3(64), 0, st, (const u32*)conv.p, K, (xyzz*)out.p);
+        else hipLaunchKernelGGL(ubench_affine_kernel, dim3((unsigned)(n_lanes / 64)), dim3(64), 0, st, (const u32*)conv.p, K, (u32*)scratch.p, (u32*)out.p);
+        ZK_HIP(hipEventRecord(b, st)); ZK_HIP(hipEventSynchronize(b));
+        float ms; ZK_HIP(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    const u64 adds = mode == 0 ? n : n / 2;
+    printf("%s: %llu lanes x K = %u: %.3f ms, %llu additions, %.3f ns per addition (whole device)\n", mode == 0 ? "xyzz madd      " : "batched affine ",
+           (unsigned long long)n_lanes, K, best, (unsigned long long)adds, best * 1e6 / adds);
+    ZK_HIP(hipEventDestroy(a)); ZK_HIP(hipEventDestroy(b));
+}
+#endif
 void msm_preconv_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points); }
 #ifdef MSM_GLV
 // ---- the curve's endomorphism phi(x, y) = (beta x, y) = [lambda](x, y): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128, so a sum
