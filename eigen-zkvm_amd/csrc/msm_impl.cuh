@@ -486,11 +486,13 @@ __global__ __launch_bounds__(256) void balance_scatter_kernel(const u32* __restr
     __syncthreads();
     order[h[c] + rank] = key;
 }
+// FIRST: the buckets start empty; otherwise this launch adds a further chunk of the points to what the buckets hold
+template <bool FIRST>
 __global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restrict__ conv, const u32* __restrict__ offsets,
                                                             const u32* __restrict__ counts, const u32* __restrict__ idx,
                                                             const u32* __restrict__ order, xyzz* __restrict__ buckets) {
     const u32 key = order[blockIdx.x * blockDim.x + threadIdx.x];  // window * 2^16 + digit, heaviest first
-    xyzz acc = pt_inf();
+    xyzz acc = FIRST ? pt_inf() : buckets[key];
     const u32 n = counts[key], off = offsets[key];
 #ifdef ZK_MSM_NO_PREFETCH
     for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(conv, idx[off + k]));
@@ -691,6 +693,14 @@ void msm_fixed_prepare_dev(const void* d_bases, uint64_t n, void* d_table, hipSt
 // d_out: 2*CW_STD + 1 u32 words (x, y Montgomery, infinity flag).  d_table != nullptr: the sum runs over the n points
 // [base_off, base_off + n) of a window table built for table_n points; d_bases is ignored
 // d_preconv != nullptr: n points already in the internal layout (PTW words each); d_bases is ignored
+// one non-blocking stream per device and host thread for the sorts that run beside an accumulation (msm_core)
+static hipStream_t msm_side_stream() {
+    thread_local hipStream_t ss[64] = {};
+    int dev = 0; ZK_HIP(hipGetDevice(&dev));
+    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    if (!ss[dev]) ZK_HIP(hipStreamCreateWithFlags(&ss[dev], hipStreamNonBlocking));
+    return ss[dev];
+}
 static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st,
                      const void* d_preconv = nullptr) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
@@ -703,57 +713,93 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         ZK_HIP(hipGetLastError());
     }
     const u32* points = d_table ? (const u32*)d_table : d_preconv ? (const u32*)d_preconv : (const u32*)conv.p;
-    counts.reserve(n_keys * 4); offsets.reserve(n_keys * 4); cursors.reserve(n_keys * 4); tops.reserve(1024 * 4);
-    idx.reserve((size_t)n * N_WIN * 4);
+    tops.reserve(1024 * 4);
     buckets.reserve(n_keys * sizeof(xyzz));
     S0.reserve((n_keys >> RED_RLOG) * sizeof(xyzz)); A0.reserve((n_keys >> RED_RLOG) * sizeof(xyzz));   // >= N_BUCKET items: the table path's merged / partial arrays fit
     S1.reserve(std::max<size_t>((size_t)C_BITS * 512, n_keys >> (2 * RED_RLOG)) * sizeof(xyzz)); A1.reserve((n_keys >> (2 * RED_RLOG)) * sizeof(xyzz));   // S1 also serves the bit-partial levels (16 x 512 items)
-    const u64 total = n * N_WIN;
-    if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
-        const u32 n_blocks = (u32)((n + SORT_PTS - 1) / SORT_PTS);
-        const size_t n_hist = ((size_t)N_COARSE * n_blocks + 1023) / 1024 * 1024;   // scan granularity
-        DevBuf hist, hist_scanned, coarse;
-        hist.reserve(n_hist * 4); hist_scanned.reserve(n_hist * 4); coarse.reserve(total * 4);
-        tops.reserve(n_hist / 1024 * 4 + 4);
-        ZK_HIP(hipMemsetAsync(hist.p, 0, n_hist * 4, st));
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(256), 0, st, (const u32*)d_scalars, n, n_blocks, (u32*)hist.p);
-        const unsigned nb = (unsigned)(n_hist / 1024);
-        hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)hist.p, (u32*)hist_scanned.p, (u32*)tops.p);
-        hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)hist_scanned.p, (const u32*)tops.p);
+    // The points go through sort -> accumulate in chunks: the sort of chunk c + 1 (memory-bound: two partition passes over its
+    // pairs, 1.6 ms per 2^23 points) runs on a side stream beside the accumulation of chunk c (integer-ALU bound, 5.7 ms), and every
+    // later chunk adds to the buckets the earlier ones left.  One chunk for small sums, for the table path and for the atomic sort.
+    static const int chunks_env = getenv("ZK_MSM_CHUNKS") ? atoi(getenv("ZK_MSM_CHUNKS")) : 4;
+    // (measured, BN254 G1 behind the endomorphism split: 2^22 points 8.80 -> 8.25 ms with 4 chunks, 8.49 with 2, 8.54 with 8; 2^20 points
+    // 2.88 -> 3.38 ms: short sums are the latency of their launch chain, which chunking lengthens)
+    const int n_chunks = (!d_table && n >= (1ull << 23) && n < (1ull << 24) && chunks_env > 1) ? std::min(chunks_env, 8) : 1;
+    const u64 chunk_n = ((n + n_chunks - 1) / n_chunks + 255) / 256 * 256;
+    struct Chunk { DevBuf counts, offsets, order, idx; };
+    std::vector<Chunk> CH(n_chunks);
+    DevBuf hist, hist_scanned, coarse, bal;
+    bal.reserve(BAL_BINS * 4);
+    hipStream_t ss = st;                                   // the stream the sorts run on
+    std::vector<hipEvent_t> ev_sorted;
+    hipEvent_t ev_ready = nullptr;
+    if (n_chunks > 1) {
+        ss = msm_side_stream();
+        on_stream(ss); on_stream(st);                      // the pool orders this thread's frees behind both streams
+        for (int c = 0; c < n_chunks; ++c) { hipEvent_t e; ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_sorted.push_back(e); }
+        ZK_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    }
+    struct EvGuard { std::vector<hipEvent_t>& v; hipEvent_t& r; ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); if (r) (void)hipEventDestroy(r); } } ev_guard{ev_sorted, ev_ready};
+    for (int c = 0; c < n_chunks; ++c) {                   // every buffer exists before the side stream starts: it waits for ONE event of `st`
+        const u64 c0 = (u64)c * chunk_n, nc = c0 < n ? std::min<u64>(chunk_n, n - c0) : 0;
+        CH[c].counts.reserve(n_keys * 4); CH[c].offsets.reserve(n_keys * 4); CH[c].order.reserve(n_keys * 4);
+        CH[c].idx.reserve(std::max<u64>(1, nc) * N_WIN * 4);
+    }
+    if (n < (1ull << 24)) {
+        const u32 nb_max = (u32)((chunk_n + SORT_PTS - 1) / SORT_PTS);
+        const size_t n_hist_max = ((size_t)N_COARSE * nb_max + 1023) / 1024 * 1024;
+        hist.reserve(n_hist_max * 4); hist_scanned.reserve(n_hist_max * 4); coarse.reserve(chunk_n * N_WIN * 4);
+        tops.reserve(n_hist_max / 1024 * 4 + 4);
+    } else cursors.reserve(n_keys * 4);
+    if (n_chunks > 1) { ZK_HIP(hipEventRecord(ev_ready, st)); ZK_HIP(hipStreamWaitEvent(ss, ev_ready, 0)); }   // (the points: converted / split on `st`)
+    for (int c = 0; c < n_chunks; ++c) {
+        const u64 c0 = (u64)c * chunk_n, nc = c0 < n ? std::min<u64>(chunk_n, n - c0) : 0;
+        const u32* sc = (const u32*)d_scalars + c0 * MSM_SC_WORDS;
+        u32 *counts_p = (u32*)CH[c].counts.p, *offsets_p = (u32*)CH[c].offsets.p, *idx_p = (u32*)CH[c].idx.p, *order_p = (u32*)CH[c].order.p;
+        const u64 total = nc * N_WIN;
+        if (nc == 0) { ZK_HIP(hipMemsetAsync(counts_p, 0, n_keys * 4, ss)); ZK_HIP(hipMemsetAsync(offsets_p, 0, n_keys * 4, ss)); }
+        else if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
+            const u32 n_blocks = (u32)((nc + SORT_PTS - 1) / SORT_PTS);
+            const size_t n_hist = ((size_t)N_COARSE * n_blocks + 1023) / 1024 * 1024;   // scan granularity
+            ZK_HIP(hipMemsetAsync(hist.p, 0, n_hist * 4, ss));
+            hipLaunchKernelGGL(sort_hist_kernel, dim3(n_blocks), dim3(256), 0, ss, sc, nc, n_blocks, (u32*)hist.p);
+            const unsigned nb = (unsigned)(n_hist / 1024);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, ss, (const u32*)hist.p, (u32*)hist_scanned.p, (u32*)tops.p);
+            hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, ss, (u32*)tops.p, nb);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, ss, (u32*)hist_scanned.p, (const u32*)tops.p);
+            ZK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(sort_coarse_kernel, dim3(n_blocks), dim3(256), 0, ss, sc, nc, n_blocks, (const u32*)hist_scanned.p, (u32*)coarse.p);
+            // the last coarse bin ends at the number of non-zero pairs: last scanned entry + last count, kept on the device
+            hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(64), 0, ss, (const u32*)hist.p, (const u32*)hist_scanned.p, (u32)(n_hist - 1), (u32*)tops.p);
+            hipLaunchKernelGGL(sort_fine_kernel2, dim3(N_COARSE), dim3(256), 0, ss, (const u32*)coarse.p, (const u32*)hist_scanned.p, n_blocks, (const u32*)tops.p,
+                               counts_p, offsets_p, idx_p, d_table ? (u32)table_n : 0u, d_table ? (u32)base_off : 0u);
+            ZK_HIP(hipGetLastError());
+        } else {
+            ZK_HIP(hipMemsetAsync(counts_p, 0, n_keys * 4, ss));
+            ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, ss));
+            const unsigned gb = (unsigned)((total + 255) / 256);
+            hipLaunchKernelGGL(msm_count_kernel, dim3(gb), dim3(256), 0, ss, sc, nc, counts_p);
+            ZK_HIP(hipGetLastError());
+            const unsigned nb = (unsigned)(n_keys / 1024);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, ss, (const u32*)counts_p, offsets_p, (u32*)tops.p);
+            hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, ss, (u32*)tops.p, nb);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, ss, offsets_p, (const u32*)tops.p);
+            ZK_HIP(hipGetLastError());
+            hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, ss, sc, nc, (const u32*)offsets_p, (u32*)cursors.p, idx_p);
+            ZK_HIP(hipGetLastError());
+        }
+        ZK_HIP(hipMemsetAsync(bal.p, 0, BAL_BINS * 4, ss));
+        hipLaunchKernelGGL(balance_hist_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, ss, (const u32*)counts_p, (u32*)bal.p);
+        hipLaunchKernelGGL(balance_scan_kernel, dim3(1), dim3(64), 0, ss, (u32*)bal.p);
+        hipLaunchKernelGGL(balance_scatter_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, ss, (const u32*)counts_p, (u32*)bal.p, order_p);
         ZK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(sort_coarse_kernel, dim3(n_blocks), dim3(256), 0, st, (const u32*)d_scalars, n, n_blocks, (const u32*)hist_scanned.p, (u32*)coarse.p);
-        // the last coarse bin ends at the number of non-zero pairs: last scanned entry + last count, kept on the device
-        hipLaunchKernelGGL(sort_total_kernel, dim3(1), dim3(64), 0, st, (const u32*)hist.p, (const u32*)hist_scanned.p, (u32)(n_hist - 1), (u32*)tops.p);
-        hipLaunchKernelGGL(sort_fine_kernel2, dim3(N_COARSE), dim3(256), 0, st, (const u32*)coarse.p, (const u32*)hist_scanned.p, n_blocks, (const u32*)tops.p,
-                           (u32*)counts.p, (u32*)offsets.p, (u32*)idx.p, d_table ? (u32)table_n : 0u, d_table ? (u32)base_off : 0u);
-        ZK_HIP(hipGetLastError());
-        // hist / coarse go back to the pool at scope exit: the pool orders their next use behind this stream (capi.hip pool_free)
-    } else {
-        ZK_HIP(hipMemsetAsync(counts.p, 0, n_keys * 4, st));
-        ZK_HIP(hipMemsetAsync(cursors.p, 0, n_keys * 4, st));
-        const unsigned gb = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(msm_count_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (u32*)counts.p);
-        ZK_HIP(hipGetLastError());
-        const unsigned nb = (unsigned)(n_keys / 1024);
-        hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(256), 0, st, (const u32*)counts.p, (u32*)offsets.p, (u32*)tops.p);
-        hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(64), 0, st, (u32*)tops.p, nb);
-        hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(256), 0, st, (u32*)offsets.p, (const u32*)tops.p);
-        ZK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, (const u32*)d_scalars, n, (const u32*)offsets.p,
-                           (u32*)cursors.p, (u32*)idx.p);
+        if (n_chunks > 1) { ZK_HIP(hipEventRecord(ev_sorted[c], ss)); ZK_HIP(hipStreamWaitEvent(st, ev_sorted[c], 0)); }
+        const u32* pts_c = points + (d_table ? 0 : c0 * PTW);             // (chunk-relative indices; the table path has one chunk)
+        if (c == 0) hipLaunchKernelGGL((msm_accumulate_kernel<true>), dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, pts_c,
+                                       (const u32*)offsets_p, (const u32*)counts_p, (const u32*)idx_p, (const u32*)order_p, (xyzz*)buckets.p);
+        else hipLaunchKernelGGL((msm_accumulate_kernel<false>), dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, pts_c,
+                                (const u32*)offsets_p, (const u32*)counts_p, (const u32*)idx_p, (const u32*)order_p, (xyzz*)buckets.p);
         ZK_HIP(hipGetLastError());
     }
-    DevBuf bal, order;
-    bal.reserve(BAL_BINS * 4); order.reserve(n_keys * 4);
-    ZK_HIP(hipMemsetAsync(bal.p, 0, BAL_BINS * 4, st));
-    hipLaunchKernelGGL(balance_hist_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, st, (const u32*)counts.p, (u32*)bal.p);
-    hipLaunchKernelGGL(balance_scan_kernel, dim3(1), dim3(64), 0, st, (u32*)bal.p);
-    hipLaunchKernelGGL(balance_scatter_kernel, dim3((unsigned)(n_keys / 256)), dim3(256), 0, st, (const u32*)counts.p, (u32*)bal.p, (u32*)order.p);
-    ZK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((unsigned)(n_keys / 64)), dim3(64), 0, st, points,
-                       (const u32*)offsets.p, (const u32*)counts.p, (const u32*)idx.p, (const u32*)order.p, (xyzz*)buckets.p);
-    ZK_HIP(hipGetLastError());
     if (d_table) {   // equal window weights: merge, 16 bit-partial tree sums, 16-step Horner
         xyzz* merged = (xyzz*)S0.p;                       // N_BUCKET items fit: S0 holds n_keys / 16 = N_BUCKET
         xyzz* pa = (xyzz*)A0.p; xyzz* pb = (xyzz*)S1.p;   // 16 * 4096 = N_BUCKET items, then 1/8 of it per level
