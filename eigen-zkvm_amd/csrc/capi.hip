@@ -168,7 +168,10 @@ void forget_stream(hipStream_t st) {                                  // before 
 namespace {
 
 std::mutex g_ws_mu;
-DevBuf g_ws_a, g_ws_b, g_ws_c;  // grow-only staging for the host-pointer API
+// grow-only staging for the host-pointer API.  Never destroyed: a static DevBuf would go back to the pool from a static
+// destructor, after the main thread's thread_local stream list is gone and possibly after the HIP runtime's own teardown
+// (a process that still had a registered side stream at exit crashed there).
+DevBuf &g_ws_a = *new DevBuf, &g_ws_b = *new DevBuf, &g_ws_c = *new DevBuf;
 
 template <class F>
 int guard(F&& f) {
