@@ -30,7 +30,7 @@ EXPORTS = [
     "zk_transcript_free",
     "zk_fri_fold_dev", "zk_fri_transpose_dev", "zk_stark_x_table_dev", "zk_stark_zh_inv_dev",
     "zk_stark_xdivxsub_dev", "zk_stark_lev_dev", "zk_stark_evals_dev", "zk_stark_qsplit_dev",
-    "zk_stream_new", "zk_stream_sync", "zk_stream_free", "zk_program_compile", "zk_program_source", "zk_program_run_dev", "zk_program_run_rows_dev", "zk_program_free",
+    "zk_stream_new", "zk_stream_sync", "zk_stream_free", "zk_program_compile", "zk_program_source", "zk_jit_cache_stats", "zk_program_run_dev", "zk_program_run_rows_dev", "zk_program_free",
     "zk_stark_get_pol_dev", "zk_stark_set_pol_dev", "zk_stark_calculate_h1h2_dev", "zk_stark_calculate_z_dev",
     "zk_msm_g1_bn254", "zk_msm_g1_bn254_dev", "zk_g1_bn254_mul_generator_dev",
     "zk_msm_g1_bls12_381", "zk_msm_g1_bls12_381_dev", "zk_g1_bls12_381_mul_generator_dev",
@@ -236,6 +236,7 @@ def _load():
         "zk_g2_bls12_381_mul_generator_dev": (C.c_int, [vp, C.c_uint64, vp, vp]),
         "zk_program_compile": (vp, [C.POINTER(Instr), C.c_uint32]),
         "zk_program_source": (C.c_char_p, [vp]),
+        "zk_jit_cache_stats": (None, [vp]),
         "zk_stream_new": (vp, []), "zk_stream_sync": (C.c_int, [vp]), "zk_stream_free": (C.c_int, [vp]),
         "zk_program_run_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, vp]),
         "zk_program_run_rows_dev": (C.c_int, [vp, C.POINTER(EvalCtx), C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, vp]),

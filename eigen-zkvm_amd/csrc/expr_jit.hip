@@ -538,6 +538,11 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
 
 const char* zk_program_source(const zk_program_t* p) { return p ? p->source.c_str() : ""; }
 
+void zk_jit_cache_stats(uint64_t out[3]) {
+    const JitStats j = jit_stats();
+    out[0] = j.compiled; out[1] = j.disk_hits; out[2] = j.mem_hits;
+}
+
 int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, void* stream) {
     return zk_program_run_rows_dev(p, ctx, nbits_domain, next, 0, nbits_domain <= 32 ? 1ull << nbits_domain : 0, stream);
 }

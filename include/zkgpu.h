@@ -406,6 +406,9 @@ typedef struct {
 typedef struct zk_program zk_program_t;
 zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr);    /* needs no GPU */
 const char* zk_program_source(const zk_program_t* p);                         /* generated HIP text */
+/* what the code-object cache of the step kernels did so far in this process: out = {compiled by hipRTC, taken from
+ * $ZK_JIT_CACHE (default ~/.cache/zkgpu; "off" disables), taken from memory} */
+void zk_jit_cache_stats(uint64_t out[3]);
 int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, void* stream);
 /* The same for rows row0 .. row0 + count - 1 only (the domain is still 2^nbits_domain rows: primed reads wrap around it).
  * calculate_exp_at_point (stark_gen.rs:558-572) is this with count = 1: a public calculator is evaluated at its one row. */

@@ -362,37 +362,37 @@ def test_wide_sections_match_reference_interpreter(zk, orc, w_cm1, w_const, nbit
 
 
 _JIT_PROBE = r'''
-import sys, time, pathlib
+import sys, pathlib
+import numpy as np
 ROOT = pathlib.Path(sys.argv[1]); sys.path.insert(0, str(ROOT / "tests"))
 import zkgpu_loader, test_program as TP
 zk = zkgpu_loader.load()
-t0 = time.perf_counter(); p = TP._compile(zk, TP._fib_like_program()); t1 = time.perf_counter()
-q = TP._compile(zk, TP._fib_like_program()); t2 = time.perf_counter()          # same text: the in-process cache
+def stats():
+    o = np.zeros(3, np.uint64); zk.lib().zk_jit_cache_stats(o.ctypes.data); return [int(v) for v in o]
+p = TP._compile(zk, TP._fib_like_program()); a = stats()
+q = TP._compile(zk, TP._fib_like_program()); b = stats()          # same text: the in-process cache
 assert p.source == q.source
-print("first %.3f second %.3f" % (t1 - t0, t2 - t1))
+print("first", *a, "second", *b)
 '''
 
 
 def test_code_objects_are_cached_in_the_process_and_on_disk(tmp_path):
     """csrc/expr_jit.hip compile_cached: a step program is compiled by hipRTC once per text -- the second compilation in a process
     comes from memory, the first one of the next process from $ZK_JIT_CACHE/<sha256>.co; a damaged file is recompiled and replaced;
-    ZK_JIT_CACHE=off writes nothing.  (Compiling needs no GPU.)"""
+    ZK_JIT_CACHE=off writes nothing.  (Compiling needs no GPU.)  Counted by zk_jit_cache_stats: {hipRTC, disk, memory}."""
     import os, subprocess, sys
     cache = tmp_path / "jit"
     def run(env_cache):
         env = dict(os.environ, ZK_JIT_CACHE=str(env_cache))
         r = subprocess.run([sys.executable, "-c", _JIT_PROBE, str(ROOT)], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
-        first, second = (float(x) for x in r.stdout.split()[1::2])
-        return first, second
-    f1, s1 = run(cache)
+        w = r.stdout.split()
+        return [int(x) for x in w[1:4]], [int(x) for x in w[5:8]]
+    assert run(cache) == ([1, 0, 0], [1, 0, 1])                         # compiled once, then from memory
     files = sorted(cache.glob("*.co"))
     assert len(files) == 1 and len(files[0].stem) == 64 and files[0].read_bytes()[:4] == b"\x7fELF"
-    assert s1 < f1 / 5, (f1, s1)                                       # memory hit: no hipRTC
-    f2, _ = run(cache)
-    assert f2 < f1 / 5, (f1, f2)                                       # disk hit in a fresh process
-    files[0].write_bytes(b"not a code object")                        # damaged: compiled again, file replaced
-    f3, _ = run(cache)
-    assert f3 > f2 * 3 and files[0].read_bytes()[:4] == b"\x7fELF", (f2, f3)
-    f4, _ = run("off")
-    assert f4 > f2 * 3 and len(list(cache.glob("*"))) == 1
+    good = files[0].read_bytes()
+    assert run(cache) == ([0, 1, 0], [0, 1, 1])                         # a fresh process: from disk
+    files[0].write_bytes(b"not a code object")                         # damaged: compiled again, file replaced
+    assert run(cache) == ([1, 0, 0], [1, 0, 1]) and files[0].read_bytes() == good
+    assert run("off") == ([1, 0, 0], [1, 0, 1]) and len(list(cache.glob("*"))) == 1
