@@ -29,15 +29,14 @@ namespace {
 constexpr int T_C0 = 0;              // C[0..12): added before round 0
 constexpr int T_FC = 12;             // [8][12]: constants added after the S-box of full round R (round 7: zeros)
 constexpr int T_PC = T_FC + 96;      // [22] partial-round constants (+2 pad)
-constexpr int T_SC = T_PC + 24;      // [22][11]: S[23r + 12 .. 23r + 22], the column applied to st[1..11]
-constexpr int T_PT = T_SC + 242;     // [12 i][12 j] split: P[j][i]
+constexpr int T_PT = T_PC + 24;      // [12 i][12 j] split: P[j][i]
 constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
-constexpr int T_SRR = T_SR + 528;    // [22][16] whole words: S[23r + l] for lane l < 12 of a cooperative permutation, 0 for its four idle lanes
-constexpr int T_DD = T_SRR + 352;    // [2 blocks][m (m - 1) / 2 + i] split: D[r][r0 + i], r = r0 + m (partial rounds, below)
+constexpr int T_DD = T_SR + 528;     // [2 blocks][m (m - 1) / 2 + i] split: D[r][r0 + i], r = r0 + m (partial rounds, below)
 constexpr int T_SCS = T_DD + 220;    // [2 blocks][11 k][11 m] split: S[23 (r0 + m) + 12 + k], the column entries regrouped by state word
-constexpr int T_WORDS = T_SCS + 484; // 2246 words = 18 KB
+constexpr int T_CD = T_SCS + 484;    // [2 blocks][11 m][16 l] split: what u_(r0 + m) weighs in lane l of a cooperative permutation (coop_partial_rounds)
+constexpr int T_WORDS = T_CD + 704;  // 2356 words = 18.4 KB
 constexpr int PR_B = 11;             // partial rounds per block
-static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0, "split constants are read as 16-byte pairs");
+static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0 && T_CD % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
 
@@ -225,46 +224,53 @@ __device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12])
         x1[j] = (u32)__shfl((int)(u32)(x >> 32), j, 16);
     }
 }
-// Partial rounds without the LDS crossbar.  A group is one 16-lane DPP row: lane 0's S-box output reaches the row by
-// three DPP moves, every lane multiplies its own word by its entry of the sparse row (idle lanes: entry 0), and the
-// twelve 128-bit products are summed towards lane 0 by four shifted row additions on five 32-bit limbs -- instead of
-// every lane gathering all twelve words (24 ds_bpermute) and computing the whole dot product itself (72 multiply-adds).
 __device__ __forceinline__ u32 dpp_opaque(u32 v) { asm volatile("" : "+v"(v)); return v; }   // keeps the DPP moves where they are written (section 3.9)
-__device__ __forceinline__ u32 row_bcast0(u32 v) {
-    v = dpp_opaque(v);
-    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x00, 0xF, 0xF, false);     // quad_perm [0,0,0,0]
-    v = dpp_opaque(v);
-    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xF, 0x2, false);    // row_shr:4, lanes 4..7 only
-    v = dpp_opaque(v);
-    v = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xF, 0xC, false);    // row_shr:8, lanes 8..15 only
-    return dpp_opaque(v);
+// x^7 + c where the two lanes of a pair hold the same x: the even lane takes x^3 = x^2 x, the odd one x^4 = x^2 x^2, each fetches the
+// other's (one DPP move per half) and both end with x^3 x^4 + c -- three dependent products where pow7_add has four.  The words of
+// a product are the digits of the exact integer, so both lanes hold the same bits.
+__device__ __forceinline__ u64 pow7_add_pair(u64 x, u64 c, bool odd) {
+    const u64 x2 = gl::mul_nc(x, x);
+    const u64 y = gl::mul_nc(x2, odd ? x2 : x);
+    const u32 y0 = dpp_opaque((u32)y), y1 = dpp_opaque((u32)(y >> 32));
+    const u32 z0 = dpp_opaque((u32)__builtin_amdgcn_update_dpp((int)y0, (int)y0, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    const u32 z1 = dpp_opaque((u32)__builtin_amdgcn_update_dpp((int)y1, (int)y1, 0xB1, 0xF, 0xF, false));
+    return gl::mul_add_nc(y, gl::mk64(z0, z1), c);
 }
-// s[lane] += s[lane + N] within the row (nothing beyond lane 15), five limbs with carry: the shifted operand rides on the
-// additions' DPP modifier.  A DPP operand written by the instruction just before needs two wait states: the leading s_nop.
-#define ZK_ROW_ADD_SHL(N)                                                                                      \
-    asm volatile("s_nop 1\n\t"                                                                                 \
-                 "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"       \
-                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-                 "v_addc_co_u32_dpp %2, vcc, %2, %2, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-                 "v_addc_co_u32_dpp %4, vcc, %4, %4, vcc row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"       \
-                 : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]) : : "vcc")
-// sum over the row of coef * a, as an nc word; meaningful in lane 0 of the row
-__device__ __forceinline__ u64 row_dot(u64 coef, u64 a) {
-    GL_OPAQUE(coef); GL_OPAQUE(a);
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)coef, b1 = (u32)(coef >> 32);
-    const u64 p0 = (u64)a0 * b0;
-    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
-    const u64 p2 = (u64)a1 * b0 + (u32)p1;
-    const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
-    u32 s[5] = {(u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32), 0u};
-    ZK_ROW_ADD_SHL(8); ZK_ROW_ADD_SHL(4); ZK_ROW_ADD_SHL(2); ZK_ROW_ADD_SHL(1);
-    // s0 + s1 2^32 + s2 2^64 + s3 2^96 + s4 2^128, and 2^128 = -2^32 (mod p): reduce four limbs, take s4 2^32 off
-    const u64 t = gl::reduce_words_nc(s[0], s[1], s[2], s[3]), b = (u64)s[4] << 32;
-    const u64 d = t - b;
-    return t < b ? d - GL_EPS : d;                                     // wrapped below zero: + p = - (2^32 - 1) mod 2^64, cannot wrap again
+// The 22 partial rounds of a cooperative permutation, in the two lazy blocks of partial_rounds() with the rounds of a block spread
+// over the lanes: lane m < 11 keeps the accumulator of st[0] after round r0 + m,
+//     sum_k S_r[k] s_k  (on entry, s = the block's first state)  +  sum_{i < m} D[r][r0 + i] u_i  +  S_r[0] u_m,
+// every lane computes every S-box (the same s0 everywhere: nothing to broadcast before it), adds its own multiple of u_m (T_CD)
+// and recombines; lane m's result is the next s0 and reaches the row through the LDS crossbar.  At the block's end lane k >= 1
+// adds sum_m SC_m[k] u_m to its own word.  Per round: one S-box of three products, six multiply-adds, one recombination and
+// one exchange -- the round-by-round form had the S-box of four, two broadcasts, a 128-bit row reduction and a product per lane.
+__device__ __forceinline__ u64 coop_partial_rounds(u64 x, const u64* __restrict__ tab, int l) {
+    const int lm = l < PR_B ? l : PR_B - 1;            // lanes 11..15: a copy of lane 10's accumulator, never read
+    const int lk = l >= 1 && l < 12 ? l : 1;           // the state word this lane updates (lane 0 takes s0, lanes 12..15 carry garbage)
+    const bool odd = l & 1;
+#pragma unroll 1
+    for (int b = 0; b < 22 / PR_B; ++b) {
+        u32 x0[12], x1[12];
+        coop_gather(x, x0, x1);
+        Acc6 A; acc_zero(A);
+        acc_dot<11>(A, tab + T_SR + 24 * (PR_B * b + lm) + 2, [&](int k, u32& a, u32& c) { a = x0[k + 1]; c = x1[k + 1]; });
+        u64 s0 = gl::mk64(x0[0], x1[0]);
+        const u64* __restrict__ CD = tab + T_CD + 2 * (16 * PR_B * b + l);
+        const u64* __restrict__ PC = tab + T_PC + PR_B * b;
+        u32 u0[PR_B], u1[PR_B];
+        static_for<0, PR_B>([&](auto MI) {
+            constexpr int m = decltype(MI)::value;
+            const u64 u = pow7_add_pair(s0, PC[m], odd);
+            u0[m] = (u32)u; u1[m] = (u32)(u >> 32);
+            acc_mac(A, CD + 32 * m, u0[m], u1[m]);
+            s0 = shfl64(acc_finish(A), m);
+        });
+        Acc6 E; acc_word(E, x);
+        acc_dot<PR_B>(E, tab + T_SCS + 2 * (11 * PR_B * b + PR_B * (lk - 1)), [&](int m, u32& a, u32& c) { a = u0[m]; c = u1[m]; });
+        const u64 e = acc_finish(E);
+        x = l == 0 ? s0 : e;
+    }
+    return x;
 }
-#undef ZK_ROW_ADD_SHL
 
 // x = this lane's state word (lanes 12..15 of a group carry garbage and only serve the shuffles)
 __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
@@ -279,14 +285,7 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
             coop_gather(x, x0, x1);
             x = dot12(tab + T_PT + 24 * lc, x0, x1);
         }
-#pragma unroll 1
-        for (int r = 0; r < 22; ++r) {
-            const u64 t = pow7_add(x, tab[T_PC + r]);
-            const u64 st0 = gl::mk64(row_bcast0((u32)t), row_bcast0((u32)(t >> 32)));   // lane 0's S-box, to its row
-            const u64 s0 = row_dot(tab[T_SRR + 16 * r + l], l == 0 ? st0 : x);         // lane 0: the new st[0]
-            const u64 rest = gl::mul_add_nc(tab[T_SC + 11 * r + (lc > 0 ? lc - 1 : 0)], st0, x);
-            x = l == 0 ? s0 : rest;
-        }
+        x = coop_partial_rounds(x, tab, l);
     }
     return x;
 }
@@ -682,8 +681,6 @@ void ensure_constants() {
         for (int j = 0; j < 12; ++j) split(T_PT + 2 * (12 * i + j), ZK_POSEIDON_P[12 * j + i]);
     for (int r = 0; r < 22; ++r) {
         for (int j = 0; j < 12; ++j) split(T_SR + 2 * (12 * r + j), ZK_POSEIDON_S[23 * r + j]);
-        for (int k = 1; k < 12; ++k) tab[T_SC + 11 * r + k - 1] = ZK_POSEIDON_S[23 * r + 11 + k];
-        for (int j = 0; j < 12; ++j) tab[T_SRR + 16 * r + j] = ZK_POSEIDON_S[23 * r + j];
     }
     for (int b = 0; b < 22 / PR_B; ++b)                  // tables of partial_rounds()
         for (int m = 0; m < PR_B; ++m) {
@@ -695,7 +692,9 @@ void ensure_constants() {
                     d = d + t >= GL_P || d + t < d ? d + t - GL_P : d + t;
                 }
                 split(T_DD + 2 * ((PR_B * (PR_B - 1) / 2) * b + m * (m - 1) / 2 + i), d);
+                split(T_CD + 2 * (16 * (PR_B * b + i) + m), d);      // round r0 + i's S-box output, in lane m > i
             }
+            split(T_CD + 2 * (16 * r + m), ZK_POSEIDON_S[23 * r]);   // ... and in lane m of its own round: S_r[0]
             for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
         }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));

@@ -14,3 +14,8 @@ for _ in range(3): P.prove([inp], 0)
 P.sync(); t0 = time.perf_counter()
 for _ in range(n): P.prove([inp], 0)
 P.sync(); print(f"{kind}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms per proof", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "timing":                         # the library's own stage report of one more proof
+    import os
+    os.environ["ZK_STARK_TIMING"] = "1"
+    P.prove([inp], 0); P.sync()
+    print(json.dumps(P.sets[0][kind].last_timing()), flush=True)
