@@ -12,6 +12,11 @@ using gl::add_word;
 struct Acc6 { u64 a00, a10, a20, a01, a11, a21; };   // a[i][h]: limb i of the constants x half h of the words
 __device__ __forceinline__ void acc_zero(Acc6& A) { A.a00 = A.a10 = A.a20 = A.a01 = A.a11 = A.a21 = 0; }
 __device__ __forceinline__ void acc_word(Acc6& A, u64 s) { A.a00 = (u32)s; A.a01 = s >> 32; A.a10 = A.a20 = A.a11 = A.a21 = 0; }   // 1 * s
+__device__ __forceinline__ void acc_mac(Acc6& A, const ulonglong2 v /* a split constant */, u32 x0, u32 x1) {
+    const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;
+    A.a00 += (u64)l0 * x0; A.a10 += (u64)l1 * x0; A.a20 += (u64)l2 * x0;
+    A.a01 += (u64)l0 * x1; A.a11 += (u64)l1 * x1; A.a21 += (u64)l2 * x1;
+}
 __device__ __forceinline__ void acc_mac(Acc6& A, const u64* __restrict__ c /* LDS, 2 words */, u32 x0, u32 x1) {
     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(c);
     const u32 l0 = (u32)v.x, l1 = (u32)(v.x >> 32), l2 = (u32)v.y;

@@ -257,12 +257,19 @@ __device__ __forceinline__ u64 coop_partial_rounds(u64 x, const u64* __restrict_
         const u64* __restrict__ CD = tab + T_CD + 2 * (16 * PR_B * b + l);
         const u64* __restrict__ PC = tab + T_PC + PR_B * b;
         u32 u0[PR_B], u1[PR_B];
+        // a round's two constants are requested a round ahead, in front of the recombination and the exchange that end the previous round (left to
+        // itself the compiler reads them where they are used and the LDS latency stands in the open twice per round)
+        ulonglong2 cd = *reinterpret_cast<const ulonglong2*>(CD);
+        u64 pc = PC[0];
         static_for<0, PR_B>([&](auto MI) {
             constexpr int m = decltype(MI)::value;
-            const u64 u = pow7_add_pair(s0, PC[m], odd);
+            const u64 u = pow7_add_pair(s0, pc, odd);
             u0[m] = (u32)u; u1[m] = (u32)(u >> 32);
-            acc_mac(A, CD + 32 * m, u0[m], u1[m]);
+            acc_mac(A, cd, u0[m], u1[m]);
+            if constexpr (m + 1 < PR_B) { cd = *reinterpret_cast<const ulonglong2*>(CD + 32 * (m + 1)); pc = PC[m + 1]; }
+            __builtin_amdgcn_sched_barrier(0);
             s0 = shfl64(acc_finish(A), m);
+            __builtin_amdgcn_sched_barrier(0);
         });
         Acc6 E; acc_word(E, x);
         acc_dot<PR_B>(E, tab + T_SCS + 2 * (11 * PR_B * b + PR_B * (lk - 1)), [&](int m, u32& a, u32& c) { a = u0[m]; c = u1[m]; });
