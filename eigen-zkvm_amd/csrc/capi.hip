@@ -2,6 +2,7 @@
 // staging for the host-pointer entry points, and the Merkle tree handle.
 #include "zk_internal.h"
 #include "../../include/zkgpu.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -37,7 +38,17 @@ hipEvent_t event_get() {                     // g_pool_mu held; never throws (De
 }
 }
 hipStream_t cur_stream() { return t_stream; }
-CallScope::CallScope() : saved(t_stream) { if (t_depth++ == 0) t_stream = nullptr; }   // a call from outside starts on the null stream,
+// The GPU of the process (zk_init).  HIP's current device is a property of the host thread and every new thread starts on device 0,
+// so a prover thread of rank k > 0 would otherwise allocate and launch on GPU 0: each thread is bound on its first call.
+static std::atomic<int> g_device{-1};          // -1: zk_init was never called, threads are left as the caller set them up
+static thread_local int t_device = -1;
+void bind_device() noexcept {
+    const int d = g_device.load(std::memory_order_relaxed);
+    if (d < 0 || t_device == d) return;
+    if (hipSetDevice(d) == hipSuccess) t_device = d;
+    else (void)hipGetLastError();              // the work that follows reports its own error
+}
+CallScope::CallScope() : saved(t_stream) { if (t_depth++ == 0) { t_stream = nullptr; bind_device(); } }   // a call from outside starts on the null stream,
 CallScope::~CallScope() { --t_depth; t_stream = saved; }                                // one made by the prover inherits the prover's
 hipStream_t on_stream(hipStream_t st) {
     t_stream = st;
@@ -267,7 +278,16 @@ static uint32_t tree_depth(uint64_t height) {
 
 extern "C" {
 
-int zk_init(int device) { return guard([&] { ZK_HIP(hipSetDevice(device)); }); }
+int zk_init(int device) {
+    return guard([&] {
+        int n = 0;
+        ZK_HIP(hipGetDeviceCount(&n));
+        ZK_REQUIRE(device >= 0 && device < n, "zk_init: no such device");
+        ZK_HIP(hipSetDevice(device));
+        g_device.store(device, std::memory_order_relaxed);   // ... and of every thread that calls into the library from now on
+        t_device = device;
+    });
+}
 const char* zk_last_error(void) { return t_err.c_str(); }
 int zk_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 uint64_t zk_gl_modulus(void) { return GL_P; }

@@ -479,6 +479,7 @@ extern "C" {
 
 zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
     zk_program_t* p = nullptr;
+    bind_device();
     try {
         ZK_REQUIRE(code || n_instr == 0, "zk_program_compile: null code");
         p = new zk_program();
@@ -549,6 +550,7 @@ int zk_program_run_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_d
 
 int zk_program_run_rows_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nbits_domain, uint64_t next, uint64_t row0, uint64_t count,
                             void* stream) {
+    bind_device();
     try {
         ZK_REQUIRE(p && ctx, "zk_program_run_dev: null");
         ZK_REQUIRE(nbits_domain <= 32, "zk_program_run_dev: domain too large");
@@ -576,6 +578,7 @@ int zk_program_run_rows_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nb
 }
 
 int zk_program_free(zk_program_t* p) {
+    bind_device();
     if (p && p->d_pow) (void)hipFree(p->d_pow);
     if (p && p->module) (void)hipModuleUnload(p->module);
     delete p;

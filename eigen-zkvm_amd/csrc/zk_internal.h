@@ -49,6 +49,7 @@ hipStream_t on_stream(hipStream_t st);
 hipStream_t cur_stream();
 // Scope of one C-ABI call: a call from outside the library starts on the null stream, a call the prover makes on its own
 // entry points inherits the prover's current stream; either way the caller's current stream is back when the call returns.
+void bind_device() noexcept;           // the calling thread onto the GPU zk_init selected (HIP's current device is per thread)
 struct CallScope { hipStream_t saved; CallScope(); ~CallScope(); CallScope(const CallScope&) = delete; CallScope& operator=(const CallScope&) = delete; };
 void forget_stream(hipStream_t st);  // call before destroying a registered stream
 

@@ -14,7 +14,9 @@
  *   - `*_dev` variants take DEVICE pointers (HBM-resident data) and a hipStream_t passed as
  *     void*; they enqueue work and return without synchronising.  The plain variants take HOST
  *     pointers, copy in/out and synchronise (drop-in for the reference's Vec<FGL> arguments).
- *   - a process drives one GPU (hipSetDevice via zk_init); handles are not re-entrant.
+ *   - a process drives one GPU, the one zk_init names: every host thread that calls into the library afterwards is
+ *     bound to it on its first call (HIP's current device is per thread and a new thread starts on device 0).
+ *     Without zk_init the threads stay on whatever device the caller gave them.  Handles are not re-entrant.
  */
 #ifndef ZKGPU_H
 #define ZKGPU_H
@@ -25,7 +27,7 @@ extern "C" {
 #endif
 
 /* ---- runtime ---------------------------------------------------------------------------- */
-int zk_init(int device);            /* select the GPU this process proves on (default 0)      */
+int zk_init(int device);            /* select the GPU this process, all its threads, proves on  */
 const char* zk_last_error(void);    /* message of the last failing call on this thread        */
 int zk_device_count(void);          /* number of visible GPUs, <= 0 when none                  */
 uint64_t zk_gl_modulus(void);       /* 0xFFFFFFFF00000001 (fields/src/field_gl.rs:12)          */

@@ -82,3 +82,35 @@ def test_coset_form_of_the_extension_is_bit_exact():
     env = dict(os.environ, ZK_LDE_COSET="1")
     r = subprocess.run([sys.executable, "-c", _COSET, str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "coset lde ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_threads_prove_on_the_device_of_zk_init(zk):
+    """HIP's current device belongs to the host thread and a new thread starts on device 0: after zk_init(d) every thread that
+    calls into the library is bound to d (csrc/capi.hip bind_device) -- the prover threads of rank k > 0 must not land on GPU 0.
+    One GPU here: the binding is exercised (a fresh thread allocates, transforms, hashes and frees), a device that does not
+    exist is refused and leaves the binding alone."""
+    import threading
+    zk.init(0)
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, P, size=1 << 12, dtype=np.uint64)
+    want = zk.fft(x, 1, 12)
+    def root_of(v):
+        t = zk.MerkleTreeGL(); t.merkelize(v, 4, 1 << 10); return [int(w) for w in t.root()]
+    want_root = root_of(x)
+    got = {}
+
+    def work():
+        try:
+            d = zk.DevArray.from_host(x)
+            got["copy"] = d.to_host()
+            got["fft"] = zk.fft(x, 1, 12)
+            got["root"] = root_of(x)
+        except Exception as e:                                   # noqa: BLE001 -- reported by the assertion below
+            got["err"] = repr(e)
+    t = threading.Thread(target=work); t.start(); t.join()
+    assert "err" not in got, got
+    assert np.array_equal(got["copy"], x) and np.array_equal(got["fft"], want) and got["root"] == want_root
+    n_dev = zk.lib().zk_device_count()
+    with pytest.raises(zk.ZkError, match="no such device"):
+        zk.init(n_dev + 7)
+    assert np.array_equal(zk.fft(x, 1, 12), want)
