@@ -501,6 +501,43 @@ __global__ __launch_bounds__(256) void linearhash_rows_coop_kernel(const u64* __
     if (r < height && l < 4) digests[4 * r + l] = x;
 }
 
+// One WAVE per row, for the trees of the fewest rows (FRI steps: 2^3 ... 2^11 rows of 48 ... 192 words).  The up to four batches of a
+// row's LinearHash are independent sponges (linearhash.rs:79-145): group g of 16 lanes digests batch g, then every group runs the
+// sponge over the digests -- a row of 96 words is 3 + 2 permutations deep where the 16-lane form above walks its 14 one after
+// the other.  Four times the lanes for the same work: only where the chip is far from full.
+__global__ __launch_bounds__(256) void linearhash_rows_wave_kernel(const u64* __restrict__ rows, u32 w, u64 height, u64* __restrict__ digests) {
+    ZK_POSEIDON_LDS;
+    load_tables(tab);
+    const int l = threadIdx.x & 15;
+    const u32 g = (threadIdx.x >> 4) & 3;
+    const u64 r = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const u64* __restrict__ row = rows + (r < height ? r : height - 1) * w;   // idle waves shadow the last row
+    const u32 bs = std::max<u32>(8, (w + 3) / 4), hsz = (w + bs - 1) / bs;   // 2 <= hsz <= 4 here
+    const u32 gb = g < hsz ? g : hsz - 1;                                    // idle groups shadow the last batch
+    const u32 len = std::min<u32>(bs, w - gb * bs);
+    const u64* __restrict__ v = row + (u64)gb * bs;
+    const bool hashed = len > 4;                                             // a last batch of <= 4 words is its own digest
+    u64 d = !hashed && (u32)l < len ? v[l] : 0, cap = 0;
+    for (u32 off = 0; off < bs; off += 8) {                                  // the same trip count in every group: the short batch idles
+        const u64 y = coop_perm(l < 8 ? (off + l < len ? v[off + l] : 0) : cap, tab);
+        if (hashed && off < len) d = y;
+        cap = shfl64(d, (l + 8) & 15);
+    }
+    if (g >= hsz) d = 0;
+    const auto digest_word = [&](u32 first) {                               // lanes 0..7 <- words of digests first, first + 1
+        const int src = 16 * (int)(first + ((l >> 2) & 1)) + (l & 3);
+        const u32 lo = (u32)__shfl((int)(u32)d, src, 64), hi = (u32)__shfl((int)(u32)(d >> 32), src, 64);
+        return ((u64)hi << 32) | lo;
+    };
+    u64 x = coop_perm(l < 8 ? digest_word(0) : 0, tab);
+    if (hsz > 2) {
+        cap = shfl64(x, (l + 8) & 15);
+        const u64 in = digest_word(2);
+        x = coop_perm(l < 8 ? in : cap, tab);
+    }
+    if (r < height && g == 0 && l < 4) digests[4 * r + l] = x;
+}
+
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
 __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
     ZK_POSEIDON_LDS;
@@ -743,7 +780,10 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
     static const u64 coop_below = getenv("ZK_LH_COOP_BELOW") ? strtoull(getenv("ZK_LH_COOP_BELOW"), nullptr, 10) : 16384;
     static const u64 batch_upto = getenv("ZK_LH_BATCH_UPTO") ? strtoull(getenv("ZK_LH_BATCH_UPTO"), nullptr, 10) : 262144;
     const u32 bs = std::max<u32>(8, (width + 3) / 4), hsz = width > 4 ? (width + bs - 1) / bs : 1;
-    if (height < coop_below && width > 4) {    // few rows: latency-bound, 16 lanes per row
+    static const u64 wave_below = getenv("ZK_LH_WAVE_BELOW") ? strtoull(getenv("ZK_LH_WAVE_BELOW"), nullptr, 10) : 4096;
+    if (height < wave_below && hsz > 1) {      // fewest rows: a wave per row, its batches side by side
+        hipLaunchKernelGGL(linearhash_rows_wave_kernel, dim3((u32)((height + 3) / 4)), dim3(256), 0, st, d_rows, width, height, d_digests);
+    } else if (height < coop_below && width > 4) {    // few rows: latency-bound, 16 lanes per row
         hipLaunchKernelGGL(linearhash_rows_coop_kernel, dim3((u32)((height + 15) / 16)), dim3(256), 0, st, d_rows, width, height, d_digests);
     } else if (hsz > 1 && height <= batch_upto) {   // too few rows to fill the chip: the batches of a row side by side
         DevBuf h; h.reserve(height * hsz * 32);

@@ -319,10 +319,13 @@ struct JOut {
     JOut& operator<<(char c) { s.push_back(c); return *this; }
     JOut& operator<<(const char* t) { s.append(t); return *this; }
     JOut& operator<<(const std::string& t) { s.append(t); return *this; }
-    JOut& operator<<(Dec d) {
-        char buf[20]; int n = 0; u64 v = d.v;
-        do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-        while (n) s.push_back(buf[--n]);
+    JOut& operator<<(Dec d) {                            // two digits per division, appended in one piece
+        static const char* const PAIRS =
+            "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+        char buf[20]; int n = 20; u64 v = d.v;
+        while (v >= 100) { const u64 q = v / 100; const unsigned r = (unsigned)(v - q * 100); v = q; buf[--n] = PAIRS[2 * r + 1]; buf[--n] = PAIRS[2 * r]; }
+        if (v >= 10) { buf[--n] = PAIRS[2 * v + 1]; buf[--n] = PAIRS[2 * v]; } else buf[--n] = (char)('0' + v);
+        s.append(buf + n, 20 - n);
         return *this;
     }
     JOut& operator<<(size_t v) { return *this << Dec{(u64)v}; }

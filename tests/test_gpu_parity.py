@@ -138,10 +138,11 @@ def test_merkle_root_kats(zk, golden):
 
 def test_merkle_shapes_around_every_kernel_switch(zk, orc):
     """node for node against the oracle across the heights where the builder changes kernels -- the one-launch tree top (64 children),
-    the 16-lanes-per-permutation levels, 16 lanes per leaf row below 2^14 rows, batches of a row side by side up to 2^18 rows -- and
+    the 16-lanes-per-permutation levels, a wave per leaf row below 2^12 rows (its batches on the wave's four groups), 16 lanes per
+    leaf row below 2^14 rows, batches of a row side by side up to 2^18 rows -- and
     the widths where LinearHash changes shape (one batch, a short last batch, two sponge steps of digests)"""
     rng = np.random.default_rng(7)
-    for height in [2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 4095, 16383, 16385, 65537, 262144, 262145]:
+    for height in [2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 4095, 4096, 16383, 16385, 65537, 262144, 262145]:
         for width in [1, 4, 5, 8, 9, 16, 17, 33, 37, 100]:
             if height * width > 12_000_000:
                 continue
