@@ -729,12 +729,17 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     run(S.step3prev, false);
     T.mark("calculate_exps_parallel");
     n_cm = S.n_cm1 + S.n_cm2;
+    // every z must close (grand product 1, stark_gen.rs:663-664): the products stay in HBM and come back with the proof's one
+    // read-back -- checking each on the spot was a host round trip in the middle of the proof
+    size_t n_z = 0, i_z = 0;
+    for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) n_z += I.at(ctx).arr.size();
+    DevBuf z_checks; z_checks.reserve(24 * std::max<size_t>(1, n_z));
     for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {                       // stark_gen.rs:329-353
         for (const JVal& o : I.at(ctx).arr) {
-            DevBuf num, den, z;
+            DevBuf num, den, z, work;
             get_pol(e2p(o.at("num_id")), num); get_pol(e2p(o.at("den_id")), den);
-            z.reserve(3 * N * 8);
-            ck(zk_stark_calculate_z_dev(C(num.u()), C(den.u()), N, M(z.u()), st));
+            z.reserve(3 * N * 8); work.reserve((N + N / 1024 + 8) * 24);
+            calculate_z_dev(num.u(), den.u(), N, z.u(), work.u(), z_checks.u() + 3 * i_z++, st);
             set_pol(S.cm_n.at(n_cm++), z.u());
             T.mark("calculate_Z");
         }
@@ -884,7 +889,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     {
         size_t open_words = 0;
         if (!bn128) for (const AnyTree* t : all_trees) open_words += (size_t)S.n_queries * ((size_t)t->width + 4 * (size_t)t->depth());
-        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub + S.n_queries + open_words, st);
+        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub + S.n_queries + open_words + 3 * n_z, st);
         const AnyTree* t4[4] = {tree1.get(), tree2.get(), tree3.get(), tree4.get()};
         u64* r4p[4] = {r1, r2, r3, r4};
         size_t off_r[4] = {}, off_ev = 0, off_last = 0, off_ys = 0;
@@ -895,6 +900,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         }
         off_ev = rb.add(d_evals.u(), 3 * (size_t)n_ev);
         off_last = rb.add(d_pol, 3 * n_last);
+        const size_t off_z = rb.add(z_checks.u(), 3 * n_z);
         const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
         if (!bn128) {
             off_ys = rb.add(d_ys.u(), S.n_queries);
@@ -905,6 +911,8 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
             }
         }
         rb.fetch();
+        for (size_t i = 0; i < n_z; ++i)
+            ZK_REQUIRE(rb.at(off_z)[3 * i] == 1 && rb.at(off_z)[3 * i + 1] == 0 && rb.at(off_z)[3 * i + 2] == 0, "calculate_Z: z does not close (grand product != 1)");
         if (pub_on_device) {
             publics.assign(rb.at(off_pub), rb.at(off_pub) + n_pub);
             // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value; a

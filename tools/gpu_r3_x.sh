@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stark_prove.py -m gpu -x -q 2>&1 | tail -2
-for u in 0 1024 4096 16384; do echo "ZK_LH_WAVE_BELOW=$u"; for k in fib c12 r1; do ZK_LH_WAVE_BELOW=$u timeout 200 python tools/small_proof_probe.py $k 100 2>&1 | tail -1; done; done
+timeout 1200 python -m pytest tests/test_gpu_stark_large.py tests/test_gpu_c12.py tests/test_gpu_stark_prove.py tests/test_gpu_stark_concurrent.py -m gpu -x -q 2>&1 | tail -2
+for k in fib c12 r1; do timeout 200 python tools/small_proof_probe.py $k 100 2>&1 | tail -1; done
