@@ -1,13 +1,17 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench, rocprof kernel trace.  Outputs under gpurun_out/.
-set -x
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 1700 python -m pytest tests -m gpu -x -q --durations=8 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -15 gpurun_out/pytest_gpu.log
-timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
-timeout 900 python bench.py --steps 50 --warmup 5 > gpurun_out/bench.log 2>&1; tail -2 gpurun_out/bench.log
-rm -rf gpurun_out/prof_trace
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -o ntt -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-prove --no-msm --no-bn128 --no-groth16 > gpurun_out/prof_trace.log 2>&1
-find gpurun_out/prof_trace -name '*stats*' | head; 
-f=$(find gpurun_out/prof_trace -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -12 "$f"
+# One GPU-box visit at the end of a round (gpurun --timeout 3600 -- 'bash tools/gpu_round.sh'): the whole GPU suite, the smoke
+# entry, everything profiles/rNN/ holds (tools/gpu_profiles.sh: bench line, rocprofv3 kernel statistics, HBM and SQ counters) and
+# the three circuits of a recursion task in a loop under the profiler (busy / idle split by tools/trace_gaps.py).
+# Outputs under gpurun_out/; copy the summaries into profiles/rNN/ afterwards.
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 3300 python -m pytest tests -m gpu -x -q --durations=5 > gpurun_out/pytest_gpu.log 2>&1; echo "rc=$?" >> gpurun_out/pytest_gpu.log
+tail -10 gpurun_out/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
+bash tools/gpu_profiles.sh > gpurun_out/profiles.log 2>&1; tail -5 gpurun_out/profiles.log
+for k in fib c12 r1; do
+  rm -rf gpurun_out/sp_$k
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sp_$k -o p -- python3 tools/small_proof_probe.py $k 20 > gpurun_out/sp_$k.log 2>&1
+  python3 tools/trace_gaps.py $(find gpurun_out/sp_$k -name '*kernel_trace.csv' | head -1) > gpurun_out/sp_${k}_gaps.txt 2>&1; head -3 gpurun_out/sp_${k}_gaps.txt
+  find gpurun_out/sp_$k -name '*kernel_trace.csv' -delete
+done
+timeout 100 python tools/coop_perm_time.py | tail -1
