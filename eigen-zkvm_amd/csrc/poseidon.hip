@@ -34,7 +34,8 @@ constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
 constexpr int T_DD = T_SR + 528;     // [2 blocks][m (m - 1) / 2 + i] split: D[r][r0 + i], r = r0 + m (partial rounds, below)
 constexpr int T_SCS = T_DD + 220;    // [2 blocks][11 k][11 m] split: S[23 (r0 + m) + 12 + k], the column entries regrouped by state word
 constexpr int T_CD = T_SCS + 484;    // [2 blocks][11 m][16 l] split: what u_(r0 + m) weighs in lane l of a cooperative permutation (coop_partial_rounds)
-constexpr int T_WORDS = T_CD + 704;  // 2356 words = 18.4 KB
+constexpr int T_K0 = T_CD + 704;     // [4]: C[8 + i]^7 + (round 0's constant of word 8 + i): what a zero capacity word is after the first S-box
+constexpr int T_WORDS = T_K0 + 4;    // 2360 words = 18.4 KB
 constexpr int PR_B = 11;             // partial rounds per block
 static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0 && T_CD % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
@@ -90,13 +91,13 @@ __device__ __forceinline__ u64 pow7_add(u64 x, u64 c) {
 }
 
 // out[i] = sum_j M[j][i] * st[j]  (poseidon_opt.rs:111-119), M[j][i] < 2^6 folded to immediates
-template <bool CANON>
+template <bool CANON, int N_OUT = 12>
 __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
     u32 lo32[12], hi32[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) { lo32[j] = (u32)st[j]; hi32[j] = (u32)(st[j] >> 32); }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < N_OUT; ++i) {                                      // (the words past N_OUT keep their inputs: the caller does not read them)
         u64 lo = 0, hi = 0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -165,19 +166,35 @@ __device__ __forceinline__ void partial_rounds(u64 (&st)[12], const u64* __restr
     }
 }
 
-// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables
-__device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab) {
+// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables.
+// Two things every LinearHash and every tree node allow (round 3):
+//   * zero_cap (wave-uniform): the capacity words are zero -- the first block of a sponge and every node of a tree.  After the
+//     first constants they are C[8..12) whatever the input, so their first S-boxes are four table words (T_K0), not 16 products;
+//   * FULL_OUT = false: only st[0..4) is read afterwards (a digest, or the capacity of the next block): the last MDS computes
+//     four of its twelve outputs.  st[4..12) are then NOT the permutation's words.
+template <bool FULL_OUT = false>
+__device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab, bool zero_cap) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) st[i] = gl::add_nc(st[i], tab[T_C0 + i]);
+    for (int i = 0; i < 8; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
+    if (zero_cap) {
+#pragma unroll
+        for (int i = 8; i < 12; ++i) st[i] = tab[T_K0 + i - 8];
+    } else {
+#pragma unroll
+        for (int i = 8; i < 12; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
+    }
+    mds_small<false>(st);
 #pragma unroll 1
-    for (int R = 0; R < 8; ++R) {
+    for (int R = 1; R < 7; ++R) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = pow7_add(st[i], tab[T_FC + R * 12 + i]);
-        if (R == 7) { mds_small<true>(st); continue; }                    // the permutation's output: canonical words
         if (R != 3) { mds_small<false>(st); continue; }
         mat_full(tab + T_PT, st);
         partial_rounds(st, tab);
     }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st[i] = pow7(st[i]);
+    mds_small<true, FULL_OUT ? 12 : 4>(st);
 }
 
 
@@ -317,7 +334,7 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 #pragma unroll
     for (int i = 8; i < 12; ++i) st[i] = 0;
     u32 b = 0, off = 0;
-    bool final_sponge = false, second = false;
+    bool final_sponge = false, second = false, cz = true;   // cz: the capacity words are zero (first block of a sponge)
     for (;;) {
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
@@ -328,13 +345,14 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = second ? h[8 + i] : h[i];
         }
-        poseidon_perm(st, tab);
+        poseidon_perm(st, tab, cz);
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
             off += 8;
             if (off < len) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
+                cz = false;
                 continue;
             }
 #pragma unroll
@@ -357,6 +375,7 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
             }
 #pragma unroll
             for (int i = 8; i < 12; ++i) st[i] = 0;
+            cz = true;
             if (b < hsz) continue;
             if (hsz == 1) break;      // st[0..4) is the digest
             final_sponge = true;
@@ -365,6 +384,7 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
             second = true;
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
+            cz = false;
         }
     }
 #pragma unroll
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_batch_kernel(cons
         for (u32 off = 0; off < len; off += 8) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[off + i] : 0;
-            poseidon_perm(st, tab);
+            poseidon_perm(st, tab, off == 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[8 + i] = st[i];            // the capacity carries the digest so far
         }
@@ -420,13 +440,13 @@ __global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_final_kernel(cons
     for (int i = 0; i < 8; ++i) st[i] = (u32)i < 4 * hsz ? v[i] : 0;
 #pragma unroll
     for (int i = 8; i < 12; ++i) st[i] = 0;
-    poseidon_perm(st, tab);
+    poseidon_perm(st, tab, true);
     if (hsz > 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = 8 + (u32)i < 4 * hsz ? v[8 + i] : 0;
-        poseidon_perm(st, tab);
+        poseidon_perm(st, tab, false);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = st[i];
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict
     for (int k = 0; k < 8; ++k) st[k] = in[8 * i + k];
 #pragma unroll
     for (int k = 8; k < 12; ++k) st[k] = 0;
-    poseidon_perm(st, tab);
+    poseidon_perm(st, tab, true);
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
 }
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(64) void zero_tree_chain_kernel(u32 levels, u64* __
     for (u32 l = 0; l < levels; ++l) {
         u64 st[12];
         for (int k = 0; k < 4; ++k) { st[k] = cur[k]; st[4 + k] = cur[k]; st[8 + k] = 0; }
-        poseidon_perm(st, tab);
+        poseidon_perm(st, tab, true);
         for (int k = 0; k < 4; ++k) { cur[k] = st[k]; h[4 * (l + 1) + k] = st[k]; }
     }
 }
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(64) void poseidon_one_kernel(const u64* in8, const 
     for (int k = 0; k < 8; ++k) st[k] = in8[k] >= GL_P ? in8[k] - GL_P : in8[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) st[8 + k] = cap4[k] >= GL_P ? cap4[k] - GL_P : cap4[k];
-    poseidon_perm(st, tab);
+    poseidon_perm<true>(st, tab, false);
 #pragma unroll
     for (int k = 0; k < 12; ++k) if (k < n_out) out[k] = st[k];
 }
@@ -720,6 +740,10 @@ void ensure_constants() {
     for (int R = 0; R < 7; ++R)
         for (int i = 0; i < 12; ++i) tab[T_FC + 12 * R + i] = ZK_POSEIDON_C[(R < 4 ? 12 * (R + 1) : 82 + 12 * (R - 4)) + i];
     for (int r = 0; r < 22; ++r) tab[T_PC + r] = ZK_POSEIDON_C[60 + r];
+    for (int i = 8; i < 12; ++i) {                        // a zero capacity word after round 0's S-box: C[i]^7 + C[12 + i]
+        const u64 c = ZK_POSEIDON_C[i], c2 = gl::hmul(c, c), c3 = gl::hmul(c2, c), c7 = gl::hmul(gl::hmul(c3, c3), c), k = ZK_POSEIDON_C[12 + i];
+        tab[T_K0 + i - 8] = c7 + k >= GL_P || c7 + k < c7 ? c7 + k - GL_P : c7 + k;
+    }
     auto split = [&](int at, u64 c) { tab[at] = (c & 0x3FFFFF) | (((c >> 22) & 0x3FFFFF) << 32); tab[at + 1] = c >> 44; };
     for (int i = 0; i < 12; ++i)
         for (int j = 0; j < 12; ++j) split(T_PT + 2 * (12 * i + j), ZK_POSEIDON_P[12 * j + i]);
