@@ -38,27 +38,32 @@ template <int LOGNX>
 __global__ __launch_bounds__(256) void fri_fold_kernel(const u64* __restrict__ pol, u64 pol2_n, const u64* __restrict__ w256inv,
                                                        u64 shift_inv, u64 wi, u64 nx_inv, const u64* __restrict__ special_x,
                                                        u64* __restrict__ out) {
+    // Four lanes per g, one per limb (the fourth idles): the three limb polynomials are independent until the last line, and a
+    // fold has few outputs (2^4 ... 2^19) with a long serial chain each (NX - 1 extension products per limb).
     constexpr int NX = 1 << LOGNX;
-    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= pol2_n) return;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 g0 = t >> 2, g = g0 < pol2_n ? g0 : pol2_n - 1;          // idle quads shadow the last one (the shuffles below need every lane)
+    const int l = (int)(t & 3) < 3 ? (int)(t & 3) : 2;
     const u64 sinv = gl::mul(shift_inv, gl::pow(wi, g));
     const f3 y = gl::f3_muls(ld3(special_x), sinv);
-    f3 S[3];
+    u64 x[NX];
 #pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        u64 x[NX];
+    for (int i = 0; i < NX; ++i) x[i] = pol[((u64)i * pol2_n + g) * 3 + l];
+    ntt_reg<LOGNX, true>(x);  // coefficient k (times NX) sits in x[bitrev(k)]
+    f3 acc{{x[bitrev_c(NX - 1, LOGNX)], 0, 0}};
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = pol[((u64)i * pol2_n + g) * 3 + l];
-        ntt_reg<LOGNX, true>(x);  // coefficient k (times NX) sits in x[bitrev(k)]
-        f3 acc{{x[bitrev_c(NX - 1, LOGNX)], 0, 0}};
-#pragma unroll
-        for (int k = NX - 2; k >= 0; --k) {
-            acc = gl::f3_mul(acc, y);
-            acc.v[0] = gl::add(acc.v[0], x[bitrev_c(k, LOGNX)]);
-        }
-        S[l] = acc;
+    for (int k = NX - 2; k >= 0; --k) {
+        acc = gl::f3_mul(acc, y);
+        acc.v[0] = gl::add(acc.v[0], x[bitrev_c(k, LOGNX)]);
     }
-    f3 r = gl::f3_add(S[0], gl::f3_add(mul_x(S[1]), mul_x(mul_x(S[2]))));
+    f3 S1, S2;                                                          // lane 0 of the quad collects the other two limbs' sums
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        S1.v[j] = ((u64)(u32)__shfl((int)(u32)(acc.v[j] >> 32), 1, 4) << 32) | (u32)__shfl((int)(u32)acc.v[j], 1, 4);
+        S2.v[j] = ((u64)(u32)__shfl((int)(u32)(acc.v[j] >> 32), 2, 4) << 32) | (u32)__shfl((int)(u32)acc.v[j], 2, 4);
+    }
+    if ((t & 3) || g0 >= pol2_n) return;
+    const f3 r = gl::f3_add(acc, gl::f3_add(mul_x(S1), mul_x(mul_x(S2))));
     st3(out + 3 * g, gl::f3_muls(r, nx_inv));
 }
 
@@ -422,7 +427,7 @@ void fri_fold_dev(const u64* d_pol, uint32_t pol_bits, uint32_t step_bits, const
         ZK_HIP(hipGetLastError());
         return;
     }
-#define ZK_FOLD(L) hipLaunchKernelGGL((fri_fold_kernel<L>), grid1(n2), dim3(256), 0, st, d_pol, n2, w256inv, shift_inv, wi, nx_inv, d_special_x, d_out)
+#define ZK_FOLD(L) hipLaunchKernelGGL((fri_fold_kernel<L>), grid1(4 * n2), dim3(256), 0, st, d_pol, n2, w256inv, shift_inv, wi, nx_inv, d_special_x, d_out)
     switch (r) {
         case 1: ZK_FOLD(1); break; case 2: ZK_FOLD(2); break; case 3: ZK_FOLD(3); break;
         case 4: ZK_FOLD(4); break; case 5: ZK_FOLD(5); break; default: ZK_FOLD(6); break;
