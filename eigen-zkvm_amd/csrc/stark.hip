@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64) void evals_final_kernel(const u64* __restrict__
     f3 res{{0, 0, 0}};
     for (u32 j = 0; j < F.dim[e]; ++j) {
         f3 acc{{0, 0, 0}};
+#pragma unroll 4
         for (u32 b = threadIdx.x; b < nblk; b += 64) acc = gl::f3_add(acc, ld3(partial + ((u64)(F.slot[e] + j) * nblk + b) * 3));
         st3(red + threadIdx.x * 3, acc);
         __syncthreads();
@@ -483,13 +484,16 @@ void evals_k_dev(const EvalDescKHost* descs, uint32_t n_ev, uint32_t nbits, u64*
     static_assert(sizeof(EvalDescKHost) == sizeof(EvalDescK), "descriptor layout");
     u32 n_slots = 0;
     for (u32 e = 0; e < n_ev; ++e) { ZK_REQUIRE(descs[e].dim == 1 || descs[e].dim == 3, "evals: dim must be 1 or 3"); n_slots += descs[e].dim; }
+    // row blocks: a block takes 8 x EV_UNROLL rows per trip; a small proof gets no more blocks than it has trips (2^10 rows:
+    // 32 blocks instead of 4096 -- the final kernel then adds 32 partial sums per evaluation, not 4096)
+    const u32 n_row_blocks = (u32)std::min<u64>(EV_BLOCKS, std::max<u64>(1, (1ull << nbits) / (8 * EV_UNROLL)));
     DevBuf partial;  // pooled block; returned to the pool at scope exit, reuse is stream ordered
-    partial.reserve((size_t)n_slots * EV_BLOCKS * 24);
+    partial.reserve((size_t)n_slots * n_row_blocks * 24);
     EvalBatch B; memset(&B, 0, sizeof B);
     u32 n = 0, slot = 0;
     auto flush = [&] {
         if (!n) return;
-        hipLaunchKernelGGL(evals_partial_kernel, dim3(EV_BLOCKS), dim3(256), 0, st, B, n, nbits, (u32)EV_BLOCKS, partial.u());
+        hipLaunchKernelGGL(evals_partial_kernel, dim3(n_row_blocks), dim3(256), 0, st, B, n, nbits, n_row_blocks, partial.u());
         n = 0;
     };
     std::vector<u32> slot0(n_ev);
@@ -507,7 +511,7 @@ void evals_k_dev(const EvalDescKHost* descs, uint32_t n_ev, uint32_t nbits, u64*
         EvalFinalBatch F; memset(&F, 0, sizeof F);
         const u32 m = std::min<u32>(64, n_ev - e0);
         for (u32 i = 0; i < m; ++i) { F.slot[i] = slot0[e0 + i]; F.dim[i] = descs[e0 + i].dim; }
-        hipLaunchKernelGGL(evals_final_kernel, dim3(m), dim3(64), 0, st, (const u64*)partial.u(), F, e0, (u32)EV_BLOCKS, d_out);
+        hipLaunchKernelGGL(evals_final_kernel, dim3(m), dim3(64), 0, st, (const u64*)partial.u(), F, e0, n_row_blocks, d_out);
     }
     ZK_HIP(hipGetLastError());
 }
