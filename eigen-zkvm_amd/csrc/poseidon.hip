@@ -521,6 +521,14 @@ __global__ __launch_bounds__(256) void linearhash_rows_coop_kernel(const u64* __
     if (r < height && l < 4) digests[4 * r + l] = x;
 }
 
+// rows of at most four words are their own zero-padded digest (linearhash.rs:85-91): no permutation, no tables
+__global__ __launch_bounds__(256) void linearhash_pad_kernel(const u64* __restrict__ rows, u32 w, u64 height, u64* __restrict__ digests) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * height) return;
+    const u32 i = (u32)(t & 3);
+    digests[t] = i < w ? rows[(t >> 2) * w + i] : 0;
+}
+
 // One WAVE per row, for the trees of the fewest rows (FRI steps: 2^3 ... 2^11 rows of 48 ... 192 words).  The up to four batches of a
 // row's LinearHash are independent sponges (linearhash.rs:79-145): group g of 16 lanes digests batch g, then every group runs the
 // sponge over the digests -- a row of 96 words is 3 + 2 permutations deep where the 16-lane form above walks its 14 one after
@@ -805,7 +813,9 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
     static const u64 batch_upto = getenv("ZK_LH_BATCH_UPTO") ? strtoull(getenv("ZK_LH_BATCH_UPTO"), nullptr, 10) : 262144;
     const u32 bs = std::max<u32>(8, (width + 3) / 4), hsz = width > 4 ? (width + bs - 1) / bs : 1;
     static const u64 wave_below = getenv("ZK_LH_WAVE_BELOW") ? strtoull(getenv("ZK_LH_WAVE_BELOW"), nullptr, 10) : 4096;
-    if (height < wave_below && hsz > 1) {      // fewest rows: a wave per row, its batches side by side
+    if (width <= 4) {
+        hipLaunchKernelGGL(linearhash_pad_kernel, dim3((u32)((4 * height + 255) / 256)), dim3(256), 0, st, d_rows, width, height, d_digests);
+    } else if (height < wave_below && hsz > 1) {      // fewest rows: a wave per row, its batches side by side
         hipLaunchKernelGGL(linearhash_rows_wave_kernel, dim3((u32)((height + 3) / 4)), dim3(256), 0, st, d_rows, width, height, d_digests);
     } else if (height < coop_below && width > 4) {    // few rows: latency-bound, 16 lanes per row
         hipLaunchKernelGGL(linearhash_rows_coop_kernel, dim3((u32)((height + 15) / 16)), dim3(256), 0, st, d_rows, width, height, d_digests);
