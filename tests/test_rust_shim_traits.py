@@ -124,3 +124,10 @@ def test_fft_seam_functions_match_fft_p():
     for name in ("fft", "ifft", "interpolate"):
         assert name in want and name in got, name
         assert got[name] == want[name], (name, got[name], want[name])
+
+
+def test_stark_prove_entry_matches_prove_rs():
+    """the shim's public `stark_prove` (src/prove.rs) takes what starky/src/prove.rs:30-41 takes: it is what zkit calls"""
+    ref = pathlib.Path("/root/reference/starky/src/prove.rs")
+    want, got = _fns(_strip(ref.read_text())), _fns(_strip((SHIM / "prove.rs").read_text()))
+    assert got["stark_prove"] == want["stark_prove"], (got["stark_prove"], want["stark_prove"])
