@@ -131,3 +131,39 @@ def test_stark_prove_entry_matches_prove_rs():
     ref = pathlib.Path("/root/reference/starky/src/prove.rs")
     want, got = _fns(_strip(ref.read_text())), _fns(_strip((SHIM / "prove.rs").read_text()))
     assert got["stark_prove"] == want["stark_prove"], (got["stark_prove"], want["stark_prove"])
+
+
+def _uses(text):
+    """(crate, [path segments], item) for every `use starky::…` / `use fields::…` of a source file"""
+    out = []
+    for m in re.finditer(r"\buse\s+((?:starky|fields)(?:::\w+)*)::(\{[^}]*\}|\w+)(?:\s+as\s+\w+)?\s*;", text):
+        segs = m.group(1).split("::")
+        items = [i.strip().split(" as ")[0].strip() for i in m.group(2).strip("{}").split(",")] if m.group(2).startswith("{") else [m.group(2)]
+        for it in items:
+            if it:
+                out.append((segs[0], segs[1:], it))
+    return out
+
+
+def test_every_imported_name_exists_in_the_reference_crates():
+    """name resolution by hand: each `use starky::a::B` / `use fields::a::B` of the shim names a public module of that crate
+    (declared `pub mod a;` in its lib.rs, file present) and a public item of that module (or a `pub use` re-export)"""
+    crates = {"starky": pathlib.Path("/root/reference/starky/src"), "fields": pathlib.Path("/root/reference/fields/src")}
+    seen = 0
+    for f in sorted(SHIM.glob("*.rs")):
+        for crate, mods, item in _uses(_strip(f.read_text())):
+            src = crates[crate]
+            lib = _strip((src / "lib.rs").read_text())
+            if not mods:                                            # `use starky::X`: a module or a re-export of lib.rs
+                assert re.search(r"pub\s+mod\s+%s\s*;" % item, lib) or re.search(r"pub\s+use\s+[^;]*\b%s\b" % item, lib), (f.name, crate, item)
+                seen += 1
+                continue
+            assert len(mods) == 1, (f.name, mods)
+            assert re.search(r"pub\s+mod\s+%s\s*;" % mods[0], lib), (f.name, "module not public", mods[0])
+            mfile = src / (mods[0] + ".rs")
+            assert mfile.exists(), mfile
+            mtext = _strip(mfile.read_text())
+            decl = r"pub\s+(?:struct|enum|trait|fn|type|const|static|mod)\s+%s\b" % item
+            assert re.search(decl, mtext) or re.search(r"pub\s+use\s+[^;]*\b%s\b" % item, mtext), (f.name, crate, mods[0], item)
+            seen += 1
+    assert seen >= 15
