@@ -167,3 +167,32 @@ def test_every_imported_name_exists_in_the_reference_crates():
             assert re.search(decl, mtext) or re.search(r"pub\s+use\s+[^;]*\b%s\b" % item, mtext), (f.name, crate, mods[0], item)
             seen += 1
     assert seen >= 15
+
+
+def _call_args(text, callee_re):
+    """the top-level argument list of the first call matching callee_re (a regex ending just before the opening parenthesis)"""
+    m = re.search(callee_re + r"\s*\(", text)
+    assert m, callee_re
+    i, depth, j = m.end(), 1, m.end()
+    while depth:
+        depth += {"(": 1, ")": -1}.get(text[j], 0)
+        j += 1
+    return [a for a in _split_args(text[i:j - 1]) if a]
+
+
+def test_calls_into_the_reference_have_the_callees_arity():
+    """`prove` (src/prove.rs) calls StarkSetup::new, stark_verify and pil2circom: argument counts against the definitions
+    (stark_setup.rs:27-32, stark_verify.rs:20-26, pil2circom.rs:21-28), and StarkOption is built with exactly its fields"""
+    ref = pathlib.Path("/root/reference/starky/src")
+    shim = _strip((SHIM / "prove.rs").read_text())
+    setup_new = _fns(_block(_strip((ref / "stark_setup.rs").read_text()), r"impl<[^>]*>\s*StarkSetup<[^>]*>"))["new"]
+    assert len(_call_args(shim, r"StarkSetup::<\w+>::new")) == len(setup_new[2])
+    verify = _fns(_strip((ref / "stark_verify.rs").read_text()))["stark_verify"]
+    assert len(_call_args(shim, r"stark_verify::stark_verify::<[^(]*>")) == len(verify[2])
+    p2c_src = _strip((ref / "pil2circom.rs").read_text())
+    p2c = _fns(p2c_src)["pil2circom"]
+    assert len(_call_args(shim, r"pil2circom::pil2circom::<\w+>")) == len(p2c[2])
+    fields = set(re.findall(r"pub\s+(\w+)\s*:", _block(p2c_src, r"pub\s+struct\s+StarkOption\b")))
+    lit = re.search(r"pil2circom::StarkOption\s*\{([^}]*)\}", shim).group(1)
+    used = {f.split(":")[0].strip() for f in lit.split(",") if f.strip()}
+    assert used == fields, (used, fields)
