@@ -406,16 +406,30 @@ std::vector<GroupProof> group_proofs(const AnyTree& t, const std::vector<u64>& i
 // Device words the host needs for the proof's JSON (roots, evaluations, the last FRI polynomial): collected in one device
 // block with asynchronous copies and fetched with ONE copy -- each of them on its own was a blocking round trip, and a
 // small proof is a chain of those.
+struct RbSegs { const u64* src[16]; u32 n[16]; u32 off[16]; };
+__global__ __launch_bounds__(256) void rb_gather_kernel(const RbSegs G, u64* __restrict__ stage) {   // block b copies segment b
+    const u64* __restrict__ s = G.src[blockIdx.x];
+    u64* __restrict__ d = stage + G.off[blockIdx.x];
+    for (u32 i = threadIdx.x; i < G.n[blockIdx.x]; i += blockDim.x) d[i] = s[i];
+}
 struct ReadBack {
     DevBuf stage; std::vector<u64> host; size_t words = 0, cap = 0; hipStream_t st;
+    RbSegs segs; u32 n_segs = 0;                         // the pieces added since the last launch: one kernel copies sixteen of them
     ReadBack(size_t capacity, hipStream_t s) : cap(std::max<size_t>(1, capacity)), st(s) { stage.reserve(cap * 8); }
+    void flush() {
+        if (!n_segs) return;
+        hipLaunchKernelGGL(rb_gather_kernel, dim3(n_segs), dim3(256), 0, st, segs, stage.u());
+        ZK_HIP(hipGetLastError());
+        n_segs = 0;
+    }
     size_t add(const u64* d_src, size_t n) {
-        ZK_REQUIRE(words + n <= cap, "ReadBack: capacity");
-        if (n) ZK_HIP(hipMemcpyAsync(stage.u() + words, d_src, n * 8, hipMemcpyDeviceToDevice, st));
+        ZK_REQUIRE(words + n <= cap && words + n < (1ull << 32), "ReadBack: capacity");
+        if (n) { segs.src[n_segs] = d_src; segs.n[n_segs] = (u32)n; segs.off[n_segs] = (u32)words; if (++n_segs == 16) flush(); }
         const size_t off = words; words += n; return off;
     }
     u64* reserve(size_t n) { ZK_REQUIRE(words + n <= cap, "ReadBack: capacity"); u64* p = stage.u() + words; words += n; return p; }
     void fetch() {
+        flush();
         host.resize(std::max<size_t>(1, words));
         if (words) ZK_HIP(hipMemcpyAsync(host.data(), stage.p, words * 8, hipMemcpyDeviceToHost, st));
         ZK_HIP(hipStreamSynchronize(st));
