@@ -159,15 +159,23 @@ def _powers(base, n, first=1):
     return out
 
 
-def stark_gen(cm_path, su, stark_struct, orc, use_c=True):
+def stark_gen(cm_path, su, stark_struct, orc, use_c=True, lean=False, log=None):
     """cm_path: a .cm file or the trace itself (flat uint64 array).  use_c: constraint programs run through
-    oracle/interp.c (same semantics as oracle/interp.py, which use_c=False selects; compared in tests/test_oracle_interp.py)"""
+    oracle/interp.c (same semantics as oracle/interp.py, which use_c=False selects; compared in tests/test_oracle_interp.py).
+    lean: sections over the N-row domain are dropped once stage 3 is committed (nothing after it reads them) and the
+    trace is not copied -- the 2^24-row golden (tools/gen_golden_full.py) has to fit the build container; same proof.
+    log: callable for progress lines (roots as they appear)."""
+    log = log or (lambda *a: None)
     info, prog = su["starkinfo"], su["program"]
     nbits, nbits_ext = stark_struct["nBits"], stark_struct["nBitsExt"]
     ext = nbits_ext - nbits
     N, Next = 1 << nbits, 1 << nbits_ext
     sN = info["map_sectionsN"]
-    cm1 = np.ascontiguousarray(cm_path, dtype=np.uint64).reshape(-1).copy() if isinstance(cm_path, np.ndarray) else load_trace(cm_path, info["n_cm1"])
+    if isinstance(cm_path, np.ndarray):
+        cm1 = np.ascontiguousarray(cm_path, dtype=np.uint64).reshape(-1)
+        cm1 = cm1 if lean else cm1.copy()                                   # cm1_n is never a destination
+    else:
+        cm1 = load_trace(cm_path, info["n_cm1"])
     bufs = {"cm1_n": cm1, "const_n": np.ascontiguousarray(su["const_n"], dtype=np.uint64),
             "const_2ns": np.ascontiguousarray(su["const_2ns"], dtype=np.uint64)}
     assert len(bufs["cm1_n"]) == N * sN["cm1_n"]
@@ -220,6 +228,7 @@ def stark_gen(cm_path, su, stark_struct, orc, use_c=True):
         return {"nodes": orc.merkelize(e, width, Next), "elements": e, "width": width}
 
     tree1 = extend_and_merkelize("cm1")
+    log("root1", [int(v) for v in tree1["nodes"][-4:]])
     tr.put(tree1["nodes"][-4:])
     challenge[0] = [int(v) for v in tr.get_field()]
     challenge[1] = [int(v) for v in tr.get_field()]
@@ -247,6 +256,11 @@ def stark_gen(cm_path, su, stark_struct, orc, use_c=True):
     bufs["tmpexp_n"][:] = 0
     run("step3", "n")
     tree3 = extend_and_merkelize("cm3")
+    log("root3", [int(v) for v in tree3["nodes"][-4:]])
+    if lean:
+        for k in ("cm1_n", "cm2_n", "cm3_n", "tmpexp_n", "const_n"):
+            bufs[k] = np.zeros(0, np.uint64)
+        cm1 = None
     tr.put(tree3["nodes"][-4:])
     challenge[4] = [int(v) for v in tr.get_field()]
     run("step42ns", "2ns")
@@ -254,8 +268,12 @@ def stark_gen(cm_path, su, stark_struct, orc, use_c=True):
     qq1 = orc.ntt(bufs["q_2ns"], q_dim, nbits_ext, inverse=True)             # :375-396
     qq2 = orc.qsplit(qq1, nbits, nbits_ext, q_dim, q_deg)
     cm4 = orc.ntt(qq2, q_dim * q_deg, nbits_ext) if q_deg > 0 else np.zeros(0, np.uint64)
+    del qq1, qq2
+    if lean:
+        bufs["q_2ns"] = np.zeros(0, np.uint64)
     bufs["cm4_2ns"] = cm4
     tree4 = {"nodes": orc.merkelize(cm4, sN["cm4_2ns"], Next), "elements": cm4, "width": sN["cm4_2ns"]}
+    log("root4", [int(v) for v in tree4["nodes"][-4:]])
     tr.put(tree4["nodes"][-4:])
     challenge[7] = [int(v) for v in tr.get_field()]                          # xi
     xi = np.array(challenge[7], np.uint64)

@@ -64,7 +64,7 @@ def test_poseidong_2p20_verifies_and_tamper_rejected(zk, orc):
     stark = _stark(zk)
     nbits = 20
     ss, const = PG.stark_struct(nbits), PG.consts(nbits)
-    assert [s["nBits"] for s in ss["steps"]] == [21, 16, 11, 6, 4]
+    assert [s["nBits"] for s in ss["steps"]] == [21, 15, 11, 7, 4]                            # the mirror of r2.starkStruct.bn128.json
     cm = PG.trace(nbits, None, PG.FIRST_ZERO, seed=20)
     info, prog, _ = SI.generate(PG.pil(nbits), ss)
     ns = _native(stark, const, json.dumps(PG.program(nbits)), ss)

@@ -4,8 +4,9 @@
   pil(nbits)            compiled PIL: the committed fixture tests/golden/poseidong.pil.json (made by tools/pilc.py from the
                         reference's source at 2^10 rows, tools/gen_poseidong_fixture.py) resized to 2^nbits rows
   consts / trace        tools/tracegen.c (semantics of starkjs/poseidon/sm_poseidong.js)
-  stark_struct(nbits)   blow-up 2, 8 queries, FRI steps of <= 5 bits down to 2^5 (SURVEY 8: 25,20,15,10,5 at nBits 24;
-                        at nBits 10 the reference's own starkStruct, main_poseidon.js:29-39)
+  stark_struct(nbits)   blow-up 2^ext_bits (default 2), 8 queries, FRI steps of <= 5 bits down to 2^5 (25,20,15,10,5 at
+                        nBits 24); at nBits 20 (BASELINE config 3) the steps SURVEY 8 states, 21,15,11,7,4 = the mirror of
+                        starky/data/r2.starkStruct.bn128.json; at nBits 10 the reference's own starkStruct, main_poseidon.js:29-39
 """
 import copy
 import ctypes as C
@@ -52,10 +53,12 @@ def resize_pil(d, nbits):
     return d
 
 
-def stark_struct(nbits, n_queries=8, hash_type="GL"):
-    ext = nbits + 1
-    if nbits == 10:
+def stark_struct(nbits, n_queries=8, hash_type="GL", ext_bits=1):
+    ext = nbits + ext_bits
+    if nbits == 10 and ext_bits == 1:
         steps = [11, 7, 3]
+    elif nbits == 20 and ext_bits == 1:
+        steps = [21, 15, 11, 7, 4]
     else:
         steps, b = [ext], ext
         while b > 5:
