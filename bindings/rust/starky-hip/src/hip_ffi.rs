@@ -48,6 +48,11 @@ extern "C" {
     ) -> *mut zk_stark_setup_t;
     pub fn zk_stark_setup_const_root(s: *const zk_stark_setup_t, out: *mut u64) -> c_int;
     pub fn zk_stark_setup_set_prover_addr(s: *mut zk_stark_setup_t, prover_addr: *const c_char) -> c_int;
+    /// stark_verify.rs:20-136 on the zkin text: 1 accepted, 0 rejected, -1 malformed input
+    pub fn zk_stark_verify(s: *const zk_stark_setup_t, zkin_json: *const c_char) -> c_int;
+    pub fn zk_stark_verify_with(starkinfo_program_json: *const c_char, stark_struct_json: *const c_char, const_root: *const u64, zkin_json: *const c_char) -> c_int;
+    /// every later zk_stark_gen* verifies its own proof first (prove.rs:124-132)
+    pub fn zk_stark_setup_set_self_check(s: *mut zk_stark_setup_t, on: c_int) -> c_int;
     pub fn zk_stark_gen(s: *mut zk_stark_setup_t, cm_pols: *const u64, n_words: u64) -> *mut c_char;
     /// the trace already in HBM, on a stream of the caller's: setups on different streams prove side by side from
     /// different host threads (one proof at a time per setup)

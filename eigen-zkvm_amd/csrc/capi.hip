@@ -758,6 +758,37 @@ void fr_mont_mul_host(const FrOps& F, const uint64_t a[4], const uint64_t b[4], 
     }
     memcpy(r, t, 32);
 }
+}  // namespace
+namespace zk {
+// decimal text of a scalar-field element (how a digest travels in zkin JSON, digest.rs:91-94) -> the raw Montgomery limbs of
+// ElementDigest<4, Fr>; false when the text is not a canonical value below the modulus
+bool fr_digest_from_dec(bool bls12381, const std::string& dec, u64 out[4]) {
+    const FrOps& F = bls12381 ? FR_BLS12381 : FR_BN128;
+    if (dec.empty() || dec.size() > 78) return false;
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (char c : dec) {
+        if (c < '0' || c > '9') return false;
+        unsigned __int128 carry = (unsigned)(c - '0');
+        for (int i = 0; i < 4; ++i) { carry += (unsigned __int128)v[i] * 10; v[i] = (uint64_t)carry; carry >>= 64; }
+        if (carry) return false;
+    }
+    for (int i = 3; i >= 0; --i) { if (v[i] < F.R[i]) break; if (v[i] > F.R[i] || i == 0) return false; }
+    uint64_t m[4];
+    fr_mont_mul_host(F, v, F.R2, m);
+    for (int i = 0; i < 4; ++i) out[i] = m[i];
+    return true;
+}
+// n hashes of 16 nodes each (hash of a group of a 16-ary tree with a zero initial state, merklehash_bn128.rs:108-128), device buffers
+// d_out [n][2][4]: the permutation's first two words -- Poseidon::hash is word 0 over BN128 (poseidon_bn128_opt.rs) and word 1 over
+// BLS12-381 (poseidon_bls12381_opt.rs:94-103)
+void fr_hash16_dev(bool bls12381, const u64* d_in /* [n][16][4] */, uint64_t n, const u64* d_zero4, u64* d_out, hipStream_t st) {
+    (bls12381 ? FR_BLS12381 : FR_BN128).poseidon_dev(d_in, n, 16, d_zero4, 2, d_out, st);
+}
+void fr_linearhash_rows_dev(bool bls12381, const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
+    (bls12381 ? FR_BLS12381 : FR_BN128).linearhash_rows_dev(d_rows, width, height, d_digests, st);
+}
+}  // namespace zk
+namespace {
 void fr_tr_update(FrTranscript* t) {   // transcript_bn128.rs:22-31
     t->pending.resize(64, 0);
     on_stream(nullptr);                         // the scalar-field sponges work on the null stream, whoever calls

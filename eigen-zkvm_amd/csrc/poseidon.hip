@@ -615,6 +615,36 @@ __global__ __launch_bounds__(1024) void merkle_top_coop_kernel(u64* nodes, u64 n
     }
 }
 
+// The verifier's side of a tree: calculate_root_from_group_proof (merklehash.rs:393-428 -> merkle_calculate_root_from_proof): from a
+// leaf digest up its path, (value, sibling) ordered by the index bit of the level.  A proof opens a handful of paths, each a chain of
+// dependent permutations: 16 lanes per path (coop_perm), four paths per wave; the paths of one launch may have different depths.
+__global__ __launch_bounds__(64) void merkle_root_from_path_kernel(const u64* __restrict__ leaves /* [n][4] */, const u64* __restrict__ paths /* [n][max_depth][4] */,
+                                                                   const u32* __restrict__ depth, const u64* __restrict__ idx, u32 n, u32 max_depth,
+                                                                   u64* __restrict__ roots /* [n][4] */) {
+    ZK_POSEIDON_LDS;
+    load_tables(tab);
+    __syncthreads();
+    const int l = threadIdx.x & 15;
+    const u32 g = blockIdx.x * 4 + (threadIdx.x >> 4);
+    const u32 gc = g < n ? g : n - 1;                               // idle groups shadow the last path (no divergence inside a wave)
+    u32 wave_depth = 0;                                             // every group of the wave runs the longest of its four chains
+    for (u32 k = 0; k < 4; ++k) { const u32 gk = blockIdx.x * 4 + k; const u32 d = depth[gk < n ? gk : n - 1]; wave_depth = d > wave_depth ? d : wave_depth; }
+    const u32 my_depth = depth[gc];
+    u64 i = idx[gc];
+    u64 cur = l < 4 ? leaves[4 * (u64)gc + l] : 0;                 // lanes 0..3 hold the running digest
+    for (u32 lv = 0; lv < wave_depth; ++lv) {
+        const bool live = lv < my_depth;
+        const u64 sib = l < 4 && live ? paths[((u64)gc * max_depth + lv) * 4 + l] : 0;
+        const bool right = (i & 1) != 0;                            // this node is the right child: (sibling, value)
+        // lane j < 4 holds value[j] and sibling[j]; the permutation's input word k is value/sibling word k & 3
+        const u64 v = shfl64(cur, l & 3), sb = shfl64(sib, l & 3);   // (a shuffle inside the 16-lane group)
+        u64 x = l < 4 ? (right ? sb : v) : l < 8 ? (right ? v : sb) : 0;
+        x = coop_perm(x, tab);
+        if (live) { cur = x; i >>= 1; }
+    }
+    if (g < n && l < 4) roots[4 * (u64)g + l] = cur;
+}
+
 // A tree over zero-width rows (tree2 / tree3 of a PIL without plookups or grand products,
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
@@ -828,6 +858,14 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
         const u64 blocks = (height + 255) / 256;
         hipLaunchKernelGGL(linearhash_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, d_rows, width, height, d_digests);
     }
+    ZK_HIP(hipGetLastError());
+}
+
+void merkle_roots_from_paths_dev(const u64* d_leaves, const u64* d_paths, const u32* d_depth, const u64* d_idx, uint32_t n, uint32_t max_depth,
+                                 u64* d_roots, hipStream_t st) {
+    ensure_constants();
+    if (n == 0) return;
+    hipLaunchKernelGGL(merkle_root_from_path_kernel, dim3((n + 3) / 4), dim3(64), 0, st, d_leaves, d_paths, d_depth, d_idx, n, max_depth, d_roots);
     ZK_HIP(hipGetLastError());
 }
 

@@ -214,6 +214,7 @@ struct zk_stark_setup {
     DevBuf const_n, const_2ns;
     const FrApi* fr = nullptr;             // verificationHashType "BN128" / "BLS12381"; nullptr = "GL"
     std::string prover_addr;               // StarkProof.prover_addr (serializer.rs:255-262), non-GL proofs only
+    bool self_check = false;               // verify every proof before handing it out, as stark_prove does (prove.rs:124-132)
     TreePtr const_tree;
     TreePtr zero_tree;                     // the tree over a zero-width section (tree2 / tree3 of a PIL without such columns): the same in every proof
     DevBuf x_n, x_2ns, zi;                 // x over the domain and the extended coset, 1 / Z_H on the coset (stark_gen.rs:231-249): functions of the sizes only
@@ -1015,6 +1016,14 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
 
 struct DeferFlush { ~DeferFlush() { pool_defer_flush(); } };   // after stark_gen's locals are gone (also when it throws)
 
+// prove.rs:124-132: `assert!(stark_verify(...))` on the fresh proof, opt-in per setup (zk_stark_setup_set_self_check)
+void self_check(const zk_stark_setup& S, const std::string& zkin) {
+    if (!S.self_check) return;
+    pool_defer_flush();                                   // the proof's buffers go back before the verifier asks for its own
+    std::string why;
+    if (!stark_verify_impl(S.info, S.prog, S.ss, S.const_root, zkin.c_str(), why)) throw Error("stark_gen: the proof does not verify: " + why);
+}
+
 template <class F>
 int guard(F&& f) {
     CallScope scope;
@@ -1049,6 +1058,7 @@ char* zk_stark_gen(zk_stark_setup_t* s, const uint64_t* cm_pols, uint64_t n_word
             ZK_REQUIRE(s, "zk_stark_gen: null setup");
             ZK_REQUIRE(cm_pols || n_words == 0, "zk_stark_gen: null trace");
             const std::string z = stark_gen(*s, cm_pols, nullptr, n_words, nullptr);
+            self_check(*s, z);
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);
@@ -1066,7 +1076,8 @@ char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64
             ZK_REQUIRE(s && d_cm_pols, "zk_stark_gen_dev: null argument");
             const auto t0 = std::chrono::steady_clock::now();
             const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words, (hipStream_t)stream);
-            const auto t1 = std::chrono::steady_clock::now();          // stark_gen's buffers, trees and events are released by now
+            const auto t1 = std::chrono::steady_clock::now();          // stark_gen's locals are gone; their blocks are stamped and released when this call's DeferFlush runs (not in host_release_ms)
+            self_check(*s, z);
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);
@@ -1086,6 +1097,21 @@ const char* zk_stark_last_timing(const zk_stark_setup_t* s) { return s ? s->last
 
 int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr) {
     return guard([&] { ZK_REQUIRE(s && prover_addr, "null argument"); s->prover_addr = prover_addr; });
+}
+
+int zk_stark_setup_set_self_check(zk_stark_setup_t* s, int on) {
+    return guard([&] { ZK_REQUIRE(s, "null argument"); s->self_check = on != 0; });
+}
+
+int zk_stark_verify(const zk_stark_setup_t* s, const char* zkin_json) {
+    int ok = -1;
+    if (guard([&] {
+            ZK_REQUIRE(s && zkin_json, "zk_stark_verify: null argument");
+            std::string why;
+            ok = stark_verify_impl(s->info, s->prog, s->ss, s->const_root, zkin_json, why);
+            if (!ok) set_error("stark_verify: " + why);
+        }) != 0) return -1;
+    return ok;
 }
 
 void zk_string_free(char* s) { free(s); }

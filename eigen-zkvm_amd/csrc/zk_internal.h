@@ -86,6 +86,9 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
 uint64_t merkle_n_nodes(uint64_t height);
 // nodes: merkle_n_nodes(height)*4 words, zero-filled by this call; leaves from [height][width] rows
 void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
+// n paths: from leaf digest [n][4] and siblings [n][max_depth][4] (path q uses its first depth[q] levels) to the root each implies
+void merkle_roots_from_paths_dev(const u64* d_leaves, const u64* d_paths, const uint32_t* d_depth, const u64* d_idx, uint32_t n, uint32_t max_depth,
+                                 u64* d_roots, hipStream_t st);
 
 // ---- device-resident transcript (poseidon.hip; transcript.rs:8-103) ----
 size_t transcript_state_bytes();
@@ -150,6 +153,13 @@ void bls12381_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u6
 uint64_t bls12381_merkle_n_nodes(uint64_t height);
 void bls12381_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
 void bls12381_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
+// stark_verify (stark_verify.hip): 1 accepted, 0 rejected (`why` names the failed check); throws Error on malformed input
+struct JVal;
+int stark_verify_impl(const JVal& info, const JVal& prog, const JVal& ss, const u64 const_root[4], const char* zkin_json, std::string& why);
+// the verifier's side of the scalar-field trees and digests (capi.hip)
+bool fr_digest_from_dec(bool bls12381, const std::string& dec, u64 out[4]);
+void fr_hash16_dev(bool bls12381, const u64* d_in, uint64_t n, const u64* d_zero4, u64* d_out, hipStream_t st);
+void fr_linearhash_rows_dev(bool bls12381, const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
 void qsplit_dev(const u64* d_qq1, uint32_t nbits, uint32_t q_dim, uint32_t q_deg, u64* d_qq2, hipStream_t st);
 // base-field elements in place: canonical integers <-> Montgomery (msm.hip); n = number of Fq elements
 void fq_bn254_canon_to_mont_dev(void* d, uint64_t n, hipStream_t st);

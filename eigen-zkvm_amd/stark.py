@@ -359,7 +359,8 @@ class NativeStarkSetup:
     """The C++ driver inside libzkgpu (csrc/stark_prover.hip): StarkSetup::new + stark_gen + FRI::prove
     behind zk_stark_setup_new / zk_stark_gen.  `program_json` = '{"starkinfo": ..., "program": ...}' text."""
 
-    def __init__(self, const_n, program_json, stark_struct_json, prover_addr=None):
+    def __init__(self, const_n, program_json, stark_struct_json, prover_addr=None, self_check=False):
+        """self_check: every gen() verifies its own proof before returning it, as stark_prove does (prove.rs:124-132)"""
         c = _np(const_n)
         hash_type = json.loads(stark_struct_json).get("verificationHashType")
         if hash_type in ("BN128", "BLS12381"):
@@ -370,6 +371,21 @@ class NativeStarkSetup:
             raise ZkError(lib().zk_last_error().decode())
         if prover_addr is not None:
             _check(lib().zk_stark_setup_set_prover_addr(self._h, prover_addr.encode()))
+        if self_check:
+            _check(lib().zk_stark_setup_set_self_check(self._h, 1))
+
+    def verify(self, zkin):
+        """stark_verify (stark_verify.rs:20-136) of a proof of this setup: zkin = the dict gen() returned or its JSON text.
+        True = accepted, False = rejected (`last_reject()` says which check); malformed input raises ZkError."""
+        text = zkin if isinstance(zkin, (str, bytes)) else json.dumps(zkin)
+        rc = lib().zk_stark_verify(self._h, text if isinstance(text, bytes) else text.encode())
+        if rc < 0:
+            raise ZkError(lib().zk_last_error().decode())
+        return rc == 1
+
+    @staticmethod
+    def last_reject():
+        return lib().zk_last_error().decode()
 
     def const_root(self):
         o = np.zeros(4, np.uint64); _check(lib().zk_stark_setup_const_root(self._h, _ptr(o))); return [int(v) for v in o]
@@ -420,6 +436,21 @@ class NativeStarkSetup:
             self.free()
         except Exception:
             pass
+
+
+def stark_verify(zkin, const_root, program_json, stark_struct_json):
+    """stark_verify without a prover's setup (zk_stark_verify_with): const_root = 4 words (GL) or the raw limbs
+    NativeStarkSetup.const_root() returns for scalar-field hashing"""
+    hash_type = json.loads(stark_struct_json).get("verificationHashType")
+    if hash_type in ("BN128", "BLS12381"):
+        from . import bn128_init
+        bn128_init(field=hash_type.lower())
+    r = np.ascontiguousarray(np.array([int(v) for v in const_root], dtype=np.uint64))
+    text = zkin if isinstance(zkin, (str, bytes)) else json.dumps(zkin)
+    rc = lib().zk_stark_verify_with(program_json.encode(), stark_struct_json.encode(), _ptr(r), text if isinstance(text, bytes) else text.encode())
+    if rc < 0:
+        raise ZkError(lib().zk_last_error().decode())
+    return rc == 1
 
 
 def load_program_json(path):

@@ -278,6 +278,21 @@ zk_stark_setup_t* zk_stark_setup_new(const char* starkinfo_program_json, const c
 int zk_stark_setup_const_root(const zk_stark_setup_t* s, uint64_t out[4]);   /* StarkSetup.const_root */
 /* stark_gen's `prover_addr` argument (stark_gen.rs:201): echoed as "proverAddr" by non-GL proofs (serializer.rs:255-262) */
 int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr);
+/* stark_verify (starky/src/stark_verify.rs:20-136, fri.rs:187-297) on a proof in the prover's own output format, the zkin
+ * JSON of serializer.rs:146-261, for all three hash types: 1 = accepted, 0 = rejected (zk_last_error() names the failed
+ * check: "Q != C * P", "FRIVerifierFailed: ...", a fold mismatch, the last polynomial's degree), -1 = malformed input.
+ * The sponge, the LinearHash of every opened row and every Merkle path run in the library's kernels; the two short
+ * verifier programs and the FRI groups' inverse transforms are scalar host work.  Scalar-field trees are checked exactly as
+ * merklehash_bn128.rs:108-128 does (only the last level of a path is bound to the root).
+ *   zk_stark_verify       against a prover's setup (its StarkInfo / Program / StarkStruct and the root of its constants)
+ *   zk_stark_verify_with  without one: the same JSON texts zk_stark_setup_new takes + const_root (GL words, or the raw
+ *                         Montgomery limbs zk_stark_setup_const_root returns for BN128 / BLS12381)
+ * zk_stark_setup_set_self_check(s, 1): every later zk_stark_gen* of the setup verifies its proof before returning it and
+ * fails (NULL, "the proof does not verify: ...") otherwise -- the `assert!(stark_verify(..))` of prove.rs:124-132.        */
+int zk_stark_verify(const zk_stark_setup_t* s, const char* zkin_json);
+int zk_stark_verify_with(const char* starkinfo_program_json, const char* stark_struct_json, const uint64_t const_root[4],
+                         const char* zkin_json);
+int zk_stark_setup_set_self_check(zk_stark_setup_t* s, int on);
 /* Where the time went, as JSON text owned by the setup (valid until the next call on it / its release).
  * zk_stark_setup_timing: StarkSetup::new (stark_setup.rs:26-66, one `#[time_profiler("stark_setup")]` span there) split into
  *   json_parse_ms, const_lde_merkle_ms, programs_ms (+ how many step programs hipRTC compiled and how many came from the

@@ -77,6 +77,18 @@ int main(int argc, char **argv) {
     if (!zkin) { fprintf(stderr, "zk_stark_gen: %s\n", zk_last_error()); return 1; }
     FILE *o = fopen(argv[6], "w"); fputs(zkin, o); fclose(o);
     printf("proof written: %zu bytes\n", strlen(zkin));
+    /* stark_verify on the prover's own output (prove.rs:124-132): accepted; with another constant root: rejected, not an error */
+    if (zk_stark_verify(su, zkin) != 1) { fprintf(stderr, "zk_stark_verify: %s\n", zk_last_error()); return 1; }
+    root2[0] ^= 1;
+    if (zk_stark_verify_with(prog, ss, root2, zkin) != 0) { fprintf(stderr, "a proof against another constant root must be rejected\n"); return 1; }
+    root2[0] ^= 1;
+    if (zk_stark_verify_with(prog, ss, root2, zkin) != 1) { fprintf(stderr, "zk_stark_verify_with: %s\n", zk_last_error()); return 1; }
+    if (zk_stark_verify(su, "{") != -1) { fprintf(stderr, "malformed zkin must be an error\n"); return 1; }
+    CHECK(zk_stark_setup_set_self_check(su, 1));
+    char *zkin2 = zk_stark_gen(su, cm, cm_bytes / 8);
+    if (!zkin2 || strcmp(zkin, zkin2) != 0) { fprintf(stderr, "self-checked proof differs: %s\n", zk_last_error()); return 1; }
+    zk_string_free(zkin2);
+    printf("verified: accepted, rejected under another constant root, self check on\n");
     zk_string_free(zkin);
     if (zk_stark_gen(su, cm, cm_bytes / 8 - 1) != NULL) { fprintf(stderr, "a short trace must be rejected\n"); return 1; }
     CHECK(zk_stark_setup_free(su));
