@@ -28,7 +28,7 @@ import time
 import numpy as np
 
 ROOT = pathlib.Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))   # the package (eigen_zkvm_amd.py); tests/: oracle_lib, the checker
 
 NBITS = 24
 SEED = 0x9E3779B97F4A7C15
@@ -64,43 +64,31 @@ def pmc_traffic(nbits):
     return d["ntt_pass_2p24"]["bytes_per_launch"], rel
 
 
-def shard_units(n_units, rank, world):
-    """Independent proving units (sub-proofs / columns sets) owned by `rank`: round-robin, so that
-    every rank gets floor or ceil of n_units/world and no unit is proved twice."""
-    return list(range(rank, n_units, world))
+def _agg():
+    """the product's aggregation driver (eigen-zkvm_amd/aggregation.py): sharding, the prover pool, the join tree, the root exchange"""
+    import importlib
+    return importlib.import_module("eigen_zkvm_amd.aggregation")
 
 
-def max_over_ranks(dist, values, device):
-    """MAX-reduce a list of floats over all ranks (the only collective on the bench path)."""
-    import torch
-    t = torch.tensor(values, device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return [float(v) for v in t]
+def _golden(nbits):
+    """the offline oracle golden of the 2^nbits PoseidonG proof (tools/gen_golden_full.py), or None"""
+    for name in ("poseidong_2p%d.json" % nbits, "poseidong_2p%d_roots.json" % nbits):
+        f = ROOT / "tests" / "golden" / name
+        if f.exists():
+            return json.loads(f.read_text())
+    return None
 
 
-def gather_roots(dist, root4, device):
-    """All-gather of each rank's Merkle roots (4 u64 words each; every rank passes the same number of words): the one
-    exchange step of sharded aggregation.  Returns a [world][n_words] list."""
-    import torch
-    to_i64 = lambda v: int(v) - (1 << 64) if int(v) >= (1 << 63) else int(v)   # u64 words travel as two's-complement int64
-    to_u64 = lambda v: int(v) + (1 << 64) if int(v) < 0 else int(v)
-    t = torch.tensor([to_i64(v) for v in root4], dtype=torch.int64, device=device)
-    if dist is None:
-        return [[to_u64(v) for v in t.tolist()]]
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return [[to_u64(v) for v in o.tolist()] for o in out]
-
-
-def prove_leg(zk, nbits, verify=True):
+def prove_leg(zk, nbits, verify=True, cpu_baseline=False, host_trace=True):
     """Third component of BASELINE's metric, "starky prove ms at 2^24 rows": one full GL-hash STARK proof
     (stark_gen.rs:193-557: LDE + Poseidon Merkle + constraint evaluation + FRI) of BASELINE's own workload, the
     PoseidonG PIL (starkjs/poseidon/poseidong.pil; compiled form tests/golden/poseidong.pil.json): 19 committed +
     18 constant columns, 36 intermediate columns (cm3), quotient in 2 x 3 columns (cm4), every 31-row slot of the trace
     hashing its own input (tools/tracegen.c).  Timed with the trace resident in HBM (`ms`) and handed over in host
     memory as `zkit stark_prove` has it after loading the .cm file (`ms_from_host_trace`).  After the clock stops the
-    restated verifier (oracle/stark_prover.py, stark_verify.rs:20-136) checks the timed proof: `verified`."""
+    timed proof is checked three ways: `verified` = the product's own stark_verify (zk_stark_verify; stark_verify.rs:20-136),
+    `verified_oracle` = the restated verifier of oracle/stark_prover.py, `golden` = roots / evaluations / sha256 of the whole
+    zkin against the fixture the CPU oracle prover produced offline (tools/gen_golden_full.py)."""
     import importlib
     sys.path.insert(0, str(ROOT / "tools"))
     import poseidong as PG
@@ -118,24 +106,26 @@ def prove_leg(zk, nbits, verify=True):
     d_cm = zk.DevArray.from_host(cm)                                        # trace resident in HBM when the clock starts
     for _ in range(4):
         t0 = time.perf_counter()
-        proof_dev = setup.gen(d_cm)
+        proof_text = setup.gen_json(d_cm)
         times.append((time.perf_counter() - t0) * 1e3)
-    for _ in range(2):                                                     # trace handed over in host memory
+    proof_dev = json.loads(proof_text)
+    for _ in range(2 if host_trace else 0):                                # trace handed over in host memory
         t0 = time.perf_counter()
         proof = setup.gen(cm)
         times_h2d.append((time.perf_counter() - t0) * 1e3)
-    assert proof_dev == proof
+        assert proof_dev == proof
     n_ext = 1 << (nbits + 1)
     sN = info["map_sectionsN"]
     perms = sum((_linearhash_perms(sN[s]) + 1) * n_ext for s in ("cm1_2ns", "cm3_2ns", "cm4_2ns"))
-    out = {"workload": "BASELINE config 3 PIL at the headline size: PoseidonG (starkjs/poseidon/poseidong.pil), nBits=%d, nBitsExt=%d, "
+    out = {"workload": "BASELINE config 3 PIL%s: PoseidonG (starkjs/poseidon/poseidong.pil), nBits=%d, nBitsExt=%d, "
                        "GL hash, %d queries, FRI steps %s; trace = %d Poseidon permutations, one input per 31-row slot"
-                       % (nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]], (1 << nbits) // 31),
+                       % (" at the headline size" if nbits == 24 else "", nbits, nbits + 1, ss["nQueries"], [s["nBits"] for s in ss["steps"]], (1 << nbits) // 31),
            "columns": {"cm1": info["n_cm1"], "const": info["n_constants"], "cm2": info["n_cm2"], "cm3": info["n_cm3"],
                        "cm4_words": sN["cm4_2ns"], "q_deg": info["q_deg"], "q_dim": info["q_dim"], "evals": len(info["ev_map"])},
            "ms": round(min(times[1:]), 1), "ms_runs": [round(t, 1) for t in times], "setup_s": round(setup_s, 2),
-           "poseidon_perms_per_proof": perms, "root1": proof["root1"],
-           "ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2), "stand_in": False}
+           "poseidon_perms_per_proof": perms, "root1": proof_dev["root1"], "stand_in": False}
+    if times_h2d:
+        out.update({"ms_from_host_trace": round(min(times_h2d), 1), "host_trace_GB": round(cm.nbytes / 1e9, 2)})
     out["setup_split"] = setup.setup_timing()                             # StarkSetup::new: JSON / constants / step programs (code-object cache)
     # The proof is four fifths Poseidon permutations (the three trees over the extended sections): rated as a whole against
     # the same integer-ALU ceiling as the Merkle leg -- every millisecond that is not hashing lowers the fraction.
@@ -143,12 +133,51 @@ def prove_leg(zk, nbits, verify=True):
     out["roofline"] = {"bound": "int-alu", "kernel": "linearhash_rows_kernel + merkle_level_kernel inside stark_gen", "achieved": round(rate / 1e9, 3),
                        "peak": round(VALU_MAD_PER_S / POSEIDON_MADS / 1e9, 3), "unit": "Gperm/s", "frac": round(rate / (VALU_MAD_PER_S / POSEIDON_MADS), 4),
                        "model": "the proof's %d permutations / its whole time, against %d v_mad_u64_u32 per permutation at the measured issue rate" % (perms, POSEIDON_MADS)}
-    if verify:                                                              # the checker, after the clock has stopped
-        sys.path.insert(0, str(ROOT / "oracle"))
-        import oracle_lib, stark_prover as SP, starkinfo as SI
-        vinfo, vprog, _ = SI.generate(PG.pil(nbits), ss)
-        p = SP.from_zkin(proof_dev)
-        out["verified"] = bool(SP.stark_verify(p, [int(v) for v in setup.const_root()], vinfo, vprog, ss, oracle_lib.load()))
+    if verify:                                                              # after the clock has stopped
+        t0 = time.perf_counter()
+        out["verified"] = bool(setup.verify(proof_text))                    # the product's verifier (zk_stark_verify)
+        out["verify_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        bad = dict(proof_dev, evals=[[str((int(proof_dev["evals"][0][0]) + 1) % 0xFFFFFFFF00000001)] + proof_dev["evals"][0][1:]] + proof_dev["evals"][1:])
+        out["tampered_rejected"] = not setup.verify(bad)
+        try:                                                                # the checker
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import oracle_lib, stark_prover as SP, starkinfo as SI
+            vinfo, vprog, _ = SI.generate(PG.pil(nbits), ss)
+            p = SP.from_zkin(proof_dev)
+            out["verified_oracle"] = bool(SP.stark_verify(p, [int(v) for v in setup.const_root()], vinfo, vprog, ss, oracle_lib.load()))
+        except Exception as e:
+            out["verified_oracle"] = "error: %s: %s" % (type(e).__name__, e)
+        gold = _golden(nbits)
+        if gold is not None and gold.get("starkStruct") == ss:
+            sys.path.insert(0, str(ROOT / "tools"))
+            from gen_golden_full import zkin_digest
+            g = {"fixture": "tests/golden/poseidong_2p%d%s.json" % (nbits, "" if "zkin_digest" in gold else "_roots"),
+                 "rootC_matches_golden": [str(v) for v in setup.const_root()] == gold["rootC"], "root1_matches_golden": proof_dev["root1"] == gold["root1"]}
+            if "zkin_digest" in gold:
+                g["zkin_sha256_matches_golden"] = zkin_digest(proof_dev) == gold["zkin_digest"]
+                g["all_roots_evals_finalpol_match"] = all(proof_dev[k] == gold[k] for k in gold if k in proof_dev)
+            out["golden"] = g
+    if cpu_baseline:
+        # the reference's CPU path beside it: the restated prover (oracle/stark_prover.py over oracle/*.c, OpenMP) on the SAME PIL at
+        # 2^16 rows -- a bounded sample; rows/s compare, a 2^24-row CPU proof takes the build container an hour (tools/gen_golden_full.py)
+        try:
+            sys.path.insert(0, str(ROOT / "oracle"))
+            import oracle_lib, stark_prover as SP
+            orc = oracle_lib.load()
+            nb = 16
+            ss16 = PG.stark_struct(nb)
+            su = SP.setup(PG.pil(nb), PG.consts(nb), ss16, orc)
+            cm16 = PG.trace(nb, None, PG.FIRST_ZERO, seed=nb)
+            t0 = time.perf_counter(); exp = SP.to_zkin(SP.stark_gen(cm16, su, ss16, orc)); cpu_s = time.perf_counter() - t0
+            ns16 = stark.NativeStarkSetup(PG.consts(nb), json.dumps(PG.program(nb)), json.dumps(ss16))
+            same = ns16.gen(cm16) == exp
+            ns16.free()
+            out["cpu_baseline"] = {"value": round((1 << nb) / cpu_s / 1e6, 4), "unit": "Mrows/s", "cores": orc.threads(), "kind": "port",
+                                   "gpu_value": round((1 << nbits) / (min(times[1:]) * 1e-3) / 1e6, 2), "gpu_proof_equals_cpu_proof_on_the_sample": bool(same),
+                                   "sample": "the same PIL at 2^16 rows, oracle/stark_prover.py stark_gen (C kernels with OpenMP, Python driver), %.2f s; "
+                                             "the offline 2^%d-row oracle proof behind tests/golden took %s s" % (cpu_s, nbits, (_golden(nbits) or {}).get("oracle_seconds", "n/a"))}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     setup.free()
     return out
 
@@ -167,9 +196,13 @@ def poseidon_leg(zk, log_height, width, cpu_baseline):
     """Poseidon-GL Merkle tree (merklehash.rs:293-346) over an HBM-resident [2^log_height][width] matrix -- 73 % of a proof.
     Integer-ALU bound: `roofline` rates the permutations per second against the multiply-add issue ceiling."""
     h = 1 << log_height
-    rng = np.random.default_rng(0x905E)
-    rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
-    d = zk.DevArray.from_host(rows)
+    if cpu_baseline or h * width < (1 << 26):
+        rng = np.random.default_rng(0x905E)
+        rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
+        d = zk.DevArray.from_host(rows)
+    else:                                                                # the large shapes are born in HBM (splitmix64 mod p)
+        d = zk.DevArray(h * width)
+        zk._check(zk.lib().zk_dev_fill_splitmix(d.ptr, h * width, 0x905E, None))
     times = []
     for _ in range(5):
         zk.lib().zk_dev_sync()
@@ -260,158 +293,34 @@ def final_wrap_leg(zk, nbits=18, log_rows=18, join_root=None):
     return out
 
 
-class GpuTaskProver:
-    """The three STARKs of one recursion task (test/recursive_proof_to_snark.sh:37-40, :68-71, :98-102) on this rank's GPU:
-    one setup per circuit (constants extended and merkelized once), per-task witnesses uploaded to HBM before the clock
-    starts, proofs through zk_stark_gen_dev_on.
-
-    These proofs are small (2^10 ... 2^18 rows): each is a chain of a few hundred launches with the transcript's round trips
-    between them, bound by latency, not by the device.  The reference runs its tasks as parallel processes
-    (test/stark_aggregation.sh:70-73); here `workers` host threads each own a set of setups and a non-blocking stream and take
-    tasks in turn, so several chains are in flight on the one GPU.  Inside a task the three proofs stay in order, as their data
-    dependency in the real pipeline demands."""
-
-    def __init__(self, zk, workers=None):
-        import importlib
-        sys.path.insert(0, str(ROOT / "tools"))
-        import aggregation_workload as AW
-        stark = importlib.import_module("eigen_zkvm_amd.stark")
-        self.zk, self.AW = zk, AW
-        self.workers = workers if workers is not None else int(os.environ.get("ZK_BENCH_WORKERS", "4"))
-        self.circ = {"c12": AW.Circuit(AW.STRUCTS["c12"]["nBits"]), "r1": AW.Circuit(AW.STRUCTS["r1"]["nBits"])}
-        # the joins' circuit (recursive2): its witness is what compressor12 exec computes -- on the device, from 17 words
-        self.join_circ = AW.JoinCircuit(AW.STRUCTS["r2"]["nBits"])
-        consts = {"fib": AW.fib_consts(), "c12": self.circ["c12"].consts, "r1": self.circ["r1"].consts, "r2": self.join_circ.consts}
-        progs = {k: json.dumps(AW.program(k)) for k in ("fib", "c12", "r1", "r2")}
-        mk = lambda k: stark.NativeStarkSetup(consts[k], progs[k], json.dumps(AW.STRUCTS[k]))
-        self.sets = [{k: mk(k) for k in ("fib", "c12", "r1", "r2")} for _ in range(self.workers)]
-        c12 = importlib.import_module("eigen_zkvm_amd.compressor12")
-        self.join_exec = c12.Compressor12Exec(self.join_circ.exec_text(), AW.JoinCircuit.N_WITNESS)   # read-only handle: shared by the workers
-        self.streams = [zk.Stream() for _ in range(self.workers)]
-        # per worker, summed over its joins: building + uploading the 17-word witness (host), compressor12 exec (device), the proof
-        self.join_exec_s, self.join_exec_dev_s, self.join_prove_s = [0.0] * self.workers, [0.0] * self.workers, [0.0] * self.workers
-        self.setups = self.sets[0]
-        self.sizes = {k: AW.STRUCTS[k]["nBits"] for k in self.setups}
-
-    def inputs(self, task):
-        D = self.zk.DevArray.from_host
-        return [("fib", D(self.AW.fib_trace(task))), ("c12", D(self.circ["c12"].witness(task))), ("r1", D(self.circ["r1"].witness(task)))]
-
-    @staticmethod
-    def _root1(zkin_json):
-        """root1 of a proof's JSON text without parsing the megabytes of openings after it (serializer.rs:146-152: rootC, root1, ...)"""
-        i = zkin_json.index(b'"root1":') + 8
-        j = zkin_json.index(b']', i) + 1 if zkin_json[i:i + 1] == b'[' else zkin_json.index(b',', i)
-        r = json.loads(zkin_json[i:j])
-        return [int(v) for v in (r if isinstance(r, list) else [r, 0, 0, 0])]
-
-    def prove(self, inputs, worker=0):
-        """-> the root of the committed trace of each of the task's three proofs, [[4 words]] * 3"""
-        st = self.streams[worker].handle
-        return [self._root1(self.sets[worker][kind].gen_bytes(d_cm, st)) for kind, d_cm in inputs]
-
-    def task_stage_times(self, inputs, worker=0):
-        """one task with ZK_STARK_TIMING on: per proof, HIP-event time on the proof's stream against the wall time of the call, and
-        the three largest stages (reference span names) -- where a task's latency goes: device work or waiting between launches"""
-        old = os.environ.get("ZK_STARK_TIMING")
-        os.environ["ZK_STARK_TIMING"] = "quiet"
-        try:
-            out, st = {}, self.streams[worker].handle
-            for kind, d_cm in inputs:
-                t0 = time.perf_counter(); self.sets[worker][kind].gen_bytes(d_cm, st); call_ms = (time.perf_counter() - t0) * 1e3
-                t = self.sets[worker][kind].last_timing()
-                stages = sorted(((k, v) for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms")), key=lambda kv: -kv[1])
-                out[kind] = {"call_ms": round(call_ms, 2), "gpu_event_ms": t.get("total_gpu_ms"), "host_after_last_launch_ms": round(call_ms - t.get("total_gpu_ms", 0), 2),
-                             "top_stages_ms": {k: round(v, 2) for k, v in stages[:4]}}
-            return out
-        finally:
-            if old is None: os.environ.pop("ZK_STARK_TIMING", None)
-            else: os.environ["ZK_STARK_TIMING"] = old
-
-    def _spread(self, jobs, fn):
-        """jobs[i] -> fn(jobs[i], worker) on worker i mod workers, the workers side by side; results in job order"""
-        import threading
-        out, errs = [None] * len(jobs), []
-        def run(w):
-            try:
-                for i in range(w, len(jobs), self.workers):
-                    out[i] = fn(jobs[i], w)
-            except BaseException as e:                                    # noqa: BLE001 -- re-raised below
-                errs.append(e)
-        threads = [threading.Thread(target=run, args=(w,)) for w in range(min(self.workers, len(jobs)))]
-        for t in threads: t.start()
-        for t in threads: t.join()
-        if errs:
-            raise errs[0]
-        return out
-
-    def prove_all(self, inputs_list):
-        return self._spread(inputs_list, self.prove)
-
-    def join(self, root_a, root_b, worker=0):
-        """One recursive2 step of the aggregation (test/stark_aggregation.sh:80-128: join_zkin + compressor12_exec +
-        stark_prove with r1.starkStruct.json, 2^18 rows): the joined circuit's primary inputs are the two child roots."""
-        primary = [int(w) for w in root_a] + [int(w) for w in root_b] + [0] * 8
-        st = self.streams[worker].handle
-        t0 = time.perf_counter()
-        d_w = self.zk.DevArray.from_host(self.AW.JoinCircuit.witness_vector(primary))       # what the circom calculator would hand over
-        t1 = time.perf_counter()
-        d_cm = self.join_exec.run(d_w, 1 << self.sizes["r2"], st)                         # PlonkAdds + s_map gather: the trace is born in HBM
-        t2 = time.perf_counter()
-        root = self._root1(self.sets[worker]["r2"].gen_bytes(d_cm, st))
-        self.join_exec_s[worker] += t1 - t0; self.join_exec_dev_s[worker] += t2 - t1; self.join_prove_s[worker] += time.perf_counter() - t2
-        return root
-
-    def warm_join(self):
-        """one join per worker before the clock: code objects of the r2 setups loaded, pool blocks of a join in place"""
-        self.join_all([([1, 2, 3, 4], [5, 6, 7, 8])] * self.workers)
-        self.sync()
-        self.join_exec_s, self.join_exec_dev_s, self.join_prove_s = [0.0] * self.workers, [0.0] * self.workers, [0.0] * self.workers
-
-    def join_all(self, pairs):
-        """the joins of one tree level: independent of each other"""
-        return self._spread(pairs, lambda ab, w: self.join(ab[0], ab[1], w))
-
-    def sync(self):
-        self.zk.lib().zk_dev_sync()
-
-    def describe(self):
-        return ("Fibonacci 2^10 (2 columns) + compressor-shaped circuit 2^15 and 2^18 (12 columns, PLONK gates, 12-column connection; "
-                "tools/pil/c12_shape.pil), GL hash; %d tasks in flight per GPU (host threads, one stream each)" % self.workers)
-
-
-def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
-    """BASELINE config 5, the sharded part of test/stark_aggregation.sh:70-73: a FIXED set of `n_tasks` independent recursion
-    tasks, task u on rank u mod world (shard_units), no collective while proving; the one exchange is the all-gather of the
-    tasks' roots (3 x 32 B per task).  Throughput = tasks / slowest rank's time, so it scales with the GPUs (strong scaling of
-    the 8-task job).  `prover` is GpuTaskProver, or a stub in the CPU tests of this control flow."""
-    units = shard_units(n_tasks, rank, world)
-    inputs = [prover.inputs(u) for u in units]                          # witness generation + upload: before the clock
+def aggregation_leg(pool, ex, n_tasks=8):
+    """BASELINE config 5 through the product's driver (eigen-zkvm_amd/aggregation.py; test/stark_aggregation.sh:70-73, :83-156): a FIXED
+    set of `n_tasks` independent recursion tasks, task u on rank u mod world, no collective while proving; the one exchange is the
+    all-gather of the tasks' roots (3 x 32 B per task), then the joins as a tree with one all-gather per level.  This function only
+    holds the clock: throughput = tasks / slowest rank's time, so it scales with the GPUs (strong scaling of the 8-task job).
+    `pool` is aggregation.ProverPool over the circuits of tools/aggregation_workload.py, or a stub in the CPU tests; `ex` the RootExchange."""
+    A = _agg()
+    rank, world = ex.rank, ex.world
+    units = A.shard_units(n_tasks, rank, world)
+    inputs = [pool.task_inputs(u) for u in units]                       # witness generation + upload: before the clock
     if inputs:                                                          # warm-up (pool, JIT modules of every worker's setups)
-        prover.prove_all(inputs) if hasattr(prover, "prove_all") else prover.prove(inputs[0])
-    prover.sync()
-    if dist is not None:
-        dist.barrier()
+        pool.prove_all(inputs) if hasattr(pool, "prove_all") else pool.prove(inputs[0])
+    pool.sync()
+    ex.barrier()
     t0 = time.perf_counter()
-    roots = prover.prove_all(inputs) if hasattr(prover, "prove_all") else [prover.prove(i) for i in inputs]
-    prover.sync()
+    roots = pool.prove_all(inputs) if hasattr(pool, "prove_all") else [pool.prove(i) for i in inputs]   # no collective inside the clock
+    pool.sync()
     dt = time.perf_counter() - t0
-    (dt,) = max_over_ranks(dist, [dt], device)
+    (dt,) = ex.max([dt])
     lat, lat_split = None, None
     if inputs:                                                          # one task alone: the floor of the job once every rank holds one task
-        t1 = time.perf_counter(); prover.prove(inputs[0]); prover.sync(); lat = time.perf_counter() - t1
-        if hasattr(prover, "task_stage_times"):                          # the same task once more with the library's stage timers on
-            lat_split = prover.task_stage_times(inputs[0])
-    per_rank = (n_tasks + world - 1) // world
-    flat = [w for task_roots in roots for r in task_roots for w in r]
-    flat += [0] * (per_rank * 12 - len(flat))                           # ranks with one task fewer pad their slot
-    gathered = gather_roots(dist, flat, device)
-    by_task = {}
-    for rk, words in enumerate(gathered):
-        for j, u in enumerate(shard_units(n_tasks, rk, world)):
-            by_task[u] = [words[12 * j + 4 * k: 12 * j + 4 * k + 4] for k in range(3)]
+        t1 = time.perf_counter(); pool.prove(inputs[0]); pool.sync(); lat = time.perf_counter() - t1
+        if hasattr(pool, "stage_times"):                                 # the same task once more with the library's stage timers on
+            lat_split = pool.stage_times(inputs[0])
+    by_task = A.gather_task_roots(roots, n_tasks, ex)
     out = {"workload": "BASELINE config 5 (sharded part): %d recursion tasks, task u on rank u mod %d, each = %s; "
-                       "witnesses resident in HBM, root all-gather only" % (n_tasks, world, prover.describe()),
+                       "witnesses resident in HBM, root all-gather only" % (n_tasks, world, getattr(pool, "description", "stub")),
+           "driver": "eigen-zkvm_amd/aggregation.py (ProverPool, prove_tasks, join_tree, RootExchange)",
            "tasks": n_tasks, "tasks_per_s": round(n_tasks / dt, 3), "proofs_per_s": round(3 * n_tasks / dt, 3), "s": round(dt, 4),
            "task_latency_s": None if lat is None else round(lat, 4),
            # what 8 GPUs can make of this job at best: every rank holds one task, so the job cannot finish before one task does
@@ -419,54 +328,19 @@ def aggregation_leg(prover, dist, rank, world, device, n_tasks=8):
            "task_latency_split": lat_split,
            "n_gpus": world, "scaling": "strong (fixed %d tasks)" % n_tasks,
            "distinct_roots": len({tuple(w for r in v for w in r) for v in by_task.values()}), "tasks_gathered": sorted(by_task)}
-    out["join_tree"] = join_tree(prover, dist, rank, world, device, [by_task[u][2] for u in sorted(by_task)])
-    return out
-
-
-def shard_all_joins(n_leaves, rank, world):
-    """(level, join) pairs of the join tree that fall on this rank"""
-    n, level = n_leaves, 0
-    while n > 1:
-        for j in shard_units(n // 2, rank, world):
-            yield level, j
-        n, level = n // 2 + n % 2, level + 1
-
-
-def join_tree(prover, dist, rank, world, device, leaves):
-    """The join phase as a tree instead of the reference's chain (test/stark_aggregation.sh:76-156 joins proof
-    k+1 into the running aggregate: NUM_PROOF - 1 sequential recursive2 proofs).  Level l joins neighbours pairwise, join j
-    on rank j mod world, one all-gather of the new roots per level: ceil(log2 n) dependent proofs on the critical path
-    instead of n - 1.  Every rank ends with the same root."""
-    if hasattr(prover, "warm_join"):
-        prover.warm_join()
-    if dist is not None:
-        dist.barrier()
+    # the join phase, timed
+    if hasattr(pool, "warm_join"):
+        pool.warm_join()
+    ex.barrier()
     t0 = time.perf_counter()
-    nodes, levels, joins = [list(r) for r in leaves], 0, 0
-    while len(nodes) > 1:
-        n_join = len(nodes) // 2
-        mine = shard_units(n_join, rank, world)
-        pairs = [(nodes[2 * j], nodes[2 * j + 1]) for j in mine]
-        made = prover.join_all(pairs) if hasattr(prover, "join_all") else [prover.join(a, b) for a, b in pairs]
-        per_rank = (n_join + world - 1) // world
-        flat = [w for r in made for w in r] + [0] * (4 * (per_rank - len(made)))
-        gathered = gather_roots(dist, flat, device)
-        nxt = [None] * n_join
-        for rk, words in enumerate(gathered):
-            for k, j in enumerate(shard_units(n_join, rk, world)):
-                nxt[j] = words[4 * k: 4 * k + 4]
-        if len(nodes) % 2:
-            nxt.append(nodes[-1])                                          # odd one out moves up unjoined
-        nodes, levels, joins = nxt, levels + 1, joins + n_join
-    prover.sync()
-    dt = time.perf_counter() - t0
-    (dt,) = max_over_ranks(dist, [dt], device)
-    out = {"levels": levels, "joins": joins, "chain_depth_of_the_reference": max(0, len(leaves) - 1), "s": round(dt, 4), "root": [int(w) for w in nodes[0]]}
-    if hasattr(prover, "join_exec_s") and joins:      # where a join's time goes on this rank: the host exec step (witness of the joined circuit) and the proof
-        mine = max(1, sum(1 for _ in shard_all_joins(len(leaves), rank, world)))
-        out["per_join_ms"] = {"exec_host": round(1e3 * sum(prover.join_exec_s) / mine, 2),
-                              "exec_dev": round(1e3 * sum(getattr(prover, "join_exec_dev_s", [0.0])) / mine, 2),
-                              "prove": round(1e3 * sum(prover.join_prove_s) / mine, 1)}
+    jt = A.join_tree(pool, [by_task[u][2] for u in sorted(by_task)], ex)
+    (jdt,) = ex.max([time.perf_counter() - t0])
+    jt["s"] = round(jdt, 4)
+    if hasattr(pool, "join_exec_s") and jt["joins"]:  # where a join's time goes on this rank: the host exec step (witness of the joined circuit) and the proof
+        mine = max(1, sum(1 for _ in A.shard_all_joins(len(by_task), rank, world)))
+        jt["per_join_ms"] = {"exec_host": round(1e3 * sum(pool.join_exec_s) / mine, 2), "exec_dev": round(1e3 * sum(pool.join_exec_dev_s) / mine, 2),
+                             "prove": round(1e3 * sum(pool.join_prove_s) / mine, 1)}
+    out["join_tree"] = jt
     return out
 
 
@@ -476,9 +350,13 @@ def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
     CPU oracle on a bounded sample, which is also the timed CPU baseline."""
     h = 1 << log_height
     zk.bn128_init()
-    rng = np.random.default_rng(0xB128)
-    rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
-    d = zk.DevArray.from_host(rows)
+    if cpu_baseline or h * width < (1 << 26):
+        rng = np.random.default_rng(0xB128)
+        rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
+        d = zk.DevArray.from_host(rows)
+    else:                                                                # the large shapes are born in HBM (splitmix64 mod p)
+        d = zk.DevArray(h * width)
+        zk._check(zk.lib().zk_dev_fill_splitmix(d.ptr, h * width, 0xB128, None))
     times = []
     for _ in range(4):
         t0 = time.perf_counter()
@@ -659,8 +537,8 @@ def main():
 
     import numpy as np
     import torch
-    import zkgpu_loader, oracle_lib
-    zk = zkgpu_loader.load()
+    import eigen_zkvm_amd, oracle_lib
+    zk = eigen_zkvm_amd                                               # the product: ctypes over libzkgpu's C ABI
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -711,13 +589,16 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                                     # HIP events on the launch stream
-    wall, dev_ms = max_over_ranks(dist, [wall, dev_ms], dev)
+    ex = _agg().RootExchange(dist, dev)                                  # the collectives of the path live in the product
+    wall, dev_ms = ex.max([wall, dev_ms])
 
     agg = None
     if not args.no_agg and not args.no_prove:                          # every rank takes part (N = 1: all 8 tasks on this GPU)
         try:
             n_workers = int(os.environ.get("ZK_BENCH_WORKERS", max(1, min(4, (8 + world - 1) // world))))   # no more provers than a rank has tasks
-            agg = aggregation_leg(GpuTaskProver(zk, workers=n_workers), dist, rank, world, dev)
+            sys.path.insert(0, str(ROOT / "tools"))
+            import aggregation_workload as AW
+            agg = aggregation_leg(AW.pool(zk, workers=n_workers), ex)
         except Exception as e:                                         # at N = 1 the bench line survives a failing extra leg
             if dist is not None:                                       # (with several ranks the others wait in a collective: fail loudly)
                 raise
@@ -766,13 +647,16 @@ def main():
             leg("msm_g1_bls12_381", msm_leg, zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
         if not args.no_poseidon and world == 1:
             leg("poseidon_merkle_gl", poseidon_leg, zk, 22, 19, not args.no_cpu_baseline)
+            leg("poseidon_merkle_gl_ref_shape", poseidon_leg, zk, 24, 10, False)   # starky/benches/merklehash.rs:26-27: 2^24 x 10, the one GL shape the reference benches
         if not args.no_bn128 and world == 1:
             leg("merkle_bn128", bn128_merkle_leg, zk, 20, 12, not args.no_cpu_baseline)
+            leg("merkle_bn128_ref_shape", bn128_merkle_leg, zk, 24, 10, False)   # starky/README.md:55: 2^24 x 10 with the BN128 hash, 11.04 s on the reference's CPU (context, other hardware)
         if not args.no_groth16 and world == 1:
             leg("groth16_prove_bn128", groth16_leg, zk, "BN128", args.groth16_log_rows, not args.no_cpu_baseline)
             leg("groth16_prove_bls12381", groth16_leg, zk, "BLS12381", args.groth16_log_rows, False)
         if not args.no_prove and world == 1:
-            leg("stark_prove", prove_leg, zk, args.prove_nbits)
+            leg("stark_prove", prove_leg, zk, args.prove_nbits, True, not args.no_cpu_baseline)
+            leg("stark_prove_cfg3", prove_leg, zk, 20, True, False, False)     # BASELINE config 3 itself: 2^20 rows, steps 21/15/11/7/4
         if agg is not None:
             out["aggregation"] = agg
         if not args.no_cpu_baseline and world == 1:                   # a reported baseline of the N = 1 line only

@@ -1,5 +1,6 @@
-"""The N>1 path of bench.py on CPU: world_size-2 gloo processes exercise unit sharding, the
-max-over-ranks timing reduction and the 32-byte root all-gather (the only collectives on the path)."""
+"""The N>1 path on CPU: the product's aggregation driver (eigen-zkvm_amd/aggregation.py: shard_units, prove_tasks, join_tree,
+RootExchange) and bench.py's timing wrapper around it on world_size-2 and -8 gloo processes -- unit sharding, the max-over-ranks
+reduction and the 32-byte root all-gather (the only collectives on the path)."""
 import os, sys, pathlib
 import torch
 import torch.distributed as dist
@@ -9,9 +10,9 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 
 class StubProver:
-    """stands in for bench.GpuTaskProver in the control-flow test: "proofs" are hashes of the task number"""
+    """stands in for aggregation.ProverPool in the control-flow test: "proofs" are hashes of the task number"""
     def __init__(self): self.proved = []
-    def inputs(self, task): return task
+    def task_inputs(self, task): return task
     def prove(self, task):
         self.proved.append(task)
         return [[(task * 1000003 + 17 * k + j) % (1 << 64) if j else (1 << 63) + task for j in range(4)] for k in range(3)]
@@ -19,7 +20,12 @@ class StubProver:
         self.joined = getattr(self, "joined", 0) + 1
         return [(3 * int(a[i]) + 5 * int(b[i]) + 7 + i) % (1 << 64) for i in range(4)]
     def sync(self): pass
-    def describe(self): return "stub"
+
+
+def _ex(dist):
+    import zkgpu_loader, importlib
+    zkgpu_loader.load()
+    return importlib.import_module("eigen_zkvm_amd.aggregation").RootExchange(dist, torch.device("cpu"))
 
 
 def _agg_worker(rank, world, port, q):
@@ -28,7 +34,7 @@ def _agg_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pr = StubProver()
-    out = bench.aggregation_leg(pr, dist, rank, world, torch.device("cpu"), n_tasks=7)   # 7: ranks get 4 and 3 tasks
+    out = bench.aggregation_leg(pr, _ex(dist), n_tasks=7)   # 7: ranks get 4 and 3 tasks
     dist.barrier()
     q.put((rank, pr.proved, out, pr.joined))
     dist.destroy_process_group()
@@ -71,7 +77,7 @@ def _agg8_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pr = StubProver()
-    out = bench.aggregation_leg(pr, dist, rank, world, torch.device("cpu"), n_tasks=8)
+    out = bench.aggregation_leg(pr, _ex(dist), n_tasks=8)
     dist.barrier()
     q.put((rank, pr.proved, out, getattr(pr, "joined", 0)))
     dist.destroy_process_group()
@@ -106,20 +112,27 @@ def test_aggregation_leg_single_rank():
     sys.path.insert(0, str(ROOT))
     import bench
     pr = StubProver()
-    out = bench.aggregation_leg(pr, None, 0, 1, torch.device("cpu"))
+    out = bench.aggregation_leg(pr, _ex(None))
     assert pr.proved == [0] + list(range(8)) + [0] and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
     assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 7)
 
 
 def _worker(rank, world, port, q):
-    sys.path.insert(0, str(ROOT))
-    import bench
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cpu")
-    mine = bench.shard_units(8, rank, world)
-    wall, ms = bench.max_over_ranks(dist, [1.0 + rank, 10.0 - rank], dev)
-    roots = bench.gather_roots(dist, [rank + 1, 2, 3, (1 << 62) + rank], dev)
+    import zkgpu_loader, importlib
+    zkgpu_loader.load()
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    ex = A.RootExchange.from_env()                       # no GPU here: gloo
+    assert (ex.rank, ex.world) == (rank, world)
+    mine = A.shard_units(8, rank, world)
+    wall, ms = ex.max([1.0 + rank, 10.0 - rank])
+    roots = ex.gather([rank + 1, 2, 3, (1 << 62) + rank])
+    # the whole driver without bench.py: prove this rank's tasks, exchange, join -- the same result on every rank
+    pr = StubProver()
+    res = A.aggregate(pr, [pr.task_inputs(u) for u in A.shard_units(5, rank, world)], 5, ex)
+    assert sorted(res["by_task"]) == list(range(5)) and res["join_tree"]["joins"] == 4
+    roots.append(res["join_tree"]["root"])
     dist.barrier()
     q.put((rank, mine, wall, ms, roots))
     dist.destroy_process_group()
@@ -141,12 +154,18 @@ def test_two_rank_gloo_sharding_and_reductions():
     assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
     for r in res:
         assert r[2] == 2.0 and r[3] == 10.0              # MAX over ranks
-        assert r[4] == [[1, 2, 3, 1 << 62], [2, 2, 3, (1 << 62) + 1]]
+        assert r[4][:2] == [[1, 2, 3, 1 << 62], [2, 2, 3, (1 << 62) + 1]]
+    assert res[0][4][2] == res[1][4][2]                  # the join tree's root
 
 
 def test_single_rank_helpers_without_dist():
-    sys.path.insert(0, str(ROOT))
-    import bench
-    assert bench.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
-    assert bench.max_over_ranks(None, [3.5, 1.0], torch.device("cpu")) == [3.5, 1.0]
-    assert bench.gather_roots(None, [1, 2, 3, 4], torch.device("cpu")) == [[1, 2, 3, 4]]
+    import zkgpu_loader, importlib
+    zkgpu_loader.load()
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    ex = A.RootExchange()
+    assert A.shard_units(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert ex.max([3.5, 1.0]) == [3.5, 1.0]
+    assert ex.gather([1, 2, 3, 4]) == [[1, 2, 3, 4]]
+    assert list(A.shard_all_joins(8, 1, 2)) == [(0, 1), (0, 3), (1, 1)] and list(A.shard_all_joins(8, 0, 2)) == [(0, 0), (0, 2), (1, 0), (2, 0)]
+    assert A.root1_of(b'{"rootC":["1","2","3","4"],"root1":["5","6","7","8"],"root2":"9"}') == [5, 6, 7, 8]
+    assert A.root1_of(b'{"rootC":"1","root1":"5","root2":"9"}') == [5, 0, 0, 0]

@@ -3,12 +3,12 @@ python tools/agg_probe.py [workers]"""
 import json, pathlib, sys, time, threading
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
-import bench
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
+import aggregation_workload as AW
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-P = bench.GpuTaskProver(zk, workers=W)
-ins = [P.inputs(t) for t in range(W)]
+P = AW.pool(zk, workers=W)
+ins = [P.task_inputs(t) for t in range(W)]
 for kind_i, kind in enumerate(("fib", "c12", "r1")):
     for rep in range(2):
         t0 = time.perf_counter()

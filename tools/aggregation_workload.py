@@ -121,3 +121,26 @@ def fib_consts():
 def fib_trace(task):
     a, b = FIB_INPUTS[task % len(FIB_INPUTS)]
     out = np.zeros(2 << 10, np.uint64); _lib().fib_trace(C.c_uint(10), C.c_uint64(a), C.c_uint64(b), _vp(out)); return out
+
+
+def circuits():
+    """{name: (constants, program_json, stark_struct_json)} of the four circuits of config 5 + the join spec ProverPool takes + the
+    Circuit objects that make per-task witnesses"""
+    circ = {"c12": Circuit(STRUCTS["c12"]["nBits"]), "r1": Circuit(STRUCTS["r1"]["nBits"])}
+    jc = JoinCircuit(STRUCTS["r2"]["nBits"])       # the joins' circuit (recursive2): its witness is what compressor12 exec computes from 17 words
+    consts = {"fib": fib_consts(), "c12": circ["c12"].consts, "r1": circ["r1"].consts, "r2": jc.consts}
+    specs = {k: (consts[k], json.dumps(program(k)), json.dumps(STRUCTS[k])) for k in ("fib", "c12", "r1", "r2")}
+    return specs, ("r2", jc.exec_text(), JoinCircuit.N_WITNESS, JoinCircuit.witness_vector), circ
+
+
+def pool(zk, workers=4, **kw):
+    """the product's ProverPool (eigen-zkvm_amd/aggregation.py) over these circuits; .task_inputs(task) makes a task's three HBM-resident traces"""
+    import importlib
+    agg = importlib.import_module("eigen_zkvm_amd.aggregation")
+    specs, join, circ = circuits()
+    p = agg.ProverPool(zk, specs, workers=workers, join=join, **kw)
+    D = zk.DevArray.from_host
+    p.task_inputs = lambda task: [("fib", D(fib_trace(task))), ("c12", D(circ["c12"].witness(task))), ("r1", D(circ["r1"].witness(task)))]
+    p.description = ("Fibonacci 2^10 (2 columns) + compressor-shaped circuit 2^15 and 2^18 (12 columns, PLONK gates, 12-column connection; "
+                     "tools/pil/c12_shape.pil), GL hash; %d tasks in flight per GPU (host threads, one stream each)" % p.workers)
+    return p

@@ -3,8 +3,8 @@ import sys, time, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0); zk.bn128_init()
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0); zk.bn128_init()
 args = [int(a) for a in sys.argv[1:]] or [16, 12, 18, 12, 20, 12, 18, 48]
 for lh, w in zip(args[::2], args[1::2]):
     h = 1 << lh

@@ -4,8 +4,8 @@ import pathlib, sys, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 d = zk.DevArray.from_host(np.arange(8 * n, dtype=np.uint64))
 best = 1e9

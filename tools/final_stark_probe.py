@@ -3,8 +3,8 @@ rocprofv3 --kernel-trace --hip-trace --stats: python tools/final_stark_probe.py 
 import json, pathlib, sys, time, importlib
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 import aggregation_workload as AW, poseidong as PG
 stark = importlib.import_module("eigen_zkvm_amd.stark")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10

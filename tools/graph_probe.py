@@ -4,8 +4,8 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch
 torch.cuda.set_device(0)
-import zkgpu_loader, oracle_lib
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd, oracle_lib
+zk = eigen_zkvm_amd; zk.init(0)
 lib = zk.lib(); vp = C.c_void_p
 nbits = 24; n = 1 << nbits
 x = torch.from_numpy(oracle_lib.splitmix64_stream(1, n).view(np.int64)).cuda()

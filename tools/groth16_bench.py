@@ -6,7 +6,7 @@ import importlib, struct, sys, time, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
+import eigen_zkvm_amd
 
 FR = {"BN128": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
       "BLS12381": 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001}
@@ -85,7 +85,7 @@ def density(r1cs_bytes, ni, n_wires):
 def main():
     args = sys.argv[1:]
     curve = args.pop(0) if args and args[0] in FR else "BN128"
-    zk = zkgpu_loader.load(); zk.init(0)
+    zk = eigen_zkvm_amd; zk.init(0)
     dev = importlib.import_module("eigen_zkvm_amd.groth16")
     for log_rows in [int(a) for a in args] or [16, 20]:
         t = time.perf_counter()

@@ -1,9 +1,9 @@
 """LDE timing: python tools/lde_time.py nbits np [np ...]   (ZK_LDE_NO_COSET=1 selects the single 2N-point forward transform)"""
 import sys, time, pathlib, ctypes
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 nbits = int(sys.argv[1])
 for np_ in [int(a) for a in sys.argv[2:]]:
     n = 1 << nbits

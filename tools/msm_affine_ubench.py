@@ -4,10 +4,10 @@ one inversion per lane (csrc/msm_impl.cuh ubench_*): python tools/msm_affine_ube
 import ctypes, os, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 os.environ.setdefault("ZKGPU_LIB", str(ROOT / "eigen-zkvm_amd" / "variants" / "libzkgpu_msmub.so"))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 lib = ctypes.CDLL(os.environ["ZKGPU_LIB"])
 lib.zk_msm_ubench_affine.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
 lanes = 1 << 17                                                          # two waves per SIMD, as the accumulation kernel runs

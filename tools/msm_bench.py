@@ -3,9 +3,9 @@ import sys, time, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
+import eigen_zkvm_amd
 
-zk = zkgpu_loader.load(); zk.init(0)
+zk = eigen_zkvm_amd; zk.init(0)
 curve = "bn254"
 args = sys.argv[1:]
 if args and args[0] in ("bn254", "bls12_381"):

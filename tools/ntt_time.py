@@ -3,8 +3,8 @@ import sys, time, pathlib
 import numpy as np
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 nbits = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 npols = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n = (1 << nbits) * npols

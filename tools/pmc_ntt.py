@@ -4,8 +4,8 @@ import sys, pathlib
 import numpy as np, torch
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 a = torch.arange(1 << 27, dtype=torch.int64, device="cuda")
 for _ in range(3):
     b = a.clone()

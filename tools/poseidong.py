@@ -92,9 +92,9 @@ def trace(nbits, n_inputs=None, first=FIRST_ZERO, seed=0):
 def native_program(pil_dict, ss):
     """{"starkinfo", "program"} from the product's own code generator (zk_starkinfo_generate, csrc/starkinfo_gen.hip)"""
     import importlib, sys
-    sys.path.insert(0, str(ROOT / "tests"))
-    import zkgpu_loader
-    zkgpu_loader.load()
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import eigen_zkvm_amd
+    eigen_zkvm_amd
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     return json.loads(stark.generate_program(json.dumps(pil_dict), json.dumps(ss)))
 

@@ -4,14 +4,14 @@ usage: python tools/prove_bench.py --nbits 16 18 20 [--w 10] [--verify]
 Prints one JSON line per size: setup (const LDE+Merkle, JIT compile) and stark_gen wall time."""
 import argparse, json, pathlib, sys, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
 import importlib
-import zkgpu_loader, synth_pil
+import eigen_zkvm_amd, synth_pil
 
 
 def poseidong_main(args):
     import poseidong as PG
-    zk = zkgpu_loader.load(); zk.init(0)
+    zk = eigen_zkvm_amd; zk.init(0)
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     for nbits in args.nbits:
         ss = PG.stark_struct(nbits, hash_type=args.hash)
@@ -50,7 +50,7 @@ def main():
     args = ap.parse_args()
     if args.pil == "poseidong":
         return poseidong_main(args)
-    zk = zkgpu_loader.load(); zk.init(0)
+    zk = eigen_zkvm_amd; zk.init(0)
     stark = importlib.import_module("eigen_zkvm_amd.stark")
     for nbits in args.nbits:
         prog, ss = synth_pil.program(nbits, args.w, args.hash)

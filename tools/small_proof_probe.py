@@ -2,14 +2,14 @@
 import json, pathlib, sys, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
-import bench
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
+import aggregation_workload as AW
 kind = sys.argv[1] if len(sys.argv) > 1 else "fib"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-P = bench.GpuTaskProver(zk, workers=1)
+P = AW.pool(zk, workers=1)
 i = {"fib": 0, "c12": 1, "r1": 2}[kind]
-inp = P.inputs(0)[i]
+inp = P.task_inputs(0)[i]
 for _ in range(3): P.prove([inp], 0)
 P.sync(); t0 = time.perf_counter()
 for _ in range(n): P.prove([inp], 0)

@@ -2,8 +2,8 @@
 proof its setup gives alone.  python tools/stress_concurrent.py"""
 import json, pathlib, sys, threading, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent; sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "tools"))
-import zkgpu_loader
-zk = zkgpu_loader.load(); zk.init(0)
+import eigen_zkvm_amd
+zk = eigen_zkvm_amd; zk.init(0)
 import importlib, aggregation_workload as AW
 stark = importlib.import_module("eigen_zkvm_amd.stark")
 W, ROUNDS, REPS = 8, 4, 6

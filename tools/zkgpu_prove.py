@@ -5,6 +5,8 @@
                              -c verifier.circom --i zkin.json [--norm_stage] [--skip_main] [--agg_stage] [--prover_addr A] \\
                              [--program starkinfo_program.json]
   zkgpu_prove.py groth16_prove -c BN128 --r1cs circuit.r1cs -w witness.wtns -p g16.key --public-input public_input.json --proof proof.json
+  zkgpu_prove.py stark_verify -s starkStruct.json -p circuit.pil.json --o circuit.const --i zkin.json [--program FILE]
+  [torchrun --nproc-per-node N] zkgpu_prove.py stark_aggregate --num_proof 8 --workspace DIR [--workers 4] [--keep_proofs]
 
 Flags, defaults and file formats are zkit's (zkit/src/main.rs:98-123 StarkProveOpt, :199-217 Groth16ProveOpt;
 starky/src/prove.rs:30-160, groth16/src/api.rs:144-205).  What differs, and why:
@@ -15,6 +17,12 @@ starky/src/prove.rs:30-160, groth16/src/api.rs:144-205).  What differs, and why:
     accepted and the file is left untouched.
   * groth16_prove: `-w` takes the `.wtns` the witness calculator wrote (zkit passes the .wasm and an input.json and runs the
     calculator in process, api.rs:150-160: WASM execution is out of scope); `-i` is accepted and ignored.
+  * stark_prove verifies its own proof before it writes anything, as the reference does (prove.rs:124-132; `--no_verify` skips it).
+  * stark_verify: the check alone, on a zkin file (the reference exposes it only inside stark_prove).
+  * stark_aggregate: test/stark_aggregation.sh:70-73 + :83-156 through eigen-zkvm_amd/aggregation.py -- NUM_PROOF recursion tasks
+    sharded over the ranks (one process per GPU), their recursive1 roots all-gathered, joined as a tree; the circuits are the
+    synthetic ones of tools/aggregation_workload.py (the real ones are circom-compiled verifiers).  Writes aggregation.json
+    (every task's roots, the join tree's root, timings) into --workspace on rank 0.
 Exit status 0 on success, 1 with the library's message on stderr otherwise (zkit: anyhow error -> exit 1)."""
 import argparse
 import json
@@ -22,12 +30,12 @@ import pathlib
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 
 
 def _zk():
-    import zkgpu_loader
-    zk = zkgpu_loader.load()
+    import eigen_zkvm_amd
+    zk = eigen_zkvm_amd
     if zk.lib().zk_device_count() < 1:
         raise SystemExit("zkgpu_prove: no GPU visible (the library has no CPU fallback)")
     zk.init(0)
@@ -53,12 +61,72 @@ def stark_prove(a):
         program_json = stark.generate_program(json.dumps(pil), json.dumps(ss))
     else:
         raise SystemExit("zkgpu_prove: --program FILE is required (this build has no code generator)")
-    setup = stark.NativeStarkSetup(const, program_json, json.dumps(ss), prover_addr=a.prover_addr if ss.get("verificationHashType") != "GL" else None)
-    zkin = setup.gen(cm)
+    setup = stark.NativeStarkSetup(const, program_json, json.dumps(ss), prover_addr=a.prover_addr if ss.get("verificationHashType") != "GL" else None,
+                                   self_check=not a.no_verify)                 # prove.rs:124-132: assert!(stark_verify(..)) before anything is written
+    zkin = setup.gen_json(cm)
     with open(a.zkin, "w") as f:
-        json.dump(zkin, f)
+        f.write(zkin)
     setup.free()
-    print("zkgpu_prove: proof of 2^%d rows written to %s (rootC %s)" % (ss["nBits"], a.zkin, zkin["rootC"]))
+    print("zkgpu_prove: proof of 2^%d rows %swritten to %s (rootC %s)" % (ss["nBits"], "" if a.no_verify else "verified and ", a.zkin, json.loads(zkin)["rootC"]))
+
+
+def _setup_from_files(a, stark, self_check=False):
+    import numpy as np
+    ss = json.load(open(a.stark_struct))
+    pil = json.load(open(a.piljson))
+    const = np.fromfile(a.const_pols, dtype="<u8")
+    program_json = open(a.program).read() if a.program else stark.generate_program(json.dumps(pil), json.dumps(ss))
+    return stark.NativeStarkSetup(const, program_json, json.dumps(ss), self_check=self_check), ss
+
+
+def stark_verify(a):
+    import importlib
+    _zk()
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    setup, ss = _setup_from_files(a, stark)
+    ok = setup.verify(open(a.zkin).read())
+    why = "" if ok else setup.last_reject()
+    setup.free()
+    if not ok:
+        raise SystemExit("zkgpu_prove: %s does not verify: %s" % (a.zkin, why))
+    print("zkgpu_prove: %s verifies (2^%d rows, %s hash)" % (a.zkin, ss["nBits"], ss["verificationHashType"]))
+
+
+def stark_aggregate(a):
+    import importlib
+    import os
+    import time
+    sys.path.insert(0, str(ROOT / "tools"))
+    import eigen_zkvm_amd as zk
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if zk.lib().zk_device_count() <= local_rank:
+        raise SystemExit("zkgpu_prove: no GPU for local rank %d (the library has no CPU fallback)" % local_rank)
+    zk.init(local_rank)
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    import aggregation_workload as AW
+    ex = A.RootExchange.from_env(local_rank)
+    n = a.num_proof
+    per_rank = (n + ex.world - 1) // ex.world
+    pool = AW.pool(zk, workers=max(1, min(a.workers, per_rank)), keep_proofs=a.keep_proofs, self_check=not a.no_verify)
+    inputs = [pool.task_inputs(u) for u in A.shard_units(n, ex.rank, ex.world)]
+    ex.barrier()
+    t0 = time.perf_counter()
+    res = A.aggregate(pool, inputs, n, ex)
+    (dt,) = ex.max([time.perf_counter() - t0])
+    if ex.rank == 0:
+        ws = pathlib.Path(a.workspace); ws.mkdir(parents=True, exist_ok=True)
+        out = {"num_proof": n, "ranks": ex.world, "seconds": round(dt, 4), "verified": not a.no_verify,
+               "tasks": {str(u): {k: [str(w) for w in r] for k, r in zip(("fibonacci", "c12", "recursive1"), res["by_task"][u])} for u in sorted(res["by_task"])},
+               "join_tree": dict(res["join_tree"], root=[str(w) for w in res["join_tree"]["root"]])}
+        (ws / "aggregation.json").write_text(json.dumps(out, indent=1) + "\n")
+        print("zkgpu_prove: %d tasks on %d rank(s), %d joins in %d levels, %.3f s; root %s -> %s"
+              % (n, ex.world, res["join_tree"]["joins"], res["join_tree"]["levels"], dt, out["join_tree"]["root"], ws / "aggregation.json"))
+    if a.keep_proofs:
+        ws = pathlib.Path(a.workspace); ws.mkdir(parents=True, exist_ok=True)
+        for i, (kind, z) in enumerate(pool.proofs):
+            (ws / ("rank%d_%03d_%s.zkin.json" % (ex.rank, i, kind))).write_bytes(z)
+    pool.free()
+    ex.barrier()
 
 
 def groth16_prove(a):
@@ -95,7 +163,22 @@ def main(argv=None):
     s.add_argument("--i", dest="zkin", default="zkin.json")
     s.add_argument("--prover_addr", default="273030697313060285579891744179749754319274977764")
     s.add_argument("--program", help='{"starkinfo", "program"} JSON of the code generator (extension, see the module text)')
+    s.add_argument("--no_verify", action="store_true", help="skip the self check of prove.rs:124-132 (extension)")
     s.set_defaults(fn=stark_prove)
+    v = sub.add_parser("stark_verify", help="stark_verify.rs:20-136 on a zkin file (extension: the reference runs it inside stark_prove only)")
+    v.add_argument("-s", "--stark_stuct", dest="stark_struct", default="stark_struct.json")
+    v.add_argument("-p", "--piljson", default="pil.json")
+    v.add_argument("--o", dest="const_pols", default="pols.const")
+    v.add_argument("--i", dest="zkin", default="zkin.json")
+    v.add_argument("--program")
+    v.set_defaults(fn=stark_verify)
+    ag = sub.add_parser("stark_aggregate", help="test/stark_aggregation.sh:70-73,83-156: NUM_PROOF tasks sharded over the GPUs + the joins")
+    ag.add_argument("--num_proof", type=int, default=8)
+    ag.add_argument("--workspace", default="/tmp/aggregation")
+    ag.add_argument("--workers", type=int, default=4, help="provers in flight per GPU")
+    ag.add_argument("--keep_proofs", action="store_true", help="write every proof's zkin into the workspace")
+    ag.add_argument("--no_verify", action="store_true")
+    ag.set_defaults(fn=stark_aggregate)
     g = sub.add_parser("groth16_prove", help="Prove with groth16 (zkit/src/main.rs:199-217)")
     g.add_argument("-c", dest="curve_type", default="BN128")
     g.add_argument("--r1cs", dest="circuit_file", required=True)
