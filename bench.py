@@ -40,7 +40,7 @@ VALU_MAD_PER_S = 1024 * 64 * 2.4e9 / 4.25
 # Fewest multiply-adds one Poseidon-GL permutation takes in the form the kernels use (csrc/poseidon.hip): 118 S-boxes x 4
 # products x 4 + 7 dense MDS x 288 (small constants: 2 per term) + pre-sparse matrix 12 x 72 + 22 sparse rounds x (72 + 44).
 POSEIDON_MADS = 118 * 16 + 7 * 288 + 12 * 72 + 22 * (72 + 44)
-# A BN254 Fq product in 9 x 29-bit limbs: 81 + 81 multiply-adds (product + Montgomery reduction), csrc/fe29_impl.cuh;
+# A BN254 Fq product in 9 x 29-bit limbs: 81 + 81 multiply-adds (product + Montgomery reduction), csrc/fe29_impl.hip.h;
 # a mixed point addition (madd-2008-s) is 8 products + 2 squares... counted as 11 products with the doubling check.
 FQ_MADS = {"bn254": 2 * 9 * 9, "bls12_381": 2 * 14 * 14}
 PADD_PRODUCTS = 11
@@ -152,7 +152,9 @@ def prove_leg(zk, nbits, verify=True, cpu_baseline=False, host_trace=True):
             sys.path.insert(0, str(ROOT / "tools"))
             from gen_golden_full import zkin_digest
             g = {"fixture": "tests/golden/poseidong_2p%d%s.json" % (nbits, "" if "zkin_digest" in gold else "_roots"),
-                 "rootC_matches_golden": [str(v) for v in setup.const_root()] == gold["rootC"], "root1_matches_golden": proof_dev["root1"] == gold["root1"]}
+                 "rootC_matches_golden": [str(v) for v in setup.const_root()] == gold["rootC"]}
+            if "root1" in gold:
+                g["root1_matches_golden"] = proof_dev["root1"] == gold["root1"]
             if "zkin_digest" in gold:
                 g["zkin_sha256_matches_golden"] = zkin_digest(proof_dev) == gold["zkin_digest"]
                 g["all_roots_evals_finalpol_match"] = all(proof_dev[k] == gold[k] for k in gold if k in proof_dev)

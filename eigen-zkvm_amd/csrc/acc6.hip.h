@@ -1,6 +1,6 @@
 // Carry-free accumulation of 64 x 64-bit products (shared by the Poseidon permutation and the evaluations at xi).
 #pragma once
-#include "gl.cuh"
+#include "gl.hip.h"
 
 namespace zk {
 using gl::add_word;

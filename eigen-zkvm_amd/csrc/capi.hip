@@ -41,12 +41,15 @@ hipStream_t cur_stream() { return t_stream; }
 // The GPU of the process (zk_init).  HIP's current device is a property of the host thread and every new thread starts on device 0,
 // so a prover thread of rank k > 0 would otherwise allocate and launch on GPU 0: each thread is bound on its first call.
 static std::atomic<int> g_device{-1};          // -1: zk_init was never called, threads are left as the caller set them up
-static thread_local int t_device = -1;
+// zk_init's device overrides whatever the caller (torch.cuda.set_device, another library) made current on this thread in the
+// meantime: pooled blocks, constant tables and code modules all belong to device d, so every outermost call re-checks the thread's
+// actual device (hipGetDevice is a thread-local read) instead of trusting a flag cached at the first call.
 void bind_device() noexcept {
     const int d = g_device.load(std::memory_order_relaxed);
-    if (d < 0 || t_device == d) return;
-    if (hipSetDevice(d) == hipSuccess) t_device = d;
-    else (void)hipGetLastError();              // the work that follows reports its own error
+    if (d < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == d) return;
+    if (hipSetDevice(d) != hipSuccess) (void)hipGetLastError();   // the work that follows reports its own error
 }
 CallScope::CallScope() : saved(t_stream) { if (t_depth++ == 0) { t_stream = nullptr; bind_device(); } }   // a call from outside starts on the null stream,
 CallScope::~CallScope() { --t_depth; t_stream = saved; }                                // one made by the prover inherits the prover's
@@ -64,6 +67,7 @@ hipStream_t on_stream(hipStream_t st) {
                 // While the null stream was the only one in use, blocks went back to the pool without an event (pool_free):
                 // work queued there may still be running on them, and a non-blocking stream does not wait for the null stream.
                 // Drain once, at the moment a second stream appears; from here on every free records its events.
+                // (under the lock on purpose: no block may be handed out between the drain and the registration)
                 if (g_streams.size() == 1) (void)hipDeviceSynchronize();
                 g_streams.push_back(st);
             }
@@ -71,23 +75,41 @@ hipStream_t on_stream(hipStream_t st) {
     }
     return st;
 }
+// A helper stream that lives inside one call (the MSM's sort stream): registered so that this thread's frees are stamped on it while it
+// is in use, WITHOUT the one-off device drain of on_stream -- the caller guarantees that the side stream's first operation waits for an
+// event recorded on the current stream after every buffer it will touch was allocated (so it is ordered behind those blocks' previous
+// users), and calls forget_stream once the current stream has waited for the side stream's last event.  The thread's current stream is kept.
+void on_side_stream(hipStream_t ss) {
+    if (!ss) return;
+    bool mine = false;
+    for (hipStream_t s : t_streams) mine |= s == ss;
+    if (!mine) t_streams.push_back(ss);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    bool known = false;
+    for (hipStream_t s : g_streams) known |= s == ss;
+    if (!known) g_streams.push_back(ss);
+}
 void* pool_alloc(size_t bytes, bool host_wait) {
     if (bytes == 0) bytes = 8;
     {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
+        std::unique_lock<std::mutex> lk(g_pool_mu);
         auto it = g_pool_free.find(bytes);
         if (it != g_pool_free.end()) {
             void* p = it->second; g_pool_free.erase(it);
-            Block& b = g_pool_blocks[p];
-            for (Ev* v : b.pending) {                                 // whoever used the block last finishes first:
-                const hipError_t rc = host_wait ? hipEventSynchronize(v->e)               // the caller may touch it from any stream (zk_dev_alloc) -> the host waits
-                                                : hipStreamWaitEvent(t_stream, v->e, 0);  // the library's own buffers -> the stream it is working on waits
+            std::vector<Ev*> pending;
+            pending.swap(g_pool_blocks[p].pending);                   // the block is out of the free list: nobody else sees it or its events' list
+            // whoever used the block last finishes first.  The library's own buffers: the stream this thread works on waits
+            // (asynchronous, under the lock).  A block that leaves the library (zk_dev_alloc: the caller may touch it from any
+            // stream): the HOST waits -- with the lock released, so that other provers' allocations and frees go on meanwhile.
+            if (host_wait) lk.unlock();
+            for (Ev* v : pending) {
+                const hipError_t rc = host_wait ? hipEventSynchronize(v->e) : hipStreamWaitEvent(t_stream, v->e, 0);
                 // an event whose stream has been destroyed since (a released setup's side stream: drained before it went) reports an
                 // error here; its work is done, and the error must not surface at some later hipGetLastError()
                 if (rc != hipSuccess) (void)hipGetLastError();
-                ev_release(v);
             }
-            b.pending.clear();
+            if (host_wait) lk.lock();
+            for (Ev* v : pending) ev_release(v);
             return p;
         }
     }
@@ -285,7 +307,6 @@ int zk_init(int device) {
         ZK_REQUIRE(device >= 0 && device < n, "zk_init: no such device");
         ZK_HIP(hipSetDevice(device));
         g_device.store(device, std::memory_order_relaxed);   // ... and of every thread that calls into the library from now on
-        t_device = device;
     });
 }
 const char* zk_last_error(void) { return t_err.c_str(); }

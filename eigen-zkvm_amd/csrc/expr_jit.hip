@@ -18,6 +18,7 @@
 #include <hip/hiprtc.h>
 #include "sha256.h"
 #include <chrono>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <sys/stat.h>
@@ -387,12 +388,20 @@ std::string hiprtc_log(hiprtcProgram prog) {
 
 // ---- code objects of the generated kernels: compiled once per text ---------------------------------------------------------
 // hipRTC takes seconds per step program (PoseidonG's five: most of a setup), and the text is a pure function of the PIL, the
-// StarkStruct and this file.  Code objects are therefore kept (a) in the process, keyed by sha256(compiler version | options |
-// text) -- the worker setups of one process compile each program once -- and (b) on disk under $ZK_JIT_CACHE (default
-// $XDG_CACHE_HOME/zkgpu or ~/.cache/zkgpu; "off" disables), one file per key, written to a temporary name and renamed.
+// StarkStruct and this file.  Code objects are therefore kept (a) in the process, keyed by sha256(compiler + runtime version |
+// options | text) -- the worker setups of one process compile each program once, and different programs compile side by side
+// (a setup starts its step programs on one host thread each) -- and (b) on disk under $ZK_JIT_CACHE (default
+// $XDG_CACHE_HOME/zkgpu or ~/.cache/zkgpu; "off" disables), one file per key: a 48-byte header (magic, payload length, sha256 of
+// the payload) + the code object, written to a temporary name and renamed.  A file whose header or digest does not match is
+// ignored and replaced; a directory that is not the user's own or that others may write to is not used; an object from disk
+// that the driver refuses to load is deleted and compiled again (zk_program_run_rows_dev).
 std::mutex g_jit_mu;
-std::map<std::string, std::shared_ptr<const std::vector<char>>> g_jit_mem;
+std::condition_variable g_jit_cv;
+struct CodeObj { std::vector<char> bytes; std::string key; bool from_disk = false; };
+std::map<std::string, std::shared_ptr<const CodeObj>> g_jit_mem;
+std::set<std::string> g_jit_inflight;                     // keys some thread is reading or compiling right now
 JitStats g_jit_stats;
+const char JIT_MAGIC[8] = {'Z', 'K', 'C', 'O', '0', '0', '0', '1'};
 
 std::string jit_cache_dir() {
     const char* e = getenv("ZK_JIT_CACHE");
@@ -406,32 +415,83 @@ void mkdirs(const std::string& d) {
     for (size_t i = 1; i <= d.size(); ++i)
         if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0700);
 }
+// code objects are executed: only a directory of the user's own that nobody else can write to is trusted
+bool jit_dir_trusted(const std::string& dir) {
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "[zkgpu] code-object cache %s is not owned by this user or is writable by others: not used\n", dir.c_str()); }
+        return false;
+    }
+    return true;
+}
+std::string jit_path(const std::string& key) {
+    const std::string dir = jit_cache_dir();
+    return dir.empty() ? "" : dir + "/" + key + ".co";
+}
+bool jit_read(const std::string& path, std::vector<char>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<char> buf;
+    char tmp[65536]; size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    if (buf.size() < 48 + 16 || memcmp(buf.data(), JIT_MAGIC, 8) != 0) return false;
+    uint64_t len = 0; memcpy(&len, buf.data() + 8, 8);
+    if (len != buf.size() - 48 || memcmp(buf.data() + 48, "\x7f" "ELF", 4) != 0) return false;   // truncated or foreign
+    const std::string h = sha256_hex(buf.data() + 48, (size_t)len);
+    char hex[65] = {0};
+    for (int i = 0; i < 32; ++i) snprintf(hex + 2 * i, 3, "%02x", (unsigned char)buf[16 + i]);
+    if (h != hex) return false;                                                                 // bit rot or a planted file
+    out.assign(buf.begin() + 48, buf.end());
+    return true;
+}
+void jit_write(const std::string& dir, const std::string& path, const std::vector<char>& code) {
+    mkdirs(dir);                                          // best effort: a read-only or missing cache directory costs nothing but the next compile
+    if (!jit_dir_trusted(dir)) return;
+    const std::string h = sha256_hex(code.data(), code.size());
+    char head[48]; memcpy(head, JIT_MAGIC, 8);
+    const uint64_t len = code.size(); memcpy(head + 8, &len, 8);
+    for (int i = 0; i < 32; ++i) { unsigned b = 0; sscanf(h.c_str() + 2 * i, "%2x", &b); head[16 + i] = (char)b; }
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string((unsigned long)(uintptr_t)&head);
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(head, 1, 48, f) == 48 && fwrite(code.data(), 1, code.size(), f) == code.size();
+        if (fclose(f) == 0 && ok) { if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str()); }
+        else (void)remove(tmp.c_str());
+    }
+}
 
-std::shared_ptr<const std::vector<char>> compile_cached(const std::string& source) {
+std::shared_ptr<const CodeObj> compile_cached(const std::string& source, bool skip_disk = false) {
     static const char* const opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    int maj = 0, min = 0; (void)hiprtcVersion(&maj, &min);
-    std::string keyed = "hiprtc " + std::to_string(maj) + "." + std::to_string(min);
+    int maj = 0, min = 0, rt = 0; (void)hiprtcVersion(&maj, &min);
+    if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); rt = 0; }
+    // the compiler behind hipRTC changes with patch releases too: the runtime's full version number and the headers' are part of the key
+    std::string keyed = "hiprtc " + std::to_string(maj) + "." + std::to_string(min) + " rt " + std::to_string(rt) + " hip " + std::to_string(HIP_VERSION);
     for (const char* o : opts) { keyed += ' '; keyed += o; }
     keyed += '\n'; keyed += source;
     const std::string key = sha256_hex(keyed.data(), keyed.size());
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    std::lock_guard<std::mutex> lk(g_jit_mu);            // one compilation at a time: a second setup of the same circuit waits and then hits
-    auto it = g_jit_mem.find(key);
-    if (it != g_jit_mem.end()) { g_jit_stats.mem_hits++; return it->second; }
-    const std::string dir = jit_cache_dir(), path = dir.empty() ? "" : dir + "/" + key + ".co";
-    if (!path.empty()) {
-        if (FILE* f = fopen(path.c_str(), "rb")) {
-            std::vector<char> buf;
-            char tmp[65536]; size_t n;
-            while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-            fclose(f);
-            if (buf.size() > 16 && !memcmp(buf.data(), "\x7f" "ELF", 4)) {     // a truncated or foreign file is recompiled and replaced
-                auto sp = std::make_shared<const std::vector<char>>(std::move(buf));
-                g_jit_mem[key] = sp; g_jit_stats.disk_hits++; g_jit_stats.ms += ms_since();
-                return sp;
-            }
+    {   // the same text once at a time (a second setup of the same circuit waits and then hits); different texts side by side
+        std::unique_lock<std::mutex> lk(g_jit_mu);
+        for (;;) {
+            auto it = g_jit_mem.find(key);
+            if (it != g_jit_mem.end()) { g_jit_stats.mem_hits++; return it->second; }
+            if (!g_jit_inflight.count(key)) break;
+            g_jit_cv.wait(lk);
         }
+        g_jit_inflight.insert(key);
+    }
+    struct Done { const std::string& k; ~Done() { std::lock_guard<std::mutex> lk(g_jit_mu); g_jit_inflight.erase(k); g_jit_cv.notify_all(); } } done{key};
+    auto sp = std::make_shared<CodeObj>();
+    sp->key = key;
+    const std::string dir = jit_cache_dir(), path = jit_path(key);
+    if (!path.empty() && !skip_disk && jit_dir_trusted(dir) && jit_read(path, sp->bytes)) {
+        sp->from_disk = true;
+        std::lock_guard<std::mutex> lk(g_jit_mu);
+        g_jit_mem[key] = sp; g_jit_stats.disk_hits++; g_jit_stats.ms += ms_since();
+        return sp;
     }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, source.c_str(), "zk_eval.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
@@ -443,21 +503,24 @@ std::shared_ptr<const std::vector<char>> compile_cached(const std::string& sourc
         throw Error("hiprtc compile failed: " + log.substr(0, 2000));
     }
     size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
-    std::vector<char> code(sz);
-    hiprtcGetCode(prog, code.data());
+    sp->bytes.resize(sz);
+    hiprtcGetCode(prog, sp->bytes.data());
     hiprtcDestroyProgram(&prog);
-    if (!path.empty()) {                                  // best effort: a read-only or missing cache directory costs nothing but the next compile
-        mkdirs(dir);
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        if (FILE* f = fopen(tmp.c_str(), "wb")) {
-            const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-            if (fclose(f) == 0 && ok) { if (rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str()); }
-            else (void)remove(tmp.c_str());
-        }
-    }
-    auto sp = std::make_shared<const std::vector<char>>(std::move(code));
+    if (!path.empty()) jit_write(dir, path, sp->bytes);
+    std::lock_guard<std::mutex> lk(g_jit_mu);
     g_jit_mem[key] = sp; g_jit_stats.compiled++; g_jit_stats.ms += ms_since();
     return sp;
+}
+// an object that came from disk and does not load: the file and the in-memory entry go, the text is compiled again
+std::shared_ptr<const CodeObj> recompile_after_bad_load(const std::shared_ptr<const CodeObj>& bad, const std::string& source) {
+    {
+        std::lock_guard<std::mutex> lk(g_jit_mu);
+        auto it = g_jit_mem.find(bad->key);
+        if (it != g_jit_mem.end() && it->second == bad) g_jit_mem.erase(it);
+    }
+    const std::string path = jit_path(bad->key);
+    if (!path.empty()) (void)remove(path.c_str());
+    return compile_cached(source, true);
 }
 }  // namespace
 JitStats jit_stats() { std::lock_guard<std::mutex> lk(g_jit_mu); return g_jit_stats; }
@@ -467,7 +530,7 @@ using namespace zk;
 
 struct zk_program {
     std::string source;
-    std::shared_ptr<const std::vector<char>> code;   // the code object, shared by every program of this process with the same text
+    std::shared_ptr<const CodeObj> code;   // the code object, shared by every program of this process with the same text
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr, fn_pow = nullptr;
     uint32_t n_instr = 0;
@@ -557,9 +620,19 @@ int zk_program_run_rows_dev(zk_program_t* p, const zk_eval_ctx* ctx, uint32_t nb
         ZK_REQUIRE(row0 <= (1ull << nbits_domain) && count <= (1ull << nbits_domain) - row0, "zk_program_run_rows_dev: rows outside the domain");
         if (count == 0) return 0;
         if (!p->module) {  // load lazily: compiling needs no GPU, running does
-            ZK_HIP(hipModuleLoadData(&p->module, p->code->data()));
-            ZK_HIP(hipModuleGetFunction(&p->fn, p->module, "zk_eval_kernel"));
-            ZK_HIP(hipModuleGetFunction(&p->fn_pow, p->module, "zk_pow_kernel"));
+            auto load = [&]() -> hipError_t {
+                hipError_t e = hipModuleLoadData(&p->module, p->code->bytes.data());
+                if (e == hipSuccess) e = hipModuleGetFunction(&p->fn, p->module, "zk_eval_kernel");
+                if (e == hipSuccess) e = hipModuleGetFunction(&p->fn_pow, p->module, "zk_pow_kernel");
+                if (e != hipSuccess) { (void)hipGetLastError(); if (p->module) { (void)hipModuleUnload(p->module); p->module = nullptr; } p->fn = p->fn_pow = nullptr; }
+                return e;
+            };
+            hipError_t e = load();
+            if (e != hipSuccess && p->code->from_disk) {   // a cached file the driver refuses: drop it, compile the text again, once
+                p->code = recompile_after_bad_load(p->code, p->source);
+                e = load();
+            }
+            if (e != hipSuccess) throw Error(std::string("loading a constraint kernel's code object failed: ") + hipGetErrorString(e));
             if (p->pow_entries) ZK_HIP(hipMalloc(&p->d_pow, (size_t)p->pow_entries * 48));
         }
         if (p->pow_entries) {   // powers of this run's challenges, on the same stream

@@ -1,4 +1,4 @@
-// Prime-field arithmetic in 29-bit limbs for gfx950, shared by the G1 MSM (msm_impl.cuh: Fq of BN254 and
+// Prime-field arithmetic in 29-bit limbs for gfx950, shared by the G1 MSM (msm_impl.hip.h: Fq of BN254 and
 // BLS12-381) and the BN128-field Poseidon (poseidon_bn128.hip: Fr of BN254).  Included inside a namespace that
 // provides NL (32-bit limbs of the external Montgomery form, R = 2^(32 NL)), NR (29-bit limbs, R' = 2^(29 NR)),
 // Q29, QINV29, ONE29 (R' mod q), CIN29 (R'^2/R mod q), COUT29 (R mod q), Q2_29 / Q4_29 / Q8_29.
@@ -84,7 +84,7 @@ __device__ FQ_MUL_ATTR fe fe_mul(const fe& a, const fe& b) {
 }
 // (a*b + c*d)/R' mod q with ONE reduction: both sets of partial products accumulate in the same 64-bit columns
 // (3 NR * 2^58 < 2^64).  Bounds: A*B + C*D <= 168 (BN254) for a result < 2q.  Half the work of two products and
-// a renormalised sum -- the Fq2 product (msm_impl.cuh) is two of these.
+// a renormalised sum -- the Fq2 product (msm_impl.hip.h) is two of these.
 __device__ __forceinline__ fe fe_mul2(const fe& a, const fe& b, const fe& c, const fe& d) {
     u64 t[2 * NR];
 #pragma unroll

@@ -1,4 +1,4 @@
-// 29-bit-limb constants of the two scalar fields (fe29_impl.cuh's parameters), shared by the scalar-field hashes
+// 29-bit-limb constants of the two scalar fields (fe29_impl.hip.h's parameters), shared by the scalar-field hashes
 // (frhash.hip) and the Groth16 scalar-field work (groth16.hip).  Include inside the field's namespace with
 // ZK_FR29_FIELD defined to 254 (BN254 Fr) or 381 (BLS12-381 Fr).  No include guard on purpose.
 #if ZK_FR29_FIELD == 254

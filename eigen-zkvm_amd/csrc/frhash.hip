@@ -9,7 +9,7 @@
 // Mapping: one lane = one permutation; the state (t <= 17 elements of 9 x 29-bit limbs) lives in the lane's
 // private segment, the parameter tables (24 060 constants, converted once per device to the internal
 // Montgomery form) in global memory behind wave-uniform addresses.  Integer-ALU bound: 5 457 Fr products per
-// t = 17 permutation, 225 instructions each (fe29_impl.cuh).  Value bounds: round-boundary state < 2r; a
+// t = 17 permutation, 225 instructions each (fe29_impl.hip.h).  Value bounds: round-boundary state < 2r; a
 // column of the dense products sums 17 products (< 34r) and is brought back below 2r by one product with
 // R' mod r; the sparse rounds' running columns are renormalised every 16 rounds (< 34r in between).
 #include "zk_internal.h"
@@ -22,13 +22,13 @@ namespace zk {
 namespace bn128fr {
 
 #define ZK_FR29_FIELD 254
-#include "fr29_consts.cuh"
+#include "fr29_consts.hip.h"
 #define FH_NRP 56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68   // poseidon_bn128_opt.rs:62
 #define FH_OUT_IDX 0                                                            // poseidon_bn128_opt.rs:80-83
 #define FH_AB_LIMIT 168u
 #define FH_NAME "bn128"
 #define FH_FN(name) bn128_##name
-#include "frhash_impl.cuh"
+#include "frhash_impl.hip.h"
 #undef FH_NRP
 #undef FH_OUT_IDX
 #undef FH_NAME
@@ -41,14 +41,14 @@ namespace bn128fr {
 // ---- so multiplicand bounds must satisfy A*B <= 68 (the permutation's largest is 34 * 1).
 namespace bls12381fr {
 #define ZK_FR29_FIELD 381
-#include "fr29_consts.cuh"
+#include "fr29_consts.hip.h"
 #define FH_NRP 55, 55, 56, 56, 56, 56, 57, 57, 57, 57, 57, 57, 57, 57, 59, 59   // poseidon_bls12381_opt.rs:67
 #define FH_OUT_IDX 1                                                            // poseidon_bls12381_opt.rs:94-103
 #undef FH_AB_LIMIT
 #define FH_AB_LIMIT 68u
 #define FH_NAME "bls12381"
 #define FH_FN(name) bls12381_##name
-#include "frhash_impl.cuh"
+#include "frhash_impl.hip.h"
 }  // namespace bls12381fr
 
 // the host entry points live in the field namespaces; zk_internal.h declares them in zk::

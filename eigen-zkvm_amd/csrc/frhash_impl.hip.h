@@ -8,7 +8,7 @@
 #define FQ_MUL_ATTR ZK_FRHASH_MUL_ATTR   // inlined into the (not unrolled) loops over t: a dozen call sites per kernel
 
 namespace {
-#include "fe29_impl.cuh"
+#include "fe29_impl.hip.h"
 
 // canonical 256-bit integer (8 words, may exceed r) -> internal Montgomery form: x * R'^2 / R' = x R'
 __device__ __forceinline__ fe fe_from_int(const u32 (&w)[NL]) {
@@ -33,7 +33,7 @@ __device__ Params g_prm[16];
 
 __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
 
-// Sums of products with deferred reduction (fe29_impl.cuh fe_wide): the tables are canonical (< r), so a group of g
+// Sums of products with deferred reduction (fe29_impl.hip.h fe_wide): the tables are canonical (< r), so a group of g
 // products with operands < B r needs g B <= FH_AB_LIMIT (168 for BN254's r, 68 for BLS12-381's).
 constexpr u32 DOT_DENSE = FE_WIDE_MAX;                                       // dense products: state < 3r (6 x 3 = 18)
 constexpr u32 PR_RENORM = 8;                                                 // sparse rounds: running columns renormalised every 8 rounds,

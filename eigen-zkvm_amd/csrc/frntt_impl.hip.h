@@ -1,5 +1,5 @@
 // Scalar-field transforms and the pointwise work of the Groth16 quotient on gfx950, generic over the field.
-// Included inside a namespace that has already pulled in fr29_consts.cuh + fe29_impl.cuh and defines
+// Included inside a namespace that has already pulled in fr29_consts.hip.h + fe29_impl.hip.h and defines
 // FRN_S (2-adicity), FRN_ROOT (8 x u32: a primitive 2^S-th root of unity, Montgomery R = 2^256; 7^((r-1)/2^S), the
 // value ff's derive macro gives bellman's Fr::root_of_unity()).  No include guard on purpose.
 //
@@ -12,7 +12,7 @@
 // ceil(k/3) out-of-place Stockham passes of radix <= 8; a lane owns the 8 points {j + t n/8}, multiplies them by
 // the pass twiddles w^(k t) from the n-entry table, runs a decimation-in-frequency 8-point transform in
 // registers and scatters to (j - k) 8 + k + bitrev(t) L.  Integer-ALU bound: 13 field products per 8 points per
-// pass (225 instructions each, fe29_impl.cuh) against 72 bytes of traffic per point.
+// pass (225 instructions each, fe29_impl.hip.h) against 72 bytes of traffic per point.
 // Value bounds: stored values are < 16q with normalised limbs; every element meets a product (twiddle, table or
 // R' mod q) on load, which brings it below 2q; three butterfly levels then grow sums to < 16q and differences
 // (biased by 2q, 4q, 8q) likewise; products inside the levels take at most 8q x 2q (A*B = 16 <= 68).

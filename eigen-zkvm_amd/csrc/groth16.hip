@@ -5,8 +5,8 @@
 //                    bellman's Parameters (groth16/src/api.rs:545-550; pairing_ce's uncompressed points, the
 //                    encoding of groth16/test-vectors/verification_key*.bin)
 //   circuit          algebraic/src/circom_circuit.rs:94-160 + the `input * 0 = 0` rows bellman's prover appends
-//   row evaluations  one lane per row of the three CSR matrices                 (frntt_impl.cuh)
-//   quotient         7 transforms over Fr + the pointwise step                  (frntt_impl.cuh)
+//   row evaluations  one lane per row of the three CSR matrices                 (frntt_impl.hip.h)
+//   quotient         7 transforms over Fr + the pointwise step                  (frntt_impl.hip.h)
 //   h, l, a, b_g1, b_g2 sums and the final assembly through msm.hip
 //   proof.json       groth16/src/json_utils.rs:305-315
 // r and s are taken from the caller (the reference draws them from OsRng, api.rs:172); everything else is a
@@ -137,12 +137,12 @@ static Params parse_params(const uint8_t* b, size_t len, int coord_bytes) {
 
 namespace bn254fr {
 #define ZK_FR29_FIELD 254
-#include "fr29_consts.cuh"
-#include "fe29_impl.cuh"
+#include "fr29_consts.hip.h"
+#include "fe29_impl.hip.h"
 #define FRN_S 28
 #define FRN_ROOT 0xb639feb8u, 0x9632c7c5u, 0x0d0ff299u, 0x985ce340u, 0x01b0ecd8u, 0xb2dd8800u, 0x6d98ce29u, 0x1d69070du   // 7^((r-1)/2^28) * 2^256
 #define FRN_FN(name) name
-#include "frntt_impl.cuh"
+#include "frntt_impl.hip.h"
 #define G16_CW 8
 #define G16_MSM_G1 msm_g1_bn254_dev
 #define G16_MSM_G2 msm_g2_bn254_dev
@@ -156,7 +156,7 @@ namespace bn254fr {
 #define G16_FQ_TO_CANON fq_bn254_mont_to_canon_dev
 #define G16_JSON_CURVE "BN128"
 #define G16_FN(name) name
-#include "groth16_impl.cuh"
+#include "groth16_impl.hip.h"
 #undef FRN_S
 #undef FRN_ROOT
 #undef G16_CW
@@ -175,11 +175,11 @@ namespace bn254fr {
 
 namespace bls12381fr {
 #define ZK_FR29_FIELD 381
-#include "fr29_consts.cuh"
-#include "fe29_impl.cuh"
+#include "fr29_consts.hip.h"
+#include "fe29_impl.hip.h"
 #define FRN_S 32
 #define FRN_ROOT 0x5f0e466au, 0xb9b58d8cu, 0x1819d7ecu, 0x5b1b4c80u, 0x52a31e64u, 0x0af53ae3u, 0x19e9b27bu, 0x5bf3addau   // 7^((r-1)/2^32) * 2^256
-#include "frntt_impl.cuh"
+#include "frntt_impl.hip.h"
 #define G16_CW 12
 #define G16_MSM_G1 msm_g1_bls12_381_dev
 #define G16_MSM_G2 msm_g2_bls12_381_dev
@@ -192,7 +192,7 @@ namespace bls12381fr {
 #define G16_FQ_TO_MONT fq_bls12_381_canon_to_mont_dev
 #define G16_FQ_TO_CANON fq_bls12_381_mont_to_canon_dev
 #define G16_JSON_CURVE "BLS12381"
-#include "groth16_impl.cuh"
+#include "groth16_impl.hip.h"
 }  // namespace bls12381fr
 
 void fr_bn254_ntt_dev(u64* d, int logn, bool inverse, bool coset, hipStream_t st) { bn254fr::ntt_dev(d, logn, inverse, coset, st); }

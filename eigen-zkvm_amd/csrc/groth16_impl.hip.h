@@ -1,5 +1,5 @@
 // The Groth16 prover around the multi-scalar sums, generic over the curve; included inside the scalar field's
-// namespace after frntt_impl.cuh with
+// namespace after frntt_impl.hip.h with
 //   G16_CW                      u32 words per base-field element (8: BN254, 12: BLS12-381)
 //   G16_MSM_G1 / G16_MSM_G2     the curve's multi-scalar sums (msm.hip)
 //   G16_FQ_TO_MONT / _TO_CANON  base-field conversions in place (msm.hip)
@@ -23,7 +23,7 @@ struct G16_FN(SetupImpl) final : Groth16Setup {
     //        g_c = sum over everything of (h, w_l, r w_b, r, s w_a, s r, s)
     //   G2: [ b_g2 (nb) | delta_g2 | beta_g2 ],  g_b = sum of (w_b, s, 1)
     DevBuf g1b, g2b;
-    // the key never changes: both arrays are expanded once into window tables (2^(16 w) P for the 16 windows, msm_impl.cuh), so a
+    // the key never changes: both arrays are expanded once into window tables (2^(16 w) P for the 16 windows, msm_impl.hip.h), so a
     // proof's sums need no doublings; keys too large for the 24-bit point index of the sort keep the plain arrays
     DevBuf g1t, g2t;
     bool tables = false;

@@ -5,7 +5,7 @@
 // bases n x 64 B (BN254 G1) affine (x, y), Fq in Montgomery form (R = 2^256), little-endian limbs; scalars
 // n x 32 B canonical little-endian; result affine + infinity flag.  96 B points for BLS12-381, twice that for G2.
 //
-// Pipeline (msm_impl.cuh; all on the device, one stream):
+// Pipeline (msm_impl.hip.h; all on the device, one stream):
 //   0. bases: external 32-bit-limb Montgomery form -> internal 29-bit limbs (one product per coordinate)
 //   1. bucket sort of the 16 n (point, window) pairs by key = window * 2^16 + digit (c = 16): two LDS-histogram
 //      partition passes, no device-scope atomics
@@ -14,7 +14,7 @@
 //   4. per-window reduction sum_k k*B_k: radix-16 hierarchy of (S, A) block summaries, 4 levels,
 //      2^16 .. 2^4 lanes; the serial chain per lane is 47 point additions
 //   5. Horner over the windows + conversion to affine (one lane)
-// Field: 29-bit limbs with 64-bit column accumulators, lazily reduced (fe29_impl.cuh); Fq2 on top of it for G2.
+// Field: 29-bit limbs with 64-bit column accumulators, lazily reduced (fe29_impl.hip.h); Fq2 on top of it for G2.
 // Integer-ALU bound (about 10 Fq products per point and window); HBM traffic is 96 B per point.
 #include "zk_internal.h"
 
@@ -72,7 +72,7 @@ using g1::GEN_X; using g1::GEN_Y;
 #define MSM_N_WIN 8
 #define MSM_SC_WORDS 4
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 }  // namespace g1half
 namespace g1 {
@@ -88,7 +88,7 @@ namespace g1 {
 #define GLV_B2 0x94d213e3u, 0x89d32568u
 #define MSM_GLV g1half
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 #undef MSM_GLV
 #undef GLV_BETA_STD
@@ -123,7 +123,7 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 #define MSM_G2_INLINE_CF   // 9 x 29-bit limbs: the Fq2 products are small enough to inline; the rare point formulas stay out of line
 #define MSM_G2
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 #undef MSM_G2_INLINE_CF
 #undef CF_MUL_ATTR
@@ -188,7 +188,7 @@ using g1::GEN_X; using g1::GEN_Y;
 #define MSM_N_WIN 8
 #define MSM_SC_WORDS 4
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 }  // namespace g1half
 namespace g1 {
@@ -201,7 +201,7 @@ namespace g1 {
 #define GLV_R 0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u
 #define MSM_GLV g1half
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 #undef MSM_GLV
 #undef GLV_BETA_STD
@@ -232,7 +232,7 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 #endif
 #define MSM_G2
 namespace {
-#include "msm_impl.cuh"
+#include "msm_impl.hip.h"
 }
 #undef CF_MUL_ATTR
 #undef PT_COLD_ATTR
@@ -246,7 +246,7 @@ void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, vo
 }
 #ifdef ZK_MSM_UBENCH
 }  // namespace zk
-// variant builds only (tools/build_variant.sh ... "-DZK_MSM_UBENCH"): msm_impl.cuh's cost probe of batched-affine additions
+// variant builds only (tools/build_variant.sh ... "-DZK_MSM_UBENCH"): msm_impl.hip.h's cost probe of batched-affine additions
 extern "C" int zk_msm_ubench_affine(const void* d_bases_std, uint64_t n_lanes, uint32_t K, int mode) {
     try { zk::bn254::g1half::ubench_affine_dev(d_bases_std, n_lanes, K, mode, nullptr); return 0; }
     catch (const std::exception& e) { fprintf(stderr, "ubench: %s\n", e.what()); return -1; }

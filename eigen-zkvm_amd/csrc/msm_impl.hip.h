@@ -6,8 +6,8 @@
 //   GEN_X, GEN_Y  the generator in the external layout
 // The curve is y^2 = x^3 + b with a = 0 (the formulas never touch b).  No include guard on purpose.
 //
-// Field arithmetic: fe29_impl.cuh (29-bit limbs, 64-bit column accumulators, lazily reduced values).
-#include "fe29_impl.cuh"
+// Field arithmetic: fe29_impl.hip.h (29-bit limbs, 64-bit column accumulators, lazily reduced values).
+#include "fe29_impl.hip.h"
 
 // ---- coordinate field `cf`: Fq for G1; Fq2 = Fq[u]/(u^2 + 1) for G2 (MSM_G2), built from the Fq operations
 // with every component brought back below 2q after a product (one extra product with R' mod q), so that the
@@ -734,7 +734,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     hipEvent_t ev_ready = nullptr;
     if (n_chunks > 1) {
         ss = msm_side_stream();
-        on_stream(ss); on_stream(st);                      // the pool orders this thread's frees behind both streams
+        on_stream(st); on_side_stream(ss);                 // the pool orders this thread's frees behind both streams while the side stream is in use
         for (int c = 0; c < n_chunks; ++c) { hipEvent_t e; ZK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_sorted.push_back(e); }
         ZK_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
     }
@@ -800,6 +800,9 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
                                 (const u32*)offsets_p, (const u32*)counts_p, (const u32*)idx_p, (const u32*)order_p, (xyzz*)buckets.p);
         ZK_HIP(hipGetLastError());
     }
+    // `st` has waited for the side stream's last event: everything it did is ordered before what follows on `st`, so the pool may forget
+    // it (frees are stamped on `st` alone again, and a process that only ever used the null stream is back on the event-free fast path)
+    if (n_chunks > 1) forget_stream(ss);
     if (d_table) {   // equal window weights: merge, 16 bit-partial tree sums, 16-step Horner
         xyzz* merged = (xyzz*)S0.p;                       // N_BUCKET items fit: S0 holds n_keys / 16 = N_BUCKET
         xyzz* pa = (xyzz*)A0.p; xyzz* pb = (xyzz*)S1.p;   // 16 * 4096 = N_BUCKET items, then 1/8 of it per level

@@ -21,7 +21,7 @@
 //     per-thread chain over the 16 outputs needs 2 lookups + 1 multiply per element.
 //   * HBM-bound: 16 B / element / pass; bytes per transform = 16 * passes * N * n_pols.
 #include "zk_internal.h"
-#include "ntt_reg.cuh"
+#include "ntt_reg.hip.h"
 #include <map>
 #include <mutex>
 #include <vector>

@@ -1,6 +1,6 @@
 // In-register radix-2 DIF transforms shared by the NTT passes (ntt.hip) and the FRI fold (stark.hip).
 #pragma once
-#include "gl.cuh"
+#include "gl.hip.h"
 #include <type_traits>
 
 namespace zk {

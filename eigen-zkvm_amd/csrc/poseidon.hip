@@ -15,8 +15,8 @@
 //     per block, broadcast reads) -- as scalar loads their 288+ SGPRs spilled into VGPR lanes.
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
-#include "ntt_reg.cuh"   // static_for
-#include "acc6.cuh"
+#include "ntt_reg.hip.h"   // static_for
+#include "acc6.hip.h"
 #include <mutex>
 
 namespace zk {
@@ -78,7 +78,7 @@ __device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[
     return acc_finish(A);
 }
 
-// Inside a permutation every word is "nc" (gl.cuh: some u64 congruent to the value); the dense MDS product and the
+// Inside a permutation every word is "nc" (gl.hip.h: some u64 congruent to the value); the dense MDS product and the
 // batched dot products accept that and the last MDS of the permutation emits canonical words.
 __device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74; any u64 in, nc out
     u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);

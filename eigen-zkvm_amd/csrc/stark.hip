@@ -8,11 +8,11 @@
 //   :416-430 (LEv/LpEv), :432-466 (evals), :481-522 (xDivXSubXi via sequential batch_inverse,
 //   polutils.rs:35-53 -- here every point is inverted independently: same field elements).
 #include "zk_internal.h"
-#include "acc6.cuh"
+#include "acc6.hip.h"
 #include <vector>
 #include <cstring>
 #include <algorithm>
-#include "ntt_reg.cuh"
+#include "ntt_reg.hip.h"
 
 namespace zk {
 
@@ -190,7 +190,7 @@ constexpr int EV_BLOCKS = 4096;  // blocks along the row axis: the row loop is l
 constexpr int EV_LANES = 32;     // evaluations per block: consecutive descriptors sit in consecutive lanes
 struct EvalBatch { EvalDescK d[EV_LANES]; u32 out[EV_LANES]; };   // 32 base-field columns (+ their partial-sum slots) travel as a kernel argument: no upload, no wait for one
 constexpr int EV_UNROLL = 4;     // rows per lane and trip, all loads issued before the first product
-constexpr int EV_FLUSH = 256;    // terms an Acc6 may take before it is folded (acc6.cuh: n * 2^54 < 2^64)
+constexpr int EV_FLUSH = 256;    // terms an Acc6 may take before it is folded (acc6.hip.h: n * 2^54 < 2^64)
 
 // One block = 8 x EV_UNROLL rows x 32 columns per trip: the 32 lanes of a row read neighbouring columns of the same section row
 // (ev_map lists a section's columns one after the other), so a trip reads whole row segments; L[k] is shared by the lanes of a row.

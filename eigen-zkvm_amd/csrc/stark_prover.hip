@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <array>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -534,12 +535,22 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     const clk::time_point t_tree = clk::now();
     const JitStats j0 = jit_stats();
     const JVal& P = S->prog;
-    S->step2prev = S->compile_segment(P.at("step2prev"), false, false);
-    S->step3prev = S->compile_segment(P.at("step3prev"), false, false);
-    S->step3 = S->compile_segment(P.at("step3"), false, false);
-    S->step42ns = S->compile_segment(P.at("step42ns"), true, false);
-    S->step52ns = S->compile_segment(P.at("step52ns"), true, false);
-    for (const JVal& seg : P.at("publics_code").arr) S->public_programs.push_back(S->compile_segment(seg, false, true));
+    {   // every step program on a host thread of its own: hipRTC takes seconds per program and the programs are independent
+        // (serially the three of PoseidonG were 8.9 of a 9.05 s cold setup; the code-object cache keeps one compilation per text)
+        const zk_stark_setup* Sc = S.get();
+        auto start = [Sc](const JVal& seg, bool ext, bool ret) {
+            return std::async(std::launch::async, [Sc, &seg, ext, ret] { return Sc->compile_segment(seg, ext, ret); });
+        };
+        std::future<ProgramPtr> f2 = start(P.at("step2prev"), false, false), f3p = start(P.at("step3prev"), false, false), f3 = start(P.at("step3"), false, false),
+                                f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
+        std::vector<std::future<ProgramPtr>> fp;
+        for (const JVal& seg : P.at("publics_code").arr) fp.push_back(start(seg, false, true));
+        std::exception_ptr err;                           // wait for all of them before an error leaves this scope (they read S)
+        auto take = [&](std::future<ProgramPtr>& f) -> ProgramPtr { try { return f.get(); } catch (...) { if (!err) err = std::current_exception(); return ProgramPtr(); } };
+        S->step2prev = take(f2); S->step3prev = take(f3p); S->step3 = take(f3); S->step42ns = take(f4); S->step52ns = take(f5);
+        for (auto& f : fp) S->public_programs.push_back(take(f));
+        if (err) std::rethrow_exception(err);
+    }
     {   // where the time went (stark_setup.rs:26 `#[time_profiler("stark_setup")]` has one number; a caller deciding whether to keep a
         // setup alive wants the split): JSON parsing, upload + extension + tree of the constants, kernel generation / compilation
         const clk::time_point t_jit = clk::now();

@@ -6,7 +6,7 @@
 #include <string>
 #include <stdexcept>
 #include <vector>
-#include "gl.cuh"
+#include "gl.hip.h"
 
 struct zk_merkle;
 struct zk_transcript;
@@ -51,7 +51,8 @@ hipStream_t cur_stream();
 // entry points inherits the prover's current stream; either way the caller's current stream is back when the call returns.
 void bind_device() noexcept;           // the calling thread onto the GPU zk_init selected (HIP's current device is per thread)
 struct CallScope { hipStream_t saved; CallScope(); ~CallScope(); CallScope(const CallScope&) = delete; CallScope& operator=(const CallScope&) = delete; };
-void forget_stream(hipStream_t st);  // call before destroying a registered stream
+void forget_stream(hipStream_t st);  // call before destroying a registered stream, or when a side stream's work has been waited for
+void on_side_stream(hipStream_t ss); // a helper stream inside one call (see capi.hip); pairs with forget_stream
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -131,7 +132,7 @@ void msm_g2_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, vo
 void g2_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
 void msm_g2_bls12_381_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st);
 void g2_bls12_381_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st);
-// window tables for fixed bases (msm_impl.cuh): table[w * n + i] = 2^(16 w) P_i; a sum over points [off, off + n) of it
+// window tables for fixed bases (msm_impl.hip.h): table[w * n + i] = 2^(16 w) P_i; a sum over points [off, off + n) of it
 #define ZK_MSM_FIXED_DECL(NAME)                                                                                             \
     size_t msm_##NAME##_fixed_table_bytes(uint64_t n);                                                                      \
     void msm_##NAME##_fixed_prepare_dev(const void* d_bases, uint64_t n, void* d_table, hipStream_t st);                     \

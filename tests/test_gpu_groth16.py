@@ -1,4 +1,4 @@
-"""Parity of the Groth16 device path (csrc/groth16.hip, frntt_impl.cuh, groth16_impl.cuh; through the C ABI) against
+"""Parity of the Groth16 device path (csrc/groth16.hip, frntt_impl.hip.h, groth16_impl.hip.h; through the C ABI) against
 the oracle (oracle/groth16_impl.h, oracle/groth16.py) -- bit exact: field elements as Montgomery limbs, proof
 points as affine coordinates.  SURVEY.md 8(f)-2."""
 import importlib, json, pathlib, random, sys

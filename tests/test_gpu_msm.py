@@ -53,7 +53,7 @@ def test_msm_edge_scalars(zk, orc):
 
 
 def test_msm_endomorphism_split_edge_scalars(zk, orc):
-    """Sums of >= 4096 points go through k P = k1 P + k2 phi(P) (csrc/msm_impl.cuh, glv_split_kernel): scalars at the edges of the
+    """Sums of >= 4096 points go through k P = k1 P + k2 phi(P) (csrc/msm_impl.hip.h, glv_split_kernel): scalars at the edges of the
     split -- 0, 1, r - 1, lambda and its neighbours, 2^127, 2^128 and neighbours, the lattice vectors, values whose halves
     change sign -- among random ones, against the closed form and against the oracle's Pippenger."""
     LAM = 4407920970296243842393367215006156084916469457145843978461

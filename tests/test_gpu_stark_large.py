@@ -178,7 +178,7 @@ def test_lde_2p24_to_2p25_three_columns(zk, orc):
 
 def test_recursion_task_proofs_match_oracle(zk, orc):
     """BASELINE config 5's unit of work: the three STARKs of one recursion task (tools/aggregation_workload.py) through
-    bench.GpuTaskProver's path -- Fibonacci 2^10 and the compressor-shaped circuit at 2^15: zkin equal to the oracle prover's;
+    aggregation.ProverPool's path (tools/aggregation_workload.py pool) -- Fibonacci 2^10 and the compressor-shaped circuit at 2^15: zkin equal to the oracle prover's;
     at 2^18 (r1.starkStruct.json: 6 queries): accepted by the restated verifier."""
     import stark_prover as SP, starkinfo as SI, aggregation_workload as AW
     stark = _stark(zk)

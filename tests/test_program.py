@@ -380,7 +380,7 @@ def test_code_objects_are_cached_in_the_process_and_on_disk(tmp_path):
     """csrc/expr_jit.hip compile_cached: a step program is compiled by hipRTC once per text -- the second compilation in a process
     comes from memory, the first one of the next process from $ZK_JIT_CACHE/<sha256>.co; a damaged file is recompiled and replaced;
     ZK_JIT_CACHE=off writes nothing.  (Compiling needs no GPU.)  Counted by zk_jit_cache_stats: {hipRTC, disk, memory}."""
-    import os, subprocess, sys
+    import hashlib, os, subprocess, sys
     cache = tmp_path / "jit"
     def run(env_cache):
         env = dict(os.environ, ZK_JIT_CACHE=str(env_cache))
@@ -390,8 +390,18 @@ def test_code_objects_are_cached_in_the_process_and_on_disk(tmp_path):
         return [int(x) for x in w[1:4]], [int(x) for x in w[5:8]]
     assert run(cache) == ([1, 0, 0], [1, 0, 1])                         # compiled once, then from memory
     files = sorted(cache.glob("*.co"))
-    assert len(files) == 1 and len(files[0].stem) == 64 and files[0].read_bytes()[:4] == b"\x7fELF"
+    good = files[0].read_bytes()
+    assert len(files) == 1 and len(files[0].stem) == 64 and good[:8] == b"ZKCO0001" and good[48:52] == b"\x7fELF"
+    assert int.from_bytes(good[8:16], "little") == len(good) - 48 and hashlib.sha256(good[48:]).digest() == good[16:48]
     assert run(cache) == ([0, 1, 0], [0, 1, 1])                         # a fresh process: from disk
-    files[0].write_bytes(b"not a code object")                         # damaged: compiled again, file replaced
-    assert run(cache) == ([1, 0, 0], [1, 0, 1]) and files[0].read_bytes()[:4] == b"\x7fELF"
+    for damaged in (b"not a code object",                               # foreign file
+                    good[:len(good) // 2],                              # truncated: the ELF magic is there, the length and digest are not
+                    good[:100] + bytes([good[100] ^ 1]) + good[101:],    # one flipped bit in the code object
+                    good[48:]):                                         # a bare code object without the header (e.g. planted)
+        files[0].write_bytes(damaged)                                   # compiled again, file replaced
+        assert run(cache) == ([1, 0, 0], [1, 0, 1]) and files[0].read_bytes() == good
     assert run("off") == ([1, 0, 0], [1, 0, 1]) and len(list(cache.glob("*"))) == 1
+    os.chmod(cache, 0o777)                                             # a directory others may write to is not trusted: nothing read, nothing written
+    files[0].unlink()
+    assert run(cache) == ([1, 0, 0], [1, 0, 1]) and list(cache.glob("*")) == []
+    os.chmod(cache, 0o700)

@@ -1,4 +1,4 @@
-#include "../../eigen-zkvm_amd/csrc/ntt_reg.cuh"
+#include "../../eigen-zkvm_amd/csrc/ntt_reg.hip.h"
 #include <cstdio>
 using gl::f3;
 using namespace zk;

@@ -1,6 +1,6 @@
 """Cost probe for batched-affine bucket additions (round-2 verdict, item 6): a variant build of libzkgpu with -DZK_MSM_UBENCH
 (tools/build_variant.sh msmub msm.hip "-DZK_MSM_UBENCH") times the shipped XYZZ mixed addition against affine additions that share
-one inversion per lane (csrc/msm_impl.cuh ubench_*): python tools/msm_affine_ubench.py"""
+one inversion per lane (csrc/msm_impl.hip.h ubench_*): python tools/msm_affine_ubench.py"""
 import ctypes, os, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 os.environ.setdefault("ZKGPU_LIB", str(ROOT / "eigen-zkvm_amd" / "variants" / "libzkgpu_msmub.so"))

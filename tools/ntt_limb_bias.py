@@ -1,4 +1,4 @@
-"""The bias of eigen-zkvm_amd/csrc/ntt_limb.cuh: limbs (k0..k3), 2^28 <= k_i < 2^29, with sum k_i 2^(24 i) = 0 (mod p).
+"""The bias of tools/ubench/ntt_limb.hip.h: limbs (k0..k3), 2^28 <= k_i < 2^29, with sum k_i 2^(24 i) = 0 (mod p).
 Added to element 0 of a radix-16 limb transform it makes every output limb non-negative without changing a value."""
 import random
 p = 2**64 - 2**32 + 1

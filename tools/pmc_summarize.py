@@ -7,7 +7,7 @@ with fetch_factor = 1 GiB / FETCH_SIZE(copy).  `src_sha16` ties the numbers to t
 import collections, csv, glob, hashlib, json, pathlib, sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-NTT_SOURCES = ["ntt.hip", "ntt_reg.cuh", "gl.cuh"]
+NTT_SOURCES = ["ntt.hip", "ntt_reg.hip.h", "gl.hip.h"]
 
 
 def ntt_src_sha16():

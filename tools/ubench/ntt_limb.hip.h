@@ -2,7 +2,7 @@
 //
 // On gfx950 an add-with-carry costs what a 64-bit multiply-add costs (4.2 cycles per wave instruction; a plain 32-bit
 // add or subtract 2.4, profiles/r02/ubench_valu.txt), and a carry consumed as data adds wait states: a 64-bit modular
-// butterfly is ~11 such instructions plus ~10 for its shift twiddle (ntt_reg.cuh).  Here a word x < 2^64 is split into
+// butterfly is ~11 such instructions plus ~10 for its shift twiddle (ntt_reg.hip.h).  Here a word x < 2^64 is split into
 // four signed limbs (l0, l1, l2, l3) in 32-bit registers, value = sum l_i 2^(24 i), taken modulo 2^96 + 1 = p (2^32 + 1):
 //   * a + b, a - b          = four plain 32-bit adds / subtracts, no carries: 24-bit limbs leave 7 bits of headroom,
 //                             enough for the four levels of a radix-16 transform;
@@ -16,7 +16,7 @@
 //                             2^64 = 2^32 - 1, 2^96 = -1 fold (gl::reduce_words) finishes.
 // Same values as ntt_reg<LOG, INV>: tools/ubench/ubench_ntt16.hip runs both on the same words and counts mismatches (none).
 #pragma once
-#include "ntt_reg.cuh"
+#include "ntt_reg.hip.h"
 
 namespace zk {
 

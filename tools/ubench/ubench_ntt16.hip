@@ -1,6 +1,6 @@
 // Radix-16 register transform, 64-bit modular butterflies (ntt_reg) against 24-bit limb butterflies (ntt_reg_limb):
 // same values, time per transform.  hipcc -O3 --offload-arch=gfx950 -I eigen-zkvm_amd/csrc -I include tools/ubench/ubench_ntt16.hip
-#include "ntt_limb.cuh"
+#include "ntt_limb.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
