@@ -94,6 +94,9 @@ DEV u64 pfin1(const u64 (&a)[6]) {
     return gl::reduce_words((unsigned)W, (unsigned)(W >> 32), (unsigned)(W >> 64), (unsigned)(W >> 96));
 }
 DEV f3 pfin(const u64 (&A)[3][6]) { return f3{{pfin1(A[0]), pfin1(A[1]), pfin1(A[2])}}; }
+// the power kernel (one lane per challenge, a few hundred extension products per launch) calls its products instead of inlining
+// them: inlined, its one basic block of ~100 cubic-extension products took hipRTC 13 of the 16 s of step52ns's compilation
+__device__ __noinline__ f3 f3_mul_call(f3 a, f3 b) { return gl::f3_mul(a, b); }
 DEV void psplit(u64* __restrict__ o, f3 p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -569,12 +572,12 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
             const uint32_t o = off_of[kv.first];
             src << "#define PW" << kv.first << "(e) (pw + (" << o << " + (e)) * 6)\n";
             powk << "    if (threadIdx.x == " << lane++ << ") {\n        const f3 v = ld3(c.challenges + " << 3 * kv.first << "); f3 P[" << kv.second + 2 << "]; P[0] = f3{{1, 0, 0}};\n"
-                 << "        for (int e = 0; e <= " << kv.second << "; ++e) { psplit(pw + (" << o << " + e) * 6, P[e]); P[e + 1] = gl::f3_mul(P[e], v); }\n";
+                 << "#pragma unroll 1\n        for (int e = 0; e <= " << kv.second << "; ++e) { psplit(pw + (" << o << " + e) * 6, P[e]); P[e + 1] = f3_mul_call(P[e], v); }\n";
             for (size_t n = 0; n < g.chain_consts.size(); ++n) {
                 if (g.chain_consts[n].ch != kv.first) continue;
                 powk << "        { f3 k = f3{{0, 0, 0}};\n";
                 for (auto& ct : g.chain_consts[n].cterms)
-                    powk << "          k = gl::f3_" << (ct.sign > 0 ? "add" : "sub") << "(k, gl::f3_mul(" << ct.expr << ", P[" << ct.e << "]));\n";
+                    powk << "          k = gl::f3_" << (ct.sign > 0 ? "add" : "sub") << "(k, f3_mul_call(" << ct.expr << ", P[" << ct.e << "]));\n";
                 powk << "          u64* o = pw + " << pow_words << " + 3 * " << n << "; o[0] = k.v[0]; o[1] = k.v[1]; o[2] = k.v[2]; }\n";
             }
             powk << "    }\n";

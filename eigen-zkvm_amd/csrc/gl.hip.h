@@ -180,6 +180,25 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {                // any u64 
     const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
     return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
 }
+#ifdef ZK_GL_NO_SQR3
+__device__ __forceinline__ u64 sqr_nc(u64 a) { return mul_nc(a, a); }
+#endif
+#ifndef ZK_GL_NO_SQR3
+// A squaring with the cross product a0 a1 taken once (round 4): three multiply-adds instead of four, the second use of the cross
+// product a 64-bit addition.  The same number of instructions as the plain product, a cheaper mix: 2^22 x 19 tree 9.39-9.44 ms against
+// 9.54-9.70 (profiles/r04/poseidon_variants.md).  Half of the S-box's products are squarings (x^2, x^6).
+__device__ __forceinline__ u64 sqr_nc(u64 a) {
+    GL_OPAQUE(a);
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+    const u64 p0 = (u64)a0 * a0;
+    const u64 c = (u64)a0 * a1;
+    const u64 p1 = c + (p0 >> 32);
+    const u64 p2 = c + (u32)p1;
+    const u64 p3 = (u64)a1 * a1 + (p1 >> 32) + (p2 >> 32);
+    return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
+}
+#else
+#endif
 __device__ __forceinline__ u64 mul_add_nc(u64 a, u64 b, u64 c) {     // a*b + c, any u64 in, nc out
     GL_OPAQUE(a); GL_OPAQUE(b); GL_OPAQUE(c);
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);

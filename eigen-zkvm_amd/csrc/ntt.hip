@@ -112,17 +112,43 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
 #pragma unroll
         for (int g = 0; g < GA; ++g) ntt_reg<LOGA, INV>(x[g]);
 #endif
-#pragma unroll
-        for (int g = 0; g < GA; ++g) {
-            const int jb = ta * GA + g;
-#pragma unroll
-            for (int ka = 0; ka < RA; ++ka) {
-                u64 v = x[g][bitrev_c(ka, LOGA)];
-#ifndef ZK_NTT_NOMATH
-                if (LOGB > 0 && ka > 0) v = gl::mul(v, P.w256[(jb * ka) << (8 - LOGR)]);
-                else if (P.pre_scale != 1) v = gl::mul(v, P.pre_scale);
+#if !defined(ZK_NTT_NOMATH) && !defined(ZK_NTT_NO_SHIFT_TW)
+        // Passes of <= 6 bits: w_R is a power of two (w_64 = 2^39, ntt_reg.hip.h), so the twiddle w_R^(jb ka) between the two halves is a
+        // shift like the butterflies' own -- once jb is a compile-time number.  jb = ta GA + g and ta = t / C with C = 4096 / R >= 64
+        // lanes: the same in every lane of a wave, so a switch over ta (R / 16 <= 4 cases) costs no divergence and turns the 15 general
+        // products of a lane into 15 shifts.  (Not for the pre-scaled last pass of a plain inverse transform: its 1/N rides on the table.)
+        if (LOGR <= 6 && LOGB > 0 && P.pre_scale == 1) {
+            static_for<0, TG>([&](auto TA) {
+                constexpr int ta_c = decltype(TA)::value;
+                if (ta == ta_c) {
+                    static_for<0, GA>([&](auto GI) {
+                        constexpr int g = decltype(GI)::value, jb = ta_c * GA + g;
+                        static_for<0, RA>([&](auto KA) {
+                            constexpr int ka = decltype(KA)::value;
+                            constexpr int e0 = (39 * (64 / (R > 64 ? 64 : R)) * jb * ka) % 192, e = INV ? (192 - e0) % 192 : e0;   // w_R^(+-jb ka) = 2^e
+                            u64 v = x[g][bitrev_c(ka, LOGA)];
+                            if constexpr (e >= 96) v = gl::neg(gl::mul_pow2<e - 96>(v));
+                            else v = gl::mul_pow2<e>(v);
+                            lds[ka * ROW + jb * C + c] = v;
+                        });
+                    });
+                }
+            });
+        } else
 #endif
-                lds[ka * ROW + jb * C + c] = v;
+        {
+#pragma unroll
+            for (int g = 0; g < GA; ++g) {
+                const int jb = ta * GA + g;
+#pragma unroll
+                for (int ka = 0; ka < RA; ++ka) {
+                    u64 v = x[g][bitrev_c(ka, LOGA)];
+#ifndef ZK_NTT_NOMATH
+                    if (LOGB > 0 && ka > 0) v = gl::mul(v, P.w256[(jb * ka) << (8 - LOGR)]);
+                    else if (P.pre_scale != 1) v = gl::mul(v, P.pre_scale);
+#endif
+                    lds[ka * ROW + jb * C + c] = v;
+                }
             }
         }
     }
@@ -139,7 +165,15 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
             for (int jb = 0; jb < RB; ++jb) y[g][jb] = lds[ka * ROW + jb * C + c];
         }
         const u64 uc = u < P.inner ? u : 0;
-        const u64 p = uc / P.s_np, rem = uc - p * P.s_np;
+        // p = uc / (s n_pols): a shift for one column; a 32-bit division when the matrix has fewer than 2^32 words per transform-axis
+        // index (every size in use); the 64-bit division otherwise -- uniform branches, the general case cost ~100 instructions per lane
+        u64 p, rem;
+#ifndef ZK_NTT_DIV64
+        if (P.np == 1) { p = uc >> P.log_s; rem = uc & (((u64)1 << P.log_s) - 1); }
+        else if ((P.inner >> 32) == 0) { const u32 p32 = (u32)uc / (u32)P.s_np; p = p32; rem = (u32)uc - p32 * (u32)P.s_np; }
+        else
+#endif
+        { p = uc / P.s_np; rem = uc - p * P.s_np; }
         u64 tw[GB][RB];
         if (P.tw_mid) {  // L <= 2^16: every twiddle w_L^(p*kappa) is one load from the 512 KB table (L2), no chain;
                          // issued here so that the radix-2^LOGB butterflies below hide the latency
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
 
         u64* __restrict__ outp = P.out + p * R * P.s_np + rem;
         u64 kstride = P.s_np;                          // words between the outputs kappa and kappa + 1 of a lane
-        const u64 row_q = (P.sc_lo || P.out_mul > 1) ? rem / P.np : 0;  // output row = kappa*s + row_q (last pass: p == 0)
+        const u64 row_q = !(P.sc_lo || P.out_mul > 1) ? 0 : P.np == 1 ? rem : (P.inner >> 32) == 0 ? (u64)((u32)rem / P.np) : rem / P.np;  // output row = kappa*s + row_q (last pass: p == 0)
         if (P.out_mul > 1) {                           // rows interleaved with another transform's: row r -> r * out_mul + out_off
             outp = P.out + ((row_q * P.out_mul + P.out_off) * P.np + (rem - row_q * P.np));
             kstride = P.s_np * P.out_mul;

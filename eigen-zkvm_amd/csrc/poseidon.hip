@@ -81,12 +81,12 @@ __device__ __forceinline__ u64 dot12(const u64* __restrict__ c, const u32 (&x0)[
 // Inside a permutation every word is "nc" (gl.hip.h: some u64 congruent to the value); the dense MDS product and the
 // batched dot products accept that and the last MDS of the permutation emits canonical words.
 __device__ __forceinline__ u64 pow7(u64 x) {  // poseidon_opt.rs:68-74; any u64 in, nc out
-    u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);
+    u64 x2 = gl::sqr_nc(x), x3 = gl::mul_nc(x2, x), x6 = gl::sqr_nc(x3);
     return gl::mul_nc(x6, x);
 }
 // x^7 + c for a canonical constant c: the addition rides on the multiply-adds of the last product
 __device__ __forceinline__ u64 pow7_add(u64 x, u64 c) {
-    u64 x2 = gl::mul_nc(x, x), x3 = gl::mul_nc(x2, x), x6 = gl::mul_nc(x3, x3);
+    u64 x2 = gl::sqr_nc(x), x3 = gl::mul_nc(x2, x), x6 = gl::sqr_nc(x3);
     return gl::mul_add_nc(x6, x, c);
 }
 

@@ -538,8 +538,9 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     {   // every step program on a host thread of its own: hipRTC takes seconds per program and the programs are independent
         // (serially the three of PoseidonG were 8.9 of a 9.05 s cold setup; the code-object cache keeps one compilation per text)
         const zk_stark_setup* Sc = S.get();
-        auto start = [Sc](const JVal& seg, bool ext, bool ret) {
-            return std::async(std::launch::async, [Sc, &seg, ext, ret] { return Sc->compile_segment(seg, ext, ret); });
+        const std::launch how = getenv("ZK_JIT_SERIAL") ? std::launch::deferred : std::launch::async;   // (ZK_JIT_SERIAL: one after the other, for measurements)
+        auto start = [Sc, how](const JVal& seg, bool ext, bool ret) {
+            return std::async(how, [Sc, &seg, ext, ret] { return Sc->compile_segment(seg, ext, ret); });
         };
         std::future<ProgramPtr> f2 = start(P.at("step2prev"), false, false), f3p = start(P.at("step3prev"), false, false), f3 = start(P.at("step3"), false, false),
                                 f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
