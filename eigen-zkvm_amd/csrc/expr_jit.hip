@@ -21,13 +21,19 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <cerrno>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <map>
 #include <set>
 #include <sstream>
 #include <tuple>
 #include <vector>
+extern "C" char** environ;                               // (for the compiler processes a setup starts: compile_spawned)
 
 namespace zk {
 
@@ -465,6 +471,60 @@ void jit_write(const std::string& dir, const std::string& path, const std::vecto
     }
 }
 
+// hipRTC (comgr) compiles one program at a time per process, whatever the number of host threads (measured: three step programs on
+// three threads take what they take one after the other, profiles/r04/cold_setup.txt).  A setup that compiles several programs at once
+// therefore hands each to a helper process, `zkgpu_jitc` next to libzkgpu.so (csrc/jitc_main.cpp: the same hipRTC call, the same
+// options, the same code object): set per thread by jit_prefer_spawn().  0 = compiled, > 0 = the compiler rejected the text (log),
+// < 0 = no helper or it could not be started (the caller compiles in process).
+thread_local bool t_jit_spawn = false;
+std::string jitc_path() {
+    if (const char* e = getenv("ZK_JITC")) return (!strcmp(e, "off") || !*e) ? "" : e;
+    Dl_info info;
+    if (!dladdr((const void*)&jitc_path, &info) || !info.dli_fname) return "";
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    p = (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/zkgpu_jitc";
+    return access(p.c_str(), X_OK) == 0 ? p : "";
+}
+int compile_spawned(const std::string& source, const char* const* opts, int n_opts, std::vector<char>& out, std::string& log) {
+    static const std::string helper = jitc_path();
+    if (helper.empty()) return -1;
+    const char* td = getenv("TMPDIR");
+    std::string dir = std::string(td && *td ? td : "/tmp") + "/zkgpu_jitc_XXXXXX";
+    if (!mkdtemp(&dir[0])) return -1;                     // 0700, ours
+    const std::string src = dir + "/k.hip", obj = dir + "/k.co", err = dir + "/k.log";
+    struct Cleanup { const std::string &a, &b, &c, &d; ~Cleanup() { (void)remove(a.c_str()); (void)remove(b.c_str()); (void)remove(c.c_str()); (void)rmdir(d.c_str()); } } cleanup{src, obj, err, dir};
+    {
+        FILE* f = fopen(src.c_str(), "wb");
+        if (!f) return -1;
+        const bool ok = fwrite(source.data(), 1, source.size(), f) == source.size();
+        if (fclose(f) != 0 || !ok) return -1;
+    }
+    std::vector<char*> argv{const_cast<char*>(helper.c_str()), const_cast<char*>(src.c_str()), const_cast<char*>(obj.c_str())};
+    for (int i = 0; i < n_opts; ++i) argv.push_back(const_cast<char*>(opts[i]));
+    argv.push_back(nullptr);
+    posix_spawn_file_actions_t fa;
+    if (posix_spawn_file_actions_init(&fa) != 0) return -1;
+    (void)posix_spawn_file_actions_addopen(&fa, 2, err.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    (void)posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) return -1;
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0) if (errno != EINTR) return -1;
+    auto slurp = [](const std::string& p, std::vector<char>& v) {
+        FILE* f = fopen(p.c_str(), "rb"); if (!f) return false;
+        char tmp[65536]; size_t n; v.clear();
+        while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) v.insert(v.end(), tmp, tmp + n);
+        fclose(f); return true;
+    };
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && slurp(obj, out) && out.size() > 16 && !memcmp(out.data(), "\x7f" "ELF", 4)) return 0;
+    std::vector<char> l;
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 1 && slurp(err, l) && !l.empty()) { log.assign(l.begin(), l.end()); return 1; }   // the compiler's verdict on the text
+    return -1;                                            // the helper itself failed (missing library, signal): compile in process
+}
+
 std::shared_ptr<const CodeObj> compile_cached(const std::string& source, bool skip_disk = false) {
     static const char* const opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     int maj = 0, min = 0, rt = 0; (void)hiprtcVersion(&maj, &min);
@@ -496,19 +556,30 @@ std::shared_ptr<const CodeObj> compile_cached(const std::string& source, bool sk
         g_jit_mem[key] = sp; g_jit_stats.disk_hits++; g_jit_stats.ms += ms_since();
         return sp;
     }
-    hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, source.c_str(), "zk_eval.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
-        throw Error("hiprtcCreateProgram failed");
-    hiprtcResult rc = hiprtcCompileProgram(prog, 3, const_cast<const char**>(opts));
-    if (rc != HIPRTC_SUCCESS) {
-        std::string log = hiprtc_log(prog);
-        hiprtcDestroyProgram(&prog);
-        throw Error("hiprtc compile failed: " + log.substr(0, 2000));
+    bool spawned = false;
+    static const bool always_spawn = getenv("ZK_JIT_SPAWN") != nullptr;   // (tests: every compilation through the helper)
+    if (t_jit_spawn || always_spawn) {                    // a setup compiling its programs side by side: one hipRTC process each
+        std::string log;
+        const int r = compile_spawned(source, opts, 3, sp->bytes, log);
+        if (r > 0) throw Error("hiprtc compile failed: " + log.substr(0, 2000));
+        spawned = r == 0;                                 // r < 0: no helper / could not start it -> in process
+        if (spawned) { std::lock_guard<std::mutex> lk(g_jit_mu); g_jit_stats.spawned++; }
     }
-    size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
-    sp->bytes.resize(sz);
-    hiprtcGetCode(prog, sp->bytes.data());
-    hiprtcDestroyProgram(&prog);
+    if (!spawned) {
+        hiprtcProgram prog;
+        if (hiprtcCreateProgram(&prog, source.c_str(), "zk_eval.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+            throw Error("hiprtcCreateProgram failed");
+        hiprtcResult rc = hiprtcCompileProgram(prog, 3, const_cast<const char**>(opts));
+        if (rc != HIPRTC_SUCCESS) {
+            std::string log = hiprtc_log(prog);
+            hiprtcDestroyProgram(&prog);
+            throw Error("hiprtc compile failed: " + log.substr(0, 2000));
+        }
+        size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
+        sp->bytes.resize(sz);
+        hiprtcGetCode(prog, sp->bytes.data());
+        hiprtcDestroyProgram(&prog);
+    }
     if (!path.empty()) jit_write(dir, path, sp->bytes);
     std::lock_guard<std::mutex> lk(g_jit_mu);
     g_jit_mem[key] = sp; g_jit_stats.compiled++; g_jit_stats.ms += ms_since();
@@ -526,6 +597,7 @@ std::shared_ptr<const CodeObj> recompile_after_bad_load(const std::shared_ptr<co
     return compile_cached(source, true);
 }
 }  // namespace
+void jit_prefer_spawn(bool on) { t_jit_spawn = on; }
 JitStats jit_stats() { std::lock_guard<std::mutex> lk(g_jit_mu); return g_jit_stats; }
 }  // namespace zk
 

@@ -535,12 +535,18 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     const clk::time_point t_tree = clk::now();
     const JitStats j0 = jit_stats();
     const JVal& P = S->prog;
-    {   // every step program on a host thread of its own: hipRTC takes seconds per program and the programs are independent
-        // (serially the three of PoseidonG were 8.9 of a 9.05 s cold setup; the code-object cache keeps one compilation per text)
+    {   // every step program on a host thread of its own, each thread handing its text to a compiler process of its own: hipRTC takes
+        // seconds per program, the programs are independent, and inside one process hipRTC compiles them one after the other whatever
+        // the threads (serially the three of PoseidonG were 8.0 of an 8.4 s cold setup; the code-object cache keeps one compilation per text)
         const zk_stark_setup* Sc = S.get();
         const std::launch how = getenv("ZK_JIT_SERIAL") ? std::launch::deferred : std::launch::async;   // (ZK_JIT_SERIAL: one after the other, for measurements)
-        auto start = [Sc, how](const JVal& seg, bool ext, bool ret) {
-            return std::async(how, [Sc, &seg, ext, ret] { return Sc->compile_segment(seg, ext, ret); });
+        const bool spawn = how == std::launch::async && !getenv("ZK_JIT_INPROCESS");   // side by side really means one compiler process each (expr_jit.hip)
+        auto start = [Sc, how, spawn](const JVal& seg, bool ext, bool ret) {
+            return std::async(how, [Sc, &seg, ext, ret, spawn] {
+                jit_prefer_spawn(spawn && seg.at("first").size() >= 32);            // (a handful of instructions compiles faster than a process starts)
+                struct Off { ~Off() { jit_prefer_spawn(false); } } off;
+                return Sc->compile_segment(seg, ext, ret);
+            });
         };
         std::future<ProgramPtr> f2 = start(P.at("step2prev"), false, false), f3p = start(P.at("step3prev"), false, false), f3 = start(P.at("step3"), false, false),
                                 f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
@@ -558,7 +564,7 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         const JitStats j1 = jit_stats();
         std::ostringstream o; o.setf(std::ios::fixed); o.precision(3);
         o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_tree, t_jit)
-          << ",\"hiprtc_compiled\":" << (j1.compiled - j0.compiled) << ",\"code_cache_disk_hits\":" << (j1.disk_hits - j0.disk_hits)
+          << ",\"hiprtc_compiled\":" << (j1.compiled - j0.compiled) << ",\"hiprtc_processes\":" << (j1.spawned - j0.spawned) << ",\"code_cache_disk_hits\":" << (j1.disk_hits - j0.disk_hits)
           << ",\"code_cache_mem_hits\":" << (j1.mem_hits - j0.mem_hits) << ",\"total_ms\":" << ms(t_begin, t_jit) << "}";
         S->setup_timing = o.str();
         if (getenv("ZK_STARK_TIMING") && strcmp(getenv("ZK_STARK_TIMING"), "0")) fprintf(stderr, "[zkgpu stark_setup] %s\n", S->setup_timing.c_str());

@@ -69,8 +69,10 @@ struct DevBuf {
 };
 
 // ---- run-time compiled kernels (expr_jit.hip): what the code-object cache did so far in this process ----
-struct JitStats { uint64_t compiled = 0, disk_hits = 0, mem_hits = 0; double ms = 0; };
+struct JitStats { uint64_t compiled = 0, disk_hits = 0, mem_hits = 0, spawned = 0; double ms = 0; };   // spawned: compilations done by a helper process (of `compiled`)
 JitStats jit_stats();
+// the next compilations of this thread go to a helper process each (a setup compiling several step programs at once: hipRTC is serial inside one process)
+void jit_prefer_spawn(bool on);
 
 // ---- NTT (ntt.hip) ----
 // natural-order batched NTT over a row-major [1<<nbits][n_pols] device matrix; dst != src.

@@ -296,7 +296,10 @@ int zk_stark_setup_set_self_check(zk_stark_setup_t* s, int on);
 /* Where the time went, as JSON text owned by the setup (valid until the next call on it / its release).
  * zk_stark_setup_timing: StarkSetup::new (stark_setup.rs:26-66, one `#[time_profiler("stark_setup")]` span there) split into
  *   json_parse_ms, const_lde_merkle_ms, programs_ms (+ how many step programs hipRTC compiled and how many came from the
- *   code-object cache: $ZK_JIT_CACHE, default ~/.cache/zkgpu, "off" disables).
+ *   code-object cache: $ZK_JIT_CACHE, default ~/.cache/zkgpu, "off" disables; `hiprtc_processes`: how many of the compilations ran
+ *   in a helper process -- a setup compiles its step programs side by side, one `zkgpu_jitc` (next to libzkgpu.so; $ZK_JITC names
+ *   another, "off" disables) per program, because hipRTC compiles serially inside one process; a code object is sha256-checked when it
+ *   comes back from disk, and a cache directory that is not the user's own or is writable by others is not used).
  * zk_stark_last_timing: the stages of the last proof of this setup in HIP-event milliseconds, named after the reference's
  *   spans (stark_gen.rs:192,624,709,734,785; fri.rs:83): extend, merkelize, calculate_exps_parallel, calculate_H1H2,
  *   calculate_Z, fri_prove, ...  Collected only when the environment has ZK_STARK_TIMING=1 (also logged to stderr); "" otherwise. */

@@ -405,3 +405,30 @@ def test_code_objects_are_cached_in_the_process_and_on_disk(tmp_path):
     files[0].unlink()
     assert run(cache) == ([1, 0, 0], [1, 0, 1]) and list(cache.glob("*")) == []
     os.chmod(cache, 0o700)
+
+
+def test_step_programs_can_compile_in_helper_processes(tmp_path):
+    """csrc/expr_jit.hip compile_spawned: hipRTC compiles serially inside one process, so a setup hands each step program to a
+    `zkgpu_jitc` process (csrc/jitc_main.cpp).  ZK_JIT_SPAWN=1 sends every compilation that way: the helper is really started (a
+    wrapper named by $ZK_JITC leaves a mark), the code object it returns is the one the in-process compiler makes (same cache file,
+    byte for byte), and a helper that cannot be started falls back to the in-process compiler.  (No GPU needed.)"""
+    import os, stat, subprocess, sys
+    real = ROOT / "eigen-zkvm_amd" / "zkgpu_jitc"
+    assert real.exists(), "make -C eigen-zkvm_amd/csrc builds it"
+    mark = tmp_path / "mark"
+    wrapper = tmp_path / "jitc.sh"
+    wrapper.write_text("#!/bin/sh\necho run >> %s\nexec %s \"$@\"\n" % (mark, real))
+    wrapper.chmod(wrapper.stat().st_mode | stat.S_IXUSR)
+    def run(cache, **env):
+        e = dict(os.environ, ZK_JIT_CACHE=str(cache), **env)
+        r = subprocess.run([sys.executable, "-c", _JIT_PROBE, str(ROOT)], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        w = r.stdout.split()
+        return [int(x) for x in w[1:4]], [int(x) for x in w[5:8]]
+    a, b = tmp_path / "a", tmp_path / "b"
+    assert run(a, ZK_JIT_SPAWN="1", ZK_JITC=str(wrapper)) == ([1, 0, 0], [1, 0, 1]) and mark.read_text() == "run\n"
+    assert run(b) == ([1, 0, 0], [1, 0, 1])                              # in process
+    fa, fb = sorted(a.glob("*.co")), sorted(b.glob("*.co"))
+    assert len(fa) == 1 and len(fb) == 1 and fa[0].name == fb[0].name and fa[0].read_bytes() == fb[0].read_bytes()
+    assert run(tmp_path / "c", ZK_JIT_SPAWN="1", ZK_JITC=str(tmp_path / "missing")) == ([1, 0, 0], [1, 0, 1])   # no helper: in process
+    assert mark.read_text() == "run\n"
