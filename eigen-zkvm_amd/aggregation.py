@@ -48,13 +48,17 @@ class RootExchange:
         if world == 1:
             return cls(None, torch.device("cuda", lr) if torch.cuda.is_available() else torch.device("cpu"))
         import torch.distributed as dist
+        # "nccl" (= RCCL over xGMI) whenever the ranks have a GPU each; ZK_AGG_BACKEND=gloo for ranks that share one GPU (tests on a
+        # one-GPU box: RCCL refuses two ranks on the same device) -- the 32-byte roots then travel through host memory
+        backend = os.environ.get("ZK_AGG_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        on_gpu = backend == "nccl"
         if not dist.is_initialized():
-            if torch.cuda.is_available():
+            if on_gpu:
                 torch.cuda.set_device(lr)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
             else:
                 dist.init_process_group("gloo")
-        return cls(dist, torch.device("cuda", lr) if torch.cuda.is_available() else torch.device("cpu"))
+        return cls(dist, torch.device("cuda", lr) if on_gpu else torch.device("cpu"))
 
     def gather(self, words):
         """-> [world][len(words)]: every rank's words, in rank order (u64 values travel as two's-complement int64)"""

@@ -1,0 +1,90 @@
+"""The product's aggregation driver (eigen-zkvm_amd/aggregation.py; test/stark_aggregation.sh:70-73, :83-156) with real proofs on the GPU:
+
+  * `aggregate()` on one rank == the same tasks and joins done by hand, one setup and one proof at a time; every kept proof is accepted
+    by zk_stark_verify, and the pool's self check (prove.rs:124-132) changes nothing;
+  * `tools/zkgpu_prove.py stark_aggregate` as one process and as TWO processes (torchrun's environment, both on this box's one GPU, roots
+    exchanged over gloo: RCCL refuses two ranks on one device) end with the same roots -- the whole multi-process path with real provers;
+  * `tools/zkgpu_prove.py stark_verify` accepts what `stark_prove` wrote and rejects a tampered copy."""
+import importlib
+import json
+import os
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+D = ROOT / "tests" / "golden" / "starky_data"
+
+
+def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
+    import aggregation_workload as AW
+    zk.init(0)
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    c12 = importlib.import_module("eigen_zkvm_amd.compressor12")
+    n = 3
+    pool = AW.pool(zk, workers=2, keep_proofs=True, self_check=True)
+    ex = A.RootExchange()
+    res = A.aggregate(pool, [pool.task_inputs(u) for u in range(n)], n, ex)
+    assert sorted(res["by_task"]) == [0, 1, 2] and (res["join_tree"]["levels"], res["join_tree"]["joins"]) == (2, 2)
+    assert len(pool.proofs) == 3 * n + 2
+    # by hand: one setup per circuit, proofs one after the other, the joins in tree order
+    specs, join, circ = AW.circuits()
+    sets = {k: stark.NativeStarkSetup(c, p, s) for k, (c, p, s) in specs.items()}
+    D_ = zk.DevArray.from_host
+    root1 = lambda z: [int(v) for v in z["root1"]]
+    for u in range(n):
+        zs = [sets["fib"].gen(D_(AW.fib_trace(u))), sets["c12"].gen(D_(circ["c12"].witness(u))), sets["r1"].gen(D_(circ["r1"].witness(u)))]
+        assert [root1(z) for z in zs] == res["by_task"][u]
+    E = c12.Compressor12Exec(join[1], join[2])
+    def join_by_hand(a, b):
+        d_cm = E.run(D_(join[3]([int(w) for w in a] + [int(w) for w in b] + [0] * 8)), 1 << AW.STRUCTS["r2"]["nBits"])
+        return root1(sets["r2"].gen(d_cm))
+    leaves = [res["by_task"][u][2] for u in range(n)]
+    assert join_by_hand(join_by_hand(leaves[0], leaves[1]), leaves[2]) == res["join_tree"]["root"]     # the odd one out joins a level up
+    for kind, z in pool.proofs:                                               # every proof the pool made verifies against its circuit's setup
+        assert sets[kind].verify(z) is True
+    E.free(); pool.free()
+    for s in sets.values():
+        s.free()
+
+
+def _cli(args, env=None, **kw):
+    return subprocess.run([sys.executable, str(ROOT / "tools" / "zkgpu_prove.py")] + args, capture_output=True, text=True, env=env, timeout=600, **kw)
+
+
+def test_cli_stark_aggregate_one_and_two_processes_agree(tmp_path):
+    one = _cli(["stark_aggregate", "--num_proof", "4", "--workers", "2", "--workspace", str(tmp_path / "one")])
+    assert one.returncode == 0, one.stdout + one.stderr
+    a = json.load(open(tmp_path / "one" / "aggregation.json"))
+    assert a["num_proof"] == 4 and a["ranks"] == 1 and a["verified"] and (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (2, 3)
+    procs = []
+    for rank in range(2):                                                     # what torchrun --nproc-per-node 2 sets, by hand; both ranks on GPU 0
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
+                   ZK_AGG_BACKEND="gloo", ZK_AGG_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tools" / "zkgpu_prove.py"), "stark_aggregate", "--num_proof", "4", "--workers", "2",
+                                       "--workspace", str(tmp_path / "two")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    b = json.load(open(tmp_path / "two" / "aggregation.json"))
+    assert b["ranks"] == 2 and b["tasks"] == a["tasks"] and b["join_tree"]["root"] == a["join_tree"]["root"]
+    assert b["join_tree"]["joins"] == 3
+
+
+def test_cli_stark_verify_accepts_and_rejects(tmp_path):
+    ss = {"nBits": 10, "nBitsExt": 11, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 11}, {"nBits": 7}, {"nBits": 3}]}
+    (tmp_path / "ss.json").write_text(json.dumps(ss))
+    common = ["-s", str(tmp_path / "ss.json"), "-p", str(D / "fib.pil.json"), "--o", str(D / "fib.const")]
+    out = _cli(["stark_prove"] + common + ["--m", str(D / "fib.cm"), "-c", str(tmp_path / "v.circom"), "--i", str(tmp_path / "zkin.json")])
+    assert out.returncode == 0 and "verified and written" in out.stdout, out.stdout + out.stderr
+    ok = _cli(["stark_verify"] + common + ["--i", str(tmp_path / "zkin.json")])
+    assert ok.returncode == 0 and "verifies" in ok.stdout, ok.stdout + ok.stderr
+    z = json.load(open(tmp_path / "zkin.json"))
+    z["evals"][0][0] = str((int(z["evals"][0][0]) + 1) % 0xFFFFFFFF00000001)
+    (tmp_path / "bad.json").write_text(json.dumps(z))
+    bad = _cli(["stark_verify"] + common + ["--i", str(tmp_path / "bad.json")])
+    assert bad.returncode != 0 and "does not verify" in (bad.stdout + bad.stderr)

@@ -98,7 +98,7 @@ def stark_aggregate(a):
     import time
     sys.path.insert(0, str(ROOT / "tools"))
     import eigen_zkvm_amd as zk
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("ZK_AGG_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # ZK_AGG_DEVICE: ranks sharing one GPU (tests)
     if zk.lib().zk_device_count() <= local_rank:
         raise SystemExit("zkgpu_prove: no GPU for local rank %d (the library has no CPU fallback)" % local_rank)
     zk.init(local_rank)
