@@ -54,6 +54,7 @@ def test_fixture_proofs_at_blowup_4_and_8(zk, orc, name, ext_bits):
     assert program == json.loads(json.dumps(SI.to_json(su["starkinfo"], su["program"])))
     ns = stark.NativeStarkSetup(np.fromfile(D / const_f, dtype="<u8"), json.dumps(program), json.dumps(ss))
     got = ns.gen(np.fromfile(D / cm_f, dtype="<u8"))
+    assert ns.verify(got) is True                                             # the library's own stark_verify at this blow-up
     ns.free()
     assert list(got) == list(exp)
     for k in exp:
@@ -75,6 +76,7 @@ def test_plookup_blowup_4_scalar_field_hash(zk, orc, hash_type):
     ns = stark.NativeStarkSetup(np.fromfile(D / "plookup.const", dtype="<u8"), json.dumps(SI.to_json(su["starkinfo"], su["program"])),
                                 json.dumps(ss), prover_addr="7")
     got = ns.gen(np.fromfile(D / "plookup.cm", dtype="<u8"))
+    assert ns.verify(got) is True
     ns.free()
     for k in exp:
         assert got[k] == exp[k], k
@@ -101,6 +103,7 @@ def test_poseidong_blowup_4_zkin_equals_oracle(zk, orc, nbits, ext_bits):
     for k in exp:
         assert got[k] == exp[k], k
     assert ns.gen(cm) == got
+    assert ns.verify(got) is True
     ns.free()
 
 
@@ -118,6 +121,9 @@ def test_poseidong_2p16_bn128_hash_zkin_equals_oracle(zk, orc):
     exp = SP.to_zkin_bn128(proof, b, "")
     ns = stark.NativeStarkSetup(const, json.dumps(PG.program(nbits, ss)), json.dumps(ss))
     got = ns.gen(zk.DevArray.from_host(cm))
+    assert ns.verify(got) is True                                             # 16-ary trees, scalar-field sponge
+    bad = json.loads(json.dumps(got)); bad["s0_vals3"][1][5] = str((int(bad["s0_vals3"][1][5]) + 1) % 0xFFFFFFFF00000001)
+    assert ns.verify(bad) is False
     ns.free()
     assert list(got) == list(exp)
     for k in exp:
@@ -148,6 +154,7 @@ def _prove_poseidong(zk, nbits, gold):
     d_cm = zk.DevArray.from_host(cm)
     del cm
     got = ns.gen(d_cm)
+    assert ns.verify(got) is True                                             # zk_stark_verify at full size
     ns.free()
     return got
 
