@@ -142,7 +142,7 @@ class ProverPool:
             for kind, d_cm in inputs:
                 t0 = time.perf_counter(); self.sets[worker][kind].gen_bytes(d_cm, st); call_ms = (time.perf_counter() - t0) * 1e3
                 t = self.sets[worker][kind].last_timing()
-                stages = sorted(((k, v) for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms")), key=lambda kv: -kv[1])
+                stages = sorted(((k, v) for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms", "call_ms", "zkin_bytes")), key=lambda kv: -kv[1])
                 out[kind] = {"call_ms": round(call_ms, 2), "gpu_event_ms": t.get("total_gpu_ms"), "host_after_last_launch_ms": round(call_ms - t.get("total_gpu_ms", 0), 2),
                              "top_stages_ms": {k: round(v, 2) for k, v in stages[:4]}}
             return out

@@ -1094,16 +1094,18 @@ char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64
             ZK_REQUIRE(s && d_cm_pols, "zk_stark_gen_dev: null argument");
             const auto t0 = std::chrono::steady_clock::now();
             const std::string z = stark_gen(*s, nullptr, K(d_cm_pols), n_words, (hipStream_t)stream);
-            const auto t1 = std::chrono::steady_clock::now();          // stark_gen's locals are gone; their blocks are stamped and released when this call's DeferFlush runs (not in host_release_ms)
+            pool_defer_flush();                                        // stark_gen's locals are gone: their blocks are stamped with one set of events and released HERE,
+            const auto t1 = std::chrono::steady_clock::now();          // inside host_release_ms (the guard's DeferFlush only covers the error paths now)
             self_check(*s, z);
+            const auto t2 = std::chrono::steady_clock::now();
             out = (char*)malloc(z.size() + 1);
             ZK_REQUIRE(out, "out of memory");
             memcpy(out, z.c_str(), z.size() + 1);
             if (!s->last_timing.empty() && s->last_timing.back() == '}') {   // a timing run: where the host time after the last launch went
                 auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                 char buf[256];
-                snprintf(buf, sizeof buf, ",\"host_json_ms\":%.3f,\"host_release_ms\":%.3f,\"host_copy_ms\":%.3f,\"call_ms\":%.3f,\"zkin_bytes\":%zu}",
-                         ms(s->t_json_begin, s->t_json_end), ms(s->t_json_end, t1), ms(t1, std::chrono::steady_clock::now()), ms(t0, std::chrono::steady_clock::now()), z.size());
+                snprintf(buf, sizeof buf, ",\"host_json_ms\":%.3f,\"host_release_ms\":%.3f,\"self_check_ms\":%.3f,\"host_copy_ms\":%.3f,\"call_ms\":%.3f,\"zkin_bytes\":%zu}",
+                         ms(s->t_json_begin, s->t_json_end), ms(s->t_json_end, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()), ms(t0, std::chrono::steady_clock::now()), z.size());
                 s->last_timing.pop_back(); s->last_timing += buf;
             }
         }) != 0) return nullptr;

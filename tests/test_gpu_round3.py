@@ -53,7 +53,7 @@ def test_stage_timers_and_setup_timing(zk, orc):
     assert timed == plain
     for k in ("extend", "merkelize", "calculate_exps_parallel", "fri_prove", "evals", "transcript", "openings_readback", "total_gpu_ms", "wall_ms", "call_ms", "zkin_bytes"):
         assert k in t, k
-    stages = sum(v for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms", "host_json_ms", "host_release_ms", "host_copy_ms", "call_ms", "zkin_bytes"))
+    stages = sum(v for k, v in t.items() if k not in ("nBits", "total_gpu_ms", "wall_ms", "host_json_ms", "host_release_ms", "self_check_ms", "host_copy_ms", "call_ms", "zkin_bytes"))
     assert abs(stages - t["total_gpu_ms"]) < 0.05 * t["total_gpu_ms"] + 0.05 and t["nBits"] == nbits
     second = stark.NativeStarkSetup(PG.consts(nbits), json.dumps(PG.program(nbits)), json.dumps(ss))    # same circuit, same process: no hipRTC
     s2 = second.setup_timing()
