@@ -84,3 +84,21 @@ def test_groth16_and_compressor_readers_without_gpu(zk):
     assert not lib.zk_groth16_setup_new(b"BLS12381", r1, len(r1), b"x", 1) and "truncated" in err()       # the circuit parses; the key does not
     assert not lib.zk_c12_exec_new(b"[1,0,5,6,7]", 11, 10) and "length does not match" in err()
     assert not lib.zk_c12_exec_new(b"[1,0,12,0,1,1]", 14, 10) and "does not exist yet" in err()
+
+
+def test_stark_verify_rejects_malformed_input_before_touching_a_device(zk):
+    """zk_stark_verify_with: -1 (an error, with a message) for unparseable or incomplete input -- decided by the host parser, so it can
+    be checked without a GPU; 0 / 1 need the device's hashes (tests/test_gpu_verify.py)"""
+    import ctypes as C, json
+    lib = zk.lib()
+    root = (C.c_uint64 * 4)(1, 2, 3, 4)
+    ss = json.dumps({"nBits": 10, "nBitsExt": 11, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 11}, {"nBits": 7}, {"nBits": 3}]})
+    prog = json.dumps({"starkinfo": {"q_deg": 1, "qs": [0], "ev_idx": {"cm": [], "const_": []}}, "program": {"verifier_code": {"first": []}, "verifier_query_code": {"first": []}}})
+    for args in ((b"{", ss.encode(), b"{}"), (prog.encode(), b"not json", b"{}"), (prog.encode(), ss.encode(), b"{"),
+                 (prog.encode(), ss.encode(), b"{}"),                                     # no root1
+                 (prog.encode(), json.dumps(dict(json.loads(ss), verificationHashType="SHA256")).encode(), b"{}"),
+                 (json.dumps({"program": {}}).encode(), ss.encode(), b"{}")):
+        assert lib.zk_stark_verify_with(args[0], args[1], root, args[2]) == -1
+        assert lib.zk_last_error()
+    assert lib.zk_stark_verify_with(None, ss.encode(), root, b"{}") == -1 and b"null" in lib.zk_last_error()
+    assert lib.zk_stark_verify(None, b"{}") == -1
