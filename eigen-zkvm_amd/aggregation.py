@@ -42,9 +42,13 @@ class RootExchange:
     def from_env(cls, local_rank=None):
         """one process per GPU as torchrun starts them (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); a lone process
         gets the no-op exchange"""
-        import torch
         world = int(os.environ.get("WORLD_SIZE", "1"))
         lr = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
+        if os.environ.get("ZK_AGG_BACKEND") == "rccl":                       # RCCL through ctypes, no torch (RcclExchange) -- decided BEFORE torch
+            import eigen_zkvm_amd as zk                                     # is imported: torch brings its own librccl / HIP runtime copies, and a
+            return RcclExchange.bootstrap(zk, int(os.environ.get("RANK", "0")), world, os.environ.get("MASTER_ADDR", "127.0.0.1"),   # librccl bound to
+                                          int(os.environ.get("MASTER_PORT", "29500")) + 1)                                        # those sees no device
+        import torch
         if world == 1:
             return cls(None, torch.device("cuda", lr) if torch.cuda.is_available() else torch.device("cpu"))
         import torch.distributed as dist
@@ -84,6 +88,112 @@ class RootExchange:
         t = torch.tensor(values, device=self.device, dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return [float(v) for v in t]
+
+
+class RcclExchange(RootExchange):
+    """The same three operations on RCCL alone, no torch: `ncclAllGather` of librccl.so through ctypes on device buffers of the library
+    (C1 of SURVEY 8e taken literally: 32-byte roots over xGMI; the barrier and the MAX are all-gathers of one word).  The communicator's
+    128-byte unique id goes from rank 0 to the others over a TCP socket on MASTER_ADDR : MASTER_PORT + 1 (`bootstrap`), the one thing
+    that has to travel before RCCL is up.  One process per GPU; `zk.init(device)` must have bound this thread to its GPU.
+    Selected by ZK_AGG_BACKEND=rccl (`RootExchange.from_env`); the default stays `torch.distributed` until this path has run on a
+    multi-GPU node (a one-rank communicator on one GPU is what the tests of this build could reach: tests/test_gpu_aggregation.py)."""
+    NCCL_UINT64 = 5                                                        # rccl.h ncclDataType_t
+
+    def __init__(self, zk, rank=0, world=1, unique_id=None, lib_path=None):
+        import ctypes as C
+        import sys
+        if "torch" in sys.modules and not (lib_path or os.environ.get("ZK_RCCL_LIB")):
+            # torch ships copies of librccl / libhsa-runtime64; the system librccl beside them finds an HSA runtime that was never
+            # initialised ("no ROCm-capable device is detected", measured).  This exchange is for processes without torch.
+            raise RuntimeError("RcclExchange: torch is loaded in this process; use RootExchange (torch.distributed) here, or name torch's own librccl in ZK_RCCL_LIB")
+        self.zk, self.rank, self.world, self.dist, self.device = zk, rank, world, None, None
+        self._C = C
+        L = self._L = C.CDLL(lib_path or os.environ.get("ZK_RCCL_LIB", "librccl.so"))
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        self._UniqueId = UniqueId
+        L.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]; L.ncclGetUniqueId.restype = C.c_int
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]; L.ncclCommInitRank.restype = C.c_int
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]; L.ncclAllGather.restype = C.c_int
+        L.ncclCommDestroy.argtypes = [C.c_void_p]; L.ncclCommDestroy.restype = C.c_int
+        L.ncclGetErrorString.argtypes = [C.c_int]; L.ncclGetErrorString.restype = C.c_char_p
+        uid = UniqueId()
+        if unique_id is None:
+            assert world == 1, "RcclExchange: ranks > 0 need rank 0's unique id (RcclExchange.bootstrap)"
+            self._check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        else:
+            C.memmove(C.byref(uid), unique_id, 128)
+        warm = zk.DevArray(1); zk._check(zk.lib().zk_dev_sync()); warm.free()   # HIP initialises lazily: RCCL finds "no ROCm-capable device" (HSA not up) before the first allocation
+        self._comm = C.c_void_p()
+        self._check(L.ncclCommInitRank(C.byref(self._comm), world, uid, rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (what, self._L.ncclGetErrorString(rc).decode()))
+
+    @classmethod
+    def bootstrap(cls, zk, rank, world, addr, port):
+        """rank 0 makes the unique id and hands it to every other rank over TCP; -> the exchange of this rank"""
+        import ctypes as C, socket
+        if world == 1:
+            return cls(zk)
+        if rank == 0:
+            L = C.CDLL(os.environ.get("ZK_RCCL_LIB", "librccl.so"))
+            buf = C.create_string_buffer(128)
+            L.ncclGetUniqueId.argtypes = [C.c_void_p]; L.ncclGetUniqueId.restype = C.c_int
+            if L.ncclGetUniqueId(buf) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            uid = buf.raw
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port)); srv.listen(world)
+            for _ in range(world - 1):
+                c, _a = srv.accept(); c.sendall(uid); c.close()
+            srv.close()
+        else:
+            uid, deadline = b"", time.time() + 120
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            while len(uid) < 128:
+                chunk = c.recv(128 - len(uid))
+                if not chunk:
+                    raise RuntimeError("RcclExchange.bootstrap: rank 0 closed the connection early")
+                uid += chunk
+            c.close()
+        return cls(zk, rank, world, uid)
+
+    def gather(self, words):
+        import numpy as np
+        n = len(words)
+        if n == 0:
+            return [[] for _ in range(self.world)]
+        send = self.zk.DevArray.from_host(np.array([int(v) for v in words], dtype=np.uint64))
+        recv = self.zk.DevArray(n * self.world)
+        self._check(self._L.ncclAllGather(send.ptr, recv.ptr, n, self.NCCL_UINT64, self._comm, None), "ncclAllGather")   # null stream
+        self.zk._check(self.zk.lib().zk_dev_sync())
+        out = recv.to_host()
+        send.free(); recv.free()
+        return [[int(v) for v in out[r * n:(r + 1) * n]] for r in range(self.world)]
+
+    def barrier(self):
+        self.gather([0])
+
+    def max(self, values):
+        import struct
+        bits = [struct.unpack("<Q", struct.pack("<d", float(v)))[0] for v in values]
+        rows = self.gather(bits)
+        return [max(struct.unpack("<d", struct.pack("<Q", r[i]))[0] for r in rows) for i in range(len(values))]
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._L.ncclCommDestroy(self._comm); self._comm = None
 
 
 def root1_of(zkin_json):

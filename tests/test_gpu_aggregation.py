@@ -53,6 +53,28 @@ def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
         s.free()
 
 
+def test_rccl_exchange_without_torch_one_rank_communicator(zk):
+    """aggregation.RcclExchange: ncclAllGather of librccl.so through ctypes on the library's device buffers -- the root exchange without
+    torch.  What one GPU can show: a one-rank communicator (ncclCommInitRank with nranks = 1), the gather / barrier / MAX on it, and the
+    join tree running on top of it."""
+    zk.init(0)
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    ex = A.RcclExchange(zk)
+    assert (ex.rank, ex.world) == (0, 1)
+    words = [1, 2, 3, (1 << 63) + 5, (1 << 64) - 1, 0]
+    assert ex.gather(words) == [words] and ex.gather([]) == [[]]
+    assert ex.max([3.5, -1.25, 0.0]) == [3.5, -1.25, 0.0]
+    ex.barrier()
+
+    class Stub:                                                               # joins as arithmetic: the tree's control flow on this exchange
+        def join(self, a, b): return [(3 * int(a[i]) + 5 * int(b[i]) + i) % (1 << 64) for i in range(4)]
+        def sync(self): pass
+    leaves = [[u + 1, 2, 3, (1 << 62) + u] for u in range(5)]
+    got = A.join_tree(Stub(), leaves, ex)
+    assert got == A.join_tree(Stub(), leaves, A.RootExchange()) and got["joins"] == 4
+    ex.close()
+
+
 def _cli(args, env=None, **kw):
     return subprocess.run([sys.executable, str(ROOT / "tools" / "zkgpu_prove.py")] + args, capture_output=True, text=True, env=env, timeout=600, **kw)
 
@@ -62,6 +84,10 @@ def test_cli_stark_aggregate_one_and_two_processes_agree(tmp_path):
     assert one.returncode == 0, one.stdout + one.stderr
     a = json.load(open(tmp_path / "one" / "aggregation.json"))
     assert a["num_proof"] == 4 and a["ranks"] == 1 and a["verified"] and (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (2, 3)
+    r = _cli(["stark_aggregate", "--num_proof", "4", "--workers", "2", "--workspace", str(tmp_path / "rccl")], env=dict(os.environ, ZK_AGG_BACKEND="rccl"))
+    assert r.returncode == 0, r.stdout + r.stderr                             # the torch-free exchange (a one-rank RCCL communicator here)
+    c = json.load(open(tmp_path / "rccl" / "aggregation.json"))
+    assert c["tasks"] == a["tasks"] and c["join_tree"]["root"] == a["join_tree"]["root"]
     procs = []
     for rank in range(2):                                                     # what torchrun --nproc-per-node 2 sets, by hand; both ranks on GPU 0
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571",
