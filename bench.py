@@ -547,12 +547,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    # ZK_BENCH_SHARED_GPU=1: every rank on GPU 0, collectives over gloo -- the N > 1 control flow of this file on a one-GPU box
+    # (tests/test_gpu_aggregation.py); RCCL refuses two ranks on one device.  Never set by the driver: its ranks own a GPU each.
+    shared_gpu = os.environ.get("ZK_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     zk.init(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = zk.lib()
     nbits, n = args.nbits, 1 << args.nbits
@@ -591,7 +599,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)                                     # HIP events on the launch stream
-    ex = _agg().RootExchange(dist, dev)                                  # the collectives of the path live in the product
+    ex = _agg().RootExchange(dist, torch.device("cpu") if shared_gpu else dev)   # the collectives of the path live in the product
     wall, dev_ms = ex.max([wall, dev_ms])
 
     agg = None

@@ -114,3 +114,30 @@ def test_cli_stark_verify_accepts_and_rejects(tmp_path):
     (tmp_path / "bad.json").write_text(json.dumps(z))
     bad = _cli(["stark_verify"] + common + ["--i", str(tmp_path / "bad.json")])
     assert bad.returncode != 0 and "does not verify" in (bad.stdout + bad.stderr)
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path -- process group, barrier + max-over-ranks timing, the sharded aggregation leg through the product's driver,
+    the rank-0 serial tail, ONE JSON line from rank 0 -- as the driver starts it (`torch.distributed.run` environment), with both ranks
+    on this box's one GPU and the collectives over gloo (ZK_BENCH_SHARED_GPU=1).  Values mean nothing here (two ranks share a device);
+    the shape of the line and the agreement of the ranks do."""
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", ZK_BENCH_SHARED_GPU="1")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nbits", "20"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(ROOT)))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # only rank 0 prints the line (gloo prints a banner of its own)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["steps"] == 3 and b["warmup"] == 1 and b["scaling"] == "weak" and b["higher_is_better"] is True
+    assert b["metric"].startswith("Goldilocks NTT GElems/s") and b["config"]["parallelism"] == "replicas x2" and b["value"] > 0
+    assert "roofline" in b and b["roofline"]["bound"] == "hbm"
+    a = b["aggregation"]
+    assert "error" not in a and a["n_gpus"] == 2 and a["tasks"] == 8 and a["tasks_gathered"] == list(range(8)) and a["distinct_roots"] == 8
+    assert (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (3, 7) and len(a["join_tree"]["root"]) == 4
+    assert a["final_wrap"].get("final_stark_verified") is True
+    for leg in ("msm_g1_bn254", "stark_prove", "cpu_baseline"):               # N = 1 legs stay out of an N > 1 line
+        assert leg not in b
