@@ -74,7 +74,8 @@ def test_ntt_2p24_properties_and_oracle(zk, orc):
 # ---- LDE ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nbits,ext,n_pols", [(0, 1, 1), (1, 2, 2), (2, 3, 3), (3, 4, 1), (3, 5, 2), (4, 5, 1),
                                               (5, 7, 3), (8, 9, 19), (10, 11, 2), (12, 13, 18), (12, 14, 1),
-                                              (15, 16, 12), (16, 17, 1), (18, 19, 3)])
+                                              (15, 16, 12), (16, 17, 1), (18, 19, 3),
+                                              (16, 18, 5), (17, 20, 2), (13, 16, 7), (20, 21, 4), (9, 12, 36)])   # blow-up 4 / 8 at size, short passes with shift twiddles
 def test_lde_matches_oracle(zk, orc, nbits, ext, n_pols):
     rng = np.random.default_rng(5000 + nbits * 31 + ext * 7 + n_pols)
     x = _rand(rng, (1 << nbits) * n_pols)
