@@ -53,26 +53,42 @@ def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
         s.free()
 
 
-def test_rccl_exchange_without_torch_one_rank_communicator(zk):
-    """aggregation.RcclExchange: ncclAllGather of librccl.so through ctypes on the library's device buffers -- the root exchange without
-    torch.  What one GPU can show: a one-rank communicator (ncclCommInitRank with nranks = 1), the gather / barrier / MAX on it, and the
-    join tree running on top of it."""
-    zk.init(0)
-    A = importlib.import_module("eigen_zkvm_amd.aggregation")
-    ex = A.RcclExchange(zk)
-    assert (ex.rank, ex.world) == (0, 1)
-    words = [1, 2, 3, (1 << 63) + 5, (1 << 64) - 1, 0]
-    assert ex.gather(words) == [words] and ex.gather([]) == [[]]
-    assert ex.max([3.5, -1.25, 0.0]) == [3.5, -1.25, 0.0]
-    ex.barrier()
+_RCCL_PROBE = r'''
+import importlib, sys
+sys.path.insert(0, sys.argv[1])
+import eigen_zkvm_amd as zk
+zk.init(0)
+A = importlib.import_module("eigen_zkvm_amd.aggregation")
+ex = A.RcclExchange(zk)
+assert "torch" not in sys.modules and (ex.rank, ex.world) == (0, 1)
+words = [1, 2, 3, (1 << 63) + 5, (1 << 64) - 1, 0]
+assert ex.gather(words) == [words] and ex.gather([]) == [[]]
+assert ex.max([3.5, -1.25, 0.0]) == [3.5, -1.25, 0.0]
+ex.barrier()
+class Stub:                                                               # joins as arithmetic: the tree's control flow on this exchange
+    def join(self, a, b): return [(3 * int(a[i]) + 5 * int(b[i]) + i) % (1 << 64) for i in range(4)]
+    def sync(self): pass
+leaves = [[u + 1, 2, 3, (1 << 62) + u] for u in range(5)]
+got = A.join_tree(Stub(), leaves, ex)
+assert got == A.join_tree(Stub(), leaves, A.RootExchange()) and got["joins"] == 4
+ex.close()
+import torch                                                              # with torch in the process the exchange refuses (two ROCm runtime copies)
+try:
+    A.RcclExchange(zk)
+    raise SystemExit("RcclExchange must refuse a process that has torch loaded")
+except RuntimeError as e:
+    assert "torch" in str(e)
+print("rccl exchange ok")
+'''
 
-    class Stub:                                                               # joins as arithmetic: the tree's control flow on this exchange
-        def join(self, a, b): return [(3 * int(a[i]) + 5 * int(b[i]) + i) % (1 << 64) for i in range(4)]
-        def sync(self): pass
-    leaves = [[u + 1, 2, 3, (1 << 62) + u] for u in range(5)]
-    got = A.join_tree(Stub(), leaves, ex)
-    assert got == A.join_tree(Stub(), leaves, A.RootExchange()) and got["joins"] == 4
-    ex.close()
+
+def test_rccl_exchange_without_torch_one_rank_communicator():
+    """aggregation.RcclExchange: ncclAllGather of librccl.so through ctypes on the library's device buffers -- the root exchange without
+    torch, in a process of its own (this test process has torch loaded by other test modules, and the two do not mix: torch ships its own
+    copies of the ROCm runtime).  What one GPU can show: a one-rank communicator (ncclCommInitRank with nranks = 1), the gather / barrier /
+    MAX on it, and the join tree running on top of it."""
+    r = subprocess.run([sys.executable, "-c", _RCCL_PROBE, str(ROOT)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl exchange ok" in r.stdout, r.stdout + r.stderr
 
 
 def _cli(args, env=None, **kw):
