@@ -198,13 +198,15 @@ def poseidon_leg(zk, log_height, width, cpu_baseline):
     """Poseidon-GL Merkle tree (merklehash.rs:293-346) over an HBM-resident [2^log_height][width] matrix -- 73 % of a proof.
     Integer-ALU bound: `roofline` rates the permutations per second against the multiply-add issue ceiling."""
     h = 1 << log_height
-    if cpu_baseline or h * width < (1 << 26):
+    if h * width < (1 << 26):
         rng = np.random.default_rng(0x905E)
         rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
         d = zk.DevArray.from_host(rows)
-    else:                                                                # the large shapes are born in HBM (splitmix64 mod p)
+    else:                                                                # the large shapes are born in HBM (splitmix64 mod p); the CPU sample is read back
         d = zk.DevArray(h * width)
         zk._check(zk.lib().zk_dev_fill_splitmix(d.ptr, h * width, 0x905E, None))
+        rows = np.empty((1 << 18) * width, np.uint64)
+        zk._check(zk.lib().zk_dev_download(zk._ptr(rows), d.ptr, rows.nbytes))
     times = []
     for _ in range(5):
         zk.lib().zk_dev_sync()
@@ -352,13 +354,15 @@ def bn128_merkle_leg(zk, log_height, width, cpu_baseline):
     CPU oracle on a bounded sample, which is also the timed CPU baseline."""
     h = 1 << log_height
     zk.bn128_init()
-    if cpu_baseline or h * width < (1 << 26):
+    if h * width < (1 << 26):
         rng = np.random.default_rng(0xB128)
         rows = rng.integers(0, 0xFFFFFFFF00000001, size=h * width, dtype=np.uint64)
         d = zk.DevArray.from_host(rows)
-    else:                                                                # the large shapes are born in HBM (splitmix64 mod p)
+    else:                                                                # the large shapes are born in HBM (splitmix64 mod p); the CPU sample is read back
         d = zk.DevArray(h * width)
         zk._check(zk.lib().zk_dev_fill_splitmix(d.ptr, h * width, 0xB128, None))
+        rows = np.empty((1 << 19) * width, np.uint64)
+        zk._check(zk.lib().zk_dev_download(zk._ptr(rows), d.ptr, rows.nbytes))
     times = []
     for _ in range(4):
         t0 = time.perf_counter()
@@ -657,10 +661,10 @@ def main():
             leg("msm_g1_bls12_381", msm_leg, zk, args.msm_logn, not args.no_cpu_baseline, "bls12_381")
         if not args.no_poseidon and world == 1:
             leg("poseidon_merkle_gl", poseidon_leg, zk, 22, 19, not args.no_cpu_baseline)
-            leg("poseidon_merkle_gl_ref_shape", poseidon_leg, zk, 24, 10, False)   # starky/benches/merklehash.rs:26-27: 2^24 x 10, the one GL shape the reference benches
+            leg("poseidon_merkle_gl_ref_shape", poseidon_leg, zk, 24, 10, not args.no_cpu_baseline)   # starky/benches/merklehash.rs:26-27: 2^24 x 10, the one GL shape the reference benches
         if not args.no_bn128 and world == 1:
             leg("merkle_bn128", bn128_merkle_leg, zk, 20, 12, not args.no_cpu_baseline)
-            leg("merkle_bn128_ref_shape", bn128_merkle_leg, zk, 24, 10, False)   # starky/README.md:55: 2^24 x 10 with the BN128 hash, 11.04 s on the reference's CPU (context, other hardware)
+            leg("merkle_bn128_ref_shape", bn128_merkle_leg, zk, 24, 10, not args.no_cpu_baseline)   # starky/README.md:55: 2^24 x 10 with the BN128 hash, 11.04 s on the reference's CPU (context, other hardware)
         if not args.no_groth16 and world == 1:
             leg("groth16_prove_bn128", groth16_leg, zk, "BN128", args.groth16_log_rows, not args.no_cpu_baseline)
             leg("groth16_prove_bls12381", groth16_leg, zk, "BLS12381", args.groth16_log_rows, False)
