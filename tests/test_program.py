@@ -339,7 +339,9 @@ def test_wide_sections_match_reference_interpreter(zk, orc, w_cm1, w_const, nbit
     chal = rng.integers(0, P, size=24, dtype=np.uint64)
     x = zk.x_table(nbits + ext, 49); zi = orc.zh_inv(nbits, ext)
     prog = _compile(zk, program)
-    if w_cm1 + w_const + 4 <= 112:                                         # words read: both wide sections whole, four words of the third
+    words = {(o["buf"], o["id"] + j, bool(o.get("prime"))) for _, _, a, b in program for o in (a, b)
+             if o is not None and o["kind"] == "mem" for j in range(o.get("dim", 1))}       # distinct (section, word, row i / i + next) reads
+    if len(words) <= 112:                                                  # Gen::HOIST_MAX: every word read once, up front, wide sections through LDS
         assert "stage_in<" in prog.source and "c.bufs[4][" in prog.source
     else:
         assert "stage_in<" not in prog.source

@@ -1,0 +1,48 @@
+"""One-off fuzz of the primitives against the oracle at random shapes (beyond the fixed parametrisations of tests/test_gpu_parity.py):
+NTT / iNTT / LDE (any blow-up), LinearHash rows, Merkle trees of any height (odd levels) with openings walked back to the root by the
+device's own path kernel (zk_stark_verify's), FRI folds.  python tools/fuzz_primitives.py SEED ROUNDS  (needs a GPU)"""
+import pathlib, sys, time
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "oracle")]
+import numpy as np
+import eigen_zkvm_amd as zk, oracle_lib
+zk.init(0)
+orc = oracle_lib.load()
+P = zk.P
+seed, rounds = int(sys.argv[1]), int(sys.argv[2])
+rng = np.random.default_rng(seed)
+R = lambda n: rng.integers(0, P, size=n, dtype=np.uint64)
+bad, t0, n_cases = [], time.time(), 0
+def check(name, ok, *info):
+    global n_cases
+    n_cases += 1
+    if not ok:
+        bad.append((name,) + info); print("MISMATCH", name, info, flush=True)
+for r in range(rounds):
+    nbits, npols = int(rng.integers(0, 17)), int(rng.integers(1, 41))
+    while (1 << nbits) * npols > (1 << 21): npols = max(1, npols // 2)
+    x = R((1 << nbits) * npols)
+    X = zk.fft(x, npols, nbits)
+    check("fft", np.array_equal(X, orc.ntt(x, npols, nbits)), nbits, npols)
+    check("ifft", np.array_equal(zk.ifft(X, npols, nbits), x), nbits, npols)
+    ext = nbits + int(rng.integers(0, 4))
+    if (1 << ext) * npols <= (1 << 22):
+        check("lde", np.array_equal(zk.interpolate(x, npols, nbits, ext), orc.lde(x, npols, nbits, ext)), nbits, ext, npols)
+    # Merkle tree of any height, openings
+    h, w = int(rng.integers(1, 6000)), int(rng.integers(0, 90))
+    rows = R(h * w) if w else np.zeros(0, np.uint64)
+    t = zk.MerkleTreeGL(); t.merkelize(rows, w, h)
+    exp = orc.merkelize(rows, w, h)
+    check("merkle", np.array_equal(t.nodes(), exp), h, w)
+    for idx in {0, h - 1, int(rng.integers(0, h))}:
+        row, path = t.get_group_proof(idx)
+        got = orc.root_from_proof(np.array(row, np.uint64), np.array(path, np.uint64).reshape(-1), idx)
+        # (a one-row tree: the reference's root() is nodes[1] of get_n_nodes(1) = 2, never written -- zeros; merklehash.rs:47-61, :455-457)
+        check("opening", [int(v) for v in got] == [int(v) for v in t.root()] if h > 1 else [int(v) for v in t.root()] == [0, 0, 0, 0], h, w, idx)
+    t.free()
+    # FRI fold
+    pb = int(rng.integers(2, 15)); sb = int(rng.integers(max(0, pb - 11), pb + 1))
+    pol = R(3 << pb); sx = R(3); sinv = int(rng.integers(1, P, dtype=np.uint64))
+    d = zk.fri_fold(zk.DevArray.from_host(pol), pb, sb, zk.DevArray.from_host(sx), sinv)
+    check("fri_fold", np.array_equal(d.to_host(), orc.fri_fold(pol, pb, sb, sx, sinv)), pb, sb)
+print("fuzz primitives seed %d: %d cases in %.0f s, mismatches: %s" % (seed, n_cases, time.time() - t0, bad), flush=True)
