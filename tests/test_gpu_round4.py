@@ -176,3 +176,11 @@ def test_headline_2p24_proof_equals_offline_oracle_golden(zk):
     assert [s["nBits"] for s in gold["starkStruct"]["steps"]] == [25, 20, 15, 10, 5]
     got = _prove_poseidong(zk, 24, gold)
     _check_against_golden(got, gold)
+
+
+def test_random_starkstructs_on_fixtures_and_wide_fibonacci():
+    """a seeded slice of the round-4 fuzz campaign (tools/fuzz_proofs.py; profiles/r04/fuzz.txt): the reference's fixtures and the
+    wide-Fibonacci PIL under random StarkStructs -- blow-up 2 / 4 / 8, 1..16 queries, random FRI steps (folds of 1..8 bits), the three hash
+    types -- device zkin == oracle zkin, accepted by zk_stark_verify and by the oracle's verifier, a tampered copy rejected"""
+    import fuzz_proofs
+    assert fuzz_proofs.run(404, 24, verbose=False) == []

@@ -11,45 +11,51 @@ stark = importlib.import_module("eigen_zkvm_amd.stark")
 orc = oracle_lib.load()
 D = ROOT / "tests" / "golden" / "starky_data"
 P = zk.P
-seed, cases = int(sys.argv[1]), int(sys.argv[2])
-rng = np.random.default_rng(seed)
-FIX = [("fib.pil.json.gl", "fib.const.gl", "fib.cm.gl"), ("plookup.pil.json.gl", "plookup.const.gl", "plookup.cm.gl"), ("fib.pil.json", "fib.const", "fib.cm"),
-       ("pe.pil.json", "pe.const", "pe.cm"), ("connection.pil.json", "connection.const", "connection.cm"), ("plookup.pil.json", "plookup.const", "plookup.cm")]
-bad, t0 = [], time.time()
-for case in range(cases):
-    if rng.random() < 0.7:
-        pil_f, const_f, cm_f = FIX[int(rng.integers(0, len(FIX)))]
-        pil, nbits = json.load(open(D / pil_f)), 10
-        const, cm, name = np.fromfile(D / const_f, dtype="<u8"), np.fromfile(D / cm_f, dtype="<u8"), pil_f
-    else:
-        nbits, W = int(rng.integers(4, 13)), int(rng.integers(1, 12))
-        pil, const, cm, name = synth_pil.wide_fib_pil(nbits, W), synth_pil.const_trace(nbits), synth_pil.wide_fib_trace(nbits, W, seed=case), "widefib%d" % W
-        pil["publics"][0]["idx"] = (1 << nbits) - 1
-    ext = nbits + int(rng.integers(1, 4))
-    steps, b = [ext], ext
-    # (a last step of 2^0 is not usable in the reference either: the root of a one-row tree is nodes[1] of get_n_nodes(1) = 2, which
-    # merkelize never writes -- merklehash.rs:47-61, :331-343, :455-457 -- so stark_verify rejects the honest proof; reproduced, excluded)
-    while b > 1 and rng.random() < 0.8 and len(steps) < 6:
-        b = max(1, b - int(rng.integers(1, 9)))
-        steps.append(b)
-    hash_type = ["GL", "GL", "BN128", "BLS12381"][int(rng.integers(0, 4))]
-    ss = {"nBits": nbits, "nBitsExt": ext, "nQueries": int(rng.integers(1, 17)), "verificationHashType": hash_type, "steps": [{"nBits": s} for s in steps]}
-    tag = (name, ext - nbits, ss["nQueries"], steps, hash_type)
-    try:
-        b_ = orc if hash_type == "GL" else SP.BN128Backend(orc, hash_type.lower())
-        su = SP.setup(pil, const, ss, b_)
-        proof = SP.stark_gen(cm, su, ss, b_)
-        ok_o = SP.stark_verify(proof, proof["rootC"], su["starkinfo"], su["program"], ss, b_)
-        exp = SP.to_zkin(proof) if hash_type == "GL" else SP.to_zkin_bn128(proof, b_, "9")
-        ns = stark.NativeStarkSetup(const, stark.generate_program(json.dumps(pil), json.dumps(ss)), json.dumps(ss), prover_addr="9")
-        got = ns.gen(cm)
-        same = got == exp
-        ok_d = ns.verify(got)
-        t = copy.deepcopy(got); t["evals"][0][0] = str((int(t["evals"][0][0]) + 1) % P)
-        rej = not ns.verify(t)
-        ns.free()
-        if not (same and ok_o and ok_d and rej):
-            bad.append((tag, same, ok_o, ok_d, rej)); print("MISMATCH", tag, same, ok_o, ok_d, rej, flush=True)
-    except Exception as e:                                                      # noqa: BLE001 -- a fuzzer reports and goes on
-        bad.append((tag, repr(e)[:200])); print("ERROR", tag, repr(e)[:300], flush=True)
-print("fuzz proofs seed %d: %d cases in %.0f s, failures: %s" % (seed, cases, time.time() - t0, bad), flush=True)
+def run(seed, cases, verbose=True):
+    rng = np.random.default_rng(seed)
+    FIX = [("fib.pil.json.gl", "fib.const.gl", "fib.cm.gl"), ("plookup.pil.json.gl", "plookup.const.gl", "plookup.cm.gl"), ("fib.pil.json", "fib.const", "fib.cm"),
+           ("pe.pil.json", "pe.const", "pe.cm"), ("connection.pil.json", "connection.const", "connection.cm"), ("plookup.pil.json", "plookup.const", "plookup.cm")]
+    bad, t0 = [], time.time()
+    for case in range(cases):
+        if rng.random() < 0.7:
+            pil_f, const_f, cm_f = FIX[int(rng.integers(0, len(FIX)))]
+            pil, nbits = json.load(open(D / pil_f)), 10
+            const, cm, name = np.fromfile(D / const_f, dtype="<u8"), np.fromfile(D / cm_f, dtype="<u8"), pil_f
+        else:
+            nbits, W = int(rng.integers(4, 13)), int(rng.integers(1, 12))
+            pil, const, cm, name = synth_pil.wide_fib_pil(nbits, W), synth_pil.const_trace(nbits), synth_pil.wide_fib_trace(nbits, W, seed=case), "widefib%d" % W
+            pil["publics"][0]["idx"] = (1 << nbits) - 1
+        ext = nbits + int(rng.integers(1, 4))
+        steps, b = [ext], ext
+        # (a last step of 2^0 is not usable in the reference either: the root of a one-row tree is nodes[1] of get_n_nodes(1) = 2, which
+        # merkelize never writes -- merklehash.rs:47-61, :331-343, :455-457 -- so stark_verify rejects the honest proof; reproduced, excluded)
+        while b > 1 and rng.random() < 0.8 and len(steps) < 6:
+            b = max(1, b - int(rng.integers(1, 9)))
+            steps.append(b)
+        hash_type = ["GL", "GL", "BN128", "BLS12381"][int(rng.integers(0, 4))]
+        ss = {"nBits": nbits, "nBitsExt": ext, "nQueries": int(rng.integers(1, 17)), "verificationHashType": hash_type, "steps": [{"nBits": s} for s in steps]}
+        tag = (name, ext - nbits, ss["nQueries"], steps, hash_type)
+        try:
+            b_ = orc if hash_type == "GL" else SP.BN128Backend(orc, hash_type.lower())
+            su = SP.setup(pil, const, ss, b_)
+            proof = SP.stark_gen(cm, su, ss, b_)
+            ok_o = SP.stark_verify(proof, proof["rootC"], su["starkinfo"], su["program"], ss, b_)
+            exp = SP.to_zkin(proof) if hash_type == "GL" else SP.to_zkin_bn128(proof, b_, "9")
+            ns = stark.NativeStarkSetup(const, stark.generate_program(json.dumps(pil), json.dumps(ss)), json.dumps(ss), prover_addr="9")
+            got = ns.gen(cm)
+            same = got == exp
+            ok_d = ns.verify(got)
+            t = copy.deepcopy(got); t["evals"][0][0] = str((int(t["evals"][0][0]) + 1) % P)
+            rej = not ns.verify(t)
+            ns.free()
+            if not (same and ok_o and ok_d and rej):
+                bad.append((tag, same, ok_o, ok_d, rej)); print("MISMATCH", tag, same, ok_o, ok_d, rej, flush=True)
+        except Exception as e:                                                      # noqa: BLE001 -- a fuzzer reports and goes on
+            bad.append((tag, repr(e)[:200])); print("ERROR", tag, repr(e)[:300], flush=True)
+    if verbose:
+        print("fuzz proofs seed %d: %d cases in %.0f s, failures: %s" % (seed, cases, time.time() - t0, bad), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]), int(sys.argv[2]))
