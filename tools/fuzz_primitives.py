@@ -45,4 +45,25 @@ for r in range(rounds):
     pol = R(3 << pb); sx = R(3); sinv = int(rng.integers(1, P, dtype=np.uint64))
     d = zk.fri_fold(zk.DevArray.from_host(pol), pb, sb, zk.DevArray.from_host(sx), sinv)
     check("fri_fold", np.array_equal(d.to_host(), orc.fri_fold(pol, pb, sb, sx, sinv)), pb, sb)
+# scalar-field trees (MerkleTreeBN128 / BLS12381: 16-ary, any height) and G1 sums at random sizes with window-boundary scalars
+zk.bn128_init(); zk.bn128_init(field="bls12381")
+hb = {"bn128": orc.bn128(), "bls12381": orc.bls12381()}
+R254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+for r in range(max(1, rounds // 4)):
+    for fld in ("bn128", "bls12381"):
+        h, w = int(rng.integers(1, 700)), int(rng.integers(0, 60))
+        rows = R(h * w) if w else np.zeros(0, np.uint64)
+        t = zk.MerkleTreeBN128(field=fld); t.merkelize(rows, w, h)
+        check("merkle_" + fld, np.array_equal(t.nodes(), hb[fld].merkelize(rows, w, h)), h, w)
+        t.free()
+    n = int(rng.integers(1, 300))
+    a, d = int(rng.integers(1, 1000)), int(rng.integers(0, 1000))
+    bases = orc.bn254_make_bases(n, a, d)
+    raw = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); raw[:, 3] &= np.uint64((1 << 60) - 1)
+    for k in range(0, n, 7):                                                # scalars on the 16-bit window boundaries
+        v = [0, 1, R254 - 1, (1 << (16 * int(rng.integers(1, 15)))) - 1, 1 << (16 * int(rng.integers(1, 15)))][int(rng.integers(0, 5))]
+        raw[k] = [(v >> (64 * j)) & (2**64 - 1) for j in range(4)]
+    got, inf = zk.msm_g1_bn254(bases, raw.reshape(-1))
+    exp, einf = orc.bn254_msm(bases, raw.reshape(-1), 8)
+    check("msm_bn254", inf == einf and np.array_equal(got, exp), n)
 print("fuzz primitives seed %d: %d cases in %.0f s, mismatches: %s" % (seed, n_cases, time.time() - t0, bad), flush=True)
