@@ -184,3 +184,12 @@ def test_random_starkstructs_on_fixtures_and_wide_fibonacci():
     types -- device zkin == oracle zkin, accepted by zk_stark_verify and by the oracle's verifier, a tampered copy rejected"""
     import fuzz_proofs
     assert fuzz_proofs.run(404, 24, verbose=False) == []
+
+
+def test_random_shapes_of_the_primitives_and_random_tamperings():
+    """seeded slices of the other two fuzzers (tools/fuzz_primitives.py, tools/fuzz_verify.py): NTT / LDE / Merkle (GL and both scalar
+    fields, any height) / FRI folds / G1 sums at random shapes against the oracle; random single-word tamperings of GL, BN128 and
+    BLS12381 proofs -- the library's verdict equals the oracle's"""
+    import fuzz_primitives, fuzz_verify
+    assert fuzz_primitives.run(77, 40, verbose=False) == []
+    assert fuzz_verify.run(77, 25, verbose=False) == []
