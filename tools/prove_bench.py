@@ -28,6 +28,7 @@ def poseidong_main(args):
         out = {"workload": "PoseidonG PIL, nBits=%d, %s hash, %d queries" % (nbits, args.hash, ss["nQueries"]),
                "setup_s": round(t_setup, 3), "setup_split": setup.setup_timing(), "stark_gen_ms": [round(t * 1e3, 1) for t in times], "root1": proof["root1"]}
         if setup.last_timing(): out["stages_ms"] = setup.last_timing()
+        t0 = time.perf_counter(); out["verified_by_library"] = bool(setup.verify(proof)); out["verify_ms"] = round((time.perf_counter() - t0) * 1e3, 1)   # zk_stark_verify
         if args.verify and args.hash == "GL":
             sys.path.insert(0, str(ROOT / "oracle"))
             import stark_prover as SP, starkinfo as SI, oracle_lib
