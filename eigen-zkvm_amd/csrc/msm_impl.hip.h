@@ -723,8 +723,16 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     static const int chunks_env = getenv("ZK_MSM_CHUNKS") ? atoi(getenv("ZK_MSM_CHUNKS")) : 4;
     // (measured, BN254 G1 behind the endomorphism split: 2^22 points 8.80 -> 8.25 ms with 4 chunks, 8.49 with 2, 8.54 with 8; 2^20 points
     // 2.88 -> 3.38 ms: short sums are the latency of their launch chain, which chunking lengthens)
-    const int n_chunks = (!d_table && n >= (1ull << 23) && n < (1ull << 24) && chunks_env > 1) ? std::min(chunks_env, 8) : 1;
+    // Round 4: sums of 2^24 and more pairs go through the same chunks -- of 2^22 pairs each, so that every chunk takes the LDS-histogram
+    // sort (its point indices are chunk-relative, 24 bits) instead of ONE sort with device-scope atomics over all pairs:
+    // 2^24 points (2^25 pairs) 48.1 -> see profiles/r04/msm_large.txt.
+    int n_chunks = 1;
+    if (!d_table && chunks_env > 1) {
+        if (n >= (1ull << 23) && n < (1ull << 24)) n_chunks = std::min(chunks_env, 8);
+        else if (n >= (1ull << 24)) n_chunks = (int)((n + (1ull << 22) - 1) >> 22);
+    }
     const u64 chunk_n = ((n + n_chunks - 1) / n_chunks + 255) / 256 * 256;
+    const bool lds_sort = chunk_n < (1ull << 24);          // the partition sort's indices are relative to the chunk
     struct Chunk { DevBuf counts, offsets, order, idx; };
     std::vector<Chunk> CH(n_chunks);
     DevBuf hist, hist_scanned, coarse, bal;
@@ -744,7 +752,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         CH[c].counts.reserve(n_keys * 4); CH[c].offsets.reserve(n_keys * 4); CH[c].order.reserve(n_keys * 4);
         CH[c].idx.reserve(std::max<u64>(1, nc) * N_WIN * 4);
     }
-    if (n < (1ull << 24)) {
+    if (lds_sort) {
         const u32 nb_max = (u32)((chunk_n + SORT_PTS - 1) / SORT_PTS);
         const size_t n_hist_max = ((size_t)N_COARSE * nb_max + 1023) / 1024 * 1024;
         hist.reserve(n_hist_max * 4); hist_scanned.reserve(n_hist_max * 4); coarse.reserve(chunk_n * N_WIN * 4);
@@ -757,7 +765,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         u32 *counts_p = (u32*)CH[c].counts.p, *offsets_p = (u32*)CH[c].offsets.p, *idx_p = (u32*)CH[c].idx.p, *order_p = (u32*)CH[c].order.p;
         const u64 total = nc * N_WIN;
         if (nc == 0) { ZK_HIP(hipMemsetAsync(counts_p, 0, n_keys * 4, ss)); ZK_HIP(hipMemsetAsync(offsets_p, 0, n_keys * 4, ss)); }
-        else if (n < (1ull << 24)) {  // LDS-histogram partition (no device-scope atomics)
+        else if (lds_sort) {  // LDS-histogram partition (no device-scope atomics)
             const u32 n_blocks = (u32)((nc + SORT_PTS - 1) / SORT_PTS);
             const size_t n_hist = ((size_t)N_COARSE * n_blocks + 1023) / 1024 * 1024;   // scan granularity
             ZK_HIP(hipMemsetAsync(hist.p, 0, n_hist * 4, ss));

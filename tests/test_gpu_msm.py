@@ -161,9 +161,11 @@ def test_generator_multiples_match_oracle(zk, orc):
         assert orc.bn254_on_curve(bases[i])
 
 
-def test_msm_full_size_closed_form(zk, orc):
-    """BASELINE config 4: n = 2^22, bases [k_i]G generated on the device, uniform scalars below r."""
-    n = 1 << 22
+@pytest.mark.parametrize("n", [1 << 22, (1 << 23) + 3])
+def test_msm_full_size_closed_form(zk, orc, n):
+    """BASELINE config 4: n = 2^22, bases [k_i]G generated on the device, uniform scalars below r; and 2^23 + 3 points -- 2^24 + 6 (point,
+    window-half) pairs behind the endomorphism: the sizes whose pairs are sorted chunk by chunk (2^22 pairs each, round 4) where ONE sort
+    with device-scope atomics used to run."""
     rng = np.random.default_rng(22)
     k = rng.integers(1, 2**64, size=n, dtype=np.uint64)
     scal = rand_scalars(rng, n)
