@@ -8,8 +8,8 @@ row) and the join phase (:83-156, `join_zkin` + `compressor12_exec` + `stark_pro
     overlap (the reference runs them as parallel processes);
   * the joins form a tree (`join_tree`): level l joins neighbours pairwise, join j of a level on rank j mod N, so
     ceil(log2 n) dependent recursive2 proofs stand on the critical path where the script's chain has n - 1;
-  * the ONE exchange (`RootExchange.gather`): an all-gather of the 4-word roots each rank made, once after the tasks
-    and once per join level -- `torch.distributed` all_gather, which is `ncclAllGather` of RCCL over xGMI under backend
+  * the ONE exchange (`RootExchange.gather`): an all-gather of the nodes each rank made (a 4-word root + a 4-word digest of
+    the whole proof, `ProverPool.node_words`), once after the tasks and once per join level -- `torch.distributed` all_gather, which is `ncclAllGather` of RCCL over xGMI under backend
     "nccl" (and gloo in the CPU tests of this control flow).  Nothing else crosses ranks.
 
 The circuits themselves are the caller's: (constants, `{"starkinfo", "program"}` JSON, StarkStruct JSON) per circuit
@@ -196,6 +196,39 @@ class RcclExchange(RootExchange):
             self._L.ncclCommDestroy(self._comm); self._comm = None
 
 
+def join_zkin(zkin1, zkin2):
+    """`zkit join_zkin` (starky/src/zkin_join.rs:9-57; test/stark_aggregation.sh:87-90, :132-135): the input of one recursive2
+    step from two proofs.  Every key k of the first proof becomes `a_k`, of the second `b_k`; `publics` = the first proof's publics
+    without their last four words (the root of the constants they end with), `rootC` = the first proof's.  zkin1 / zkin2: dicts (parsed
+    zkin) or their JSON text; -> dict with keys in the BTreeMap's (sorted) order, which `join_zkin_text` serialises as serde_json does."""
+    a = json.loads(zkin1) if isinstance(zkin1, (bytes, str)) else zkin1
+    b = json.loads(zkin2) if isinstance(zkin2, (bytes, str)) else zkin2
+    out = {}
+    for k in sorted(a):
+        v = a[k]
+        out["a_" + k] = v
+        if k == "publics" and isinstance(v, list):
+            out["publics"] = v[:-4] if len(v) >= 4 else v
+        if k == "rootC":
+            out[k] = v
+    for k in sorted(b):
+        out["b_" + k] = b[k]
+    return {k: out[k] for k in sorted(out)}
+
+
+def join_zkin_text(zkin1, zkin2):
+    """the bytes `join_zkin` writes: serde_json::to_string of the BTreeMap (no spaces, keys sorted)"""
+    return json.dumps(join_zkin(zkin1, zkin2), separators=(",", ":"))
+
+
+def proof_digest(zkin_json):
+    """4 words that stand for a whole proof where only 32 bytes may travel (the root gather): sha256 of the zkin text, as four
+    little-endian u64 words reduced into the Goldilocks field (they become primary inputs of the join circuit)"""
+    import hashlib
+    d = hashlib.sha256(zkin_json).digest()
+    return [int.from_bytes(d[8 * i: 8 * i + 8], "little") % 0xFFFFFFFF00000001 for i in range(4)]
+
+
 def root1_of(zkin_json):
     """root1 of a proof's JSON text (bytes) without parsing the openings after it (serializer.rs:146-152: rootC, root1, ...)"""
     i = zkin_json.index(b'"root1":') + 8
@@ -209,7 +242,16 @@ class ProverPool:
     (circuit name, HBM-resident trace) proved in that order on one worker's stream; join = (circuit name, .exec text,
     n_witness, witness_fn(primary16) -> host vector) describes the recursive2 step.  keep_proofs: keep every proof's
     zkin text (`proofs`) instead of only its root.  self_check: every proof is verified before it is handed out
-    (prove.rs:124-132)."""
+    (prove.rs:124-132).
+
+    What a proof hands on (a *node* of the aggregation, `node_words` = 8): root1 of its committed trace + `proof_digest` of its whole
+    zkin.  A join's 16 primary inputs are the two child nodes, so a recursive2 proof is bound to both children's full proofs, and the
+    8 words are all that has to cross ranks (the root gather).  **The join circuit is a stand-in**: the reference's recursive2 is the
+    circom-compiled *verifier* of both children (zkin_join.rs + the witness calculator feed it the full proofs); circom is out of
+    scope here, so the joined circuit has the real one's shape and size and takes the children's nodes as inputs, but it does
+    not re-verify them -- the tree's root commits to the leaves, it does not attest their validity.  Validity of every proof is what
+    `self_check` (the library's own stark_verify on each proof) establishes, per proof."""
+    node_words = 8
 
     def __init__(self, zk, circuits, workers=4, join=None, keep_proofs=False, self_check=False):
         import importlib
@@ -236,10 +278,10 @@ class ProverPool:
         if self.keep_proofs:
             with self._lock:
                 self.proofs.append((kind, z))
-        return root1_of(z)
+        return root1_of(z) + proof_digest(z)
 
     def prove(self, inputs, worker=0):
-        """one task -> the root of the committed trace of each of its proofs, [[4 words]] * len(inputs)"""
+        """one task -> the node (root1 + digest of the whole zkin) of each of its proofs, [[8 words]] * len(inputs)"""
         return [self._gen(kind, d_cm, worker) for kind, d_cm in inputs]
 
     def stage_times(self, inputs, worker=0):
@@ -279,12 +321,13 @@ class ProverPool:
     def prove_all(self, inputs_list):
         return self._spread(inputs_list, self.prove)
 
-    def join(self, root_a, root_b, worker=0):
-        """One recursive2 step (test/stark_aggregation.sh:83-128: join_zkin + compressor12_exec + stark_prove): the joined
-        circuit's primary inputs are the two child roots; its trace is born in HBM by compressor12 exec on the device."""
+    def join(self, node_a, node_b, worker=0):
+        """One recursive2 step (test/stark_aggregation.sh:83-128: join_zkin + compressor12_exec + stark_prove) on the stand-in
+        circuit (class text): the joined circuit's 16 primary inputs are the two child nodes (root1 + digest of the whole child
+        proof each); its trace is born in HBM by compressor12 exec on the device.  -> the join's own node."""
         if self.join_exec is None:
             raise ValueError("ProverPool: no join circuit was given")
-        primary = [int(w) for w in root_a] + [int(w) for w in root_b] + [0] * 8
+        primary = ([int(w) for w in node_a] + [int(w) for w in node_b] + [0] * 16)[:16]
         st = self.streams[worker].handle
         t0 = time.perf_counter()
         d_w = self.zk.DevArray.from_host(self.join_witness(primary))         # what the circom witness calculator would hand over
@@ -298,7 +341,7 @@ class ProverPool:
     def warm_join(self):
         """one join per worker: code objects of the join setups loaded, pool blocks of a join in place"""
         kept, self.keep_proofs = self.keep_proofs, False
-        self.join_all([([1, 2, 3, 4], [5, 6, 7, 8])] * self.workers)
+        self.join_all([([1, 2, 3, 4, 5, 6, 7, 8], [9, 10, 11, 12, 13, 14, 15, 16])] * self.workers)
         self.keep_proofs = kept
         self.sync()
         self.reset_join_times()
@@ -330,23 +373,23 @@ def prove_tasks(pool, inputs, n_tasks, exchange, proofs_per_task=3):
     assert len(inputs) == len(units)
     roots = pool.prove_all(inputs) if hasattr(pool, "prove_all") else [pool.prove(i) for i in inputs]
     pool.sync()
-    return roots, gather_task_roots(roots, n_tasks, exchange, proofs_per_task)
+    return roots, gather_task_roots(roots, n_tasks, exchange, proofs_per_task, getattr(pool, "node_words", 4))
 
 
-def gather_task_roots(roots, n_tasks, exchange, proofs_per_task=3):
-    """roots: this rank's [[root per proof] per task] -> {task: [root per proof]} on every rank (one all-gather; a task of
-    recursive_proof_to_snark.sh is three proofs)"""
+def gather_task_roots(roots, n_tasks, exchange, proofs_per_task=3, node_words=4):
+    """roots: this rank's [[node per proof] per task] -> {task: [node per proof]} on every rank (one all-gather; a task of
+    recursive_proof_to_snark.sh is three proofs; a node is `node_words` words: a 4-word root, or root + proof digest)"""
     world = exchange.world
     per_rank = (n_tasks + world - 1) // world
-    per_task = proofs_per_task
-    assert all(len(r) == per_task for r in roots)
+    per_task, nw = proofs_per_task, node_words
+    assert all(len(r) == per_task and all(len(x) == nw for x in r) for r in roots)
     flat = [w for task_roots in roots for r in task_roots for w in r]
-    flat += [0] * (per_rank * 4 * per_task - len(flat))                     # ranks with one task fewer pad their slot
+    flat += [0] * (per_rank * nw * per_task - len(flat))                    # ranks with one task fewer pad their slot
     gathered = exchange.gather(flat)
     by_task = {}
     for rk, words in enumerate(gathered):
         for j, u in enumerate(shard_units(n_tasks, rk, world)):
-            by_task[u] = [words[4 * per_task * j + 4 * k: 4 * per_task * j + 4 * k + 4] for k in range(per_task)]
+            by_task[u] = [words[nw * per_task * j + nw * k: nw * per_task * j + nw * k + nw] for k in range(per_task)]
     return by_task
 
 
@@ -366,18 +409,19 @@ def join_tree(pool, leaves, exchange):
     -> {"levels", "joins", "chain_depth_of_the_reference", "root"}"""
     rank, world = exchange.rank, exchange.world
     nodes, levels, joins = [list(r) for r in leaves], 0, 0
+    nw = len(nodes[0]) if nodes else 4
     while len(nodes) > 1:
         n_join = len(nodes) // 2
         mine = shard_units(n_join, rank, world)
         pairs = [(nodes[2 * j], nodes[2 * j + 1]) for j in mine]
         made = pool.join_all(pairs) if hasattr(pool, "join_all") else [pool.join(a, b) for a, b in pairs]
         per_rank = (n_join + world - 1) // world
-        flat = [w for r in made for w in r] + [0] * (4 * (per_rank - len(made)))
+        flat = [w for r in made for w in r] + [0] * (nw * (per_rank - len(made)))
         gathered = exchange.gather(flat)
         nxt = [None] * n_join
         for rk, words in enumerate(gathered):
             for k, j in enumerate(shard_units(n_join, rk, world)):
-                nxt[j] = words[4 * k: 4 * k + 4]
+                nxt[j] = words[nw * k: nw * k + nw]
         if len(nodes) % 2:
             nxt.append(nodes[-1])                                          # odd one out moves up unjoined
         nodes, levels, joins = nxt, levels + 1, joins + n_join

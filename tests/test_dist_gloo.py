@@ -52,7 +52,8 @@ def test_aggregation_leg_control_flow_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     # each rank proves its own tasks once after one warm-up of its first task, nobody else's; then its first task alone (task_latency_s)
-    assert res[0][1] == [0, 0, 2, 4, 6, 0] and res[1][1] == [1, 1, 3, 5, 1]
+    # ... and once more in the end-to-end pass (one clock over tasks + joins)
+    assert res[0][1] == [0, 0, 2, 4, 6, 0, 0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5, 1, 1, 3, 5]
     assert all(r[2]["task_latency_s"] is not None for r in res)
     # the join tree over 7 leaves: 3 + 2 + 1 joins in 3 levels, shared between the ranks, same root everywhere and equal
     # to the tree computed in one process
@@ -62,10 +63,11 @@ def test_aggregation_leg_control_flow_two_ranks():
     while len(lvl) > 1:
         nxt = [st.join(lvl[2 * j], lvl[2 * j + 1]) for j in range(len(lvl) // 2)]
         lvl = nxt + ([lvl[-1]] if len(lvl) % 2 else [])
-    assert res[0][3] + res[1][3] == 6 and res[0][3] == 4
+    assert res[0][3] + res[1][3] == 2 * 6 and res[0][3] == 2 * 4          # twice: the phase clock and the end-to-end pass
     for r in res:
         jt = r[2]["join_tree"]
         assert (jt["levels"], jt["joins"], jt["chain_depth_of_the_reference"]) == (3, 6, 6) and jt["root"] == lvl[0]
+        assert r[2]["end_to_end"]["root_equals_phase_run"] and r[2]["end_to_end_s"] >= r[2]["end_to_end"]["tasks_and_joins_s"] > 0
     for _, _, out, _ in res:                                 # every rank sees every task's roots after the all-gather
         assert out["tasks_gathered"] == list(range(7)) and out["distinct_roots"] == 7 and out["n_gpus"] == 2
         assert out["tasks"] == 7 and out["proofs_per_s"] == round(3 * out["tasks_per_s"], 3) or abs(out["proofs_per_s"] - 3 * out["tasks_per_s"]) < 0.01
@@ -96,8 +98,8 @@ def test_aggregation_leg_eight_ranks_one_task_each():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [[k, k, k] for k in range(8)]           # warm-up, the timed proof, the latency probe: its own task only
-    assert [r[3] for r in res] == [3, 2, 1, 1, 0, 0, 0, 0]                # join j of a level on rank j
+    assert [r[1] for r in res] == [[k, k, k, k] for k in range(8)]        # warm-up, the timed proof, the latency probe, the end-to-end pass: its own task only
+    assert [r[3] for r in res] == [6, 4, 2, 2, 0, 0, 0, 0]                # join j of a level on rank j (phase clock + end-to-end pass)
     st = StubProver()
     lvl = [st.prove(u)[2] for u in range(8)]
     while len(lvl) > 1:
@@ -113,8 +115,50 @@ def test_aggregation_leg_single_rank():
     import bench
     pr = StubProver()
     out = bench.aggregation_leg(pr, _ex(None))
-    assert pr.proved == [0] + list(range(8)) + [0] and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
-    assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 7)
+    assert pr.proved == [0] + list(range(8)) + [0] + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+    assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 14)
+    assert out["end_to_end"]["includes_final_wrap"] is False and out["end_to_end"]["root_equals_phase_run"]
+
+
+def test_aggregation_leg_runs_the_wrap_inside_the_end_to_end_clock():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    calls = []
+    class Wrap:
+        def leg(self, root): calls.append(("leg", list(root))); return {"ms": 1.0}
+        def run(self, root): calls.append(("run", list(root))); return {}, None
+        def free(self): calls.append(("free",))
+    pr = StubProver()
+    out = bench.aggregation_leg(pr, _ex(None), make_wrap=Wrap)
+    assert [c[0] for c in calls] == ["leg", "run", "free"] and calls[0][1] == calls[1][1] == out["join_tree"]["root"]
+    assert out["final_wrap"] == {"ms": 1.0} and out["end_to_end"]["includes_final_wrap"] is True
+
+
+def test_bench_gpus_2_without_rank_env_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher in front: the command starts its own two rank processes (eigen-zkvm_amd/launcher.py)
+    BEFORE importing torch or the library; the collective (gloo here, RCCL on the GPU box) sees both, rank 0's one line reports them.
+    --dry-run: no GPU in this container, so the NTT itself is skipped -- the line says so."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                          # ONE line on stdout; library chatter went to stderr
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["dry_run"] is True and b["value"] is None
+
+
+def test_launcher_reports_a_failing_rank():
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); from eigen_zkvm_amd import launcher\n"
+            "if launcher.under_launcher():\n    sys.exit(3 if os.environ['RANK'] == '1' else 0)\n"
+            "sys.exit(launcher.spawn_ranks([__file__] if False else ['-c', open(sys.argv[1]).read(), sys.argv[1]], 2))\n" % str(ROOT))
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code.replace("\\n", "\n"))
+    r = subprocess.run([sys.executable, f.name, f.name], capture_output=True, text=True, timeout=120)
+    os.unlink(f.name)
+    assert r.returncode == 3 and "rank 1 exited with status 3" in r.stderr, r.stderr
 
 
 def _worker(rank, world, port, q):
@@ -169,3 +213,23 @@ def test_single_rank_helpers_without_dist():
     assert list(A.shard_all_joins(8, 1, 2)) == [(0, 1), (0, 3), (1, 1)] and list(A.shard_all_joins(8, 0, 2)) == [(0, 0), (0, 2), (1, 0), (2, 0)]
     assert A.root1_of(b'{"rootC":["1","2","3","4"],"root1":["5","6","7","8"],"root2":"9"}') == [5, 6, 7, 8]
     assert A.root1_of(b'{"rootC":"1","root1":"5","root2":"9"}') == [5, 0, 0, 0]
+
+
+def test_join_zkin_follows_zkin_join_rs():
+    """starky/src/zkin_join.rs:9-57: a_* / b_* copies, `publics` = the first proof's without its last four words, `rootC` = the first's;
+    keys in BTreeMap order, compact serde_json text"""
+    import zkgpu_loader, importlib, json
+    zkgpu_loader.load()
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    a = {"root1": ["1", "2", "3", "4"], "rootC": ["9", "9", "9", "9"], "publics": ["5", "6", "7", "c0", "c1", "c2", "c3"], "evals": [["1", "0", "0"]]}
+    b = {"root1": ["11", "12", "13", "14"], "rootC": ["8", "8", "8", "8"], "publics": ["15", "c0", "c1", "c2", "c3"], "s0_vals1": [[1]]}
+    j = A.join_zkin(a, json.dumps(b))
+    assert j == {"a_evals": [["1", "0", "0"]], "a_publics": a["publics"], "a_root1": a["root1"], "a_rootC": a["rootC"],
+                 "b_publics": b["publics"], "b_root1": b["root1"], "b_rootC": b["rootC"], "b_s0_vals1": [[1]],
+                 "publics": ["5", "6", "7"], "rootC": a["rootC"]}
+    assert list(j) == sorted(j)
+    assert A.join_zkin({"publics": ["1", "2"]}, {})["publics"] == ["1", "2"]          # fewer than four publics: copied whole (:35-37)
+    t = A.join_zkin_text(a, b)
+    assert " " not in t and json.loads(t) == j and t.startswith('{"a_evals":')
+    d = A.proof_digest(b'{"root1":["1"]}')
+    assert len(d) == 4 and all(0 <= w < 0xFFFFFFFF00000001 for w in d) and d != A.proof_digest(b'{"root1":["2"]}')

@@ -36,16 +36,23 @@ def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
     specs, join, circ = AW.circuits()
     sets = {k: stark.NativeStarkSetup(c, p, s) for k, (c, p, s) in specs.items()}
     D_ = zk.DevArray.from_host
-    root1 = lambda z: [int(v) for v in z["root1"]]
+    # a node = root1 of the proof + the digest of its whole zkin text (ProverPool.node_words = 8)
+    node = lambda zb: [int(v) for v in json.loads(zb)["root1"]] + A.proof_digest(zb)
     for u in range(n):
-        zs = [sets["fib"].gen(D_(AW.fib_trace(u))), sets["c12"].gen(D_(circ["c12"].witness(u))), sets["r1"].gen(D_(circ["r1"].witness(u)))]
-        assert [root1(z) for z in zs] == res["by_task"][u]
+        zs = [sets["fib"].gen_bytes(D_(AW.fib_trace(u))), sets["c12"].gen_bytes(D_(circ["c12"].witness(u))), sets["r1"].gen_bytes(D_(circ["r1"].witness(u)))]
+        assert [node(z) for z in zs] == res["by_task"][u]
     E = c12.Compressor12Exec(join[1], join[2])
-    def join_by_hand(a, b):
-        d_cm = E.run(D_(join[3]([int(w) for w in a] + [int(w) for w in b] + [0] * 8)), 1 << AW.STRUCTS["r2"]["nBits"])
-        return root1(sets["r2"].gen(d_cm))
+    def join_by_hand(a, b):                                                   # the join's 16 primary inputs = the two child nodes
+        d_cm = E.run(D_(join[3]([int(w) for w in a] + [int(w) for w in b])), 1 << AW.STRUCTS["r2"]["nBits"])
+        return node(sets["r2"].gen_bytes(d_cm))
     leaves = [res["by_task"][u][2] for u in range(n)]
+    assert all(len(l) == 8 for l in leaves)
     assert join_by_hand(join_by_hand(leaves[0], leaves[1]), leaves[2]) == res["join_tree"]["root"]     # the odd one out joins a level up
+    # zkit join_zkin on two kept recursive1 proofs: a_* / b_* copies, publics of the first without their last four words, its rootC
+    r1s = [json.loads(z) for kind, z in pool.proofs if kind == "r1"][:2]
+    j = A.join_zkin(r1s[0], r1s[1])
+    assert j["a_root1"] == r1s[0]["root1"] and j["b_root1"] == r1s[1]["root1"] and j["rootC"] == r1s[0]["rootC"]
+    assert j["publics"] == r1s[0]["publics"][:-4] and list(j) == sorted(j)
     for kind, z in pool.proofs:                                               # every proof the pool made verifies against its circuit's setup
         assert sets[kind].verify(z) is True
     E.free(); pool.free()
@@ -99,7 +106,7 @@ def test_cli_stark_aggregate_one_and_two_processes_agree(tmp_path):
     one = _cli(["stark_aggregate", "--num_proof", "4", "--workers", "2", "--workspace", str(tmp_path / "one")])
     assert one.returncode == 0, one.stdout + one.stderr
     a = json.load(open(tmp_path / "one" / "aggregation.json"))
-    assert a["num_proof"] == 4 and a["ranks"] == 1 and a["verified"] and (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (2, 3)
+    assert a["num_proof"] == 4 and a["ranks"] == 1 and a["ranks_seen"] == 1 and a["each_proof_self_checked"] and (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (2, 3)
     r = _cli(["stark_aggregate", "--num_proof", "4", "--workers", "2", "--workspace", str(tmp_path / "rccl")], env=dict(os.environ, ZK_AGG_BACKEND="rccl"))
     assert r.returncode == 0, r.stdout + r.stderr                             # the torch-free exchange (a one-rank RCCL communicator here)
     c = json.load(open(tmp_path / "rccl" / "aggregation.json"))
@@ -153,7 +160,32 @@ def test_bench_two_ranks_control_flow_on_one_gpu(tmp_path):
     assert "roofline" in b and b["roofline"]["bound"] == "hbm"
     a = b["aggregation"]
     assert "error" not in a and a["n_gpus"] == 2 and a["tasks"] == 8 and a["tasks_gathered"] == list(range(8)) and a["distinct_roots"] == 8
-    assert (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (3, 7) and len(a["join_tree"]["root"]) == 4
+    assert (a["join_tree"]["levels"], a["join_tree"]["joins"]) == (3, 7) and len(a["join_tree"]["root"]) == 8
     assert a["final_wrap"].get("final_stark_verified") is True
+    assert b["ranks_seen"] == 2 and a["end_to_end"]["includes_final_wrap"] and a["end_to_end"]["root_equals_phase_run"] and a["end_to_end_s"] > 0
     for leg in ("msm_g1_bn254", "stark_prove", "cpu_baseline"):               # N = 1 legs stay out of an N > 1 line
         assert leg not in b
+
+
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO rank environment (the driver's N = 1 command with another number): the command itself becomes
+    the launcher, two fresh rank processes run, RCCL's stand-in on this one-GPU box (gloo, ZK_BENCH_SHARED_GPU=1) sees both, and the parent
+    prints rank 0's one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZK_BENCH_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nbits", "20", "--no-agg"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["value"] > 0 and b["config"]["parallelism"] == "replicas x2"
+
+
+def test_cli_stark_aggregate_gpus_2_starts_its_own_ranks(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ZK_AGG_BACKEND="gloo", ZK_AGG_DEVICE="0")
+    r = _cli(["stark_aggregate", "--gpus", "2", "--num_proof", "4", "--workers", "2", "--workspace", str(tmp_path / "self")], env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a = json.load(open(tmp_path / "self" / "aggregation.json"))
+    assert a["ranks"] == 2 and a["ranks_seen"] == 2 and a["join_tree"]["joins"] == 3 and len(a["join_tree"]["root"]) == 8

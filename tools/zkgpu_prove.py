@@ -6,7 +6,9 @@
                              [--program starkinfo_program.json]
   zkgpu_prove.py groth16_prove -c BN128 --r1cs circuit.r1cs -w witness.wtns -p g16.key --public-input public_input.json --proof proof.json
   zkgpu_prove.py stark_verify -s starkStruct.json -p circuit.pil.json --o circuit.const --i zkin.json [--program FILE]
-  [torchrun --nproc-per-node N] zkgpu_prove.py stark_aggregate --num_proof 8 --workspace DIR [--workers 4] [--keep_proofs]
+  zkgpu_prove.py join_zkin --zkin1 a.zkin.json --zkin2 b.zkin.json --zkinout out.zkin.json
+  zkgpu_prove.py stark_aggregate --gpus N --num_proof 8 --workspace DIR [--workers 4] [--keep_proofs]     (starts its own N ranks;
+  [torchrun --nproc-per-node N] zkgpu_prove.py stark_aggregate ...                                         or runs under torchrun)
 
 Flags, defaults and file formats are zkit's (zkit/src/main.rs:98-123 StarkProveOpt, :199-217 Groth16ProveOpt;
 starky/src/prove.rs:30-160, groth16/src/api.rs:144-205).  What differs, and why:
@@ -14,14 +16,16 @@ starky/src/prove.rs:30-160, groth16/src/api.rs:144-205).  What differs, and why:
     `--program FILE`, or -- when the file is absent -- the library's own generator (zk_starkinfo_generate) if this build has one.
     The reference runs `StarkInfo::new` in process; with the Rust shim (bindings/rust/starky-hip) that is still what happens.
   * `-c/--circom`: the circom verifier text comes from `pil2circom` (template rendering, out of scope): the flag is
-    accepted and the file is left untouched.
+    accepted, the file is NOT written and a warning on stderr says so.
   * groth16_prove: `-w` takes the `.wtns` the witness calculator wrote (zkit passes the .wasm and an input.json and runs the
     calculator in process, api.rs:150-160: WASM execution is out of scope); `-i` is accepted and ignored.
   * stark_prove verifies its own proof before it writes anything, as the reference does (prove.rs:124-132; `--no_verify` skips it).
   * stark_verify: the check alone, on a zkin file (the reference exposes it only inside stark_prove).
   * stark_aggregate: test/stark_aggregation.sh:70-73 + :83-156 through eigen-zkvm_amd/aggregation.py -- NUM_PROOF recursion tasks
-    sharded over the ranks (one process per GPU), their recursive1 roots all-gathered, joined as a tree; the circuits are the
-    synthetic ones of tools/aggregation_workload.py (the real ones are circom-compiled verifiers).  Writes aggregation.json
+    sharded over the ranks (one process per GPU), their recursive1 nodes (root1 + digest of the whole proof) all-gathered, joined as
+    a tree; the circuits are the synthetic ones of tools/aggregation_workload.py (the real ones are circom-compiled verifiers), so
+    the join tree is a workload-shaped stand-in: its root commits to the leaves' proofs, it does not attest them -- each proof's
+    validity is the per-proof self check (`each_proof_self_checked`).  Writes aggregation.json
     (every task's roots, the join tree's root, timings) into --workspace on rank 0.
 Exit status 0 on success, 1 with the library's message on stderr otherwise (zkit: anyhow error -> exit 1)."""
 import argparse
@@ -67,6 +71,9 @@ def stark_prove(a):
     with open(a.zkin, "w") as f:
         f.write(zkin)
     setup.free()
+    # prove.rs:134-150 always renders the circom verifier into -c; pil2circom is out of scope here: say so, loudly
+    print("zkgpu_prove: warning: no circom verifier is written to %s (pil2circom is out of scope of this backend; "
+          "the reference's stark_prove writes it)" % a.circom_file, file=sys.stderr)
     print("zkgpu_prove: proof of 2^%d rows %swritten to %s (rootC %s)" % (ss["nBits"], "" if a.no_verify else "verified and ", a.zkin, json.loads(zkin)["rootC"]))
 
 
@@ -92,11 +99,23 @@ def stark_verify(a):
     print("zkgpu_prove: %s verifies (2^%d rows, %s hash)" % (a.zkin, ss["nBits"], ss["verificationHashType"]))
 
 
+def join_zkin(a):
+    """zkit join_zkin --zkin1 A --zkin2 B --zkinout OUT (zkit/src/main.rs JoinZkinExecOpt -> starky/src/zkin_join.rs:9-57); host-only"""
+    import importlib
+    A = importlib.import_module("eigen_zkvm_amd.aggregation")
+    with open(a.zkinout, "w") as f:
+        f.write(A.join_zkin_text(open(a.zkin1).read(), open(a.zkin2).read()))
+    print("zkgpu_prove: %s + %s -> %s" % (a.zkin1, a.zkin2, a.zkinout))
+
+
 def stark_aggregate(a):
     import importlib
     import os
     import time
     sys.path.insert(0, str(ROOT / "tools"))
+    from eigen_zkvm_amd import launcher
+    if a.gpus > 1 and not launcher.under_launcher():                       # --gpus N with no torchrun in front: become the launcher (before any GPU call)
+        raise SystemExit(launcher.spawn_ranks([str(pathlib.Path(__file__).resolve())] + a._argv, a.gpus, json_stdout=False))
     import eigen_zkvm_amd as zk
     local_rank = int(os.environ.get("ZK_AGG_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # ZK_AGG_DEVICE: ranks sharing one GPU (tests)
     if zk.lib().zk_device_count() <= local_rank:
@@ -113,9 +132,13 @@ def stark_aggregate(a):
     t0 = time.perf_counter()
     res = A.aggregate(pool, inputs, n, ex)
     (dt,) = ex.max([time.perf_counter() - t0])
+    seen = ex.gather([ex.rank])
     if ex.rank == 0:
         ws = pathlib.Path(a.workspace); ws.mkdir(parents=True, exist_ok=True)
-        out = {"num_proof": n, "ranks": ex.world, "seconds": round(dt, 4), "verified": not a.no_verify,
+        out = {"num_proof": n, "ranks": ex.world, "ranks_seen": len({r[0] for r in seen}), "seconds": round(dt, 4),
+               # per proof: the library's stark_verify ran on it before it was handed out (prove.rs:124-132).  NOT a statement about the
+               # join tree: recursive2 is a stand-in that takes the children's (root, proof digest) as inputs and does not re-verify them
+               "each_proof_self_checked": not a.no_verify, "node": "root1 (4 words) + sha256 digest of the whole zkin (4 words)",
                "tasks": {str(u): {k: [str(w) for w in r] for k, r in zip(("fibonacci", "c12", "recursive1"), res["by_task"][u])} for u in sorted(res["by_task"])},
                "join_tree": dict(res["join_tree"], root=[str(w) for w in res["join_tree"]["root"]])}
         (ws / "aggregation.json").write_text(json.dumps(out, indent=1) + "\n")
@@ -174,11 +197,15 @@ def main(argv=None):
     v.set_defaults(fn=stark_verify)
     ag = sub.add_parser("stark_aggregate", help="test/stark_aggregation.sh:70-73,83-156: NUM_PROOF tasks sharded over the GPUs + the joins")
     ag.add_argument("--num_proof", type=int, default=8)
+    ag.add_argument("--gpus", type=int, default=1, help="ranks to start (one process per GPU) when no launcher (torchrun) is in front")
     ag.add_argument("--workspace", default="/tmp/aggregation")
     ag.add_argument("--workers", type=int, default=4, help="provers in flight per GPU")
     ag.add_argument("--keep_proofs", action="store_true", help="write every proof's zkin into the workspace")
     ag.add_argument("--no_verify", action="store_true")
     ag.set_defaults(fn=stark_aggregate)
+    j = sub.add_parser("join_zkin", help="zkin_join.rs:9-57: the input of one recursive2 step from two proofs")
+    j.add_argument("--zkin1", required=True); j.add_argument("--zkin2", required=True); j.add_argument("--zkinout", required=True)
+    j.set_defaults(fn=join_zkin)
     g = sub.add_parser("groth16_prove", help="Prove with groth16 (zkit/src/main.rs:199-217)")
     g.add_argument("-c", dest="curve_type", default="BN128")
     g.add_argument("--r1cs", dest="circuit_file", required=True)
@@ -190,6 +217,7 @@ def main(argv=None):
     g.add_argument("-t", dest="to_hex", action="store_true")
     g.set_defaults(fn=groth16_prove)
     a = ap.parse_args(argv)
+    a._argv = list(sys.argv[1:] if argv is None else argv)
     try:
         a.fn(a)
     except SystemExit:
