@@ -51,6 +51,8 @@ extern "C" {
     /// stark_verify.rs:20-136 on the zkin text: 1 accepted, 0 rejected, -1 malformed input
     pub fn zk_stark_verify(s: *const zk_stark_setup_t, zkin_json: *const c_char) -> c_int;
     pub fn zk_stark_verify_with(starkinfo_program_json: *const c_char, stark_struct_json: *const c_char, const_root: *const u64, zkin_json: *const c_char) -> c_int;
+    /// 1: check 16-ary Merkle paths as loosely as merklehash_bn128.rs:108-128 (default 0 = strict: every level linked); returns the old setting
+    pub fn zk_stark_verify_set_reference_compat(on: c_int) -> c_int;
     /// every later zk_stark_gen* verifies its own proof first (prove.rs:124-132)
     pub fn zk_stark_setup_set_self_check(s: *mut zk_stark_setup_t, on: c_int) -> c_int;
     pub fn zk_stark_gen(s: *mut zk_stark_setup_t, cm_pols: *const u64, n_words: u64) -> *mut c_char;

@@ -46,7 +46,7 @@ EXPORTS = [
     "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_group_proofs", "zk_bls12381_merkle_free",
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
-    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_setup_set_self_check", "zk_stark_verify", "zk_stark_verify_with", "zk_stark_setup_timing", "zk_stark_last_timing", "zk_stark_gen", "zk_stark_gen_dev", "zk_stark_gen_dev_on", "zk_string_free", "zk_stark_setup_free",
+    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_setup_set_self_check", "zk_stark_verify", "zk_stark_verify_with", "zk_stark_verify_set_reference_compat", "zk_stark_setup_timing", "zk_stark_last_timing", "zk_stark_gen", "zk_stark_gen_dev", "zk_stark_gen_dev_on", "zk_string_free", "zk_stark_setup_free",
     "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
     "zk_c12_exec_new", "zk_c12_exec_dev", "zk_c12_exec_depth", "zk_c12_exec_free",
@@ -188,6 +188,7 @@ def _load():
         "zk_stark_setup_set_self_check": (C.c_int, [vp, C.c_int]),
         "zk_stark_verify": (C.c_int, [vp, C.c_char_p]),
         "zk_stark_verify_with": (C.c_int, [C.c_char_p, C.c_char_p, vp, C.c_char_p]),
+        "zk_stark_verify_set_reference_compat": (C.c_int, [C.c_int]),
         "zk_stark_setup_timing": (C.c_char_p, [vp]),
         "zk_stark_last_timing": (C.c_char_p, [vp]),
         "zk_stark_gen": (vp, [vp, vp, C.c_uint64]),

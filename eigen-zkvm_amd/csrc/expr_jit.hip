@@ -402,8 +402,12 @@ std::string hiprtc_log(hiprtcProgram prog) {
 // (a setup starts its step programs on one host thread each) -- and (b) on disk under $ZK_JIT_CACHE (default
 // $XDG_CACHE_HOME/zkgpu or ~/.cache/zkgpu; "off" disables), one file per key: a 48-byte header (magic, payload length, sha256 of
 // the payload) + the code object, written to a temporary name and renamed.  A file whose header or digest does not match is
-// ignored and replaced; a directory that is not the user's own or that others may write to is not used; an object from disk
-// that the driver refuses to load is deleted and compiled again (zk_program_run_rows_dev).
+// ignored and replaced (the digest sits in the same file: it catches truncation and bit rot, NOT a planted file -- whoever can write
+// the file can write a matching digest).  What keeps foreign code objects out is ownership: the cache directory AND every directory
+// above it up to $HOME (or /) must be the user's own or root's and not writable by group or others (sticky /tmp-style directories
+// excepted), and a cache file is opened with O_NOFOLLOW and must be a regular file owned by this user with no group / other write
+// bit; anything else is ignored.  An object from disk that the driver refuses to load is deleted and compiled again
+// (zk_program_run_rows_dev).
 std::mutex g_jit_mu;
 std::condition_variable g_jit_cv;
 struct CodeObj { std::vector<char> bytes; std::string key; bool from_disk = false; };
@@ -426,12 +430,25 @@ void mkdirs(const std::string& d) {
 }
 // code objects are executed: only a directory of the user's own that nobody else can write to is trusted
 bool jit_dir_trusted(const std::string& dir) {
-    struct stat st;
-    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
-    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) {
+    auto warn = [&](const std::string& which, const char* why) {
         static bool warned = false;
-        if (!warned) { warned = true; fprintf(stderr, "[zkgpu] code-object cache %s is not owned by this user or is writable by others: not used\n", dir.c_str()); }
+        if (!warned) { warned = true; fprintf(stderr, "[zkgpu] code-object cache %s: %s %s: not used\n", dir.c_str(), which.c_str(), why); }
         return false;
+    };
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;               // (a symlink in place of the directory is not followed)
+    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return warn(dir, "is not owned by this user or is writable by others");
+    // the directories above: whoever can rename or replace one of them can swap the cache.  Walk up to $HOME (the user's own, checked like the
+    // leaf) or to /; a parent must belong to this user or to root, and must not be writable by group / others unless it is sticky (/tmp)
+    const char* home = getenv("HOME");
+    std::string p = dir;
+    while (p.size() > 1) {
+        const size_t k = p.rfind('/');
+        p = k == 0 || k == std::string::npos ? "/" : p.substr(0, k);
+        if (stat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+        const bool sticky = st.st_mode & S_ISVTX;
+        if ((st.st_uid != geteuid() && st.st_uid != 0) || ((st.st_mode & (S_IWGRP | S_IWOTH)) && !sticky)) return warn(p, "(above the cache) is writable by others");
+        if (home && p == home) break;
     }
     return true;
 }
@@ -440,8 +457,12 @@ std::string jit_path(const std::string& key) {
     return dir.empty() ? "" : dir + "/" + key + ".co";
 }
 bool jit_read(const std::string& path, std::vector<char>& out) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);                 // the file itself: ours, regular, nobody else may write it
+    if (fd < 0) return false;
+    struct stat fst;
+    if (fstat(fd, &fst) != 0 || !S_ISREG(fst.st_mode) || fst.st_uid != geteuid() || (fst.st_mode & (S_IWGRP | S_IWOTH))) { close(fd); return false; }
+    FILE* f = fdopen(fd, "rb");
+    if (!f) { close(fd); return false; }
     std::vector<char> buf;
     char tmp[65536]; size_t n;
     while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
@@ -452,7 +473,7 @@ bool jit_read(const std::string& path, std::vector<char>& out) {
     const std::string h = sha256_hex(buf.data() + 48, (size_t)len);
     char hex[65] = {0};
     for (int i = 0; i < 32; ++i) snprintf(hex + 2 * i, 3, "%02x", (unsigned char)buf[16 + i]);
-    if (h != hex) return false;                                                                 // bit rot or a planted file
+    if (h != hex) return false;                                                                 // truncation or bit rot (not a defence against a planted file: see above)
     out.assign(buf.begin() + 48, buf.end());
     return true;
 }
@@ -521,8 +542,8 @@ int compile_spawned(const std::string& source, const char* const* opts, int n_op
     };
     if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && slurp(obj, out) && out.size() > 16 && !memcmp(out.data(), "\x7f" "ELF", 4)) return 0;
     std::vector<char> l;
-    if (WIFEXITED(status) && WEXITSTATUS(status) == 1 && slurp(err, l) && !l.empty()) { log.assign(l.begin(), l.end()); return 1; }   // the compiler's verdict on the text
-    return -1;                                            // the helper itself failed (missing library, signal): compile in process
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 1 && slurp(err, l) && !l.empty()) { log.assign(l.begin(), l.end()); return 1; }   // the compiler's verdict on the text (jitc_main.cpp: 1 = hiprtcCompileProgram rejected)
+    return -1;                                            // the helper itself failed (status 3: I/O, a full $TMPDIR, hiprtcCreateProgram; a missing library; a signal): compile in process
 }
 
 std::shared_ptr<const CodeObj> compile_cached(const std::string& source, bool skip_disk = false) {

@@ -13,6 +13,7 @@
 #include "../../include/zkgpu.h"
 #include "json_min.h"
 #include <array>
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -272,9 +273,14 @@ F3 execute_code(const JVal& code, const ExecCtx& c) {
 }
 
 // The root every opening implies (verify_group_proof: merklehash.rs:440-453, merklehash_bn128.rs:260-269), all trees at once, on the
-// device.  Note the scalar-field trees: merkle_calculate_root_from_proof (merklehash_bn128.rs:108-128) hashes the 16 nodes of each level of
-// the path but never looks for the value carried up among them, so the root it returns is the hash of the LAST level's 16 nodes (or the
-// leaf digest for an empty path); reproduced as is -- the same proofs are accepted and rejected as by the reference.
+// device.  Scalar-field trees: the reference's merkle_calculate_root_from_proof (merklehash_bn128.rs:108-128) hashes the 16 nodes of each
+// level of the path but never looks for the value carried up among them, so the root it returns is the hash of the LAST level's 16 nodes
+// (or the leaf digest for an empty path): rows and lower levels are not bound to the root.  The reference only runs that check on its
+// own proof; this verifier takes untrusted zkin, so by default it is STRICT: at every level the node at position idx & 15 must equal the
+// value carried up (the leaf digest first), then idx >>= 4 -- every honest proof passes, and proofs the reference would wave through
+// with forged rows are rejected.  g_reference_compat (zk_stark_verify_set_reference_compat) restores the reference's behaviour for the
+// parity tests against the restated verifier.
+std::atomic<int> g_reference_compat{0};
 struct PathRef { const Opening* o; u64 idx; const u64* want; const char* what; };
 void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths of one tree share the row width */) {
     size_t n = 0; u32 max_depth = 1;
@@ -282,13 +288,14 @@ void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths
     if (n == 0) return;
     hipStream_t st = cur_stream();                       // (the scalar-field sponges move the thread to the null stream: come back)
     on_stream(st);
-    const size_t lw = h == H_GL ? 4 : 64;
-    std::vector<u64> h_paths(n * (h == H_GL ? max_depth : 1) * lw, 0), h_idx(n);
+    size_t levels = 0;                                  // scalar fields: every level of every path is hashed (16 nodes of 4 words each)
+    for (auto& t : trees) for (auto& p : t) levels += p.o->depth;
+    std::vector<u64> h_paths(h == H_GL ? n * max_depth * 4 : std::max<size_t>(1, levels) * 64, 0), h_idx(n);
     std::vector<u32> h_depth(n);
     DevBuf d_leaves, d_paths, d_idx, d_depth, d_roots, d_zero;
-    d_leaves.reserve(n * 32); d_roots.reserve(n * 64); d_paths.reserve(h_paths.size() * 8); d_idx.reserve(n * 8); d_depth.reserve(n * 4);
+    d_leaves.reserve(n * 32); d_roots.reserve(std::max(n, levels) * 64); d_paths.reserve(h_paths.size() * 8); d_idx.reserve(n * 8); d_depth.reserve(n * 4);
     std::vector<std::unique_ptr<DevBuf>> rows_keep;
-    size_t k = 0;
+    size_t k = 0, lv = 0;
     for (auto& t : trees) {
         if (t.empty()) continue;
         const size_t w = t[0].o->row.size();
@@ -299,7 +306,7 @@ void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths
             const Opening& o = *t[i].o;
             h_idx[k + i] = t[i].idx; h_depth[k + i] = o.depth;
             if (h == H_GL) memcpy(h_paths.data() + (k + i) * max_depth * 4, o.path.data(), (size_t)o.depth * 32);
-            else if (o.depth) memcpy(h_paths.data() + (k + i) * 64, o.path.data() + (size_t)(o.depth - 1) * 64, 512);
+            else if (o.depth) { memcpy(h_paths.data() + lv * 64, o.path.data(), (size_t)o.depth * 512); lv += o.depth; }
         }
         rows_keep.emplace_back(new DevBuf); DevBuf& d_rows = *rows_keep.back(); d_rows.reserve(rows.size() * 8);
         h2d_sync(d_rows.p, rows.data(), rows.size() * 8);
@@ -308,21 +315,34 @@ void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths
         k += t.size();
     }
     h2d_sync(d_paths.p, h_paths.data(), h_paths.size() * 8);
-    std::vector<u64> got(8 * n), leaves;                // scalar fields: two words of the permutation per path, the hash is word 0 (BN128) or 1 (BLS12-381)
+    std::vector<u64> got(8 * std::max(n, levels)), leaves;   // scalar fields: two words of the permutation per level, the hash is word 0 (BN128) or 1 (BLS12-381)
     const size_t stride = h == H_GL ? 4 : 8, pick = h == H_BLS12381 ? 4 : 0;
     if (h == H_GL) {
         h2d_sync(d_idx.p, h_idx.data(), n * 8); h2d_sync(d_depth.p, h_depth.data(), n * 4);
         merkle_roots_from_paths_dev(d_leaves.u(), d_paths.u(), (const u32*)d_depth.p, d_idx.u(), (u32)n, max_depth, d_roots.u(), st);
     } else {
         d_zero.reserve(32); ZK_HIP(hipMemsetAsync(d_zero.p, 0, 32, st));
-        fr_hash16_dev(h == H_BLS12381, d_paths.u(), n, d_zero.u(), d_roots.u(), st);
+        if (levels) fr_hash16_dev(h == H_BLS12381, d_paths.u(), levels, d_zero.u(), d_roots.u(), st);
         leaves.resize(4 * n); d2h_sync(leaves.data(), d_leaves.p, n * 32);
     }
-    d2h_sync(got.data(), d_roots.p, n * stride * 8);
-    k = 0;
+    d2h_sync(got.data(), d_roots.p, (h == H_GL ? n : levels) * stride * 8);
+    const bool strict = g_reference_compat.load() == 0;
+    k = 0; lv = 0;
     for (auto& t : trees)
         for (auto& p : t) {
-            const u64* r = (h != H_GL && p.o->depth == 0) ? leaves.data() + 4 * k : got.data() + stride * k + pick;
+            const u64* r;
+            if (h == H_GL) r = got.data() + stride * k;
+            else {                                       // walk the 16-ary path: leaf digest -> level 0 -> ... -> root
+                r = leaves.data() + 4 * k;
+                u64 idx = p.idx;
+                for (u32 L = 0; L < p.o->depth; ++L, ++lv) {
+                    if (strict && memcmp(h_paths.data() + lv * 64 + 4 * (idx & 15), r, 32) != 0)
+                        throw Reject{std::string("FRIVerifierFailed: ") + p.what + ": level " + std::to_string(L) + " of the path does not hold the value carried up (strict check; "
+                                     "merklehash_bn128.rs:108-128 does not make it)"};
+                    r = got.data() + stride * lv + pick;
+                    idx >>= 4;
+                }
+            }
             if (memcmp(r, p.want, 32) != 0) throw Reject{std::string("FRIVerifierFailed: ") + p.what + " does not open to its root"};
             ++k;
         }
@@ -384,6 +404,8 @@ bool verify(const JVal& info, const JVal& prog, const JVal& ss, const u64 const_
         else { std::vector<u64> w; for (const F3& e : P.last) w.insert(w.end(), e.v, e.v + 3); tr.put_words(w.data(), w.size()); }
     }
     std::vector<u64> ys = tr.get_permutations(nq, steps[0]);
+    // untrusted input: the last polynomial has exactly 2^steps.last values (the reference indexes it blindly, fri.rs:262-276) ...
+    if (P.last.size() != (1ull << steps.back())) throw Reject{"the last polynomial does not hold 2^steps.last values"};
 
     // every opening against its root: the five trees at ys, the folded polynomials' trees at the reduced indices
     {
@@ -394,6 +416,13 @@ bool verify(const JVal& info, const JVal& prog, const JVal& ss, const u64 const_
         for (size_t si = 1; si < n_steps; ++si) {
             for (u64& y : yr) y &= (1ull << steps[si]) - 1;
             for (u32 i = 0; i < nq; ++i) trees[4 + si].push_back(PathRef{&P.steps[si - 1].q[i], yr[i], P.steps[si - 1].root, "a FRI step"});
+        }
+        // ... and every path is as deep as the tree its StarkStruct implies (binary GL trees: log2 height; 16-ary scalar-field trees: ceil(log16))
+        auto want_depth = [&](u32 height_bits) -> u32 { return h == H_GL ? height_bits : (height_bits + 3) / 4; };
+        for (size_t j = 0; j < trees.size(); ++j) {
+            const u32 hb = j < 5 ? nbits_ext : steps[j - 4];
+            for (const PathRef& pr : trees[j])
+                if (pr.o->depth != want_depth(hb)) throw Reject{std::string(pr.what) + ": the Merkle path has " + std::to_string(pr.o->depth) + " levels, the tree has " + std::to_string(want_depth(hb))};
         }
         check_paths(h, trees);
     }
@@ -459,6 +488,11 @@ int stark_verify_impl(const JVal& info, const JVal& prog, const JVal& ss, const 
     }
 }
 }  // namespace zk
+
+extern "C" int zk_stark_verify_set_reference_compat(int on) {
+    const int old = g_reference_compat.exchange(on ? 1 : 0);
+    return old;
+}
 
 extern "C" int zk_stark_verify_with(const char* starkinfo_program_json, const char* stark_struct_json, const uint64_t const_root[4], const char* zkin_json) {
     CallScope scope;

@@ -438,6 +438,17 @@ class NativeStarkSetup:
             pass
 
 
+class reference_compat_paths:
+    """`with reference_compat_paths():` -- inside, 16-ary Merkle paths are checked as loosely as merklehash_bn128.rs:108-128 checks them
+    (only the last level bound to the root).  The library's default is strict (every level linked, zkgpu.h); this switch exists for parity
+    tests against a verifier that follows the reference to the letter.  Process-wide."""
+    def __enter__(self):
+        self._old = lib().zk_stark_verify_set_reference_compat(1)
+        return self
+    def __exit__(self, *a):
+        lib().zk_stark_verify_set_reference_compat(self._old)
+
+
 def stark_verify(zkin, const_root, program_json, stark_struct_json):
     """stark_verify without a prover's setup (zk_stark_verify_with): const_root = 4 words (GL) or the raw limbs
     NativeStarkSetup.const_root() returns for scalar-field hashing"""

@@ -282,8 +282,12 @@ int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr)
  * JSON of serializer.rs:146-261, for all three hash types: 1 = accepted, 0 = rejected (zk_last_error() names the failed
  * check: "Q != C * P", "FRIVerifierFailed: ...", a fold mismatch, the last polynomial's degree), -1 = malformed input.
  * The sponge, the LinearHash of every opened row and every Merkle path run in the library's kernels; the two short
- * verifier programs and the FRI groups' inverse transforms are scalar host work.  Scalar-field trees are checked exactly as
- * merklehash_bn128.rs:108-128 does (only the last level of a path is bound to the root).
+ * verifier programs and the FRI groups' inverse transforms are scalar host work.  This is a verifier for UNTRUSTED zkin, stricter
+ * than the reference where the reference is loose: scalar-field (16-ary) Merkle paths are walked level by level -- the node at position
+ * idx & 15 of every level must be the value carried up, starting from the row's digest -- whereas merklehash_bn128.rs:108-128 binds only
+ * the last level to the root (rows unbound); finalPol must hold exactly 2^steps.last values and every path must have the depth its tree
+ * implies.  Honest proofs pass either way.  zk_stark_verify_set_reference_compat(1) switches the process to the reference's lenient path
+ * check (for parity tests against a verifier that follows the reference to the letter); it returns the previous setting.
  *   zk_stark_verify       against a prover's setup (its StarkInfo / Program / StarkStruct and the root of its constants)
  *   zk_stark_verify_with  without one: the same JSON texts zk_stark_setup_new takes + const_root (GL words, or the raw
  *                         Montgomery limbs zk_stark_setup_const_root returns for BN128 / BLS12381)
@@ -292,6 +296,7 @@ int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr)
 int zk_stark_verify(const zk_stark_setup_t* s, const char* zkin_json);
 int zk_stark_verify_with(const char* starkinfo_program_json, const char* stark_struct_json, const uint64_t const_root[4],
                          const char* zkin_json);
+int zk_stark_verify_set_reference_compat(int on);
 int zk_stark_setup_set_self_check(zk_stark_setup_t* s, int on);
 /* Where the time went, as JSON text owned by the setup (valid until the next call on it / its release).
  * zk_stark_setup_timing: StarkSetup::new (stark_setup.rs:26-66, one `#[time_profiler("stark_setup")]` span there) split into

@@ -90,11 +90,19 @@ def test_scalar_field_fixture_proofs_accepted(zk, orc, name, hash_type):
     bad = copy.deepcopy(z); bad["s0_siblings1"][2][-1][5] = _bump(bad["s0_siblings1"][2][-1][5])
     assert ns.verify(bad) is False and _oracle_verdict(bad, ns, program, ss, orc) is False
     assert "FRIVerifierFailed" in ns.last_reject()
-    # ... the levels below it are not (merklehash_bn128.rs:108-128 never compares the value carried up): the reference accepts, so do we
+    # ... the levels below it are not in the reference (merklehash_bn128.rs:108-128 never compares the value carried up): the restated
+    # verifier accepts such a proof, and so does the library in its reference-compatible mode -- but NOT by default: this is a verifier
+    # for untrusted zkin, and by default every level of a 16-ary path must hold the value carried up (strict; zkgpu.h)
     if len(z["s0_siblings1"][2]) > 1:
         lenient = copy.deepcopy(z); lenient["s0_siblings1"][2][0][5] = _bump(lenient["s0_siblings1"][2][0][5])
         assert _oracle_verdict(lenient, ns, program, ss, orc) is True
-        assert ns.verify(lenient) is True
+        with stark.reference_compat_paths():
+            assert ns.verify(lenient) is True
+        assert ns.verify(lenient) is False and "does not hold the value carried up" in ns.last_reject()
+        # a forged ROW under an honest path: the reference's check never looks at the row's digest once the path has a level
+        forged = copy.deepcopy(z); forged["s0_valsC"][1][0] = _bump(forged["s0_valsC"][1][0])
+        assert ns.verify(forged) is False
+    assert ns.verify(z) is True                                               # honest proofs pass the strict walk
     ns.free()
 
 
