@@ -52,7 +52,8 @@ def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
     r1s = [json.loads(z) for kind, z in pool.proofs if kind == "r1"][:2]
     j = A.join_zkin(r1s[0], r1s[1])
     assert j["a_root1"] == r1s[0]["root1"] and j["b_root1"] == r1s[1]["root1"] and j["rootC"] == r1s[0]["rootC"]
-    assert j["publics"] == r1s[0]["publics"][:-4] and list(j) == sorted(j)
+    pub = r1s[0]["publics"]
+    assert j["publics"] == (pub[:-4] if len(pub) >= 4 else pub) and list(j) == sorted(j)      # zkin_join.rs:29-37
     for kind, z in pool.proofs:                                               # every proof the pool made verifies against its circuit's setup
         assert sets[kind].verify(z) is True
     E.free(); pool.free()
