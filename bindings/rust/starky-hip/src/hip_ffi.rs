@@ -15,6 +15,16 @@ pub struct zk_transcript_t {
 pub struct zk_stark_setup_t {
     _private: [u8; 0],
 }
+/// one proof in progress (the staged prover: stark_gen cut at its own seams)
+#[repr(C)]
+pub struct zk_stark_ctx_t {
+    _private: [u8; 0],
+}
+pub const ZK_STEP_2PREV: c_int = 0;
+pub const ZK_STEP_3PREV: c_int = 1;
+pub const ZK_STEP_3: c_int = 2;
+pub const ZK_STEP_42NS: c_int = 3;
+pub const ZK_STEP_52NS: c_int = 4;
 
 extern "C" {
     pub fn zk_init(device: c_int) -> c_int;
@@ -59,6 +69,24 @@ extern "C" {
     /// the trace already in HBM, on a stream of the caller's: setups on different streams prove side by side from
     /// different host threads (one proof at a time per setup)
     pub fn zk_stark_gen_dev_on(s: *mut zk_stark_setup_t, d_cm_pols: *const u64, n_words: u64, stream: *mut c_void) -> *mut c_char;
+    // ---- the staged prover: what a stark_gen.rs that stays in Rust calls where it calls calculate_exps_parallel (stark_gen.rs:786-792),
+    // extend_and_merkelize (:709-750), transcript.get_field, calculate_H1H2 / calculate_Z, the evaluations and FRI::prove (fri.rs:84-89)
+    pub fn zk_stark_new(s: *mut zk_stark_setup_t, cm_pols: *const u64, d_cm_pols: *const u64, n_words: u64, stream: *mut c_void) -> *mut zk_stark_ctx_t;
+    pub fn zk_stark_commit_stage(c: *mut zk_stark_ctx_t, stage: c_int, root: *mut u64) -> c_int;
+    pub fn zk_stark_challenge(c: *mut zk_stark_ctx_t, i: c_int, out: *mut u64) -> c_int;
+    pub fn zk_stark_set_challenge(c: *mut zk_stark_ctx_t, i: c_int, v: *const u64) -> c_int;
+    pub fn zk_stark_eval(c: *mut zk_stark_ctx_t, step: c_int) -> c_int;
+    pub fn zk_stark_calculate_h1h2(c: *mut zk_stark_ctx_t) -> c_int;
+    pub fn zk_stark_calculate_z(c: *mut zk_stark_ctx_t) -> c_int;
+    pub fn zk_stark_evals(c: *mut zk_stark_ctx_t, evals_out: *mut u64, cap_words: u64) -> c_int;
+    pub fn zk_stark_fri_prove(c: *mut zk_stark_ctx_t) -> c_int;
+    pub fn zk_stark_finish(c: *mut zk_stark_ctx_t) -> *mut c_char;
+    pub fn zk_stark_fri_pol_dev(c: *const zk_stark_ctx_t) -> *const u64;
+    pub fn zk_stark_tree(c: *const zk_stark_ctx_t, j: c_int) -> *const zk_merkle_t;
+    pub fn zk_stark_free(c: *mut zk_stark_ctx_t) -> c_int;
+    /// FRI::prove(transcript, pol, query_pol) alone: the caller's TranscriptGL, a device polynomial, the trees its queries open
+    pub fn zk_fri_prove_dev(transcript: *mut zk_transcript_t, d_pol: *const u64, nbits_ext: u32, steps: *const u32, n_steps: u32, n_queries: u32,
+                            query_trees: *const *const zk_merkle_t, n_query_trees: u32, stream: *mut c_void) -> *mut c_char;
     pub fn zk_stream_new() -> *mut c_void;
     pub fn zk_stream_sync(stream: *mut c_void) -> c_int;
     pub fn zk_stream_free(stream: *mut c_void) -> c_int;

@@ -46,7 +46,7 @@ EXPORTS = [
     "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_group_proofs", "zk_bls12381_merkle_free",
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
     "zk_bls12381_transcript_get_permutations", "zk_bls12381_transcript_free",
-    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_setup_set_self_check", "zk_stark_verify", "zk_stark_verify_with", "zk_stark_verify_set_reference_compat", "zk_stark_setup_timing", "zk_stark_last_timing", "zk_stark_gen", "zk_stark_gen_dev", "zk_stark_gen_dev_on", "zk_string_free", "zk_stark_setup_free",
+    "zk_starkinfo_generate", "zk_stark_setup_new", "zk_stark_setup_const_root", "zk_stark_setup_set_prover_addr", "zk_stark_setup_set_self_check", "zk_stark_verify", "zk_stark_verify_with", "zk_stark_verify_set_reference_compat", "zk_stark_setup_timing", "zk_stark_last_timing", "zk_stark_gen", "zk_stark_gen_dev", "zk_stark_gen_dev_on", "zk_stark_new", "zk_stark_commit_stage", "zk_stark_challenge", "zk_stark_set_challenge", "zk_stark_eval", "zk_stark_calculate_h1h2", "zk_stark_calculate_z", "zk_stark_evals", "zk_stark_fri_prove", "zk_stark_finish", "zk_stark_fri_pol_dev", "zk_stark_tree", "zk_stark_free", "zk_fri_prove_dev", "zk_string_free", "zk_stark_setup_free",
     "zk_msm_g1_bn254_table_bytes", "zk_msm_g1_bn254_table_build_dev", "zk_msm_g1_bn254_table_dev", "zk_msm_g1_bls12_381_table_bytes", "zk_msm_g1_bls12_381_table_build_dev", "zk_msm_g1_bls12_381_table_dev", "zk_msm_g2_bn254_table_bytes", "zk_msm_g2_bn254_table_build_dev", "zk_msm_g2_bn254_table_dev", "zk_msm_g2_bls12_381_table_bytes", "zk_msm_g2_bls12_381_table_build_dev", "zk_msm_g2_bls12_381_table_dev",
     "zk_fr_bn254_ntt", "zk_fr_bn254_ntt_dev", "zk_fr_bls12_381_ntt", "zk_fr_bls12_381_ntt_dev", "zk_fr_bn254_quotient_dev", "zk_fr_bls12_381_quotient_dev",
     "zk_c12_exec_new", "zk_c12_exec_dev", "zk_c12_exec_depth", "zk_c12_exec_free",
@@ -194,6 +194,20 @@ def _load():
         "zk_stark_gen": (vp, [vp, vp, C.c_uint64]),
         "zk_stark_gen_dev": (vp, [vp, vp, C.c_uint64]),
         "zk_stark_gen_dev_on": (vp, [vp, vp, C.c_uint64, vp]),
+        "zk_stark_new": (vp, [vp, vp, vp, C.c_uint64, vp]),
+        "zk_stark_commit_stage": (C.c_int, [vp, C.c_int, vp]),
+        "zk_stark_challenge": (C.c_int, [vp, C.c_int, vp]),
+        "zk_stark_set_challenge": (C.c_int, [vp, C.c_int, vp]),
+        "zk_stark_eval": (C.c_int, [vp, C.c_int]),
+        "zk_stark_calculate_h1h2": (C.c_int, [vp]),
+        "zk_stark_calculate_z": (C.c_int, [vp]),
+        "zk_stark_evals": (C.c_int, [vp, vp, C.c_uint64]),
+        "zk_stark_fri_prove": (C.c_int, [vp]),
+        "zk_stark_finish": (vp, [vp]),
+        "zk_stark_fri_pol_dev": (vp, [vp]),
+        "zk_stark_tree": (vp, [vp, C.c_int]),
+        "zk_stark_free": (C.c_int, [vp]),
+        "zk_fri_prove_dev": (vp, [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp]),
         "zk_string_free": (None, [vp]),
         "zk_stark_setup_free": (C.c_int, [vp]),
         "zk_msm_g1_bn254_table_bytes": (C.c_size_t, [C.c_uint64]),

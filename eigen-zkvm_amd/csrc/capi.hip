@@ -493,6 +493,12 @@ int zk_merkle_elements(const zk_merkle_t* t, uint64_t* out) {
 }
 
 uint32_t zk_merkle_depth(const zk_merkle_t* t) { return t ? t->depth : 0; }
+}  // extern "C"
+namespace zk {
+uint32_t merkle_width(const zk_merkle* t) { return t->width; }
+uint64_t merkle_height(const zk_merkle* t) { return t->height; }
+}
+extern "C" {
 
 int zk_merkle_group_proof(const zk_merkle_t* t, uint64_t idx, uint64_t* row_out, uint64_t* path_out) {
     return guard([&] {

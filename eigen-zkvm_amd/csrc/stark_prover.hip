@@ -110,8 +110,10 @@ struct AnyTree {
         if (F) fr = F->merkelize_dev(C(d_rows), w, h, st); else gl = zk_gl_merkelize_dev(C(d_rows), w, h, st);
         if (!gl && !fr) throw Error(zk_last_error());
     }
+    bool owned = true;
+    AnyTree(const zk_merkle_t* callers, u32 w, u64 h) : gl(const_cast<zk_merkle_t*>(callers)), width(w), height(h), owned(false) {}   // a caller's MerkleTreeGL, borrowed
     AnyTree(const AnyTree&) = delete; AnyTree& operator=(const AnyTree&) = delete;
-    ~AnyTree() { if (gl) zk_merkle_free(gl); if (fr) F->tree_free(fr); }
+    ~AnyTree() { if (!owned) return; if (gl) zk_merkle_free(gl); if (fr) F->tree_free(fr); }
     void root(u64* out) const { ck(gl ? zk_merkle_root(gl, M(out)) : F->root(fr, M(out))); }
     const u64* root_dev() const { return gl ? K(zk_merkle_nodes_dev(gl)) + 4 * (zk_merkle_n_nodes(height) - 1) : nullptr; }   // last node (merklehash.rs:455-457)
     u32 depth() const { return gl ? zk_merkle_depth(gl) : F->depth(fr); }
@@ -120,12 +122,14 @@ struct AnyTree {
 using TreePtr = std::shared_ptr<AnyTree>;       // shared: a setup lends its all-zero tree to every proof
 struct AnyTranscript {
     zk_transcript_t* gl = nullptr; const FrApi* F = nullptr; void* fr = nullptr;
+    bool owned = true;
     explicit AnyTranscript(const FrApi* f) : F(f) {
         if (F) fr = F->tr_new(); else gl = zk_transcript_new();
         if (!gl && !fr) throw Error(zk_last_error());
     }
+    explicit AnyTranscript(zk_transcript_t* callers) : gl(callers), owned(false) { ZK_REQUIRE(gl != nullptr, "null transcript"); }   // a caller's TranscriptGL, borrowed
     AnyTranscript(const AnyTranscript&) = delete; AnyTranscript& operator=(const AnyTranscript&) = delete;
-    ~AnyTranscript() { if (gl) zk_transcript_free(gl); if (fr) F->tr_free(fr); }
+    ~AnyTranscript() { if (!owned) return; if (gl) zk_transcript_free(gl); if (fr) F->tr_free(fr); }
     // n Goldilocks words, one transcript element each (publics, evals, the last FRI polynomial)
     void put_words_dev(const u64* d, size_t n, hipStream_t st) {
         if (!n) return;
@@ -591,129 +595,207 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     return S.release();
 }
 
-// cm_pols: host trace, or nullptr when d_cm (device-resident trace, borrowed) is given
-std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words, hipStream_t st) {
-    const JVal& I = S.info;
-    const u32 nbits = S.nbits, nbits_ext = S.nbits_ext, ext = nbits_ext - nbits;
-    const u64 N = 1ull << nbits, Next = 1ull << nbits_ext;
-    const u64* sN = S.sN;
-    ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
-    on_stream(st);                                        // everything below is issued on (or ordered against) the caller's stream
-    StageTimer T(st);
+// FRI::prove's commit phase (fri.rs:84-157) on a device polynomial, whoever owns the transcript: the folds, the trees over their groups, the
+// last polynomial's absorption, then the query indices (fri.rs:158-159).  Used by a proof context and by zk_fri_prove_dev.
+struct FriState {
+    std::vector<TreePtr> trees;                            // tree of step i+1's groups at [i]
+    std::vector<u32> width;
+    std::vector<std::array<u64, 4>> roots;
+    const u64* d_pol = nullptr;                            // the last polynomial, 3 << steps.back() words
+    std::vector<u64> ys;
+    DevBuf d_ys, d_sx;
+    std::vector<std::unique_ptr<DevBuf>> keep;
+    void commit(AnyTranscript& tr, const FrApi* bn128, const u64* d_f, u32 nbits_ext, const std::vector<u32>& steps, u32 n_queries, hipStream_t st, StageTimer* T) {
+        const size_t n_steps = steps.size();
+        u32 pol_bits = nbits_ext;
+        u64 shift_inv = gl::hinv(49);
+        trees.assign(n_steps, TreePtr()); width.assign(n_steps, 0); roots.resize(n_steps);
+        d_sx.reserve(24);
+        d_pol = d_f;
+        for (size_t si = 0; si < n_steps; ++si) {
+            const u32 step_bits = steps[si];
+            ZK_REQUIRE(step_bits <= pol_bits, "FRI steps must not grow");
+            tr.get_field_dev(d_sx.u(), st);                                            // special_x
+            keep.emplace_back(new DevBuf); DevBuf& folded = *keep.back(); folded.reserve((3ull << step_bits) * 8);
+            fri_fold_dev(d_pol, pol_bits, step_bits, d_sx.u(), shift_inv, folded.u(), st);
+            d_pol = folded.u();
+            if (si + 1 < n_steps) {
+                const u32 nxt = steps[si + 1];
+                ZK_REQUIRE(nxt <= step_bits, "FRI steps must not grow");
+                const u64 n_groups = 1ull << nxt, group_size = (1ull << step_bits) >> nxt;
+                keep.emplace_back(new DevBuf); DevBuf& tb = *keep.back(); tb.reserve((3ull << step_bits) * 8);
+                fri_transpose_dev(d_pol, 1ull << step_bits, nxt, tb.u(), st);
+                width[si] = (u32)(3 * group_size);
+                trees[si].reset(new AnyTree(bn128, tb.u(), width[si], n_groups, st));
+                tr.put_root(*trees[si], st);                                           // (its words are read for the JSON below)
+            } else {
+                tr.put_words_dev(d_pol, 3ull << step_bits, st);                         // fri.rs:136-141
+            }
+            for (u32 k = 0; k < pol_bits - step_bits; ++k) shift_inv = gl::hmul(shift_inv, shift_inv);
+            pol_bits = step_bits;
+        }
+        if (T) T->mark("fri_prove");
+        // ---- queries (fri.rs:158-181)
+        // Goldilocks hashing: the query indices are squeezed into HBM, every tree is opened there at (index mod its height) and ONE copy
+        // brings back roots, evaluations, the last polynomial, the publics, the indices and all openings -- one host round trip where
+        // the indices, the proof's words and the openings used to be three.  Scalar-field hashing keeps its host-side sponge and trees.
+        ys.assign(n_queries, 0);
+        if (!bn128) { d_ys.reserve(std::max<u32>(1, n_queries) * 8); tr.get_permutations_dev(n_queries, steps[0], d_ys.u(), st); }
+        else tr.get_permutations(n_queries, steps[0], ys.data());
+        if (T) T->mark("fri_query_indices");
+    }
+};
 
-    // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
+// One proof in progress: the body of StarkProof::stark_gen (stark_gen.rs:193-557) cut at the reference's own seams -- the places where its
+// stark_gen calls calculate_exps_parallel (:786-792), extend_and_merkelize (:709-750), the transcript, calculate_H1H2 / calculate_Z and
+// FRI::prove (fri.rs:84-184).  `stark_gen` below runs the stages in the reference's order; the staged C entry points (zk_stark_new,
+// zk_stark_eval, zk_stark_commit_stage, zk_stark_challenge / zk_stark_set_challenge, zk_stark_evals, zk_stark_fri_prove, zk_stark_finish:
+// zkgpu.h) hand the same stages to a caller that keeps its own stark_gen.rs.  Every section stays in HBM between the calls.
+enum Step { STEP_2PREV = 0, STEP_3PREV = 1, STEP_3 = 2, STEP_42NS = 3, STEP_52NS = 4 };
+}  // namespace
+
+struct zk_stark_ctx {
+    zk_stark_setup& S;
+    hipStream_t st;
+    StageTimer T;
+    const JVal& I;
+    const u32 nbits, nbits_ext, ext;
+    const u64 N, Next;
+    const u64* sN;
     DevBuf B[S_COUNT];
     u64* ptr[S_COUNT] = {};
-    auto alloc = [&](int s, u64 words, bool zeroed = true) {
-        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words, st); ptr[s] = B[s].u();
-    };
-    if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
-    else {
-        B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
-        ZK_HIP(hipStreamSynchronize(st));                 // the block's previous user is ordered before `st`, not before this copy
-        if (n_words) h2d_sync(ptr[S_CM1_N], cm_pols, n_words * 8);
-    }
-    for (int s : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(s, sN[s] * N);
-    // sections that a kernel writes in full before anything reads them are not cleared: the extended sections (LDE
-    // output), cm4 (the forward NTT of the split quotient), q and f (every row written by step42ns / step52ns)
-    for (int s : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS}) alloc(s, sN[s] * Next, false);
-    alloc(S_CM4_2NS, sN[S_CM4_2NS] * Next, S.q_deg == 0);
-    alloc(S_Q_2NS, S.q_dim * Next, false); alloc(S_F_2NS, 3 * Next, false); alloc(S_SCRATCH, 3 * Next);
-    ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
-
-    DevBuf d_chal, d_evals, d_pub, xdiv, xdivw;                                      // stark_gen.rs:231-249 (x, Zi: the setup's tables)
-    const DevBuf &x_n = S.x_n, &x_2ns = S.x_2ns, &zi = S.zi;
-    d_chal.reserve(24 * 8); zero(d_chal, 24, st);                                        // challenge[8] (constant.rs:39-50)
-    const u32 n_ev = (u32)I.at("ev_map").size();
-    const u32 n_pub = (u32)I.at("publics").size();
-    d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3, st);
-    d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub), st);
-
-    auto run = [&](const ProgramPtr& p, bool e, hipStream_t on = nullptr, u64 row0 = 0, u64 count = ~0ull) {
-        if (!p) return;
-        zk_eval_ctx c; memset(&c, 0, sizeof c);
-        for (int s = 0; s < S_COUNT; ++s) c.bufs[s] = M(ptr[s]);
-        c.publics = C(d_pub.u()); c.challenges = C(d_chal.u()); c.evals = C(d_evals.u());
-        c.x = C(e ? x_2ns.u() : x_n.u()); c.zi = C(zi.u()); c.zi_mask = (1ull << ext) - 1;
-        c.xdivxsubxi = C(xdiv.u()); c.xdivxsubwxi = C(xdivw.u());
-        const u32 nb = e ? nbits_ext : nbits;
-        ck(zk_program_run_rows_dev(p.get(), &c, nb, e ? (1ull << ext) : 1, row0, count == ~0ull ? 1ull << nb : count, on ? on : st));
-        if (on) on_stream(st);                                                     // this thread goes on issuing on `st`
-    };
-    auto get_pol = [&](u64 pol_id, DevBuf& out) {                                  // stark_gen.rs:683-707
-        const PolRef p = S.pol(pol_id);
-        out.reserve(3 * N * 8);
-        pol_get_dev(ptr[p.slot], p.width, p.pos, p.dim, N, out.u(), st);
-    };
-    auto set_pol = [&](u64 pol_id, const u64* d_pol3) {                            // stark_gen.rs:594-622
-        const PolRef p = S.pol(pol_id);
-        pol_set_dev(ptr[p.slot], p.width, p.pos, p.dim, N, d_pol3, st);
-    };
-    auto e2p = [&](const JVal& v) {
-        auto it = S.exp2pol.find(v.u64());
-        if (it == S.exp2pol.end()) throw Error("exp2pol: unknown expression");
-        return it->second;
-    };
-
-    // publics (stark_gen.rs:256-270) and their absorption (:272-277)
+    DevBuf d_chal, d_evals, d_pub, xdiv, xdivw, d_pub_ext, z_checks;
+    u32 n_ev = 0, n_pub = 0;
     std::vector<u64> publics;
-    DevBuf d_pub_ext;                                     // words 1 and 2 of every computed public: checked to be zero at the end
-    const bool pub_on_device = d_cm != nullptr;           // device-resident trace: no host round trip per public
-    if (pub_on_device) {
-        d_pub_ext.reserve(std::max<u32>(1, n_pub) * 16); zero(d_pub_ext, 2 * (size_t)std::max<u32>(1, n_pub), st);
-        for (u32 i = 0; i < n_pub; ++i) {
+    bool pub_on_device = false;
+    const FrApi* bn128;
+    std::unique_ptr<AnyTranscript> tr;
+    std::vector<std::unique_ptr<DevBuf>> keep;            // workspaces alive until the end
+    TreePtr tree[4];
+    u64 n_cm = 0;
+    size_t n_z = 0, i_z = 0;
+    const u64* d_qq2 = nullptr;                           // the split quotient's coefficients [N][q_dim q_deg] (kept for the evaluations)
+    bool stage3_early = false, stage3_started = false;
+    FriState F;
+    bool fri_done = false;
+    // what has happened so far (the staged entry points refuse calls out of the reference's order)
+    int committed = 0;                                    // trees 1..committed exist
+    bool ran[5] = {false, false, false, false, false};
+    bool h1h2_done = false, z_done = false, evals_done = false;
+
+    zk_stark_ctx(zk_stark_setup& s, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words, hipStream_t stream)
+        : S(s), st(stream), T((on_stream(stream), stream)), I(s.info), nbits(s.nbits), nbits_ext(s.nbits_ext), ext(s.nbits_ext - s.nbits),
+          N(1ull << s.nbits), Next(1ull << s.nbits_ext), sN(s.sN), bn128(s.fr) {
+        ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
+        // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
+        if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
+        else {
+            B[S_CM1_N].reserve(std::max<u64>(1, n_words) * 8); ptr[S_CM1_N] = B[S_CM1_N].u();
+            ZK_HIP(hipStreamSynchronize(st));                 // the block's previous user is ordered before `st`, not before this copy
+            if (n_words) h2d_sync(ptr[S_CM1_N], cm_pols, n_words * 8);
+        }
+        for (int sec : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) alloc(sec, sN[sec] * N);
+        // sections that a kernel writes in full before anything reads them are not cleared: the extended sections (LDE
+        // output), cm4 (the forward NTT of the split quotient), q and f (every row written by step42ns / step52ns)
+        for (int sec : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS}) alloc(sec, sN[sec] * Next, false);
+        alloc(S_CM4_2NS, sN[S_CM4_2NS] * Next, S.q_deg == 0);
+        alloc(S_Q_2NS, S.q_dim * Next, false); alloc(S_F_2NS, 3 * Next, false); alloc(S_SCRATCH, 3 * Next);
+        ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
+
+        d_chal.reserve(24 * 8); zero(d_chal, 24, st);                                        // challenge[8] (constant.rs:39-50)
+        n_ev = (u32)I.at("ev_map").size();
+        n_pub = (u32)I.at("publics").size();
+        d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3, st);
+        d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub), st);
+        for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) n_z += I.at(ctx).arr.size();
+        z_checks.reserve(24 * std::max<size_t>(1, n_z));
+
+        // publics (stark_gen.rs:256-270) and their absorption (:272-277)
+        pub_on_device = d_cm != nullptr;                  // device-resident trace: no host round trip per public
+        if (pub_on_device) {
+            d_pub_ext.reserve(std::max<u32>(1, n_pub) * 16); zero(d_pub_ext, 2 * (size_t)std::max<u32>(1, n_pub), st);   // words 1 and 2 of every computed public: checked to be zero at the end
+            for (u32 i = 0; i < n_pub; ++i) {
+                const JVal& pe = I.at("publics").at(i);
+                const std::string& ty = pe.at("polType").str();
+                const u64 idx = pe.at("idx").u64();
+                if (ty == "cmP") {
+                    const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
+                    ZK_REQUIRE(pos < n_words, "public out of range");
+                    ZK_HIP(hipMemcpyAsync(d_pub.u() + i, d_cm + pos, 8, hipMemcpyDeviceToDevice, st));
+                } else if (ty == "imP") {                                              // calculate_exp_at_point :558-572
+                    ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
+                    ZK_REQUIRE(idx < N, "public out of range");
+                    run(S.public_programs[i], false, nullptr, idx, 1);                 // its one row; reads the publics before it from d_pub
+                    ZK_HIP(hipMemcpyAsync(d_pub.u() + i, ptr[S_SCRATCH] + 3 * idx, 8, hipMemcpyDeviceToDevice, st));
+                    ZK_HIP(hipMemcpyAsync(d_pub_ext.u() + 2 * i, ptr[S_SCRATCH] + 3 * idx + 1, 16, hipMemcpyDeviceToDevice, st));
+                } else throw Error("Invalid public type " + ty);
+            }
+        }
+        for (u32 i = 0; i < n_pub && !pub_on_device; ++i) {
             const JVal& pe = I.at("publics").at(i);
             const std::string& ty = pe.at("polType").str();
             const u64 idx = pe.at("idx").u64();
             if (ty == "cmP") {
                 const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
                 ZK_REQUIRE(pos < n_words, "public out of range");
-                ZK_HIP(hipMemcpyAsync(d_pub.u() + i, d_cm + pos, 8, hipMemcpyDeviceToDevice, st));
-            } else if (ty == "imP") {                                              // calculate_exp_at_point :558-572
+                publics.push_back(cm_pols[pos]);
+            } else if (ty == "imP") {                                                  // calculate_exp_at_point :558-572
+                ZK_HIP(hipStreamSynchronize(st));                                      // (the clearing of d_pub is on `st`)
+                if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
                 ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
                 ZK_REQUIRE(idx < N, "public out of range");
-                run(S.public_programs[i], false, nullptr, idx, 1);                 // its one row; reads the publics before it from d_pub
-                ZK_HIP(hipMemcpyAsync(d_pub.u() + i, ptr[S_SCRATCH] + 3 * idx, 8, hipMemcpyDeviceToDevice, st));
-                ZK_HIP(hipMemcpyAsync(d_pub_ext.u() + 2 * i, ptr[S_SCRATCH] + 3 * idx + 1, 16, hipMemcpyDeviceToDevice, st));
+                run(S.public_programs[i], false, nullptr, idx, 1);                     // its one row, not the domain
+                u64 v[3];
+                ZK_HIP(hipStreamSynchronize(st));
+                ZK_HIP(hipMemcpy(v, ptr[S_SCRATCH] + 3 * idx, 24, hipMemcpyDeviceToHost));
+                // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value.
+                // Every operand a public calculator can see is base-field at this point (columns, numbers, earlier publics,
+                // x; the challenges are still F3G::ZERO of dim 1), so an extension-valued result means a malformed program.
+                ZK_REQUIRE(v[1] == 0 && v[2] == 0, "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
+                publics.push_back(v[0]);
             } else throw Error("Invalid public type " + ty);
         }
-    }
-    for (u32 i = 0; i < n_pub && !pub_on_device; ++i) {
-        const JVal& pe = I.at("publics").at(i);
-        const std::string& ty = pe.at("polType").str();
-        const u64 idx = pe.at("idx").u64();
-        if (ty == "cmP") {
-            const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
-            ZK_REQUIRE(pos < n_words, "public out of range");
-            if (cm_pols) publics.push_back(cm_pols[pos]);
-            else { u64 v; ZK_HIP(hipMemcpy(&v, d_cm + pos, 8, hipMemcpyDeviceToHost)); publics.push_back(v); }
-        } else if (ty == "imP") {                                                  // calculate_exp_at_point :558-572
-            ZK_HIP(hipStreamSynchronize(st));                                      // (the clearing of d_pub is on `st`)
-            if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
-            ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
-            ZK_REQUIRE(idx < N, "public out of range");
-            run(S.public_programs[i], false, nullptr, idx, 1);                     // its one row, not the domain
-            u64 v[3];
+        if (!pub_on_device) {
             ZK_HIP(hipStreamSynchronize(st));
-            ZK_HIP(hipMemcpy(v, ptr[S_SCRATCH] + 3 * idx, 24, hipMemcpyDeviceToHost));
-            // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value.
-            // Every operand a public calculator can see is base-field at this point (columns, numbers, earlier publics,
-            // x; the challenges are still F3G::ZERO of dim 1), so an extension-valued result means a malformed program.
-            ZK_REQUIRE(v[1] == 0 && v[2] == 0, "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
-            publics.push_back(v[0]);
-        } else throw Error("Invalid public type " + ty);
+            if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
+        }
+        tr.reset(new AnyTranscript(bn128));
+        tr->put_words_dev(d_pub.u(), n_pub, st);
+        T.mark("inputs_publics");
+        stage3_early = S.early_stage3;
+        n_cm = S.n_cm1;
     }
-    if (!pub_on_device) {
-        ZK_HIP(hipStreamSynchronize(st));
-        if (!publics.empty()) ZK_HIP(hipMemcpy(d_pub.p, publics.data(), 8 * publics.size(), hipMemcpyHostToDevice));
-    }
-    const FrApi* bn128 = S.fr;                            // non-null: a scalar-field hash type
-    AnyTranscript tr(bn128);
-    tr.put_words_dev(d_pub.u(), n_pub, st);
-    T.mark("inputs_publics");
+    zk_stark_ctx(const zk_stark_ctx&) = delete; zk_stark_ctx& operator=(const zk_stark_ctx&) = delete;
 
-    std::vector<std::unique_ptr<DevBuf>> keep;                                     // workspaces alive until the end
-    auto extend_and_merkelize = [&](int sec_n, int sec_2ns) {                     // stark_gen.rs:709-732
+    void alloc(int s, u64 words, bool zeroed = true) {
+        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words, st); ptr[s] = B[s].u();
+    }
+    void run(const ProgramPtr& p, bool e, hipStream_t on = nullptr, u64 row0 = 0, u64 count = ~0ull) {
+        if (!p) return;
+        zk_eval_ctx c; memset(&c, 0, sizeof c);
+        for (int s = 0; s < S_COUNT; ++s) c.bufs[s] = M(ptr[s]);
+        c.publics = C(d_pub.u()); c.challenges = C(d_chal.u()); c.evals = C(d_evals.u());
+        c.x = C(e ? S.x_2ns.u() : S.x_n.u()); c.zi = C(S.zi.u()); c.zi_mask = (1ull << ext) - 1;
+        c.xdivxsubxi = C(xdiv.u()); c.xdivxsubwxi = C(xdivw.u());
+        const u32 nb = e ? nbits_ext : nbits;
+        ck(zk_program_run_rows_dev(p.get(), &c, nb, e ? (1ull << ext) : 1, row0, count == ~0ull ? 1ull << nb : count, on ? on : st));
+        if (on) on_stream(st);                                                     // this thread goes on issuing on `st`
+    }
+    void get_pol(u64 pol_id, DevBuf& out) {                                        // stark_gen.rs:683-707
+        const PolRef p = S.pol(pol_id);
+        out.reserve(3 * N * 8);
+        pol_get_dev(ptr[p.slot], p.width, p.pos, p.dim, N, out.u(), st);
+    }
+    void set_pol(u64 pol_id, const u64* d_pol3) {                                  // stark_gen.rs:594-622
+        const PolRef p = S.pol(pol_id);
+        pol_set_dev(ptr[p.slot], p.width, p.pos, p.dim, N, d_pol3, st);
+    }
+    u64 e2p(const JVal& v) const {
+        auto it = S.exp2pol.find(v.u64());
+        if (it == S.exp2pol.end()) throw Error("exp2pol: unknown expression");
+        return it->second;
+    }
+    TreePtr extend_and_merkelize(int sec_n, int sec_2ns) {                         // stark_gen.rs:709-732
         const u64 width = sN[sec_n];
         if (width) {
             keep.emplace_back(new DevBuf); keep.back()->reserve(width * Next * 8);
@@ -724,14 +806,25 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         TreePtr t(new AnyTree(bn128, ptr[sec_2ns], (u32)width, Next, st));
         T.mark("merkelize");
         return t;
-    };
-    auto challenge = [&](int i) { tr.get_field_dev(d_chal.u() + 3 * i, st); };
-    auto put_root = [&](const TreePtr& t, u64) { tr.put_root(*t, st); };
+    }
+    // transcript.get_field() -> challenge i (u, defVal, gamma, beta, vc, v1, v2, xi: constant.rs:39-50), kept in HBM for the step programs
+    void challenge(int i) { ZK_REQUIRE(i >= 0 && i < 8, "challenge index"); tr->get_field_dev(d_chal.u() + 3 * i, st); }
+    void set_challenge(int i, const u64 v[3]) {                                    // a caller with its own transcript
+        ZK_REQUIRE(i >= 0 && i < 8, "challenge index");
+        ZK_HIP(hipMemcpyAsync(d_chal.u() + 3 * i, v, 24, hipMemcpyHostToDevice, st));
+        ZK_HIP(hipStreamSynchronize(st));                                          // (v is the caller's)
+    }
+    void get_challenge(int i, u64 out[3]) {
+        ZK_REQUIRE(i >= 0 && i < 8, "challenge index");
+        ZK_HIP(hipMemcpyAsync(out, d_chal.u() + 3 * i, 24, hipMemcpyDeviceToHost, st));
+        ZK_HIP(hipStreamSynchronize(st));
+    }
 
     // Stage-3 columns that depend on no challenge (setup_new decided): evaluated and extended on the side stream while the
     // main stream hashes tree 1 -- memory-bound work beside ALU-bound work.  Values and transcript order are the same.
-    const bool stage3_early = S.early_stage3;
-    if (stage3_early) {
+    void start_early_stage3() {
+        if (!stage3_early || stage3_started) return;
+        stage3_started = true;
         ZK_HIP(hipEventRecord(S.ev_inputs, st));                                   // tables, cleared sections, publics: issued on `st`
         ZK_HIP(hipStreamWaitEvent(S.side_stream, S.ev_inputs, 0));
         run(S.step3, false, S.side_stream);
@@ -741,81 +834,111 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         ZK_HIP(hipEventRecord(S.ev_stage3, S.side_stream));
         on_stream(st);
     }
-    TreePtr tree1 = extend_and_merkelize(S_CM1_N, S_CM1_2NS); put_root(tree1, Next);
-    challenge(0); challenge(1);                                                    // u, defVal
-    T.mark("transcript");
-    run(S.step2prev, false);
-    T.mark("calculate_exps_parallel");
-    u64 n_cm = S.n_cm1;
-    for (const JVal& pu : I.at("pu_ctx").arr) {                                    // stark_gen.rs:300-308
-        DevBuf f, t, h1, h2;
-        get_pol(e2p(pu.at("f_exp_id")), f); get_pol(e2p(pu.at("t_exp_id")), t);
-        h1.reserve(24 * N); h2.reserve(24 * N);
-        ck(zk_stark_calculate_h1h2_dev(C(f.u()), C(t.u()), N, M(h1.u()), M(h2.u()), st));
-        set_pol(S.cm_n.at(n_cm++), h1.u()); set_pol(S.cm_n.at(n_cm++), h2.u());
-        T.mark("calculate_H1H2");
+
+    // extend_and_merkelize of stage `stage` (1..3) or the Q split + tree 4 (stark_gen.rs:375-405), and the root's absorption
+    void commit(int stage) {
+        ZK_REQUIRE(stage == committed + 1 && stage >= 1 && stage <= 4, "commit_stage: stages are committed in order 1, 2, 3, 4");
+        on_stream(st);
+        if (stage == 1) {
+            start_early_stage3();
+            tree[0] = extend_and_merkelize(S_CM1_N, S_CM1_2NS);
+        } else if (stage == 2) {
+            ZK_REQUIRE(ran[STEP_2PREV] && h1h2_done, "commit_stage 2: step2prev and calculate_H1H2 come first (stark_gen.rs:296-311)");
+            tree[1] = extend_and_merkelize(S_CM2_N, S_CM2_2NS);
+        } else if (stage == 3) {
+            ZK_REQUIRE(ran[STEP_3PREV] && z_done && ran[STEP_3], "commit_stage 3: step3prev, calculate_Z and step3 come first (stark_gen.rs:323-362)");
+            if (stage3_early) {
+                ZK_HIP(hipStreamWaitEvent(st, S.ev_stage3, 0));                    // cm3_n and its extension are ready
+                T.mark("wait_side_stream");
+                tree[2].reset(new AnyTree(bn128, ptr[S_CM3_2NS], (u32)sN[S_CM3_N], Next, st));
+                T.mark("merkelize");
+            } else tree[2] = extend_and_merkelize(S_CM3_N, S_CM3_2NS);
+        } else {
+            ZK_REQUIRE(ran[STEP_42NS], "commit_stage 4: step42ns comes first (stark_gen.rs:371-373)");
+            const u32 q_dim = S.q_dim, q_deg = S.q_deg;                            // Q split (stark_gen.rs:375-396)
+            keep.emplace_back(new DevBuf); DevBuf& qq1 = *keep.back(); qq1.reserve(q_dim * Next * 8);
+            keep.emplace_back(new DevBuf); DevBuf& tmpq = *keep.back(); tmpq.reserve(q_dim * Next * 8);
+            ntt_dev(ptr[S_Q_2NS], qq1.u(), tmpq.u(), q_dim, nbits_ext, true, st);
+            if (q_deg > 0) {
+                keep.emplace_back(new DevBuf); DevBuf& qq2 = *keep.back(); qq2.reserve((u64)q_dim * q_deg * Next * 8);
+                ZK_HIP(hipMemsetAsync(qq2.p, 0, (u64)q_dim * q_deg * Next * 8, st));
+                qsplit_dev(qq1.u(), nbits, q_dim, q_deg, qq2.u(), st);
+                d_qq2 = qq2.u();
+                keep.emplace_back(new DevBuf); DevBuf& tmp4 = *keep.back(); tmp4.reserve((u64)q_dim * q_deg * Next * 8);
+                ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
+            }
+            T.mark("q_split_ntt");
+            tree[3].reset(new AnyTree(bn128, ptr[S_CM4_2NS], (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
+            T.mark("merkelize");
+        }
+        tr->put_root(*tree[stage - 1], st);
+        committed = stage;
     }
-    TreePtr tree2 = extend_and_merkelize(S_CM2_N, S_CM2_2NS); put_root(tree2, Next);
-    challenge(2); challenge(3);                                                    // gamma, beta
-    T.mark("transcript");
-    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);         // an output-only section starts from zero (stark_gen.rs:944-951)
-    run(S.step3prev, false);
-    T.mark("calculate_exps_parallel");
-    n_cm = S.n_cm1 + S.n_cm2;
+
+    // calculate_exps_parallel(ctx, starkinfo, segment, domain, step) (stark_gen.rs:786-792) for one of the five step programs
+    void eval(int step) {
+        ZK_REQUIRE(step >= 0 && step <= 4, "eval: step id");
+        on_stream(st);
+        switch (step) {
+            case STEP_2PREV:
+                ZK_REQUIRE(committed >= 1, "step2prev follows the first commitment and the challenges u, defVal");
+                run(S.step2prev, false); break;
+            case STEP_3PREV:
+                ZK_REQUIRE(committed >= 2, "step3prev follows the second commitment and the challenges gamma, beta");
+                zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);                       // an output-only section starts from zero (stark_gen.rs:944-951)
+                run(S.step3prev, false); break;
+            case STEP_3:
+                ZK_REQUIRE(ran[STEP_3PREV] && z_done, "step3 follows step3prev and calculate_Z");
+                if (!stage3_early) run(S.step3, false);                            // (early: already running on the side stream since commit 1)
+                break;
+            case STEP_42NS:
+                ZK_REQUIRE(committed >= 3, "step42ns follows the third commitment and the challenge vc");
+                run(S.step42ns, true); break;
+            default:
+                ZK_REQUIRE(evals_done, "step52ns follows the evaluations and the challenges v1, v2");
+                xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);            // stark_gen.rs:481-522
+                xdivxsub_dev(d_chal.u() + 3 * 7, 1, nbits_ext, xdiv.u(), st);
+                xdivxsub_dev(d_chal.u() + 3 * 7, gl::hroot(nbits), nbits_ext, xdivw.u(), st);
+                T.mark("xDivXSubXi");
+                run(S.step52ns, true); break;
+        }
+        ran[step] = true;
+        T.mark("calculate_exps_parallel");
+    }
+    void calculate_h1h2() {                                                        // stark_gen.rs:300-308, every plookup of the PIL
+        ZK_REQUIRE(ran[STEP_2PREV] && !h1h2_done, "calculate_H1H2 follows step2prev, once");
+        on_stream(st);
+        n_cm = S.n_cm1;
+        for (const JVal& pu : I.at("pu_ctx").arr) {
+            DevBuf f, t, h1, h2;
+            get_pol(e2p(pu.at("f_exp_id")), f); get_pol(e2p(pu.at("t_exp_id")), t);
+            h1.reserve(24 * N); h2.reserve(24 * N);
+            ck(zk_stark_calculate_h1h2_dev(C(f.u()), C(t.u()), N, M(h1.u()), M(h2.u()), st));
+            set_pol(S.cm_n.at(n_cm++), h1.u()); set_pol(S.cm_n.at(n_cm++), h2.u());
+            T.mark("calculate_H1H2");
+        }
+        h1h2_done = true;
+    }
     // every z must close (grand product 1, stark_gen.rs:663-664): the products stay in HBM and come back with the proof's one
     // read-back -- checking each on the spot was a host round trip in the middle of the proof
-    size_t n_z = 0, i_z = 0;
-    for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) n_z += I.at(ctx).arr.size();
-    DevBuf z_checks; z_checks.reserve(24 * std::max<size_t>(1, n_z));
-    for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {                       // stark_gen.rs:329-353
-        for (const JVal& o : I.at(ctx).arr) {
-            DevBuf num, den, z, work;
-            get_pol(e2p(o.at("num_id")), num); get_pol(e2p(o.at("den_id")), den);
-            z.reserve(3 * N * 8); work.reserve((N + N / 1024 + 8) * 24);
-            calculate_z_dev(num.u(), den.u(), N, z.u(), work.u(), z_checks.u() + 3 * i_z++, st);
-            set_pol(S.cm_n.at(n_cm++), z.u());
-            T.mark("calculate_Z");
+    void calculate_z() {                                                           // stark_gen.rs:329-353
+        ZK_REQUIRE(ran[STEP_3PREV] && !z_done, "calculate_Z follows step3prev, once");
+        on_stream(st);
+        n_cm = S.n_cm1 + S.n_cm2;
+        for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) {
+            for (const JVal& o : I.at(ctx).arr) {
+                DevBuf num, den, z, work;
+                get_pol(e2p(o.at("num_id")), num); get_pol(e2p(o.at("den_id")), den);
+                z.reserve(3 * N * 8); work.reserve((N + N / 1024 + 8) * 24);
+                calculate_z_dev(num.u(), den.u(), N, z.u(), work.u(), z_checks.u() + 3 * i_z++, st);
+                set_pol(S.cm_n.at(n_cm++), z.u());
+                T.mark("calculate_Z");
+            }
         }
+        zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);
+        z_done = true;
     }
-    zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);
-    TreePtr tree3;
-    if (stage3_early) {
-        ZK_HIP(hipStreamWaitEvent(st, S.ev_stage3, 0));                            // cm3_n and its extension are ready
-        T.mark("wait_side_stream");
-        tree3.reset(new AnyTree(bn128, ptr[S_CM3_2NS], (u32)sN[S_CM3_N], Next, st));
-        T.mark("merkelize");
-    } else {
-        run(S.step3, false);
-        T.mark("calculate_exps_parallel");
-        tree3 = extend_and_merkelize(S_CM3_N, S_CM3_2NS);
-    }
-    put_root(tree3, Next);
-    challenge(4);                                                                  // vc
-    T.mark("transcript");
-    run(S.step42ns, true);
-    T.mark("calculate_exps_parallel");
-    const u64* d_qq2 = nullptr;                           // the split quotient's coefficients [N][q_dim q_deg] (kept for the evaluations)
-    {   // Q split (stark_gen.rs:375-396)
-        const u32 q_dim = S.q_dim, q_deg = S.q_deg;
-        keep.emplace_back(new DevBuf); DevBuf& qq1 = *keep.back(); qq1.reserve(q_dim * Next * 8);
-        keep.emplace_back(new DevBuf); DevBuf& tmpq = *keep.back(); tmpq.reserve(q_dim * Next * 8);
-        ntt_dev(ptr[S_Q_2NS], qq1.u(), tmpq.u(), q_dim, nbits_ext, true, st);
-        if (q_deg > 0) {
-            keep.emplace_back(new DevBuf); DevBuf& qq2 = *keep.back(); qq2.reserve((u64)q_dim * q_deg * Next * 8);
-            ZK_HIP(hipMemsetAsync(qq2.p, 0, (u64)q_dim * q_deg * Next * 8, st));
-            qsplit_dev(qq1.u(), nbits, q_dim, q_deg, qq2.u(), st);
-            d_qq2 = qq2.u();
-            keep.emplace_back(new DevBuf); DevBuf& tmp4 = *keep.back(); tmp4.reserve((u64)q_dim * q_deg * Next * 8);
-            ntt_dev(qq2.u(), ptr[S_CM4_2NS], tmp4.u(), q_dim * q_deg, nbits_ext, false, st);
-        }
-    }
-    T.mark("q_split_ntt");
-    TreePtr tree4(new AnyTree(bn128, ptr[S_CM4_2NS], (u32)sN[S_CM4_2NS], Next, st));  // stark_gen.rs:399-405
-    T.mark("merkelize");
-    put_root(tree4, Next);
-    challenge(7);                                                                  // xi
-    T.mark("transcript");
-    const u64* d_xi = d_chal.u() + 3 * 7;
+
     // Evaluations at xi and xi w (stark_gen.rs:416-466).  The reference weighs the rows k 2^ext of the EXTENDED sections with
     // LEv = ifft(powers of xi / shift).  The same values come from the sections themselves -- p(xi) = sum_k p(w^k) L'[k] with
     // L' = ifft(powers of xi), the shift-1 instance of the same identity -- and, for the quotient's pieces (which only exist
@@ -823,213 +946,209 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     // every other row of a 2N-row one, half the bytes.  Field arithmetic is exact: the evaluations, hence the proof, are the same words.
     // (cm4_2ns is the plain transform of qq2, i.e. the coset values of the polynomial with coefficients qq2_i / shift^i: its value at
     // xi is sum_i qq2_i (xi / shift)^i -- the weights of the coefficients are the powers the reference feeds its ifft.)
-    DevBuf LEv, LpEv, pw, pwp, lt1, lt2;
-    LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
-    lev_dev(d_xi, nbits, false, 1, LEv.u(), lt1.u(), lt2.u(), st);
-    lev_dev(d_xi, nbits, true, 1, LpEv.u(), lt1.u(), lt2.u(), st);
-    bool q_plain = false, q_prime = false;                // which openings of the quotient's pieces exist
-    for (const JVal& ev : I.at("ev_map").arr)
-        if (ev.at("type_").str() == "cm" && S.pol(S.cm_2ns.at(ev.at("id").u64())).slot == S_CM4_2NS) (ev.at("prime").boolean() ? q_prime : q_plain) = true;
-    if (d_qq2 && q_plain) { pw.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, false, 49, pw.u(), st); }
-    if (d_qq2 && q_prime) { pwp.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, true, 49, pwp.u(), st); }
-    if (n_ev) {
-        std::vector<EvalDescKHost> descs;
-        for (const JVal& ev : I.at("ev_map").arr) {
-            const std::string& ty = ev.at("type_").str();
-            const bool prime = ev.at("prime").boolean();
-            EvalDescKHost d; d.rshift = 0; d.L = prime ? LpEv.u() : LEv.u();
-            if (ty == "const") { d.buf = ptr[S_CONST_N]; d.width = S.n_constants; d.offset = ev.at("id").u64(); d.dim = 1; }
-            else if (ty == "cm") {
-                const u64 id = ev.at("id").u64();
-                const PolRef p2 = S.pol(S.cm_2ns.at(id));
-                if (p2.slot == S_CM4_2NS) {                                        // a piece of the quotient: its coefficients (Q split above)
-                    ZK_REQUIRE(d_qq2 != nullptr, "evaluation of a quotient piece without a split quotient");
-                    d.buf = d_qq2; d.width = p2.width; d.offset = p2.pos; d.dim = p2.dim; d.L = prime ? pwp.u() : pw.u();
-                } else {
-                    ZK_REQUIRE(id < S.cm_n.size(), "ev_map: cm id out of range");
-                    const PolRef p = S.pol(S.cm_n.at(id));                         // the same column before its extension
-                    ZK_REQUIRE(p.dim == p2.dim, "ev_map: section mismatch");
-                    d.buf = ptr[p.slot]; d.width = p.width; d.offset = p.pos; d.dim = p.dim;
-                }
-            } else throw Error("Invalid ev type: " + ty);
-            descs.push_back(d);
-        }
-        evals_k_dev(descs.data(), n_ev, nbits, d_evals.u(), st);
-        tr.put_words_dev(d_evals.u(), 3 * (size_t)n_ev, st);                          // stark_gen.rs:469-472
-    }
-    T.mark("evals");
-    challenge(5); challenge(6);                                                    // v1, v2
-    T.mark("transcript");
-    xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);                        // stark_gen.rs:481-522
-    xdivxsub_dev(d_xi, 1, nbits_ext, xdiv.u(), st);
-    xdivxsub_dev(d_xi, gl::hroot(nbits), nbits_ext, xdivw.u(), st);
-    T.mark("xDivXSubXi");
-    run(S.step52ns, true);
-    T.mark("calculate_exps_parallel");
-
-    // ---- FRI::prove (fri.rs:84-184)
-    const std::vector<u32>& steps = S.steps;
-    const size_t n_steps = steps.size();
-    u32 pol_bits = nbits_ext;
-    u64 shift_inv = gl::hinv(49);
-    std::vector<TreePtr> fri_trees(n_steps);                                       // tree of step i+1's groups at [i]
-    std::vector<u32> fri_width(n_steps, 0);
-    std::vector<std::array<u64, 4>> fri_roots(n_steps);
-    DevBuf d_sx; d_sx.reserve(24);
-    const u64* d_pol = ptr[S_F_2NS];
-    for (size_t si = 0; si < n_steps; ++si) {
-        const u32 step_bits = steps[si];
-        ZK_REQUIRE(step_bits <= pol_bits, "FRI steps must not grow");
-        tr.get_field_dev(d_sx.u(), st);                                                // special_x
-        keep.emplace_back(new DevBuf); DevBuf& folded = *keep.back(); folded.reserve((3ull << step_bits) * 8);
-        fri_fold_dev(d_pol, pol_bits, step_bits, d_sx.u(), shift_inv, folded.u(), st);
-        d_pol = folded.u();
-        if (si + 1 < n_steps) {
-            const u32 nxt = steps[si + 1];
-            ZK_REQUIRE(nxt <= step_bits, "FRI steps must not grow");
-            const u64 n_groups = 1ull << nxt, group_size = (1ull << step_bits) >> nxt;
-            keep.emplace_back(new DevBuf); DevBuf& tb = *keep.back(); tb.reserve((3ull << step_bits) * 8);
-            fri_transpose_dev(d_pol, 1ull << step_bits, nxt, tb.u(), st);
-            fri_width[si] = (u32)(3 * group_size);
-            fri_trees[si].reset(new AnyTree(bn128, tb.u(), fri_width[si], n_groups, st));
-            tr.put_root(*fri_trees[si], st);                                           // (its words are read for the JSON below)
-        } else {
-            tr.put_words_dev(d_pol, 3ull << step_bits, st);                             // fri.rs:136-141
-        }
-        for (u32 k = 0; k < pol_bits - step_bits; ++k) shift_inv = gl::hmul(shift_inv, shift_inv);
-        pol_bits = step_bits;
-    }
-    T.mark("fri_prove");
-    // ---- queries (fri.rs:158-181) and the proof's words
-    // Goldilocks hashing: the query indices are squeezed into HBM, every tree is opened there at (index mod its height) and ONE copy
-    // brings back roots, evaluations, the last polynomial, the publics, the indices and all openings -- one host round trip where
-    // the indices, the proof's words and the openings used to be three.  Scalar-field hashing keeps its host-side sponge and trees.
-    std::vector<u64> ys(S.n_queries);
-    DevBuf d_ys;
-    if (!bn128) { d_ys.reserve(std::max<u32>(1, S.n_queries) * 8); tr.get_permutations_dev(S.n_queries, steps[0], d_ys.u(), st); }
-    else tr.get_permutations(S.n_queries, steps[0], ys.data());
-    T.mark("fri_query_indices");
-
-    // ---- proof -> zkin JSON (serializer.rs:146-261)
-    u64 r1[4], r2[4], r3[4], r4[4];
-    const u64 n_last = 1ull << steps.back();
-    std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev)), last(3 * n_last);
-    // the trees a proof opens: the folded polynomials' trees at the reduced indices, then the five trees at ys
-    std::vector<const AnyTree*> all_trees; std::vector<u64> all_mask;
-    for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(fri_trees[si - 1].get()); all_mask.push_back((1ull << steps[si]) - 1); }
-    for (const AnyTree* t : {tree1.get(), tree2.get(), tree3.get(), tree4.get(), S.const_tree.get()}) { all_trees.push_back(t); all_mask.push_back((1ull << steps[0]) - 1); }
-    std::vector<std::vector<GroupProof>> all_gp;
-    {
-        size_t open_words = 0;
-        if (!bn128) for (const AnyTree* t : all_trees) open_words += (size_t)S.n_queries * ((size_t)t->width + 4 * (size_t)t->depth());
-        ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub + S.n_queries + open_words + 3 * n_z, st);
-        const AnyTree* t4[4] = {tree1.get(), tree2.get(), tree3.get(), tree4.get()};
-        u64* r4p[4] = {r1, r2, r3, r4};
-        size_t off_r[4] = {}, off_ev = 0, off_last = 0, off_ys = 0;
-        std::vector<size_t> off_fri(n_steps, 0), off_open(all_trees.size(), 0);
-        if (!bn128) {
-            for (int j = 0; j < 4; ++j) off_r[j] = rb.add(t4[j]->root_dev(), 4);
-            for (size_t si = 0; si + 1 < n_steps; ++si) off_fri[si] = rb.add(fri_trees[si]->root_dev(), 4);
-        }
-        off_ev = rb.add(d_evals.u(), 3 * (size_t)n_ev);
-        off_last = rb.add(d_pol, 3 * n_last);
-        const size_t off_z = rb.add(z_checks.u(), 3 * n_z);
-        const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
-        if (!bn128) {
-            off_ys = rb.add(d_ys.u(), S.n_queries);
-            for (size_t j = 0; j < all_trees.size(); ++j) {
-                const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
-                off_open[j] = rb.words;
-                merkle_group_proofs_masked_async(all_trees[j]->gl, d_ys.u(), all_mask[j], S.n_queries, rb.reserve(per * S.n_queries), st);
+    void evals() {
+        ZK_REQUIRE(committed == 4 && !evals_done, "the evaluations follow the fourth commitment and the challenge xi, once");
+        on_stream(st);
+        const u64* d_xi = d_chal.u() + 3 * 7;
+        DevBuf LEv, LpEv, pw, pwp, lt1, lt2;
+        LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
+        lev_dev(d_xi, nbits, false, 1, LEv.u(), lt1.u(), lt2.u(), st);
+        lev_dev(d_xi, nbits, true, 1, LpEv.u(), lt1.u(), lt2.u(), st);
+        bool q_plain = false, q_prime = false;            // which openings of the quotient's pieces exist
+        for (const JVal& ev : I.at("ev_map").arr)
+            if (ev.at("type_").str() == "cm" && S.pol(S.cm_2ns.at(ev.at("id").u64())).slot == S_CM4_2NS) (ev.at("prime").boolean() ? q_prime : q_plain) = true;
+        if (d_qq2 && q_plain) { pw.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, false, 49, pw.u(), st); }
+        if (d_qq2 && q_prime) { pwp.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, true, 49, pwp.u(), st); }
+        if (n_ev) {
+            std::vector<EvalDescKHost> descs;
+            for (const JVal& ev : I.at("ev_map").arr) {
+                const std::string& ty = ev.at("type_").str();
+                const bool prime = ev.at("prime").boolean();
+                EvalDescKHost d; d.rshift = 0; d.L = prime ? LpEv.u() : LEv.u();
+                if (ty == "const") { d.buf = ptr[S_CONST_N]; d.width = S.n_constants; d.offset = ev.at("id").u64(); d.dim = 1; }
+                else if (ty == "cm") {
+                    const u64 id = ev.at("id").u64();
+                    const PolRef p2 = S.pol(S.cm_2ns.at(id));
+                    if (p2.slot == S_CM4_2NS) {                                    // a piece of the quotient: its coefficients (Q split above)
+                        ZK_REQUIRE(d_qq2 != nullptr, "evaluation of a quotient piece without a split quotient");
+                        d.buf = d_qq2; d.width = p2.width; d.offset = p2.pos; d.dim = p2.dim; d.L = prime ? pwp.u() : pw.u();
+                    } else {
+                        ZK_REQUIRE(id < S.cm_n.size(), "ev_map: cm id out of range");
+                        const PolRef p = S.pol(S.cm_n.at(id));                     // the same column before its extension
+                        ZK_REQUIRE(p.dim == p2.dim, "ev_map: section mismatch");
+                        d.buf = ptr[p.slot]; d.width = p.width; d.offset = p.pos; d.dim = p.dim;
+                    }
+                } else throw Error("Invalid ev type: " + ty);
+                descs.push_back(d);
             }
+            evals_k_dev(descs.data(), n_ev, nbits, d_evals.u(), st);
+            tr->put_words_dev(d_evals.u(), 3 * (size_t)n_ev, st);                      // stark_gen.rs:469-472
         }
-        rb.fetch();
-        for (size_t i = 0; i < n_z; ++i)
-            ZK_REQUIRE(rb.at(off_z)[3 * i] == 1 && rb.at(off_z)[3 * i + 1] == 0 && rb.at(off_z)[3 * i + 2] == 0, "calculate_Z: z does not close (grand product != 1)");
-        if (pub_on_device) {
-            publics.assign(rb.at(off_pub), rb.at(off_pub) + n_pub);
-            // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value; a
-            // computed public with extension words means a malformed program (see the host-trace path above)
-            for (u32 i = 0; i < n_pub; ++i)
-                ZK_REQUIRE(rb.at(off_ext)[2 * i] == 0 && rb.at(off_ext)[2 * i + 1] == 0,
-                           "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
-        }
-        if (!bn128) {
-            for (int j = 0; j < 4; ++j) memcpy(r4p[j], rb.at(off_r[j]), 32);
-            for (size_t si = 0; si + 1 < n_steps; ++si) memcpy(fri_roots[si].data(), rb.at(off_fri[si]), 32);
-            if (S.n_queries) memcpy(ys.data(), rb.at(off_ys), 8 * (size_t)S.n_queries);
-            all_gp.resize(all_trees.size());
-            for (size_t j = 0; j < all_trees.size(); ++j) {
-                const u32 depth = all_trees[j]->depth(), w = all_trees[j]->width;
-                const size_t per = (size_t)w + 4 * (size_t)depth;
-                all_gp[j].resize(S.n_queries);
-                for (u32 q = 0; q < S.n_queries; ++q) {
-                    const u64* p = rb.at(off_open[j] + q * per);
-                    all_gp[j][q].depth = depth; all_gp[j][q].row.assign(p, p + w); all_gp[j][q].path.assign(p + w, p + per);
+        evals_done = true;
+        T.mark("evals");
+    }
+
+    // ---- FRI::prove (fri.rs:84-184) over the polynomial step52ns left in f_2ns: folds, their trees, the last polynomial, the query indices
+    void fri_prove() {
+        ZK_REQUIRE(ran[STEP_52NS] && !fri_done, "FRI::prove follows step52ns, once");
+        on_stream(st);
+        F.commit(*tr, bn128, ptr[S_F_2NS], nbits_ext, S.steps, S.n_queries, st, &T);
+        fri_done = true;
+    }
+
+    // ---- the openings, one read-back, proof -> zkin JSON (serializer.rs:146-261)
+    std::string finish() {
+        ZK_REQUIRE(fri_done, "finish follows FRI::prove");
+        on_stream(st);
+        const std::vector<u32>& steps = S.steps;
+        const size_t n_steps = steps.size();
+        u64 r1[4], r2[4], r3[4], r4[4];
+        const u64 n_last = 1ull << steps.back();
+        std::vector<u64> ev_host(3 * (size_t)std::max<u32>(1, n_ev)), last(3 * n_last);
+        // the trees a proof opens: the folded polynomials' trees at the reduced indices, then the five trees at ys
+        std::vector<const AnyTree*> all_trees; std::vector<u64> all_mask;
+        for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(F.trees[si - 1].get()); all_mask.push_back((1ull << steps[si]) - 1); }
+        for (const AnyTree* t : {tree[0].get(), tree[1].get(), tree[2].get(), tree[3].get(), S.const_tree.get()}) { all_trees.push_back(t); all_mask.push_back((1ull << steps[0]) - 1); }
+        std::vector<std::vector<GroupProof>> all_gp;
+        {
+            size_t open_words = 0;
+            if (!bn128) for (const AnyTree* t : all_trees) open_words += (size_t)S.n_queries * ((size_t)t->width + 4 * (size_t)t->depth());
+            ReadBack rb(4 * (4 + n_steps) + 3 * (size_t)n_ev + 3 * n_last + 3 * (size_t)n_pub + S.n_queries + open_words + 3 * n_z, st);
+            const AnyTree* t4[4] = {tree[0].get(), tree[1].get(), tree[2].get(), tree[3].get()};
+            u64* r4p[4] = {r1, r2, r3, r4};
+            size_t off_r[4] = {}, off_ev = 0, off_last = 0, off_ys = 0;
+            std::vector<size_t> off_fri(n_steps, 0), off_open(all_trees.size(), 0);
+            if (!bn128) {
+                for (int j = 0; j < 4; ++j) off_r[j] = rb.add(t4[j]->root_dev(), 4);
+                for (size_t si = 0; si + 1 < n_steps; ++si) off_fri[si] = rb.add(F.trees[si]->root_dev(), 4);
+            }
+            off_ev = rb.add(d_evals.u(), 3 * (size_t)n_ev);
+            off_last = rb.add(F.d_pol, 3 * n_last);
+            const size_t off_z = rb.add(z_checks.u(), 3 * n_z);
+            const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
+            if (!bn128) {
+                off_ys = rb.add(F.d_ys.u(), S.n_queries);
+                for (size_t j = 0; j < all_trees.size(); ++j) {
+                    const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
+                    off_open[j] = rb.words;
+                    merkle_group_proofs_masked_async(all_trees[j]->gl, F.d_ys.u(), all_mask[j], S.n_queries, rb.reserve(per * S.n_queries), st);
                 }
             }
-        } else {
-            for (int j = 0; j < 4; ++j) t4[j]->root(r4p[j]);
-            for (size_t si = 0; si + 1 < n_steps; ++si) fri_trees[si]->root(fri_roots[si].data());
+            rb.fetch();
+            for (size_t i = 0; i < n_z; ++i)
+                ZK_REQUIRE(rb.at(off_z)[3 * i] == 1 && rb.at(off_z)[3 * i + 1] == 0 && rb.at(off_z)[3 * i + 2] == 0, "calculate_Z: z does not close (grand product != 1)");
+            if (pub_on_device) {
+                publics.assign(rb.at(off_pub), rb.at(off_pub) + n_pub);
+                // The reference absorbs ctx.publics[i].as_elements() (stark_gen.rs:272-277): one word for a base-field value; a
+                // computed public with extension words means a malformed program (see the host-trace path above)
+                for (u32 i = 0; i < n_pub; ++i)
+                    ZK_REQUIRE(rb.at(off_ext)[2 * i] == 0 && rb.at(off_ext)[2 * i + 1] == 0,
+                               "public " + std::to_string(i) + ": extension-field value (only base-field publics exist in the reference)");
+            }
+            if (!bn128) {
+                for (int j = 0; j < 4; ++j) memcpy(r4p[j], rb.at(off_r[j]), 32);
+                for (size_t si = 0; si + 1 < n_steps; ++si) memcpy(F.roots[si].data(), rb.at(off_fri[si]), 32);
+                if (S.n_queries) memcpy(F.ys.data(), rb.at(off_ys), 8 * (size_t)S.n_queries);
+                all_gp.resize(all_trees.size());
+                for (size_t j = 0; j < all_trees.size(); ++j) {
+                    const u32 depth = all_trees[j]->depth(), w = all_trees[j]->width;
+                    const size_t per = (size_t)w + 4 * (size_t)depth;
+                    all_gp[j].resize(S.n_queries);
+                    for (u32 q = 0; q < S.n_queries; ++q) {
+                        const u64* p = rb.at(off_open[j] + q * per);
+                        all_gp[j][q].depth = depth; all_gp[j][q].row.assign(p, p + w); all_gp[j][q].path.assign(p + w, p + per);
+                    }
+                }
+            } else {
+                for (int j = 0; j < 4; ++j) t4[j]->root(r4p[j]);
+                for (size_t si = 0; si + 1 < n_steps; ++si) F.trees[si]->root(F.roots[si].data());
+            }
+            if (n_ev) memcpy(ev_host.data(), rb.at(off_ev), 24 * (size_t)n_ev);
+            memcpy(last.data(), rb.at(off_last), 24 * n_last);
         }
-        if (n_ev) memcpy(ev_host.data(), rb.at(off_ev), 24 * (size_t)n_ev);
-        memcpy(last.data(), rb.at(off_last), 24 * n_last);
-    }
-    if (bn128) {   // scalar-field trees: the reduced indices on the host, one round trip per tree
-        std::vector<std::vector<u64>> ysi(all_trees.size(), ys);
-        std::vector<const std::vector<u64>*> all_idx;
-        for (size_t j = 0; j < all_trees.size(); ++j) { for (u64& y : ysi[j]) y &= all_mask[j]; all_idx.push_back(&ysi[j]); }
-        all_gp = group_proofs_all(all_trees, all_idx, st);
-    }
-    T.mark("openings_readback");
-    S.last_timing = T.finish(nbits);
-    S.t_json_begin = std::chrono::steady_clock::now();
-    JOut o;
-    o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
-    o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
-    o << ",\"root3\":"; put_digest(o, r3, bn128); o << ",\"root4\":"; put_digest(o, r4, bn128);
-    o << ",\"evals\":[";
-    for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
-    o << ']';
-    // queries of the later steps: group proofs of the folded polynomials (fri.rs:160-181)
-    for (size_t si = 1; si < n_steps; ++si) {
-        const std::vector<GroupProof>& gp = all_gp[si - 1];
-        o << ",\"s" << si << "_root\":"; put_digest(o, fri_roots[si - 1].data(), bn128);
-        o << ",\"s" << si << "_vals\":[";
-        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
-        o << "],\"s" << si << "_siblings\":[";
-        for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_path(o, gp[q], bn128); }
+        if (bn128) {   // scalar-field trees: the reduced indices on the host, one round trip per tree
+            std::vector<std::vector<u64>> ysi(all_trees.size(), F.ys);
+            std::vector<const std::vector<u64>*> all_idx;
+            for (size_t j = 0; j < all_trees.size(); ++j) { for (u64& y : ysi[j]) y &= all_mask[j]; all_idx.push_back(&ysi[j]); }
+            all_gp = group_proofs_all(all_trees, all_idx, st);
+        }
+        T.mark("openings_readback");
+        S.last_timing = T.finish(nbits);
+        S.t_json_begin = std::chrono::steady_clock::now();
+        JOut o;
+        o << "{\"rootC\":"; put_digest(o, S.const_root, bn128);
+        o << ",\"root1\":"; put_digest(o, r1, bn128); o << ",\"root2\":"; put_digest(o, r2, bn128);
+        o << ",\"root3\":"; put_digest(o, r3, bn128); o << ",\"root4\":"; put_digest(o, r4, bn128);
+        o << ",\"evals\":[";
+        for (u32 e = 0; e < n_ev; ++e) { if (e) o << ','; put_list(o, ev_host.data() + 3 * e, 3); }
         o << ']';
-    }
-    {   // step 0: openings of the five trees at the query indices
-        const char* names[5] = {"1", "2", "3", "4", "C"};
-        const std::vector<GroupProof>* gp = all_gp.data() + (n_steps - 1);
-        for (int j = 0; j < 5; ++j) {
-            o << ",\"s0_vals" << names[j] << "\":[";
-            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
+        // queries of the later steps: group proofs of the folded polynomials (fri.rs:160-181)
+        for (size_t si = 1; si < n_steps; ++si) {
+            const std::vector<GroupProof>& gp = all_gp[si - 1];
+            o << ",\"s" << si << "_root\":"; put_digest(o, F.roots[si - 1].data(), bn128);
+            o << ",\"s" << si << "_vals\":[";
+            for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_list(o, gp[q].row.data(), gp[q].row.size()); }
+            o << "],\"s" << si << "_siblings\":[";
+            for (size_t q = 0; q < gp.size(); ++q) { if (q) o << ','; put_path(o, gp[q], bn128); }
             o << ']';
         }
-        for (int j = 0; j < 5; ++j) {
-            o << ",\"s0_siblings" << names[j] << "\":[";
-            for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_path(o, gp[j][q], bn128); }
+        {   // step 0: openings of the five trees at the query indices
+            const char* names[5] = {"1", "2", "3", "4", "C"};
+            const std::vector<GroupProof>* gp = all_gp.data() + (n_steps - 1);
+            for (int j = 0; j < 5; ++j) {
+                o << ",\"s0_vals" << names[j] << "\":[";
+                for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_list(o, gp[j][q].row.data(), gp[j][q].row.size()); }
+                o << ']';
+            }
+            for (int j = 0; j < 5; ++j) {
+                o << ",\"s0_siblings" << names[j] << "\":[";
+                for (size_t q = 0; q < gp[j].size(); ++q) { if (q) o << ','; put_path(o, gp[j][q], bn128); }
+                o << ']';
+            }
+        }
+        {
+            o << ",\"finalPol\":[";
+            for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, last.data() + 3 * i, 3); }
             o << ']';
         }
+        o << ",\"publics\":"; put_list(o, publics.data(), publics.size());
+        if (bn128) {                                          // serializer.rs:255-262: non-GL proofs carry the prover address
+            o << ",\"proverAddr\":\"";
+            for (char c : S.prover_addr) { if (c == '"' || c == '\\') o << '\\'; o << c; }
+            o << '"';
+        }
+        o << '}';
+        S.t_json_end = std::chrono::steady_clock::now();
+        return o.str();
     }
+};
+
+namespace {
+
+// cm_pols: host trace, or nullptr when d_cm (device-resident trace, borrowed) is given.  The reference's stark_gen, stage by stage.
+std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words, hipStream_t st) {
+    std::string zkin;
     {
-        o << ",\"finalPol\":[";
-        for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, last.data() + 3 * i, 3); }
-        o << ']';
+        zk_stark_ctx P(S, cm_pols, d_cm, n_words, st);
+        auto T = [&](const char* name) { P.T.mark(name); };
+        P.commit(1); P.challenge(0); P.challenge(1); T("transcript");              // u, defVal (stark_gen.rs:279-294)
+        P.eval(STEP_2PREV);
+        P.calculate_h1h2();
+        P.commit(2); P.challenge(2); P.challenge(3); T("transcript");              // gamma, beta (:310-321)
+        P.eval(STEP_3PREV);
+        P.calculate_z();
+        P.eval(STEP_3);
+        P.commit(3); P.challenge(4); T("transcript");                              // vc (:355-369)
+        P.eval(STEP_42NS);
+        P.commit(4); P.challenge(7); T("transcript");                              // xi (:399-414)
+        P.evals();
+        P.challenge(5); P.challenge(6); T("transcript");                           // v1, v2 (:474-479)
+        P.eval(STEP_52NS);
+        P.fri_prove();
+        zkin = P.finish();
+        pool_defer_begin();                               // nothing is launched from here on: the buffers and trees go back as one burst
     }
-    o << ",\"publics\":"; put_list(o, publics.data(), publics.size());
-    if (bn128) {                                          // serializer.rs:255-262: non-GL proofs carry the prover address
-        o << ",\"proverAddr\":\"";
-        for (char c : S.prover_addr) { if (c == '"' || c == '\\') o << '\\'; o << c; }
-        o << '"';
-    }
-    o << '}';
-    S.t_json_end = std::chrono::steady_clock::now();
-    pool_defer_begin();                                   // nothing is launched from here on: the buffers and trees go back as one burst
-    return o.str();
+    return zkin;
 }
 
 struct DeferFlush { ~DeferFlush() { pool_defer_flush(); } };   // after stark_gen's locals are gone (also when it throws)
@@ -1132,6 +1251,145 @@ int zk_stark_verify(const zk_stark_setup_t* s, const char* zkin_json) {
             if (!ok) set_error("stark_verify: " + why);
         }) != 0) return -1;
     return ok;
+}
+
+// ---- the staged prover (zk_stark_new / zk_stark_eval / zk_stark_commit_stage / zk_stark_set_challenge / zk_stark_evals / zk_fri_prove) ----
+zk_stark_ctx_t* zk_stark_new(zk_stark_setup_t* s, const uint64_t* cm_pols, const uint64_t* d_cm_pols, uint64_t n_words, void* stream) {
+    zk_stark_ctx* c = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(s, "zk_stark_new: null setup");
+            ZK_REQUIRE((cm_pols != nullptr) != (d_cm_pols != nullptr) || n_words == 0, "zk_stark_new: the trace is given once, in host memory or in device memory");
+            c = new zk_stark_ctx(*s, cm_pols, K(d_cm_pols), n_words, (hipStream_t)stream);
+        }) != 0) return nullptr;
+    return c;
+}
+int zk_stark_commit_stage(zk_stark_ctx_t* c, int stage, uint64_t root[4]) {
+    return guard([&] {
+        ZK_REQUIRE(c, "null context");
+        c->commit(stage);
+        if (root) { u64 r[4]; c->tree[stage - 1]->root(r); memcpy(root, r, 32); }
+    });
+}
+int zk_stark_challenge(zk_stark_ctx_t* c, int i, uint64_t out[3]) {
+    return guard([&] {
+        ZK_REQUIRE(c, "null context");
+        on_stream(c->st);
+        c->challenge(i);
+        if (out) { u64 v[3]; c->get_challenge(i, v); memcpy(out, v, 24); }
+    });
+}
+int zk_stark_set_challenge(zk_stark_ctx_t* c, int i, const uint64_t v[3]) {
+    return guard([&] { ZK_REQUIRE(c && v, "null argument"); on_stream(c->st); c->set_challenge(i, K(v)); });
+}
+int zk_stark_eval(zk_stark_ctx_t* c, int step) { return guard([&] { ZK_REQUIRE(c, "null context"); c->eval(step); }); }
+int zk_stark_calculate_h1h2(zk_stark_ctx_t* c) { return guard([&] { ZK_REQUIRE(c, "null context"); c->calculate_h1h2(); }); }
+int zk_stark_calculate_z(zk_stark_ctx_t* c) { return guard([&] { ZK_REQUIRE(c, "null context"); c->calculate_z(); }); }
+int zk_stark_evals(zk_stark_ctx_t* c, uint64_t* evals_out, uint64_t cap_words) {
+    int n = -1;
+    if (guard([&] {
+            ZK_REQUIRE(c, "null context");
+            c->evals();
+            if (evals_out) {
+                ZK_REQUIRE(cap_words >= 3ull * c->n_ev, "zk_stark_evals: the output holds fewer than 3 words per evaluation");
+                if (c->n_ev) ZK_HIP(hipMemcpyAsync(evals_out, c->d_evals.p, 24ull * c->n_ev, hipMemcpyDeviceToHost, c->st));
+                ZK_HIP(hipStreamSynchronize(c->st));
+            }
+            n = (int)c->n_ev;
+        }) != 0) return -1;
+    return n;
+}
+int zk_stark_fri_prove(zk_stark_ctx_t* c) { return guard([&] { ZK_REQUIRE(c, "null context"); c->fri_prove(); }); }
+char* zk_stark_finish(zk_stark_ctx_t* c) {
+    char* out = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(c, "null context");
+            const std::string z = c->finish();
+            self_check(c->S, z);
+            out = (char*)malloc(z.size() + 1);
+            ZK_REQUIRE(out, "out of memory");
+            memcpy(out, z.c_str(), z.size() + 1);
+        }) != 0) return nullptr;
+    return out;
+}
+const uint64_t* zk_stark_fri_pol_dev(const zk_stark_ctx_t* c) { return c && c->ran[STEP_52NS] ? C(c->ptr[S_F_2NS]) : nullptr; }
+const zk_merkle_t* zk_stark_tree(const zk_stark_ctx_t* c, int j) {
+    if (!c || j < 1 || j > 5) return nullptr;
+    const AnyTree* t = j == 5 ? c->S.const_tree.get() : (j <= c->committed ? c->tree[j - 1].get() : nullptr);
+    return t ? t->gl : nullptr;                           // (scalar-field trees have no zk_merkle_t: NULL)
+}
+int zk_stark_free(zk_stark_ctx_t* c) { return guard([&] { if (c) { on_stream(c->st); pool_defer_begin(); delete c; } }); }
+
+// FRI::prove(transcript, pol, query_pol) (fri.rs:84-184) on its own: the caller's TranscriptGL, a device polynomial of 2^nbits_ext extension
+// values and the trees the queries open (the reference passes them as the `query_pol` closure).  -> JSON text, the FRI part of a zkin
+// (serializer.rs:189-252) with the query trees numbered from 1: s<k>_root / s<k>_vals / s<k>_siblings for the folded polynomials,
+// s0_vals<j> / s0_siblings<j> for query tree j, finalPol, plus "ys", the query indices.
+char* zk_fri_prove_dev(zk_transcript_t* transcript, const uint64_t* d_pol, uint32_t nbits_ext, const uint32_t* steps, uint32_t n_steps,
+                       uint32_t n_queries, const zk_merkle_t* const* query_trees, uint32_t n_query_trees, void* stream) {
+    char* out = nullptr;
+    if (guard([&] {
+            ZK_REQUIRE(transcript && d_pol && steps && n_steps >= 1 && (query_trees || n_query_trees == 0), "zk_fri_prove_dev: null argument");
+            ZK_REQUIRE(nbits_ext <= 32 && steps[0] <= nbits_ext, "zk_fri_prove_dev: the first step cannot exceed the polynomial's size");
+            hipStream_t st = (hipStream_t)stream;
+            on_stream(st);
+            AnyTranscript tr(transcript);
+            const std::vector<u32> sv(steps, steps + n_steps);
+            FriState F;
+            F.commit(tr, nullptr, K(d_pol), nbits_ext, sv, n_queries, st, nullptr);
+            std::vector<std::unique_ptr<AnyTree>> borrowed;
+            std::vector<const AnyTree*> all_trees; std::vector<u64> all_mask;
+            for (size_t si = 1; si < n_steps; ++si) { all_trees.push_back(F.trees[si - 1].get()); all_mask.push_back((1ull << sv[si]) - 1); }
+            for (u32 j = 0; j < n_query_trees; ++j) {
+                ZK_REQUIRE(query_trees[j], "zk_fri_prove_dev: null query tree");
+                borrowed.emplace_back(new AnyTree(query_trees[j], merkle_width(query_trees[j]), merkle_height(query_trees[j])));
+                ZK_REQUIRE(borrowed.back()->height >= (1ull << sv[0]), "zk_fri_prove_dev: a query tree is shorter than the first FRI step");
+                all_trees.push_back(borrowed.back().get()); all_mask.push_back((1ull << sv[0]) - 1);
+            }
+            const u64 n_last = 1ull << sv.back();
+            size_t open_words = 0;
+            for (const AnyTree* t : all_trees) open_words += (size_t)n_queries * ((size_t)t->width + 4 * (size_t)t->depth());
+            ReadBack rb(4 * n_steps + 3 * n_last + n_queries + open_words, st);
+            std::vector<size_t> off_root(n_steps, 0), off_open(all_trees.size(), 0);
+            for (size_t si = 0; si + 1 < n_steps; ++si) off_root[si] = rb.add(F.trees[si]->root_dev(), 4);
+            const size_t off_last = rb.add(F.d_pol, 3 * n_last), off_ys = rb.add(F.d_ys.u(), n_queries);
+            for (size_t j = 0; j < all_trees.size(); ++j) {
+                const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
+                off_open[j] = rb.words;
+                merkle_group_proofs_masked_async(all_trees[j]->gl, F.d_ys.u(), all_mask[j], n_queries, rb.reserve(per * n_queries), st);
+            }
+            rb.fetch();
+            auto openings = [&](JOut& o, size_t j, bool paths) {
+                const u32 depth = all_trees[j]->depth(), w = all_trees[j]->width;
+                const size_t per = (size_t)w + 4 * (size_t)depth;
+                o << '[';
+                for (u32 q = 0; q < n_queries; ++q) {
+                    const u64* p = rb.at(off_open[j] + q * per);
+                    if (q) o << ',';
+                    if (!paths) { put_list(o, p, w); continue; }
+                    o << '[';
+                    for (u32 l = 0; l < depth; ++l) { if (l) o << ','; put_list(o, p + w + 4 * l, 4); }
+                    o << ']';
+                }
+                o << ']';
+            };
+            JOut o;
+            o << "{\"ys\":"; put_list(o, rb.at(off_ys), n_queries);
+            for (size_t si = 1; si < n_steps; ++si) {
+                o << ",\"s" << si << "_root\":"; put_digest(o, rb.at(off_root[si - 1]), nullptr);
+                o << ",\"s" << si << "_vals\":"; openings(o, si - 1, false);
+                o << ",\"s" << si << "_siblings\":"; openings(o, si - 1, true);
+            }
+            for (u32 j = 0; j < n_query_trees; ++j) { o << ",\"s0_vals" << (size_t)(j + 1) << "\":"; openings(o, n_steps - 1 + j, false); }
+            for (u32 j = 0; j < n_query_trees; ++j) { o << ",\"s0_siblings" << (size_t)(j + 1) << "\":"; openings(o, n_steps - 1 + j, true); }
+            o << ",\"finalPol\":[";
+            for (u64 i = 0; i < n_last; ++i) { if (i) o << ','; put_list(o, rb.at(off_last) + 3 * i, 3); }
+            o << "]}";
+            const std::string z = o.str();
+            pool_defer_begin();
+            out = (char*)malloc(z.size() + 1);
+            ZK_REQUIRE(out, "out of memory");
+            memcpy(out, z.c_str(), z.size() + 1);
+        }) != 0) return nullptr;
+    return out;
 }
 
 void zk_string_free(char* s) { free(s); }

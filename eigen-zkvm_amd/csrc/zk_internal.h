@@ -118,6 +118,8 @@ void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint
 // openings of a GL tree at n device-resident (already range-checked) indices, written to device memory as
 // n x (width + 4 * depth) words: no host round trip (capi.hip; the prover batches the openings of all its trees)
 void merkle_group_proofs_async(const struct ::zk_merkle* t, const u64* d_idx, uint32_t n, u64* d_out, hipStream_t st);
+uint32_t merkle_width(const struct ::zk_merkle* t);
+uint64_t merkle_height(const struct ::zk_merkle* t);
 void merkle_group_proofs_masked_async(const struct ::zk_merkle* t, const u64* d_idx, u64 mask, uint32_t n, u64* d_out, hipStream_t st);
 void transcript_permutations_async(struct ::zk_transcript* t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st);
 uint64_t h1h2_work_words(uint64_t n);

@@ -427,6 +427,10 @@ class NativeStarkSetup:
         finally:
             lib().zk_string_free(p)
 
+    def staged(self, cm_n, stream=None):
+        """one proof in progress, stage by stage (zk_stark_new ...): the seams a caller with its own stark_gen.rs binds"""
+        return StagedProof(self, cm_n, stream)
+
     def free(self):
         if self._h:
             lib().zk_stark_setup_free(self._h); self._h = None
@@ -436,6 +440,98 @@ class NativeStarkSetup:
             self.free()
         except Exception:
             pass
+
+
+STEP_2PREV, STEP_3PREV, STEP_3, STEP_42NS, STEP_52NS = range(5)                # zkgpu.h ZK_STEP_*
+
+
+class StagedProof:
+    """stark_gen cut at the reference's seams (include/zkgpu.h "the staged prover"): `commit_stage` = extend_and_merkelize + transcript.put
+    (stark_gen.rs:709-750), `eval` = calculate_exps_parallel (:786-792), `challenge` = transcript.get_field into ctx.challenges, `evals`
+    (:416-472), `fri_prove` (fri.rs:84-184), `finish` = openings + zkin.  `run_all()` is the reference's order; its zkin equals gen()'s."""
+
+    def __init__(self, setup, cm_n, stream=None):
+        self._setup = setup                                                          # (keeps the setup alive)
+        if isinstance(cm_n, DevArray):
+            self._h = lib().zk_stark_new(setup._h, None, cm_n.ptr, cm_n.n, stream)
+        else:
+            c = _np(cm_n)
+            self._h = lib().zk_stark_new(setup._h, _ptr(c), None, c.size, stream)
+        if not self._h:
+            raise ZkError(lib().zk_last_error().decode())
+
+    def commit_stage(self, stage):
+        o = np.zeros(4, np.uint64); _check(lib().zk_stark_commit_stage(self._h, stage, _ptr(o))); return [int(v) for v in o]
+
+    def challenge(self, i):
+        o = np.zeros(3, np.uint64); _check(lib().zk_stark_challenge(self._h, i, _ptr(o))); return [int(v) for v in o]
+
+    def set_challenge(self, i, v):
+        a = np.ascontiguousarray(np.array([int(x) for x in v], dtype=np.uint64)); _check(lib().zk_stark_set_challenge(self._h, i, _ptr(a)))
+
+    def eval(self, step): _check(lib().zk_stark_eval(self._h, step))
+    def calculate_h1h2(self): _check(lib().zk_stark_calculate_h1h2(self._h))
+    def calculate_z(self): _check(lib().zk_stark_calculate_z(self._h))
+
+    def evals(self):
+        n = lib().zk_stark_evals(self._h, None, 0)
+        if n < 0:
+            raise ZkError(lib().zk_last_error().decode())
+        return n
+
+    def fri_prove(self): _check(lib().zk_stark_fri_prove(self._h))
+
+    def fri_pol_dev(self): return lib().zk_stark_fri_pol_dev(self._h)
+    def tree(self, j): return lib().zk_stark_tree(self._h, j)
+
+    def finish(self):
+        import ctypes
+        p = lib().zk_stark_finish(self._h)
+        if not p:
+            raise ZkError(lib().zk_last_error().decode())
+        try:
+            return ctypes.string_at(p)
+        finally:
+            lib().zk_string_free(p)
+
+    def run_all(self):
+        """stark_gen.rs:279-545, in order -> zkin bytes"""
+        self.commit_stage(1); self.challenge(0); self.challenge(1)
+        self.eval(STEP_2PREV); self.calculate_h1h2()
+        self.commit_stage(2); self.challenge(2); self.challenge(3)
+        self.eval(STEP_3PREV); self.calculate_z(); self.eval(STEP_3)
+        self.commit_stage(3); self.challenge(4)
+        self.eval(STEP_42NS)
+        self.commit_stage(4); self.challenge(7)
+        self.evals(); self.challenge(5); self.challenge(6)
+        self.eval(STEP_52NS)
+        self.fri_prove()
+        return self.finish()
+
+    def free(self):
+        if self._h:
+            lib().zk_stark_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def fri_prove_dev(transcript, d_pol, nbits_ext, steps, n_queries, query_trees, stream=None):
+    """FRI::prove(transcript, pol, query_pol) (fri.rs:84-184) alone: transcript = a TranscriptGL handle of this library (zk_transcript_t*),
+    d_pol = device pointer to 3 << nbits_ext words, query_trees = zk_merkle_t* handles -> the FRI part of a zkin as a dict (+ "ys")"""
+    import ctypes
+    st = (ctypes.c_uint32 * len(steps))(*steps)
+    tr = (ctypes.c_void_p * max(1, len(query_trees)))(*query_trees)
+    p = lib().zk_fri_prove_dev(transcript, d_pol, nbits_ext, st, len(steps), n_queries, tr, len(query_trees), stream)
+    if not p:
+        raise ZkError(lib().zk_last_error().decode())
+    try:
+        return json.loads(ctypes.string_at(p))
+    finally:
+        lib().zk_string_free(p)
 
 
 class reference_compat_paths:

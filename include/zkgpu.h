@@ -319,6 +319,48 @@ char* zk_stark_gen_dev(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t 
  * (test/stark_aggregation.sh:70-73 runs its recursion tasks as parallel processes for the same reason).  One setup serves
  * one proof at a time. */
 char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64_t n_words, void* stream);
+
+/* ---- the staged prover: stark_gen cut at the reference's own seams ----
+ * For a caller that keeps its own stark_gen.rs and swaps in the device for the heavy calls it makes:
+ *   calculate_exps_parallel(ctx, starkinfo, segment, domain, step)   stark_gen.rs:786-792   -> zk_stark_eval
+ *   extend_and_merkelize(ctx, stage) + transcript.put(root)          stark_gen.rs:709-750   -> zk_stark_commit_stage
+ *   transcript.get_field() into ctx.challenges[i]                    stark_gen.rs:285-294   -> zk_stark_challenge (or zk_stark_set_challenge)
+ *   calculate_H1H2 / calculate_Z over every argument of the PIL      stark_gen.rs:300-353   -> zk_stark_calculate_h1h2 / _z
+ *   the evaluations at xi, w xi + their absorption                   stark_gen.rs:416-472   -> zk_stark_evals
+ *   FRI::prove(transcript, pol, query_pol)                           fri.rs:84-184          -> zk_stark_fri_prove, or zk_fri_prove_dev alone
+ * A context (one proof in progress) belongs to one setup and one stream; its sections stay in HBM between the calls.  The calls are
+ * accepted in the reference's order only (an out-of-order call fails with a message naming what comes first):
+ *   new -> commit 1 -> challenge 0, 1 -> eval 2PREV -> calculate_h1h2 -> commit 2 -> challenge 2, 3 -> eval 3PREV -> calculate_z ->
+ *   eval 3 -> commit 3 -> challenge 4 -> eval 42NS -> commit 4 -> challenge 7 -> evals -> challenge 5, 6 -> eval 52NS -> fri_prove -> finish.
+ * zk_stark_gen* is exactly this sequence; a proof driven through the stages is byte-equal to zk_stark_gen's (tests/cabi/zkgpu_cabi_test.c).
+ *   zk_stark_new            the trace in host memory (cm_pols) or in HBM (d_cm_pols), the other NULL; sections allocated, publics computed and absorbed
+ *   zk_stark_commit_stage   stage 1..3: LDE + Merkle tree of cm<stage>; stage 4: Q split (inverse NTT, split, NTT) + tree 4; the root is absorbed by the
+ *                           context's transcript and copied to root[4] when non-NULL (GL words, or the raw Montgomery limbs of a scalar-field digest)
+ *   zk_stark_challenge      challenge i <- the context's transcript (copied to out[3] when non-NULL); i: 0 u, 1 defVal, 2 gamma, 3 beta, 4 vc, 5 v1, 6 v2, 7 xi
+ *   zk_stark_set_challenge  challenge i <- v: for a caller whose own sponge does Fiat-Shamir; such a caller also runs FRI through zk_fri_prove_dev
+ *                           with its own transcript (zk_stark_fri_pol_dev, zk_stark_tree give it the polynomial and the query trees)
+ *   zk_stark_evals          -> number of evaluations; 3 words each into evals_out (host, may be NULL)
+ *   zk_stark_finish         the openings, the one read-back, the zkin JSON (malloc'ed: zk_string_free); honours zk_stark_setup_set_self_check
+ *   zk_fri_prove_dev        FRI::prove on any device polynomial of 2^nbits_ext extension values (3 words each) with the caller's TranscriptGL and the
+ *                           GL trees its queries open: -> JSON {"ys", "s<k>_root", "s<k>_vals", "s<k>_siblings", "s0_vals<j>", "s0_siblings<j>", "finalPol"}
+ *                           (query trees numbered from 1; serializer.rs:189-252's layout), malloc'ed                                              */
+typedef struct zk_stark_ctx zk_stark_ctx_t;
+enum { ZK_STEP_2PREV = 0, ZK_STEP_3PREV = 1, ZK_STEP_3 = 2, ZK_STEP_42NS = 3, ZK_STEP_52NS = 4 };
+zk_stark_ctx_t* zk_stark_new(zk_stark_setup_t* s, const uint64_t* cm_pols, const uint64_t* d_cm_pols, uint64_t n_words, void* stream);
+int zk_stark_commit_stage(zk_stark_ctx_t* c, int stage, uint64_t root[4]);
+int zk_stark_challenge(zk_stark_ctx_t* c, int i, uint64_t out[3]);
+int zk_stark_set_challenge(zk_stark_ctx_t* c, int i, const uint64_t v[3]);
+int zk_stark_eval(zk_stark_ctx_t* c, int step);
+int zk_stark_calculate_h1h2(zk_stark_ctx_t* c);
+int zk_stark_calculate_z(zk_stark_ctx_t* c);
+int zk_stark_evals(zk_stark_ctx_t* c, uint64_t* evals_out, uint64_t cap_words);
+int zk_stark_fri_prove(zk_stark_ctx_t* c);
+char* zk_stark_finish(zk_stark_ctx_t* c);
+const uint64_t* zk_stark_fri_pol_dev(const zk_stark_ctx_t* c);            /* f_2ns after step 52NS: FRI's input, 3 << nBitsExt words in HBM */
+const zk_merkle_t* zk_stark_tree(const zk_stark_ctx_t* c, int j);         /* 1..4 once committed, 5 = the constants' tree; NULL for scalar-field hashing */
+int zk_stark_free(zk_stark_ctx_t* c);
+char* zk_fri_prove_dev(zk_transcript_t* transcript, const uint64_t* d_pol, uint32_t nbits_ext, const uint32_t* steps, uint32_t n_steps,
+                       uint32_t n_queries, const zk_merkle_t* const* query_trees, uint32_t n_query_trees, void* stream);
 void zk_string_free(char* s);
 int zk_stark_setup_free(zk_stark_setup_t* s);
 

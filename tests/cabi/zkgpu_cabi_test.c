@@ -30,7 +30,9 @@ int main(int argc, char **argv) {
                        (void *)zk_merkle_group_proof, (void *)zk_merkle_free, (void *)zk_transcript_new, (void *)zk_fri_fold_dev,
                        (void *)zk_stark_calculate_z_dev, (void *)zk_msm_g1_bn254, (void *)zk_stark_setup_new, (void *)zk_stark_gen,
                        (void *)zk_stark_gen_dev, (void *)zk_stark_gen_dev_on, (void *)zk_program_run_rows_dev, (void *)zk_string_free, (void *)zk_stark_setup_free, (void *)zk_c12_exec_new,
-                       (void *)zk_groth16_setup_new, (void *)zk_program_compile};
+                       (void *)zk_groth16_setup_new, (void *)zk_program_compile, (void *)zk_stark_new, (void *)zk_stark_eval, (void *)zk_stark_commit_stage,
+                       (void *)zk_stark_set_challenge, (void *)zk_stark_challenge, (void *)zk_stark_evals, (void *)zk_stark_fri_prove, (void *)zk_stark_finish, (void *)zk_stark_free,
+                       (void *)zk_fri_prove_dev, (void *)zk_stark_verify_set_reference_compat};
         unsigned n = 0;
         for (unsigned i = 0; i < sizeof fns / sizeof fns[0]; ++i) n += fns[i] != NULL;
         printf("linked %u entry points; p = %llu; devices = %d\n", n, (unsigned long long)zk_gl_modulus(), zk_device_count());
@@ -89,6 +91,32 @@ int main(int argc, char **argv) {
     if (!zkin2 || strcmp(zkin, zkin2) != 0) { fprintf(stderr, "self-checked proof differs: %s\n", zk_last_error()); return 1; }
     zk_string_free(zkin2);
     printf("verified: accepted, rejected under another constant root, self check on\n");
+    /* the same proof through the staged seams (zkgpu.h "the staged prover"; stark_gen.rs:279-545 in the reference's order): byte-equal */
+    {
+        zk_stark_ctx_t *c = zk_stark_new(su, cm, NULL, cm_bytes / 8, NULL);
+        if (!c) { fprintf(stderr, "zk_stark_new: %s\n", zk_last_error()); return 1; }
+        uint64_t r[4], ch[3];
+        if (zk_stark_eval(c, ZK_STEP_2PREV) == 0) { fprintf(stderr, "step2prev before the first commitment must be refused\n"); return 1; }
+        CHECK(zk_stark_commit_stage(c, 1, r)); CHECK(zk_stark_challenge(c, 0, ch)); CHECK(zk_stark_challenge(c, 1, NULL));
+        CHECK(zk_stark_eval(c, ZK_STEP_2PREV)); CHECK(zk_stark_calculate_h1h2(c));
+        CHECK(zk_stark_commit_stage(c, 2, NULL)); CHECK(zk_stark_challenge(c, 2, NULL)); CHECK(zk_stark_challenge(c, 3, NULL));
+        CHECK(zk_stark_eval(c, ZK_STEP_3PREV)); CHECK(zk_stark_calculate_z(c)); CHECK(zk_stark_eval(c, ZK_STEP_3));
+        CHECK(zk_stark_commit_stage(c, 3, NULL)); CHECK(zk_stark_challenge(c, 4, NULL));
+        CHECK(zk_stark_eval(c, ZK_STEP_42NS));
+        CHECK(zk_stark_commit_stage(c, 4, NULL)); CHECK(zk_stark_challenge(c, 7, NULL));
+        const int n_ev = zk_stark_evals(c, NULL, 0);
+        if (n_ev < 1) { fprintf(stderr, "zk_stark_evals: %s\n", zk_last_error()); return 1; }
+        CHECK(zk_stark_challenge(c, 5, NULL)); CHECK(zk_stark_challenge(c, 6, NULL));
+        CHECK(zk_stark_eval(c, ZK_STEP_52NS));
+        if (zk_stark_fri_pol_dev(c) == NULL || zk_stark_tree(c, 1) == NULL || zk_stark_tree(c, 5) == NULL) { fprintf(stderr, "staged accessors\n"); return 1; }
+        CHECK(zk_stark_fri_prove(c));
+        char *zs = zk_stark_finish(c);
+        if (!zs || strcmp(zs, zkin) != 0) { fprintf(stderr, "the staged proof differs from zk_stark_gen's: %s\n", zk_last_error()); return 1; }
+        if (strstr(zkin, "\"root1\"") == NULL || r[0] == 0) { fprintf(stderr, "commit_stage did not hand out the root\n"); return 1; }
+        zk_string_free(zs);
+        CHECK(zk_stark_free(c));
+        printf("staged prover: %d evaluations, zkin byte-equal to zk_stark_gen's\n", n_ev);
+    }
     zk_string_free(zkin);
     if (zk_stark_gen(su, cm, cm_bytes / 8 - 1) != NULL) { fprintf(stderr, "a short trace must be rejected\n"); return 1; }
     CHECK(zk_stark_setup_free(su));

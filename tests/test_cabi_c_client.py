@@ -25,7 +25,7 @@ def test_c_client_compiles_links_and_loads(zk, tmp_path):
     exe = _build(tmp_path)
     out = subprocess.run([str(exe), "link"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    assert "linked 25 entry points; p = 18446744069414584321" in out.stdout
+    assert "linked 36 entry points; p = 18446744069414584321" in out.stdout
 
 
 def test_header_is_self_contained_c(tmp_path):

@@ -29,6 +29,9 @@ def c_type(t):
     if arr: t = t[:arr.start()].strip() + "*"
     if t.endswith("*"):
         inner = t[:-1].strip()
+        if "*" in inner:                             # a pointer to a pointer: `T* const*` (the pointee pointer is const) or `T**`
+            pointee_const = inner.endswith("const")
+            return ("ptr", pointee_const, c_type(inner[:-5] if pointee_const else inner))
         const = bool(re.search(r"\bconst\b", inner))
         inner = re.sub(r"\bconst\b", "", inner).strip()
         inner = re.sub(r"^struct\s+", "", inner)
@@ -62,7 +65,10 @@ def rs_type(t):
     t = t.strip()
     m = re.match(r"^\*(const|mut)\s+(.+)$", t)
     if m:
-        return ("ptr", m.group(1) == "const", RS_BASE.get(m.group(2).strip(), m.group(2).strip()))
+        inner = m.group(2).strip()
+        if inner.startswith("*"):                    # `*const *const T`
+            return ("ptr", m.group(1) == "const", rs_type(inner))
+        return ("ptr", m.group(1) == "const", RS_BASE.get(inner, inner))
     return ("val", RS_BASE.get(t, t))
 
 

@@ -8,5 +8,5 @@ for k in fib c12 r1; do
   python3 tools/proof_timeline.py $f > gpurun_out/tl_$k.txt 2>&1
   python3 tools/proof_timeline.py $f --full > gpurun_out/tl_${k}_full.txt 2>&1
   tail -3 gpurun_out/sp_$k.log; head -30 gpurun_out/tl_$k.txt
-  find gpurun_out/sp_$k -name '*kernel_trace.csv' -delete
+
 done
