@@ -255,6 +255,24 @@ __global__ void gather_proofs_kernel(const u64* __restrict__ elements, const u64
         }
     }
 }
+// every tree of a proof in ONE launch: block (q, j) serves query q of tree j (a small proof opened its seven or eight trees in as many
+// launches of ~5 us each); lane d copies the sibling of level d
+struct GatherMulti { const u64* elements[16]; const u64* nodes[16]; u64* out[16]; u64 height[16], mask[16]; u32 width[16], depth[16]; };
+__global__ void gather_proofs_multi_kernel(const GatherMulti G, const u64* __restrict__ idxs) {
+    const u32 t = threadIdx.x, j = blockIdx.y;
+    const u32 width = G.width[j], depth = G.depth[j];
+    const u64 idx = idxs[blockIdx.x] & G.mask[j];
+    const u64* __restrict__ elements = G.elements[j];
+    const u64* __restrict__ nodes = G.nodes[j];
+    u64* __restrict__ out = G.out[j] + (u64)blockIdx.x * (width + 4 * depth);
+    for (u32 i = t; i < width; i += blockDim.x) out[i] = elements[idx * width + i];
+    for (u32 d = t; d < depth; d += blockDim.x) {
+        u64 n = G.height[j], off = 0;
+        for (u32 k = 0; k < d; ++k) { const u64 next = (n - 1) / 2 + 1; off += next * 2; n = next; }
+        const u64* sib = nodes + 4 * (off + ((idx >> d) ^ 1));
+        for (int k = 0; k < 4; ++k) out[width + 4 * d + k] = sib[k];
+    }
+}
 // arity-16 trees of the scalar-field hashes (merklehash_bn128.rs:86-106): block q -> row + depth groups of 16 digests
 __global__ void fr_gather_proofs_kernel(const u64* __restrict__ elements, const u64* __restrict__ nodes, u32 width, u64 height,
                                         u32 depth, const u64* __restrict__ idxs, u64* __restrict__ outs) {
@@ -550,10 +568,30 @@ void merkle_group_proofs_masked_async(const zk_merkle* t, const u64* d_idx, u64 
     hipLaunchKernelGGL(gather_proofs_kernel, dim3(n), dim3(64), 0, st, t->d_elements, t->nodes.u(), t->width, t->height, t->depth, d_idx, d_out, mask);
     ZK_HIP(hipGetLastError());
 }
+// up to 16 trees at once: tree j at d_idx[q] & mask[j] into d_out[j] (rows of width_j + 4 depth_j words per query)
+void merkle_group_proofs_multi_async(const zk_merkle* const* trees, const u64* masks, u64* const* d_outs, uint32_t n_trees, const u64* d_idx, uint32_t n, hipStream_t st) {
+    if (n == 0 || n_trees == 0) return;
+    for (uint32_t j0 = 0; j0 < n_trees; j0 += 16) {
+        GatherMulti G; memset(&G, 0, sizeof G);
+        const uint32_t m = std::min<uint32_t>(16, n_trees - j0);
+        for (uint32_t j = 0; j < m; ++j) {
+            const zk_merkle* t = trees[j0 + j];
+            ZK_REQUIRE(masks[j0 + j] < t->height, "MerkleTreeError: access invalid node");
+            G.elements[j] = t->d_elements; G.nodes[j] = t->nodes.u(); G.out[j] = d_outs[j0 + j];
+            G.height[j] = t->height; G.mask[j] = masks[j0 + j]; G.width[j] = t->width; G.depth[j] = t->depth;
+        }
+        hipLaunchKernelGGL(gather_proofs_multi_kernel, dim3(n, m), dim3(64), 0, st, G, d_idx);
+        ZK_HIP(hipGetLastError());
+    }
+}
 // get_permutations (transcript.rs:73-102) into device memory, on `st`: the indices feed the gather kernels without visiting the host
 void transcript_permutations_async(zk_transcript* t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st) {
     t->stream = st;
     transcript_permutations_dev(t->state.p, n, nbits, d_dst, st);
+}
+void transcript_put_get_async(zk_transcript* t, const u64* d_src, uint64_t n_put, u64* d_dst, uint32_t n_get, uint32_t bits, hipStream_t st) {
+    if (t->stream != st) { ZK_HIP(hipStreamSynchronize(t->stream)); t->stream = st; }
+    transcript_put_get_dev(t->state.p, d_src, n_put, d_dst, n_get, bits, st);
 }
 }  // namespace zk
 extern "C" {

@@ -112,7 +112,25 @@ __device__ __forceinline__ u64 pow(u64 a, u64 e) {  // field_gl.rs:467-479
     while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; }
     return r;
 }
-__device__ __forceinline__ u64 inv(u64 a) { return pow(a, GL_P - 2); }  // field_gl.rs:415-449
+// a^(p - 2), p - 2 = 0xFFFFFFFE_FFFFFFFF = (2^31 - 1) 2^33 + (2^32 - 1): an addition chain of 64 squarings and 10 products (field_gl.rs:415-449
+// walks its own chain of 72); square-and-multiply over the 63 one-bits took 125 -- an inversion is a single dependent chain wherever it occurs
+__device__ __forceinline__ u64 sqr_n(u64 a, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) a = mul(a, a);
+    return a;
+}
+__device__ __forceinline__ u64 inv(u64 a) {
+    const u64 t2 = mul(mul(a, a), a);                 // a^(2^2 - 1)
+    const u64 t3 = mul(mul(t2, t2), a);               // a^(2^3 - 1)
+    const u64 t6 = mul(sqr_n(t3, 3), t3);
+    const u64 t7 = mul(mul(t6, t6), a);
+    const u64 t14 = mul(sqr_n(t7, 7), t7);
+    const u64 t15 = mul(mul(t14, t14), a);
+    const u64 t30 = mul(sqr_n(t15, 15), t15);
+    const u64 t31 = mul(mul(t30, t30), a);            // a^(2^31 - 1)
+    const u64 t32 = mul(mul(t31, t31), a);            // a^(2^32 - 1)
+    return mul(sqr_n(t31, 33), t32);
+}
 
 // GF(p^3) = GF(p)[x]/(x^3 - x - 1)  (starky/src/f3g.rs).  Device values never carry the
 // reference's runtime `dim` tag: the width (1 or 3 words) is a static property of each buffer.

@@ -762,6 +762,44 @@ __global__ __launch_bounds__(64) void tr_get_kernel(TranscriptState* t, u64* __r
     tr_store(t, &ts);
 }
 
+// put(src[0..n_put)) then squeeze n_get words (or n_get indices of `bits` bits) in ONE launch: a proof's Fiat-Shamir steps are "absorb a root,
+// draw one or two challenges" -- three launches of ~5 us floor each around a single permutation
+__global__ __launch_bounds__(64) void tr_put_get_kernel(TranscriptState* t, const u64* __restrict__ src, u64 n_put, u64* __restrict__ dst, u32 n, u32 bits) {
+    ZK_POSEIDON_LDS;
+    __shared__ TranscriptState ts;
+    load_tables(tab);
+    tr_load(&ts, t);
+    for (u64 i = 0; i < n_put; ++i) {                                       // tr_put_kernel
+        if (threadIdx.x == 0) { ts.n_out = 0; ts.out_pos = 0; ts.pending[ts.n_pending++] = src[i]; }
+        __syncthreads();
+        if (ts.n_pending == 8) tr_update(&ts, tab);
+    }
+    if (bits == 0) {                                                        // tr_get_kernel
+        for (u32 i = 0; i < n; ++i) {
+            if (ts.out_pos >= ts.n_out) tr_update(&ts, tab);
+            if (threadIdx.x == 0) dst[i] = ts.out[ts.out_pos++];
+            __syncthreads();
+        }
+        tr_store(t, &ts);
+        return;
+    }
+    u64 field = 0; u32 cur_bit = 63, i = 0, j = 0; u64 a = 0;
+    while (i < n) {
+        if (cur_bit == 63) {
+            if (ts.out_pos >= ts.n_out) tr_update(&ts, tab);
+            field = ts.out[ts.out_pos];
+            __syncthreads();
+            if (threadIdx.x == 0) ts.out_pos++;
+            __syncthreads();
+            cur_bit = 0;
+        }
+        if ((field >> cur_bit) & 1) a += 1ull << j;
+        ++cur_bit; ++j;
+        if (j == bits) { if (threadIdx.x == 0) dst[i] = a; ++i; a = 0; j = 0; }
+    }
+    tr_store(t, &ts);
+}
+
 bool g_consts_loaded[64] = {};
 
 std::mutex g_consts_mu;
@@ -822,6 +860,11 @@ void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st)
 }
 void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st) {
     hipLaunchKernelGGL(tr_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_dst, n_words, 0u);
+    ZK_HIP(hipGetLastError());
+}
+void transcript_put_get_dev(void* d_t, const u64* d_src, uint64_t n_put, u64* d_dst, uint32_t n_get, uint32_t bits, hipStream_t st) {
+    ZK_REQUIRE(bits <= 63, "get_permutations: nbits out of range");
+    hipLaunchKernelGGL(tr_put_get_kernel, dim3(1), dim3(64), 0, st, (TranscriptState*)d_t, d_src, n_put, d_dst, n_get, bits);
     ZK_HIP(hipGetLastError());
 }
 void transcript_permutations_dev(void* d_t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st) {

@@ -147,9 +147,13 @@ __global__ void zh_inv_kernel(u64 sn, u64 we, u32 n, u64* __restrict__ out) {   
 // Eight consecutive points per lane: one exponentiation for the first x, one extension-field inversion for all
 // eight denominators (Montgomery's trick: prefix products, invert the last, walk back).
 constexpr int XD_PER = 8;
-__global__ __launch_bounds__(256) void xdivxsub_kernel(const u64* __restrict__ xi, u64 mulw, u64 w_ext, u64 n, u64* __restrict__ out) {
+// (blockIdx.y picks one of two multipliers / outputs: x/(x - xi) and x/(x - xi w) of a proof are one launch -- each is a latency-bound
+// chain of an exponentiation and an inversion per lane, and two launches stood one behind the other)
+__global__ __launch_bounds__(256) void xdivxsub_kernel(const u64* __restrict__ xi, u64 mulw0, u64 mulw1, u64 w_ext, u64 n, u64* __restrict__ out0, u64* __restrict__ out1) {
     const u64 k0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * XD_PER;
     if (k0 >= n) return;
+    const u64 mulw = blockIdx.y ? mulw1 : mulw0;
+    u64* __restrict__ out = blockIdx.y ? out1 : out0;
     const f3 z = gl::f3_muls(ld3(xi), mulw);
     u64 x[XD_PER]; f3 den[XD_PER], pre[XD_PER];
     x[0] = gl::mul(49, gl::pow(w_ext, k0));
@@ -169,9 +173,12 @@ __global__ __launch_bounds__(256) void xdivxsub_kernel(const u64* __restrict__ x
     }
 }
 // LEv[i] = (xi * mulw / 49)^i                                                   stark_gen.rs:416-427
-__global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi, u64 mul_c, u64 n, u64* __restrict__ out) {
+struct LevPowArgs { u64 c[4]; u64* out[4]; };           // up to four tables of powers in one launch (blockIdx.y): LEv, LpEv, the quotient's weights
+__global__ __launch_bounds__(256) void lev_pow_kernel(const u64* __restrict__ xi, const LevPowArgs A, u64 n) {
     const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * XD_PER;   // eight consecutive powers per lane
     if (i0 >= n) return;
+    const u64 mul_c = A.c[blockIdx.y];
+    u64* __restrict__ out = A.out[blockIdx.y];
     const f3 b = gl::f3_muls(ld3(xi), mul_c);
     f3 p = f3_pow(b, i0);
 #pragma unroll
@@ -459,7 +466,13 @@ void zh_inv_dev(uint32_t nbits, uint32_t extend_bits, u64* d_out, hipStream_t st
 
 void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hipStream_t st) {
     const u64 n = 1ull << nbits_ext;
-    hipLaunchKernelGGL(xdivxsub_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, mulw, gl::hroot(nbits_ext), n, d_out);
+    hipLaunchKernelGGL(xdivxsub_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, mulw, mulw, gl::hroot(nbits_ext), n, d_out, d_out);
+    ZK_HIP(hipGetLastError());
+}
+void xdivxsub2_dev(const u64* d_xi, u64 mulw0, u64 mulw1, uint32_t nbits_ext, u64* d_out0, u64* d_out1, hipStream_t st) {   // both tables of a proof, one launch
+    const u64 n = 1ull << nbits_ext;
+    dim3 g = grid1((n + XD_PER - 1) / XD_PER); g.y = 2;
+    hipLaunchKernelGGL(xdivxsub_kernel, g, dim3(256), 0, st, d_xi, mulw0, mulw1, gl::hroot(nbits_ext), n, d_out0, d_out1);
     ZK_HIP(hipGetLastError());
 }
 
@@ -470,7 +483,18 @@ void lev_pow_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_
     const u64 n = 1ull << nbits;
     u64 c = gl::hinv(shift);
     if (prime) c = gl::hmul(c, gl::hroot(nbits));
-    hipLaunchKernelGGL(lev_pow_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, c, n, d_pow);
+    LevPowArgs A; memset(&A, 0, sizeof A); A.c[0] = c; A.out[0] = d_pow;
+    hipLaunchKernelGGL(lev_pow_kernel, grid1((n + XD_PER - 1) / XD_PER), dim3(256), 0, st, d_xi, A, n);
+    ZK_HIP(hipGetLastError());
+}
+// several tables of powers in one launch: table v holds (xi w^prime[v] / shift[v])^k, k < 2^nbits
+void lev_pow_multi_dev(const u64* d_xi, uint32_t nbits, uint32_t n_tables, const bool* prime, const u64* shift, u64* const* d_pow, hipStream_t st) {
+    ZK_REQUIRE(n_tables >= 1 && n_tables <= 4, "lev_pow_multi: 1..4 tables");
+    const u64 n = 1ull << nbits;
+    LevPowArgs A; memset(&A, 0, sizeof A);
+    for (u32 v = 0; v < n_tables; ++v) { u64 c = gl::hinv(shift[v]); if (prime[v]) c = gl::hmul(c, gl::hroot(nbits)); A.c[v] = c; A.out[v] = d_pow[v]; }
+    dim3 g = grid1((n + XD_PER - 1) / XD_PER); g.y = n_tables;
+    hipLaunchKernelGGL(lev_pow_kernel, g, dim3(256), 0, st, d_xi, A, n);
     ZK_HIP(hipGetLastError());
 }
 void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_out, u64* d_pow, u64* d_tmp2, hipStream_t st) {

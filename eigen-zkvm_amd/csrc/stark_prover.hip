@@ -129,32 +129,58 @@ struct AnyTranscript {
     }
     explicit AnyTranscript(zk_transcript_t* callers) : gl(callers), owned(false) { ZK_REQUIRE(gl != nullptr, "null transcript"); }   // a caller's TranscriptGL, borrowed
     AnyTranscript(const AnyTranscript&) = delete; AnyTranscript& operator=(const AnyTranscript&) = delete;
-    ~AnyTranscript() { if (!owned) return; if (gl) zk_transcript_free(gl); if (fr) F->tr_free(fr); }
+    ~AnyTranscript() {
+        if (!owned) { if (gl && pend_n) (void)zk_transcript_put_dev(gl, C(pend_src), pend_n, pend_st); return; }   // (a borrowed sponge must not lose an absorbed word)
+        if (gl) zk_transcript_free(gl);
+        if (fr) F->tr_free(fr);
+    }
+    // Goldilocks sponge: a put is DEFERRED until the next squeeze and rides in its launch (tr_put_get_kernel) -- "absorb a root, draw two
+    // challenges" is one launch instead of three.  The absorbed words must stay in HBM until then: they are roots inside live trees, the
+    // context's evaluations / publics, the last FRI polynomial.  Two puts in a row, or the end of the object, flush as a plain put.
+    const u64* pend_src = nullptr; size_t pend_n = 0; hipStream_t pend_st = nullptr;
+    void flush() {
+        if (!pend_n) return;
+        ck(zk_transcript_put_dev(gl, C(pend_src), pend_n, pend_st));
+        pend_n = 0;
+    }
+    void defer(const u64* d, size_t n, hipStream_t st) { flush(); pend_src = d; pend_n = n; pend_st = st; }
     // n Goldilocks words, one transcript element each (publics, evals, the last FRI polynomial)
     void put_words_dev(const u64* d, size_t n, hipStream_t st) {
         if (!n) return;
-        if (gl) { ck(zk_transcript_put_dev(gl, C(d), n, st)); return; }
+        if (gl) { defer(d, n, st); return; }
         std::vector<u64> h(n);
         ZK_HIP(hipStreamSynchronize(st));
         ZK_HIP(hipMemcpy(h.data(), d, 8 * n, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) ck(F->tr_put(fr, M(&h[i]), 1));
     }
     void put_root(const AnyTree& t, hipStream_t st) {   // a digest is ONE element of the scalar-field transcripts
-        if (gl) { ck(zk_transcript_put_dev(gl, zk_merkle_nodes_dev(t.gl) + 4 * (zk_merkle_n_nodes(t.height) - 1), 4, st)); return; }
+        if (gl) { defer(K(zk_merkle_nodes_dev(t.gl)) + 4 * (zk_merkle_n_nodes(t.height) - 1), 4, st); return; }
         u64 r[4]; t.root(r);
         ck(F->tr_put(fr, M(r), 4));
     }
-    void get_field_dev(u64* d_out3, hipStream_t st) {
-        if (gl) { ck(zk_transcript_get_field_dev(gl, M(d_out3), st)); return; }
-        u64 f[3];
-        ck(F->tr_get_field(fr, M(f)));
-        ZK_HIP(hipMemcpy(d_out3, f, 24, hipMemcpyHostToDevice));
+    // n_fields consecutive get_field()s into d_out (3 words each)
+    void get_fields_dev(u64* d_out, u32 n_fields, hipStream_t st) {
+        if (gl) {
+            if (pend_n) ZK_REQUIRE(pend_st == st, "transcript: a deferred put moved streams");
+            transcript_put_get_async(gl, pend_src, pend_n, d_out, 3 * n_fields, 0, st);
+            pend_n = 0;
+            return;
+        }
+        for (u32 k = 0; k < n_fields; ++k) {
+            u64 f[3];
+            ck(F->tr_get_field(fr, M(f)));
+            ZK_HIP(hipMemcpy(d_out + 3 * k, f, 24, hipMemcpyHostToDevice));
+        }
     }
+    void get_field_dev(u64* d_out3, hipStream_t st) { get_fields_dev(d_out3, 1, st); }
     void get_permutations_dev(u32 n, u32 nbits, u64* d_out, hipStream_t st) {   // Goldilocks transcript only: the indices stay in HBM
         ZK_REQUIRE(gl != nullptr, "get_permutations_dev: scalar-field transcripts keep their sponge on the host");
-        transcript_permutations_async(gl, n, nbits, d_out, st);
+        ZK_REQUIRE(nbits >= 1 && nbits <= 63, "get_permutations: nbits out of range");
+        transcript_put_get_async(gl, pend_src, pend_n, d_out, n, nbits, st);
+        pend_n = 0;
     }
     void get_permutations(u32 n, u32 nbits, u64* out) {
+        if (gl) flush();
         ck(gl ? zk_transcript_get_permutations(gl, n, nbits, M(out)) : F->tr_get_permutations(fr, n, nbits, M(out)));
     }
 };
@@ -222,6 +248,7 @@ struct zk_stark_setup {
     bool self_check = false;               // verify every proof before handing it out, as stark_prove does (prove.rs:124-132)
     TreePtr const_tree;
     TreePtr zero_tree;                     // the tree over a zero-width section (tree2 / tree3 of a PIL without such columns): the same in every proof
+    DevBuf d_pub_pos;                      // word position in cm1_n of every public that is a cell of a committed column (~0: a computed public)
     DevBuf x_n, x_2ns, zi;                 // x over the domain and the extended coset, 1 / Z_H on the coset (stark_gen.rs:231-249): functions of the sizes only
     u64 const_root[4] = {};
     ProgramPtr step2prev, step3prev, step3, step42ns, step52ns;
@@ -418,6 +445,30 @@ __global__ __launch_bounds__(256) void rb_gather_kernel(const RbSegs G, u64* __r
     u64* __restrict__ d = stage + G.off[blockIdx.x];
     for (u32 i = threadIdx.x; i < G.n[blockIdx.x]; i += blockDim.x) d[i] = s[i];
 }
+// A proof's preamble cleared eight small buffers and copied its publics with one hipMemsetAsync / hipMemcpyAsync each: a dozen launches of
+// ~5 us before the first real kernel.  One launch clears up to sixteen buffers (block row y = buffer y), one gathers the publics.
+struct ClearSegs { u64* p[16]; u64 n[16]; };
+__global__ __launch_bounds__(256) void clear_list_kernel(const ClearSegs G) {
+    u64* __restrict__ p = G.p[blockIdx.y];
+    const u64 n = G.n[blockIdx.y];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] = 0;
+}
+struct ClearList {
+    ClearSegs G; u32 k = 0; u64 longest = 0; hipStream_t st;
+    explicit ClearList(hipStream_t s) : st(s) {}
+    void add(void* p, u64 words) { if (!words) return; G.p[k] = (u64*)p; G.n[k] = words; longest = std::max(longest, words); if (++k == 16) flush(); }
+    void flush() {
+        if (!k) return;
+        const u32 bx = (u32)std::min<u64>(2048, (longest + 1023) / 1024);   // ~4 words per lane and trip at most; big sections get the whole chip
+        hipLaunchKernelGGL(clear_list_kernel, dim3(std::max<u32>(1, bx), k), dim3(256), 0, st, G);
+        ZK_HIP(hipGetLastError());
+        k = 0; longest = 0;
+    }
+};
+__global__ void gather_publics_kernel(const u64* __restrict__ cm, const u64* __restrict__ pos, u32 n, u64* __restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && pos[i] != ~0ull) out[i] = cm[pos[i]];
+}
 struct ReadBack {
     DevBuf stage; std::vector<u64> host; size_t words = 0, cap = 0; hipStream_t st;
     RbSegs segs; u32 n_segs = 0;                         // the pieces added since the last launch: one kernel copies sixteen of them
@@ -535,6 +586,14 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         for (int sec : {S_CM1_N, S_CM2_N, S_CM3_N}) any_empty |= S->sN[sec] == 0;
         if (any_empty) S->zero_tree.reset(new AnyTree(S->fr, nullptr, 0, Next, nullptr));
         ZK_HIP(hipStreamSynchronize(nullptr));
+    }
+    {
+        const JVal& pubs = I.at("publics");
+        std::vector<u64> pos(std::max<size_t>(1, pubs.size()), ~0ull);
+        for (size_t i = 0; i < pubs.size(); ++i)
+            if (pubs.at(i).at("polType").str() == "cmP") pos[i] = pubs.at(i).at("idx").u64() * S->sN[S_CM1_N] + pubs.at(i).at("polId").u64();
+        S->d_pub_pos.reserve(pos.size() * 8);
+        h2d_sync(S->d_pub_pos.p, pos.data(), pos.size() * 8);
     }
     const clk::time_point t_tree = clk::now();
     const JitStats j0 = jit_stats();
@@ -687,6 +746,7 @@ struct zk_stark_ctx {
         : S(s), st(stream), T((on_stream(stream), stream)), I(s.info), nbits(s.nbits), nbits_ext(s.nbits_ext), ext(s.nbits_ext - s.nbits),
           N(1ull << s.nbits), Next(1ull << s.nbits_ext), sN(s.sN), bn128(s.fr) {
         ZK_REQUIRE(n_words == N * sN[S_CM1_N], "cm trace size mismatch");
+        ClearList clear_list(st); clr = &clear_list;
         // sections (stark_gen.rs:204-229); const_n / const_2ns belong to the setup
         if (d_cm) ptr[S_CM1_N] = const_cast<u64*>(d_cm);   // read-only for the prover: cm1_n is never a destination
         else {
@@ -702,33 +762,38 @@ struct zk_stark_ctx {
         alloc(S_Q_2NS, S.q_dim * Next, false); alloc(S_F_2NS, 3 * Next, false); alloc(S_SCRATCH, 3 * Next);
         ptr[S_CONST_N] = S.const_n.u(); ptr[S_CONST_2NS] = S.const_2ns.u();
 
-        d_chal.reserve(24 * 8); zero(d_chal, 24, st);                                        // challenge[8] (constant.rs:39-50)
+        d_chal.reserve(24 * 8); zero_(d_chal, 24);                                           // challenge[8] (constant.rs:39-50)
         n_ev = (u32)I.at("ev_map").size();
         n_pub = (u32)I.at("publics").size();
-        d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero(d_evals, std::max<u32>(1, n_ev) * 3, st);
-        d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero(d_pub, std::max<u32>(1, n_pub), st);
+        d_evals.reserve(std::max<u32>(1, n_ev) * 24); zero_(d_evals, std::max<u32>(1, n_ev) * 3);
+        d_pub.reserve(std::max<u32>(1, n_pub) * 8); zero_(d_pub, std::max<u32>(1, n_pub));
         for (const char* ctx : {"pu_ctx", "pe_ctx", "ci_ctx"}) n_z += I.at(ctx).arr.size();
         z_checks.reserve(24 * std::max<size_t>(1, n_z));
 
         // publics (stark_gen.rs:256-270) and their absorption (:272-277)
         pub_on_device = d_cm != nullptr;                  // device-resident trace: no host round trip per public
         if (pub_on_device) {
-            d_pub_ext.reserve(std::max<u32>(1, n_pub) * 16); zero(d_pub_ext, 2 * (size_t)std::max<u32>(1, n_pub), st);   // words 1 and 2 of every computed public: checked to be zero at the end
+            d_pub_ext.reserve(std::max<u32>(1, n_pub) * 16); zero_(d_pub_ext, 2 * (size_t)std::max<u32>(1, n_pub));   // words 1 and 2 of every computed public: checked to be zero at the end
+        }
+        clear_list.flush(); clr = nullptr;                // one launch for every clearing above
+        if (pub_on_device && n_pub) {
             for (u32 i = 0; i < n_pub; ++i) {
                 const JVal& pe = I.at("publics").at(i);
                 const std::string& ty = pe.at("polType").str();
+                if (ty == "cmP") ZK_REQUIRE(pe.at("idx").u64() * sN[S_CM1_N] + pe.at("polId").u64() < n_words, "public out of range");
+                else if (ty != "imP") throw Error("Invalid public type " + ty);
+            }
+            hipLaunchKernelGGL(gather_publics_kernel, dim3((n_pub + 63) / 64), dim3(64), 0, st, d_cm, (const u64*)S.d_pub_pos.u(), n_pub, d_pub.u());   // every cell-of-a-column public, one launch
+            ZK_HIP(hipGetLastError());
+            for (u32 i = 0; i < n_pub; ++i) {
+                const JVal& pe = I.at("publics").at(i);
+                if (pe.at("polType").str() != "imP") continue;                         // calculate_exp_at_point :558-572
                 const u64 idx = pe.at("idx").u64();
-                if (ty == "cmP") {
-                    const u64 pos = idx * sN[S_CM1_N] + pe.at("polId").u64();
-                    ZK_REQUIRE(pos < n_words, "public out of range");
-                    ZK_HIP(hipMemcpyAsync(d_pub.u() + i, d_cm + pos, 8, hipMemcpyDeviceToDevice, st));
-                } else if (ty == "imP") {                                              // calculate_exp_at_point :558-572
-                    ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
-                    ZK_REQUIRE(idx < N, "public out of range");
-                    run(S.public_programs[i], false, nullptr, idx, 1);                 // its one row; reads the publics before it from d_pub
-                    ZK_HIP(hipMemcpyAsync(d_pub.u() + i, ptr[S_SCRATCH] + 3 * idx, 8, hipMemcpyDeviceToDevice, st));
-                    ZK_HIP(hipMemcpyAsync(d_pub_ext.u() + 2 * i, ptr[S_SCRATCH] + 3 * idx + 1, 16, hipMemcpyDeviceToDevice, st));
-                } else throw Error("Invalid public type " + ty);
+                ZK_REQUIRE(i < S.public_programs.size(), "missing public program");
+                ZK_REQUIRE(idx < N, "public out of range");
+                run(S.public_programs[i], false, nullptr, idx, 1);                     // its one row; reads the publics before it from d_pub
+                ZK_HIP(hipMemcpyAsync(d_pub.u() + i, ptr[S_SCRATCH] + 3 * idx, 8, hipMemcpyDeviceToDevice, st));
+                ZK_HIP(hipMemcpyAsync(d_pub_ext.u() + 2 * i, ptr[S_SCRATCH] + 3 * idx + 1, 16, hipMemcpyDeviceToDevice, st));
             }
         }
         for (u32 i = 0; i < n_pub && !pub_on_device; ++i) {
@@ -767,8 +832,10 @@ struct zk_stark_ctx {
     }
     zk_stark_ctx(const zk_stark_ctx&) = delete; zk_stark_ctx& operator=(const zk_stark_ctx&) = delete;
 
+    ClearList* clr = nullptr;                             // the constructor's clearings travel as one launch
+    void zero_(DevBuf& b, size_t words) { if (clr) clr->add(b.p, words); else zero(b, words, st); }
     void alloc(int s, u64 words, bool zeroed = true) {
-        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero(B[s], words, st); ptr[s] = B[s].u();
+        B[s].reserve(std::max<u64>(1, words) * 8); if (zeroed) zero_(B[s], words); ptr[s] = B[s].u();
     }
     void run(const ProgramPtr& p, bool e, hipStream_t on = nullptr, u64 row0 = 0, u64 count = ~0ull) {
         if (!p) return;
@@ -808,7 +875,8 @@ struct zk_stark_ctx {
         return t;
     }
     // transcript.get_field() -> challenge i (u, defVal, gamma, beta, vc, v1, v2, xi: constant.rs:39-50), kept in HBM for the step programs
-    void challenge(int i) { ZK_REQUIRE(i >= 0 && i < 8, "challenge index"); tr->get_field_dev(d_chal.u() + 3 * i, st); }
+    // (count consecutive challenges in one launch, together with the root absorbed just before)
+    void challenge(int i, int count = 1) { ZK_REQUIRE(i >= 0 && count >= 1 && i + count <= 8, "challenge index"); tr->get_fields_dev(d_chal.u() + 3 * i, (u32)count, st); }
     void set_challenge(int i, const u64 v[3]) {                                    // a caller with its own transcript
         ZK_REQUIRE(i >= 0 && i < 8, "challenge index");
         ZK_HIP(hipMemcpyAsync(d_chal.u() + 3 * i, v, 24, hipMemcpyHostToDevice, st));
@@ -897,8 +965,7 @@ struct zk_stark_ctx {
             default:
                 ZK_REQUIRE(evals_done, "step52ns follows the evaluations and the challenges v1, v2");
                 xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);            // stark_gen.rs:481-522
-                xdivxsub_dev(d_chal.u() + 3 * 7, 1, nbits_ext, xdiv.u(), st);
-                xdivxsub_dev(d_chal.u() + 3 * 7, gl::hroot(nbits), nbits_ext, xdivw.u(), st);
+                xdivxsub2_dev(d_chal.u() + 3 * 7, 1, gl::hroot(nbits), nbits_ext, xdiv.u(), xdivw.u(), st);   // both tables, one launch
                 T.mark("xDivXSubXi");
                 run(S.step52ns, true); break;
         }
@@ -950,15 +1017,21 @@ struct zk_stark_ctx {
         ZK_REQUIRE(committed == 4 && !evals_done, "the evaluations follow the fourth commitment and the challenge xi, once");
         on_stream(st);
         const u64* d_xi = d_chal.u() + 3 * 7;
-        DevBuf LEv, LpEv, pw, pwp, lt1, lt2;
-        LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
-        lev_dev(d_xi, nbits, false, 1, LEv.u(), lt1.u(), lt2.u(), st);
-        lev_dev(d_xi, nbits, true, 1, LpEv.u(), lt1.u(), lt2.u(), st);
+        DevBuf LEv, LpEv, pw, pwp, lt1, lt1p, lt2;
+        LEv.reserve(3 * N * 8); LpEv.reserve(3 * N * 8); lt1.reserve(3 * N * 8); lt1p.reserve(3 * N * 8); lt2.reserve(3 * N * 8);
         bool q_plain = false, q_prime = false;            // which openings of the quotient's pieces exist
         for (const JVal& ev : I.at("ev_map").arr)
             if (ev.at("type_").str() == "cm" && S.pol(S.cm_2ns.at(ev.at("id").u64())).slot == S_CM4_2NS) (ev.at("prime").boolean() ? q_prime : q_plain) = true;
-        if (d_qq2 && q_plain) { pw.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, false, 49, pw.u(), st); }
-        if (d_qq2 && q_prime) { pwp.reserve(3 * N * 8); lev_pow_dev(d_xi, nbits, true, 49, pwp.u(), st); }
+        {   // every table of powers this stage needs in ONE launch (each is an exponentiation chain per lane: two to four launches stood in a row):
+            // the powers of xi and xi w (-> LEv, LpEv by the inverse transforms below), of xi / 49 and xi w / 49 (the quotient's weights)
+            bool prime[4] = {false, true, false, true}; u64 shift[4] = {1, 1, 49, 49}; u64* out[4] = {lt1.u(), lt1p.u(), nullptr, nullptr};
+            u32 nt = 2;
+            if (d_qq2 && q_plain) { pw.reserve(3 * N * 8); prime[nt] = false; shift[nt] = 49; out[nt++] = pw.u(); }
+            if (d_qq2 && q_prime) { pwp.reserve(3 * N * 8); prime[nt] = true; shift[nt] = 49; out[nt++] = pwp.u(); }
+            lev_pow_multi_dev(d_xi, nbits, nt, prime, shift, out, st);
+            ntt_dev(lt1.u(), LEv.u(), lt2.u(), 3, nbits, true, st);                   // FFT::ifft over F3G == per-limb iNTT (base-field roots)
+            ntt_dev(lt1p.u(), LpEv.u(), lt2.u(), 3, nbits, true, st);
+        }
         if (n_ev) {
             std::vector<EvalDescKHost> descs;
             for (const JVal& ev : I.at("ev_map").arr) {
@@ -1028,11 +1101,14 @@ struct zk_stark_ctx {
             const size_t off_pub = pub_on_device ? rb.add(d_pub.u(), n_pub) : 0, off_ext = pub_on_device ? rb.add(d_pub_ext.u(), 2 * (size_t)n_pub) : 0;
             if (!bn128) {
                 off_ys = rb.add(F.d_ys.u(), S.n_queries);
+                std::vector<const zk_merkle_t*> mt; std::vector<u64*> mo;
                 for (size_t j = 0; j < all_trees.size(); ++j) {
                     const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
                     off_open[j] = rb.words;
-                    merkle_group_proofs_masked_async(all_trees[j]->gl, F.d_ys.u(), all_mask[j], S.n_queries, rb.reserve(per * S.n_queries), st);
+                    mt.push_back(all_trees[j]->gl); mo.push_back(rb.reserve(per * S.n_queries));
                 }
+                rb.flush();                                   // (the pieces collected so far are copied before the openings' launch is queued: one order on `st`)
+                merkle_group_proofs_multi_async(mt.data(), all_mask.data(), mo.data(), (u32)mt.size(), F.d_ys.u(), S.n_queries, st);   // every tree, one launch
             }
             rb.fetch();
             for (size_t i = 0; i < n_z; ++i)
@@ -1131,10 +1207,10 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
     {
         zk_stark_ctx P(S, cm_pols, d_cm, n_words, st);
         auto T = [&](const char* name) { P.T.mark(name); };
-        P.commit(1); P.challenge(0); P.challenge(1); T("transcript");              // u, defVal (stark_gen.rs:279-294)
+        P.commit(1); P.challenge(0, 2); T("transcript");                           // u, defVal (stark_gen.rs:279-294)
         P.eval(STEP_2PREV);
         P.calculate_h1h2();
-        P.commit(2); P.challenge(2); P.challenge(3); T("transcript");              // gamma, beta (:310-321)
+        P.commit(2); P.challenge(2, 2); T("transcript");                           // gamma, beta (:310-321)
         P.eval(STEP_3PREV);
         P.calculate_z();
         P.eval(STEP_3);
@@ -1142,7 +1218,7 @@ std::string stark_gen(zk_stark_setup& S, const uint64_t* cm_pols, const u64* d_c
         P.eval(STEP_42NS);
         P.commit(4); P.challenge(7); T("transcript");                              // xi (:399-414)
         P.evals();
-        P.challenge(5); P.challenge(6); T("transcript");                           // v1, v2 (:474-479)
+        P.challenge(5, 2); T("transcript");                                        // v1, v2 (:474-479)
         P.eval(STEP_52NS);
         P.fri_prove();
         zkin = P.finish();
@@ -1351,11 +1427,13 @@ char* zk_fri_prove_dev(zk_transcript_t* transcript, const uint64_t* d_pol, uint3
             std::vector<size_t> off_root(n_steps, 0), off_open(all_trees.size(), 0);
             for (size_t si = 0; si + 1 < n_steps; ++si) off_root[si] = rb.add(F.trees[si]->root_dev(), 4);
             const size_t off_last = rb.add(F.d_pol, 3 * n_last), off_ys = rb.add(F.d_ys.u(), n_queries);
+            std::vector<const zk_merkle_t*> mt; std::vector<u64*> mo;
             for (size_t j = 0; j < all_trees.size(); ++j) {
                 const size_t per = (size_t)all_trees[j]->width + 4 * (size_t)all_trees[j]->depth();
                 off_open[j] = rb.words;
-                merkle_group_proofs_masked_async(all_trees[j]->gl, F.d_ys.u(), all_mask[j], n_queries, rb.reserve(per * n_queries), st);
+                mt.push_back(all_trees[j]->gl); mo.push_back(rb.reserve(per * n_queries));
             }
+            merkle_group_proofs_multi_async(mt.data(), all_mask.data(), mo.data(), (u32)mt.size(), F.d_ys.u(), n_queries, st);
             rb.fetch();
             auto openings = [&](JOut& o, size_t j, bool paths) {
                 const u32 depth = all_trees[j]->depth(), w = all_trees[j]->width;

@@ -99,6 +99,7 @@ void transcript_init_dev(void* d_t, hipStream_t st);
 void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st);
 void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st);
 void transcript_permutations_dev(void* d_t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st);
+void transcript_put_get_dev(void* d_t, const u64* d_src, uint64_t n_put, u64* d_dst, uint32_t n_get, uint32_t bits, hipStream_t st);
 
 // ---- prover glue (stark.hip) ----
 const u64* ntt_w256_table(bool inverse);  // w_256^(+-e), e < 256, device pointer (ntt.hip)
@@ -111,6 +112,8 @@ void xdivxsub_dev(const u64* d_xi, u64 mulw, uint32_t nbits_ext, u64* d_out, hip
 struct EvalDescKHost { const u64* buf; const u64* L; uint64_t width; uint64_t offset; uint32_t dim; uint32_t rshift; };   // L: weights per row; rows k << rshift
 void lev_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_out, u64* d_pow, u64* d_tmp2, hipStream_t st);
 void lev_pow_dev(const u64* d_xi, uint32_t nbits, bool prime, u64 shift, u64* d_pow, hipStream_t st);
+void lev_pow_multi_dev(const u64* d_xi, uint32_t nbits, uint32_t n_tables, const bool* prime, const u64* shift, u64* const* d_pow, hipStream_t st);
+void xdivxsub2_dev(const u64* d_xi, u64 mulw0, u64 mulw1, uint32_t nbits_ext, u64* d_out0, u64* d_out1, hipStream_t st);
 void evals_k_dev(const EvalDescKHost* descs, uint32_t n_ev, uint32_t nbits, u64* d_out, hipStream_t st);
 void evals_dev(const EvalDescHost* descs, uint32_t n_ev, uint32_t nbits, uint32_t ext, const u64* d_LEv, const u64* d_LpEv, u64* d_out, hipStream_t st);
 void pol_get_dev(const u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint64_t n, u64* d_out, hipStream_t st);
@@ -118,10 +121,13 @@ void pol_set_dev(u64* d_buf, uint64_t width, uint64_t offset, uint32_t dim, uint
 // openings of a GL tree at n device-resident (already range-checked) indices, written to device memory as
 // n x (width + 4 * depth) words: no host round trip (capi.hip; the prover batches the openings of all its trees)
 void merkle_group_proofs_async(const struct ::zk_merkle* t, const u64* d_idx, uint32_t n, u64* d_out, hipStream_t st);
+void merkle_group_proofs_multi_async(const struct ::zk_merkle* const* trees, const u64* masks, u64* const* d_outs, uint32_t n_trees, const u64* d_idx, uint32_t n, hipStream_t st);
 uint32_t merkle_width(const struct ::zk_merkle* t);
 uint64_t merkle_height(const struct ::zk_merkle* t);
 void merkle_group_proofs_masked_async(const struct ::zk_merkle* t, const u64* d_idx, u64 mask, uint32_t n, u64* d_out, hipStream_t st);
 void transcript_permutations_async(struct ::zk_transcript* t, uint32_t n, uint32_t nbits, u64* d_dst, hipStream_t st);
+// put d_src[0..n_put) and squeeze n_get words (bits == 0) or n_get indices of `bits` bits, one launch on `st`
+void transcript_put_get_async(struct ::zk_transcript* t, const u64* d_src, uint64_t n_put, u64* d_dst, uint32_t n_get, uint32_t bits, hipStream_t st);
 uint64_t h1h2_work_words(uint64_t n);
 void calculate_h1h2_dev(const u64* d_f, const u64* d_t, uint64_t n, u64* d_h1, u64* d_h2, u64* d_work, u64** d_missing, hipStream_t st);
 void calculate_z_dev(const u64* d_num, const u64* d_den, uint64_t n, u64* d_z, u64* d_work, u64* d_check, hipStream_t st);
