@@ -217,6 +217,17 @@ __device__ __forceinline__ u64 shfl64(u64 v, int src) {
     const u32 lo = (u32)__shfl((int)(u32)v, src, 16), hi = (u32)__shfl((int)(u32)(v >> 32), src, 16);
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u32 dpp_opaque(u32 v) { asm volatile("" : "+v"(v)); return v; }   // keeps the DPP moves where they are written (section 3.9)
+// lane SRC of every 16-lane row to the whole row: one DPP move per half (row_newbcast, gfx90a and later) -- a VALU move, where
+// __shfl(.., SRC, 16) is a ds_bpermute round trip through the LDS crossbar (~120 cycles on the critical path of a lone wave)
+template <int SRC>
+__device__ __forceinline__ u64 bcast64(u64 v) {
+    static_assert(SRC >= 0 && SRC < 16, "a lane of the row");
+    const u32 v0 = dpp_opaque((u32)v), v1 = dpp_opaque((u32)(v >> 32));
+    const u32 z0 = dpp_opaque((u32)__builtin_amdgcn_update_dpp(0, (int)v0, 0x150 + SRC, 0xF, 0xF, false));
+    const u32 z1 = dpp_opaque((u32)__builtin_amdgcn_update_dpp(0, (int)v1, 0x150 + SRC, 0xF, 0xF, false));
+    return gl::mk64(z0, z1);
+}
 __device__ __forceinline__ u64 coop_mds(u64 x, int l) {
     const u32 lo = (u32)x, hi = (u32)(x >> 32);
     const u32 c0 = (u32)ZK_POSEIDON_M[13] + (l == 0 ? 8u : 0u);
@@ -235,13 +246,12 @@ __device__ __forceinline__ u64 coop_mds(u64 x, int l) {
     return r >= GL_P ? r - GL_P : r;
 }
 __device__ __forceinline__ void coop_gather(u64 x, u32 (&x0)[12], u32 (&x1)[12]) {
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        x0[j] = (u32)__shfl((int)(u32)x, j, 16);
-        x1[j] = (u32)__shfl((int)(u32)(x >> 32), j, 16);
-    }
+    static_for<0, 12>([&](auto JI) {
+        constexpr int j = decltype(JI)::value;
+        const u64 b = bcast64<j>(x);
+        x0[j] = (u32)b; x1[j] = (u32)(b >> 32);
+    });
 }
-__device__ __forceinline__ u32 dpp_opaque(u32 v) { asm volatile("" : "+v"(v)); return v; }   // keeps the DPP moves where they are written (section 3.9)
 // x^7 + c where the two lanes of a pair hold the same x: the even lane takes x^3 = x^2 x, the odd one x^4 = x^2 x^2, each fetches the
 // other's (one DPP move per half) and both end with x^3 x^4 + c -- three dependent products where pow7_add has four.  The words of
 // a product are the digits of the exact integer, so both lanes hold the same bits.
@@ -285,7 +295,7 @@ __device__ __forceinline__ u64 coop_partial_rounds(u64 x, const u64* __restrict_
             acc_mac(A, cd, u0[m], u1[m]);
             if constexpr (m + 1 < PR_B) { cd = *reinterpret_cast<const ulonglong2*>(CD + 32 * (m + 1)); pc = PC[m + 1]; }
             __builtin_amdgcn_sched_barrier(0);
-            s0 = shfl64(acc_finish(A), m);
+            s0 = bcast64<m>(acc_finish(A));                                  // lane m's accumulator is the next round's s0 in every lane of the row
             __builtin_amdgcn_sched_barrier(0);
         });
         Acc6 E; acc_word(E, x);

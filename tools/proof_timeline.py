@@ -3,7 +3,7 @@
 import csv, re, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 nm = lambda r: re.sub(r"^void ", "", re.sub(r"zk::\(anonymous namespace\)::", "", r["Kernel_Name"])).split("(")[0][:44]
-ends = [i for i, r in enumerate(rows[:-1]) if "gather_proofs_kernel" in r["Kernel_Name"] and "gather_proofs_kernel" not in rows[i + 1]["Kernel_Name"]]
+ends = [i for i, r in enumerate(rows[:-1]) if "gather_proofs" in r["Kernel_Name"] and "gather_proofs" not in rows[i + 1]["Kernel_Name"]]
 a, b = ends[len(ends) // 2] + 1, ends[len(ends) // 2 + 1] + 1           # one proof in the middle of the run (a proof ends with its last gather_proofs_kernel)
 pr = rows[a:b]
 t0 = int(pr[0]["Start_Timestamp"])
