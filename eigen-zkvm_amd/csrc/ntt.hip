@@ -33,6 +33,11 @@ namespace {
 #ifndef ZK_NTT_WAVES
 #define ZK_NTT_WAVES
 #endif
+// elements per tile (a workgroup of ZK_NTT_TILE / 16 lanes, 8 bytes of LDS per element).  4096 ships; 2048 and 1024 exist for the
+// tile-granularity measurements of profiles/r05/ntt_bound.md (tools/build_variant.sh ... "-DZK_NTT_TILE=2048")
+#ifndef ZK_NTT_TILE
+#define ZK_NTT_TILE 4096
+#endif
 constexpr int TW_LO_BITS = 12;
 constexpr int TW_LO = 1 << TW_LO_BITS;
 
@@ -64,9 +69,9 @@ __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __res
 }
 
 template <int LOGA, int LOGB, bool KMODE, bool INV>
-__global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassParams P) {
+__global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel(const PassParams P) {
     constexpr int LOGR = LOGA + LOGB, R = 1 << LOGR, RA = 1 << LOGA, RB = 1 << LOGB;
-    constexpr int C = 4096 / R;                // lanes per tile
+    constexpr int C = ZK_NTT_TILE / R;         // lanes per tile
     constexpr int GA = 16 / RA, GB = 16 / RB;  // independent sub-transforms per thread
     constexpr int TG = R / 16;                 // threads along the transform axis
     constexpr int PAD = KMODE ? 512 / R : 0;   // words; spreads kappa_a rows over banks (KMODE reads)
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) ZK_NTT_WAVES void ntt_pass_kernel(const PassPa
         // shift like the butterflies' own -- once jb is a compile-time number.  jb = ta GA + g and ta = t / C with C = 4096 / R >= 64
         // lanes: the same in every lane of a wave, so a switch over ta (R / 16 <= 4 cases) costs no divergence and turns the 15 general
         // products of a lane into 15 shifts.  (Not for the pre-scaled last pass of a plain inverse transform: its 1/N rides on the table.)
-        if (LOGR <= 6 && LOGB > 0 && P.pre_scale == 1) {
+        if (LOGR <= 6 && C >= 64 && LOGB > 0 && P.pre_scale == 1) {
             static_for<0, TG>([&](auto TA) {
                 constexpr int ta_c = decltype(TA)::value;
                 if (ta == ta_c) {
@@ -326,10 +331,10 @@ ScaleTables get_scale(u32 nbits, u64 g, u64 cst) {  // cst * g^k, k < 2^nbits
 
 template <int LOGA, int LOGB>
 void launch_pass(const PassParams& P, bool kmode, bool inverse, hipStream_t st) {
-    constexpr int C = 4096 >> (LOGA + LOGB);
+    constexpr int C = ZK_NTT_TILE >> (LOGA + LOGB);
     const u64 blocks = (P.inner + C - 1) / C;
     ZK_REQUIRE(blocks < (1ull << 31), "ntt: grid too large");
-    const dim3 g((u32)blocks), b(256);
+    const dim3 g((u32)blocks), b(ZK_NTT_TILE / 16);
     const int variant = (kmode ? 2 : 0) | (inverse ? 1 : 0);
 #define ZK_PASS(K, I) hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, K, I>), g, b, 0, st, P)
     switch (variant) {
