@@ -11,8 +11,9 @@ timed region.  One step = forward NTT then inverse NTT of that column (2 transfo
              transform's passes) / average launch duration measured with HIP events on the launch
              stream; `pass_hbm_frac` additionally rates the bytes each pass really moves (16 B per
              element per pass) against the 8 TB/s peak.
-  cpu_baseline = the CPU oracle (a port of the reference algorithm, fft.rs:39-83) on the same
-             2^24 column, one step, timed on rank 0's host cores.
+  cpu_baseline = the CPU oracle's blocked transform (oracle/oracle.c orc_ntt_blocked: in-cache row transforms +
+             transposes over all host threads, a port of the structure of fft_p.rs:174-239 -- not the scalar
+             fft.rs:39-83) on the same 2^24 column, one step, timed on rank 0's host cores.
 
 N > 1: one process per GPU, each transforming its own column (independent replicas: a single NTT
 does not shard without an all-to-all that no BASELINE config needs -- DESIGN.md (e)); no data-path
@@ -174,7 +175,7 @@ def prove_leg(zk, nbits, verify=True, cpu_baseline=False, host_trace=True):
             ns16 = stark.NativeStarkSetup(PG.consts(nb), json.dumps(PG.program(nb)), json.dumps(ss16))
             same = ns16.gen(cm16) == exp
             ns16.free()
-            out["cpu_baseline"] = {"value": round((1 << nb) / cpu_s / 1e6, 4), "unit": "Mrows/s", "cores": orc.threads(), "kind": "port",
+            out["cpu_baseline"] = {"value": round((1 << nb) / cpu_s / 1e6, 4), "unit": "Mrows/s", "cores": orc.threads(), "kind": "port, python-driven, 2^16-row sample",
                                    "gpu_value": round((1 << nbits) / (min(times[1:]) * 1e-3) / 1e6, 2), "gpu_proof_equals_cpu_proof_on_the_sample": bool(same),
                                    "sample": "the same PIL at 2^16 rows, oracle/stark_prover.py stark_gen (C kernels with OpenMP, Python driver), %.2f s; "
                                              "the offline 2^%d-row oracle proof behind tests/golden took %s s" % (cpu_s, nbits, (_golden(nbits) or {}).get("oracle_seconds", "n/a"))}

@@ -78,15 +78,20 @@ __device__ __forceinline__ u64 mad_eps(u32 r2, u64 t) {
     return mk64(d1 ? v0 : (u32)u, d1 ? v1 : (u32)(u >> 32));
 }
 // lo + r2*2^64 + r3*2^96 mod p = lo - r3 + r2*(2^32-1), canonical; any 32-bit words
-__device__ __forceinline__ u64 reduce_words(u32 w0, u32 w1, u32 r2, u32 r3) {
-    u32 bw0, bw1, e0, e1;
-    u32 t0 = __builtin_subc(w0, r3, 0u, &bw0);           // t = lo - r3
-    u32 t1 = __builtin_subc(w1, 0u, bw0, &bw1);
-    const u32 mb = 0u - bw1;                             // borrowed: t -= 2^32 - 1
-    t0 = __builtin_subc(t0, mb, 0u, &e0);
-    t1 = __builtin_subc(t1, 0u, e0, &e1);
-    return mad_eps(r2, mk64(t0, t1));
+// (w1:w0) - r3, minus 2^32 - 1 more if that borrowed: five instructions with the borrows travelling as carry-ins.  Written as asm
+// because the compiler lowers `subc(w1, 0, borrow)` to a v_cndmask + v_sub_co pair (one instruction more per field product: round 5);
+// the wait states between a flag's producer and its consumer are the compiler's own (s_nop 1), which it cannot add inside asm.
+__device__ __forceinline__ u64 sub_word_fold(u32 w0, u32 w1, u32 r3) {
+    u32 t0, t1, mb;
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_nop 1\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %2\n\ts_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+        : "=&v"(t0), "=&v"(t1), "=&v"(mb) : "v"(w0), "v"(w1), "v"(r3) : "vcc");
+    return mk64(t0, t1);
 }
+__device__ __forceinline__ u64 reduce_words(u32 w0, u32 w1, u32 r2, u32 r3) { return mad_eps(r2, sub_word_fold(w0, w1, r3)); }
 __device__ __forceinline__ u64 mul(u64 a, u64 b) {
     GL_OPAQUE(a); GL_OPAQUE(b);
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -172,17 +177,15 @@ __device__ __forceinline__ u64 mad_eps_nc(u32 r2, u64 t) {          // t + r2*(2
     u64 u; u32 m;
     asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
                  : "=&v"(u), "=v"(m) : "v"(r2), "v"(t) : "vcc");
+#ifdef ZK_GL_EPS_MAD
+    u64 d, carry;                                                    // u + m as ONE multiply-add (m * 1 + u): no zero-extending move for the addend
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry) : "v"(m), "v"(u));
+    return d;
+#else
     return u + m;                                                    // carried: += 2^32 - 1 (cannot carry again)
+#endif
 }
-__device__ __forceinline__ u64 reduce_words_nc(u32 w0, u32 w1, u32 r2, u32 r3) {
-    u32 bw0, bw1, e0, e1;
-    u32 t0 = __builtin_subc(w0, r3, 0u, &bw0);
-    u32 t1 = __builtin_subc(w1, 0u, bw0, &bw1);
-    const u32 mb = 0u - bw1;
-    t0 = __builtin_subc(t0, mb, 0u, &e0);
-    t1 = __builtin_subc(t1, 0u, e0, &e1);
-    return mad_eps_nc(r2, mk64(t0, t1));
-}
+__device__ __forceinline__ u64 reduce_words_nc(u32 w0, u32 w1, u32 r2, u32 r3) { return mad_eps_nc(r2, sub_word_fold(w0, w1, r3)); }
 // acc + x for a 32-bit word x as ONE multiply-add (x * 1 + acc) instead of a zero-extending move and a 64-bit addition
 __device__ __forceinline__ u64 add_word(u64 acc, u32 x) {
     u64 d, carry;
