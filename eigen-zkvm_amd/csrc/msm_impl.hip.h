@@ -701,8 +701,11 @@ static hipStream_t msm_side_stream() {
     if (!ss[dev]) ZK_HIP(hipStreamCreateWithFlags(&ss[dev], hipStreamNonBlocking));
     return ss[dev];
 }
+// produce(ctx, first, count, stream): optional -- makes the points / scalars [first, first + count) of a pre-converted sum on `stream` just before
+// that chunk is sorted there (the endomorphism split of the outer sum: chunk c + 1's split then runs beside chunk c's accumulation, like its sort)
+typedef void (*msm_chunk_producer)(void* ctx, uint64_t first, uint64_t count, hipStream_t stream);
 static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st,
-                     const void* d_preconv = nullptr) {
+                     const void* d_preconv = nullptr, msm_chunk_producer produce = nullptr, void* produce_ctx = nullptr) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
     ZK_REQUIRE(!d_table || (n < (1ull << 24) && base_off + n <= table_n && table_n < (1ull << 24)), "msm table: range out of bounds");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;
@@ -764,6 +767,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         const u32* sc = (const u32*)d_scalars + c0 * MSM_SC_WORDS;
         u32 *counts_p = (u32*)CH[c].counts.p, *offsets_p = (u32*)CH[c].offsets.p, *idx_p = (u32*)CH[c].idx.p, *order_p = (u32*)CH[c].order.p;
         const u64 total = nc * N_WIN;
+        if (produce && nc) { produce(produce_ctx, c0, nc, ss); ZK_HIP(hipGetLastError()); }
         if (nc == 0) { ZK_HIP(hipMemsetAsync(counts_p, 0, n_keys * 4, ss)); ZK_HIP(hipMemsetAsync(offsets_p, 0, n_keys * 4, ss)); }
         else if (lds_sort) {  // LDS-histogram partition (no device-scope atomics)
             const u32 n_blocks = (u32)((nc + SORT_PTS - 1) / SORT_PTS);
@@ -920,6 +924,9 @@ void ubench_affine_dev(const void* d_bases_std, uint64_t n_lanes, uint32_t K, in
 }
 #endif
 void msm_preconv_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points); }
+void msm_preconv_chunked_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st, msm_chunk_producer produce, void* ctx) {
+    msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points, produce, ctx);
+}
 #ifdef MSM_GLV
 // ---- the curve's endomorphism phi(x, y) = (beta x, y) = [lambda](x, y): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128, so a sum
 // over n points with 254-bit scalars becomes a sum over 2n points with 128-bit scalars: the same number of bucket additions, half
@@ -1020,9 +1027,26 @@ void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_
     if (off || n < 4096 || n >= (1ull << 27)) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); return; }
     DevBuf conv2, sc2;
     conv2.reserve((size_t)2 * n * PTW * 4); sc2.reserve((size_t)2 * n * 16);
-    hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
-    ZK_HIP(hipGetLastError());
-    MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);     // asynchronous: conv2 / sc2 go back to the pool with the sum still in flight; pool_free's events order their reuse
+    static const bool chunked = getenv("ZK_MSM_SPLIT_CHUNKED") != nullptr;
+    if (!chunked) {                                                       // the default: the split of all points in front of the sum
+        hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
+        ZK_HIP(hipGetLastError());
+        MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);
+        return;
+    }
+    // Round 5, measured and NOT the default (ZK_MSM_SPLIT_CHUNKED=1): the split (a 256-bit division by lambda and an Fq product per point: 0.37 ms of an
+    // 8 ms sum at 2^22 points) made chunk by chunk on the stream the chunk is sorted on, so that only the first chunk's quarter stands in front of the
+    // sum.  BN254 2^22: 8.04-8.13 ms against 8.03-8.10; 2^23: 15.0 against 14.6-14.7 (profiles/r05/msm_ab_raw.txt) -- the split is integer work like
+    // the accumulation it would run beside (the sort, which does overlap, is memory-bound): nothing to hide it behind.
+    struct SplitCtx { const u32* bases; const u32* scalars; u64 n; u32* conv2; u32* sc2; } ctx{(const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p};
+    auto split_chunk = [](void* c_, uint64_t first, uint64_t count, hipStream_t s) {
+        const SplitCtx* c = (const SplitCtx*)c_;
+        const u64 i0 = first / 2, i1 = std::min<u64>(c->n, (first + count + 1) / 2);      // pairs (2 i, 2 i + 1) belong to point i; chunk boundaries are even
+        if (i1 <= i0) return;
+        hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, c->bases + i0 * (2 * CW_STD), c->scalars + i0 * 8, i1 - i0,
+                           c->conv2 + 2 * i0 * PTW, c->sc2 + 2 * i0 * 4);
+    };
+    MSM_GLV::msm_preconv_chunked_dev(conv2.p, sc2.p, 2 * n, d_out, st, split_chunk, &ctx);     // asynchronous: conv2 / sc2 go back to the pool with the sum still in flight; pool_free's events order their reuse
 }
 #else
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); }
