@@ -408,6 +408,10 @@ std::string hiprtc_log(hiprtcProgram prog) {
 // excepted), and a cache file is opened with O_NOFOLLOW and must be a regular file owned by this user with no group / other write
 // bit; anything else is ignored.  An object from disk that the driver refuses to load is deleted and compiled again
 // (zk_program_run_rows_dev).
+int jit_waves() {                                      // minimum waves per SIMD asked of the step kernels (launch bounds)
+    static const int w = [] { const char* e = getenv("ZK_JIT_WAVES"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    return w;
+}
 std::mutex g_jit_mu;
 std::condition_variable g_jit_cv;
 struct CodeObj { std::vector<char> bytes; std::string key; bool from_disk = false; };
@@ -447,7 +451,7 @@ bool jit_dir_trusted(const std::string& dir) {
         p = k == 0 || k == std::string::npos ? "/" : p.substr(0, k);
         if (stat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
         const bool sticky = st.st_mode & S_ISVTX;
-        if ((st.st_uid != geteuid() && st.st_uid != 0) || ((st.st_mode & (S_IWGRP | S_IWOTH)) && !sticky)) return warn(p, "(above the cache) is writable by others");
+        if ((st.st_uid != geteuid() && st.st_uid != 0) || ((st.st_mode & (S_IWGRP | S_IWOTH)) && !sticky)) return warn(p, "(above the cache) belongs to another user or is writable by others");
         if (home && p == home) break;
     }
     return true;
@@ -680,7 +684,10 @@ zk_program_t* zk_program_compile(const zk_instr* code, uint32_t n_instr) {
         if (g.lds_words) pro_src = "    __shared__ u64 zk_stage[4][" + std::to_string(g.lds_words) + "];\n    u64* const wl = zk_stage[wave];\n" + pro_src;
         p->pow_entries = (pow_words + 3 * (uint32_t)g.chain_consts.size() + 5) / 6;
         src << "extern \"C\" __global__ __launch_bounds__(64) void zk_pow_kernel(const EvalCtx c, u64* __restrict__ pw) {\n" << powk.str() << "}\n"
-            << "extern \"C\" __global__ __launch_bounds__(256) void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw, const u64 row0, const u64 count) {\n"
+            // (256, W): at least W waves per SIMD.  A step program of a wide PIL keeps a row's every operand live -- 280 VGPRs for the compressor-shaped
+            // circuit's step42ns: ONE wave per SIMD, and a lone wave issues a dependent instruction every 8.3 cycles where two waves fill the 4.2-cycle issue
+            // slots (profiles/r05/ubench_lat.txt).  W = 2 caps the kernel at 256 registers (24 spills in that kernel); ZK_JIT_WAVES overrides (1 = no cap).
+            << "extern \"C\" __global__ __launch_bounds__(256" << (jit_waves() > 1 ? ", " + std::to_string(jit_waves()) : std::string()) << ") void zk_eval_kernel(const EvalCtx c, const u64 n, const u64 next, const u64* __restrict__ pw, const u64 row0, const u64 count) {\n"
             << "    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
             << "    const u64 k0 = (u64)blockIdx.x * blockDim.x + wave * 64u;\n"
             << "    if (k0 >= count) return;                                  // whole wave past the range\n"
