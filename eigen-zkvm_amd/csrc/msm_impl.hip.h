@@ -487,8 +487,17 @@ __global__ __launch_bounds__(256) void balance_scatter_kernel(const u32* __restr
     order[h[c] + rank] = key;
 }
 // FIRST: the buckets start empty; otherwise this launch adds a further chunk of the points to what the buckets hold
+// G2 (Fq2 coordinates): the accumulator, the incoming point and the products' 64-bit columns are 300-340 VGPRs -- one wave per SIMD, and a lone
+// wave issues at most every ~6.5 cycles even with independent instructions at hand (profiles/r05/ubench_lat.txt).  ZK_MSM_G2_WAVES=2 (variant
+// builds: tools/build_variant.sh) caps the kernel at 256 registers for two waves per SIMD.
+#undef MSM_ACC_BOUNDS
+#if defined(MSM_G2) && defined(ZK_MSM_G2_WAVES)
+#define MSM_ACC_BOUNDS __launch_bounds__(64, ZK_MSM_G2_WAVES)
+#else
+#define MSM_ACC_BOUNDS __launch_bounds__(64)
+#endif
 template <bool FIRST>
-__global__ __launch_bounds__(64) void msm_accumulate_kernel(const u32* __restrict__ conv, const u32* __restrict__ offsets,
+__global__ MSM_ACC_BOUNDS void msm_accumulate_kernel(const u32* __restrict__ conv, const u32* __restrict__ offsets,
                                                             const u32* __restrict__ counts, const u32* __restrict__ idx,
                                                             const u32* __restrict__ order, xyzz* __restrict__ buckets) {
     const u32 key = order[blockIdx.x * blockDim.x + threadIdx.x];  // window * 2^16 + digit, heaviest first
