@@ -266,6 +266,8 @@ class ProverPool:
             self.join_kind, exec_text, n_witness, self.join_witness = join
             self.join_exec = c12.Compressor12Exec(exec_text, n_witness)      # read-only handle: shared by the workers
         self.proofs = []
+        self.join_inputs = []                      # keep_proofs: (node of the join's proof, zkit join_zkin text of its two children) when both children were proved on this rank
+        self._by_node = {}                         # keep_proofs: node -> zkin text of the proof that made it
         self._lock = threading.Lock()
         self.reset_join_times()
 
@@ -275,10 +277,12 @@ class ProverPool:
 
     def _gen(self, kind, d_cm, worker):
         z = self.sets[worker][kind].gen_bytes(d_cm, self.streams[worker].handle)
+        node = root1_of(z) + proof_digest(z)
         if self.keep_proofs:
             with self._lock:
                 self.proofs.append((kind, z))
-        return root1_of(z) + proof_digest(z)
+                self._by_node[tuple(node)] = z
+        return node
 
     def prove(self, inputs, worker=0):
         """one task -> the node (root1 + digest of the whole zkin) of each of its proofs, [[8 words]] * len(inputs)"""
@@ -336,6 +340,11 @@ class ProverPool:
         t2 = time.perf_counter()
         root = self._gen(self.join_kind, d_cm, worker)
         self.join_exec_s[worker] += t1 - t0; self.join_exec_dev_s[worker] += t2 - t1; self.join_prove_s[worker] += time.perf_counter() - t2
+        if self.keep_proofs:                                                 # `zkit join_zkin` of the two children (stark_aggregation.sh:87-90), when this rank holds both
+            za, zb = self._by_node.get(tuple(int(w) for w in node_a)), self._by_node.get(tuple(int(w) for w in node_b))
+            if za is not None and zb is not None:
+                with self._lock:
+                    self.join_inputs.append((root, join_zkin_text(za, zb)))
         return root
 
     def warm_join(self):

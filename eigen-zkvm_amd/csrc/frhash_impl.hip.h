@@ -28,7 +28,8 @@ __device__ __forceinline__ fe fe_from_int(const u32 (&w)[NL]) {
 __device__ __forceinline__ fe fe_renorm(const fe& a) { return fe_mul(a, fe_one()); }   // value < 168r -> < 2r, same residue
 
 // ---- parameter tables: per t (index t-2) offsets into one array of fe --------------------------------
-struct Params { u32 t, n_rp; const fe* c; const fe* m; const fe* p; const fe* s; };
+struct Params { u32 t, n_rp; const fe* c; const fe* m; const fe* p; const fe* s;
+                const u32* coef; const u32* rebw; u32 b1; };   // cooperative form of the sparse rounds (coop_tables_kernel): [round][limb][lane], [phase][word - 1][limb][lane], first round of phase 1
 __device__ Params g_prm[16];
 
 __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
@@ -171,21 +172,23 @@ __device__ __forceinline__ fe reg_dot(const fe* __restrict__ a, u32 stride, cons
     });
     return (u32)T > grp ? fe_renorm(acc) : acc;
 }
+// (The rolled loops carry interleave(disable) besides unroll(disable): with an even trip count the loop vectoriser otherwise
+// interleaves two trips, doubling the live state -- T = 8 took 512 registers, T = 10 and up spilled to scratch.)
 template <int T>
 __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
     const Params P = g_prm[T - 2];
     fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = fe_add(st[decltype(I)::value], P.c[decltype(I)::value]); });
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 fr = 0; fr < 8; ++fr) {
         if (fr == 4) {
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (u32 r = 0; r < P.n_rp; ++r) {
                 pow5(st[0]);
                 st[0] = fe_add(st[0], P.c[5 * T + r]);
                 const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
                 const fe s0 = reg_dot<T>(S, 1, st, DOT_SPARSE);
                 const bool renorm = r % PR_RENORM == PR_RENORM - 1;
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (int k = 1; k < T; ++k) {                       // word 1 is updated, then the tail st[1..T) rotates
                     fe v = fe_add(st[1], fe_mul(S[T + k - 1], st[0]));
                     if (renorm) v = fe_renorm(v);
@@ -194,7 +197,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
                 }
                 st[0] = s0;
             }
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (int k = 1; k < T; ++k) {
                 const fe v = fe_renorm(st[1]);
                 fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
@@ -204,7 +207,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
         // S-boxes + round constants of the next linear layer (none after the last S-box layer)
         const fe* __restrict__ c = fr < 3 ? P.c + (fr + 1) * T : fr == 3 ? P.c + 4 * T : P.c + 5 * T + P.n_rp + (fr - 4) * T;
         const bool has_c = fr < 7;
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int i = 0; i < T; ++i) {
             fe x = st[0];
             pow5(x);
@@ -214,7 +217,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
         const fe* __restrict__ mat = fr == 3 ? P.p : P.m;
         fe out[T];
         fh_static_for<0, T>([&](auto I) { out[decltype(I)::value] = fe_zero(); });
-#pragma unroll 1
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int i = 0; i < T; ++i) reg_rotate_in<T>(out, reg_dot<T>(mat + i, T, st, DOT_DENSE));
         fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = out[decltype(I)::value]; });
     }
@@ -247,17 +250,41 @@ __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__
     store_raw(st[FH_OUT_IDX], out + 4 * i);
 }
 
+// the same with the 17 words in registers (poseidon_fr_reg<17>: no scratch arrays behind run-time indices)
+__global__ __launch_bounds__(64) void bn128_level_reg_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ops) return;
+    fe st[17];
+    st[0] = fe_zero();
+    fh_static_for<0, 16>([&](auto K) { st[decltype(K)::value + 1] = load_raw(in + (i * 16 + decltype(K)::value) * 4); });
+    poseidon_fr_reg<17>(st);
+    store_raw(st[FH_OUT_IDX], out + 4 * i);
+}
 
-// ---- cooperative permutation for the small levels of a tree: 32 lanes per permutation, lane l < t owns st[l].
-// A one-lane t = 17 permutation is a 1.2 M-instruction dependent chain (4.6 ms): the last three levels of every
-// tree (1 + 16 + 256 parents) would cost 14 ms.  Here the 17 columns of a dense product, the 17 S-boxes and the
-// 16 column updates of a sparse round run side by side; words are exchanged through LDS (`xs`: 17 x 9 words per
-// group).  Same bounds as poseidon_fr.  Called by all 64 threads of a block (two groups), uniform control flow.
-__device__ __forceinline__ void coop_put(u32* xs, int l, u32 t, const fe& v) {
-    if ((u32)l < t) {
+// ---- cooperative permutation for the latency-bound places (small tree levels, few wide rows, the transcript): ONE WAVE per
+// permutation.  A one-lane t = 17 permutation is a 1.2 M-instruction dependent chain (4.6 ms); a lone wave is bound by the
+// instructions it issues (4.2 cycles each), so the form below is chosen for the fewest instructions per round, not for the
+// shortest dependency chain:
+//  * dense rounds: lane l = 17 g + i (g < 3) sums a third of column i's products (<= 6: one deferred reduction), the three partial
+//    sums meet through LDS -- a column costs 6 multiply passes instead of 17 + 3 reductions + a renormalisation; every replica
+//    g holds word i afterwards, the S-boxes run on all of them;
+//  * sparse rounds (poseidon_bn128_opt.rs:150-189) unrolled into the recurrence they are.  With y_r = x_r^5 + c_r, w_r = S_r[0..t),
+//    v_r[k] = S_r[t + k - 1]:    st_r[k] = st_b[k] + sum_{b <= q < r} v_q[k] y_q,
+//    x_{r+1} = w_r[0] y_r + sum_k w_r[k] st_b[k] + sum_{b <= q < r} (sum_k w_r[k] v_q[k]) y_q
+//    for any base round b.  Lane 16 + (rho - b) carries x_rho for the rounds of one phase (b < rho <= e), lanes 1..t-1 the words
+//    st[k]; each round is x^5 on the wave-uniform x_r, ONE product coef[r][lane] * y_r added into every lane's running value
+//    inside the same reduction (fe_mul_acc), and nine v_readlane for x_{r+1} -- against S-box, product, a 32-lane sum and a
+//    second product before.  Two phases (at most 47 future rounds fit beside the 16 words); a phase starts by giving the lanes of
+//    its rounds sum_k w[k] st_b[k] (16 products).  The coefficient tables are built on the device from S when the constants load.
+// Bounds (units of r): dense inputs < 3, thirds < 2, sums < 6 -> S-box (36 <= FH_AB_LIMIT); running values start < 2 and grow by
+// < 1.05 a round, renormalised every CO_RENORM = 5 rounds (< 7.3: the S-box's square stays <= 54 <= FH_AB_LIMIT).
+constexpr u32 CO_RENORM = 5, CO_XL0 = 17, CO_XLANES = 47;
+static_assert((2 + CO_RENORM * 21 / 20 + 1) * (2 + CO_RENORM * 21 / 20 + 1) <= FH_AB_LIMIT, "running values too large for the S-box square");
+__host__ __device__ constexpr u32 co_phase1(u32 n_rp) { return (n_rp + 1) / 2; }   // first round of the second phase; both halves <= CO_XLANES
+struct CoopLds { u32 xs[18 * NR]; u32 xp[64 * NR]; };
+__device__ __forceinline__ void coop_put(u32* xs, u32 slot, const fe& v) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k) xs[l * NR + k] = v.l[k];
-    }
+    for (int k = 0; k < NR; ++k) xs[slot * NR + k] = v.l[k];
 }
 __device__ __forceinline__ fe coop_get(const u32* xs, u32 j) {
     fe v;
@@ -265,144 +292,226 @@ __device__ __forceinline__ fe coop_get(const u32* xs, u32 j) {
     for (int k = 0; k < NR; ++k) v.l[k] = xs[j * NR + k];
     return v;
 }
-__device__ fe coop_matmul(const fe* __restrict__ mat, const fe& x, u32* xs, int l, u32 t) {
-    __syncthreads();
-    coop_put(xs, l, t, x);
-    __syncthreads();
-    const u32 lc = (u32)l < t ? l : 0;
-    return dot_products(mat + lc, t, [&](u32 j) { return coop_get(xs, j); }, t, DOT_DENSE);
-}
-// Partial rounds exchange nothing through LDS.  A block is one wave holding two groups of 32 lanes (two DPP rows each): lane 0's
-// S-box output reaches its group through v_readlane; the t products S[j] st[j] are summed towards lane 0 by shifted row
-// additions (limbs are 29 bits wide: four summands fit a word, then a carry pass) and one v_readlane across the two rows --
-// instead of seventeen LDS round trips walked by lane 0 alone while the other lanes wait, with four barriers a round.
 __device__ __forceinline__ fe fe_pick(bool c, const fe& a, const fe& b) {        // limb-wise: a ?: on the structs becomes branches
     fe r;
 #pragma unroll
     for (int k = 0; k < NR; ++k) r.l[k] = c ? a.l[k] : b.l[k];
     return r;
 }
-__device__ __forceinline__ fe group_bcast0(const fe& v, int g) {                 // lane 0 of each 32-lane group -> its group
+__device__ __forceinline__ fe wave_bcast(const fe& v, u32 lane) {                 // lane (wave-uniform) -> every lane
     fe r;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-        const u32 lo = (u32)__builtin_amdgcn_readlane((int)v.l[k], 0), hi = (u32)__builtin_amdgcn_readlane((int)v.l[k], 32);
-        r.l[k] = g ? hi : lo;
+        u32 w = (u32)__builtin_amdgcn_readlane((int)v.l[k], (int)lane);
+        asm("" : "+v"(w));   // kept in a vector register on purpose: the compiler would otherwise run the whole S-box of a wave-uniform
+        r.l[k] = w;          // x on the scalar unit, four instructions per partial product instead of one
     }
     return r;
 }
-static_assert(NR == 9, "the row additions below name nine limbs");
-#define ZK_FR_ROW_ADD_SHL(N)                                                                                                   \
-    asm volatile("s_nop 1\n\t"                                                                                                 \
-                 "v_add_u32_dpp %0, %0, %0 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %1, %1, %1 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %2, %2, %2 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %3, %3, %3 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %4, %4, %4 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %5, %5, %5 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %6, %6, %6 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %7, %7, %7 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                               \
-                 "v_add_u32_dpp %8, %8, %8 row_shl:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                    \
-                 : "+v"(v.l[0]), "+v"(v.l[1]), "+v"(v.l[2]), "+v"(v.l[3]), "+v"(v.l[4]), "+v"(v.l[5]), "+v"(v.l[6]), "+v"(v.l[7]), "+v"(v.l[8]))
-// sum of v over the 32 lanes of the group (values < 2r, normalised limbs), valid in lane 0 of the group, < 64r
-__device__ __forceinline__ fe group_sum32(fe v, int g) {
-    ZK_FR_ROW_ADD_SHL(1); ZK_FR_ROW_ADD_SHL(2);      // four summands per limb: < 2^31
-    fe_norm_u(v);
-    ZK_FR_ROW_ADD_SHL(4); ZK_FR_ROW_ADD_SHL(8);      // lanes 0 and 16 of the group: the sums of their rows
-    fe_norm_u(v);
-    fe o;
+__device__ __forceinline__ fe load_words(const u32* __restrict__ p) {            // an fe, one limb per load (as a struct it arrives in three pieces that must be repacked -- and waited for -- at once)
+    fe r;
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const u32 lo = (u32)__builtin_amdgcn_readlane((int)v.l[k], 16), hi = (u32)__builtin_amdgcn_readlane((int)v.l[k], 48);
-        o.l[k] = g ? hi : lo;
-    }
-    return fe_add(v, o);
+    for (int k = 0; k < NR; ++k) r.l[k] = p[k];
+    return r;
 }
-#undef ZK_FR_ROW_ADD_SHL
-__device__ fe coop_poseidon_fr(fe x, u32* xs, u32 t) {
-    const int l = threadIdx.x & 31, g = (threadIdx.x >> 5) & 1;
-    const u32 lc = (u32)l < t ? l : 0;
+__device__ __forceinline__ fe load_lanes(const u32* __restrict__ tab, u32 lane) { // [limb][lane] slice of a table
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r.l[k] = tab[k * 64 + lane];
+    return r;
+}
+// A lone wave cannot hide a load behind other waves: every table entry a step needs is requested BEFORE the S-box (or the
+// product) in front of it, so that the 600-odd instructions of x^5 cover the latency.
+struct Cols6 { fe a[6]; };
+// the six entries of column i = l % 17 that lane l multiplies: rows 6 g .. 6 g + 5 (rows >= t are met by zero words)
+__device__ __forceinline__ void coop_cols_load(Cols6& m, const fe* __restrict__ mat, u32 l, u32 t) {
+    const u32 g = l / 17, i = l - 17 * g, ic = i < t ? i : 0, j0 = g * 6;
+#pragma unroll
+    for (u32 jj = 0; jj < 6; ++jj) {
+        const u32 j = j0 + jj;
+        m.a[jj] = mat[(size_t)(j < t ? j : t - 1) * t + ic];
+    }
+}
+// st <- (sum_j MAT[j][i] st[j])_i: x = word l of the state in lanes l < t (< 3r); returns word l % 17 in every lane < 51 (< 6r)
+__device__ __forceinline__ fe coop_matmul(const Cols6& m, const fe& x, CoopLds& L, u32 l, u32 t) {
+    const u32 g = l / 17, i = l - 17 * g, ic = i < t ? i : 0, j0 = g * 6;
+    __syncthreads();
+    if (l < 18) coop_put(L.xs, l, l < t ? x : fe_zero());             // words t..17 read as zero
+    __syncthreads();
+    fe_wide w; fe_wide_zero(w);
+#pragma unroll
+    for (u32 jj = 0; jj < 6; ++jj) {
+        const u32 j = j0 + jj < 17 ? j0 + jj : 17;                     // lanes 51..63 (g = 3) and the 18th product of g = 2: times zero
+        fe_wide_mac(w, m.a[jj], coop_get(L.xs, j));
+    }
+    coop_put(L.xp, l, fe_wide_reduce(w));
+    __syncthreads();
+    fe r;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r.l[k] = L.xp[ic * NR + k] + L.xp[(17 + ic) * NR + k] + L.xp[(34 + ic) * NR + k];
+    fe_norm_u(r);
+    return r;
+}
+// six of a phase's start-up weights: words j0 .. j0 + 5 of this lane's round (zero table rows beyond t - 1: slot 17 of xs is zero too)
+__device__ __forceinline__ void coop_reb_load(Cols6& m, const u32* __restrict__ W, u32 j0, u32 l) {
+#pragma unroll
+    for (u32 jj = 0; jj < 6; ++jj) {
+        const u32 j = j0 + jj < 17 ? j0 + jj : 16;
+        m.a[jj] = load_lanes(W + (size_t)(j - 1) * NR * 64, l);
+    }
+}
+__device__ __forceinline__ fe coop_poseidon_fr(fe x, CoopLds& L, u32 t) {   // inlined: as a call it saves and restores 140 registers through scratch
+    const u32 l = threadIdx.x & 63, lc = l % 17 < t ? l % 17 : 0;
     const Params P = g_prm[t - 2];
-    x = fe_add(x, P.c[lc]);
-    for (u32 r = 0; r < 3; ++r) {
-        pow5(x); x = fe_add(x, P.c[(r + 1) * t + lc]);
-        x = coop_matmul(P.m, x, xs, l, t);
+    Cols6 m;
+    {
+        coop_cols_load(m, P.m, l, t);
+        const fe c1 = P.c[t + lc];
+        x = fe_add(x, P.c[lc]);
+        pow5(x); x = fe_add(x, c1);
+        x = coop_matmul(m, x, L, l, t);
     }
-    pow5(x); x = fe_add(x, P.c[4 * t + lc]);
-    x = coop_matmul(P.p, x, xs, l, t);
-    const fe one = fe_one(), zero = fe_zero();
-    for (u32 r = 0; r < P.n_rp; ++r) {
-        const fe* __restrict__ S = P.s + (size_t)(2 * t - 1) * r;
-        fe y = x;
-        pow5(y); y = fe_add(y, P.c[5 * t + r]);                 // only lane 0's result is used: the new st[0]
-        const fe st0 = group_bcast0(y, g);
-        const fe prod = fe_pick((u32)l < t, fe_mul(S[lc], fe_pick(l == 0, st0, x)), zero);   // S[j] * st[j]; idle lanes add nothing
-        const fe s0 = group_sum32(prod, g);                     // lane 0: < 34r
-        // one multiplication serves both sides: lane 0 brings its sum back below 2r (x 1), lane k adds S[t + k - 1] * st[0]
-        const fe m = fe_mul(fe_pick(l == 0, s0, S[t + (lc > 0 ? lc : 1) - 1]), fe_pick(l == 0, one, st0));
-        x = fe_pick(l == 0, m, fe_add(x, m));
-        if (r % PR_RENORM == PR_RENORM - 1) x = fe_pick(l == 0, x, fe_renorm(x));
+#pragma unroll 1
+    for (u32 r = 1; r < 4; ++r) {                                       // dense rounds 2..4; the fourth multiplies by P
+        coop_cols_load(m, r < 3 ? P.m : P.p, l, t);
+        const fe c = P.c[(r + 1) * t + lc];
+        pow5(x); x = fe_add(x, c);
+        x = coop_matmul(m, x, L, l, t);
     }
-    x = fe_pick(l == 0, x, fe_renorm(x));
-    for (u32 r = 0; r < 3; ++r) {
-        pow5(x); x = fe_add(x, P.c[5 * t + P.n_rp + r * t + lc]);
-        x = coop_matmul(P.m, x, xs, l, t);
+    // sparse rounds
+    fe xr = wave_bcast(x, 0);                                           // x_0 < 6r
+    fe acc = x;                                                         // lanes 1..t-1: st_0[k]
+    const fe one = fe_one();
+    const u32 n_grp = (t + 4) / 6;                                      // groups of six among the words 1..t-1
+#pragma unroll 1
+    for (u32 ph = 0; ph < 2; ++ph) {
+        const u32 b = ph ? P.b1 : 0, e = ph ? P.n_rp : P.b1;
+        const u32* __restrict__ W = P.rebw + (size_t)ph * 16 * NR * 64;
+        const u32* __restrict__ C = P.coef + (size_t)b * NR * 64;
+        coop_reb_load(m, W, 1, l);
+        const u32* __restrict__ RC = (const u32*)(P.c + 5 * t);         // the sparse rounds' constants, limb by limb (wave-uniform)
+        fe coef = load_lanes(C, l), cnext = load_words(RC + (size_t)b * NR);
+        __syncthreads();
+        if (l < 18) coop_put(L.xs, l, l >= 1 && l < t ? acc : fe_zero());   // < 6r entering the first phase, < 2r the second
+        __syncthreads();
+        {   // lanes of this phase's rounds: sum_k w_{rho-1}[k] st_b[k] (the tables hold zeros for every other lane)
+            fe a = fe_zero();
+#pragma unroll 1
+            for (u32 gi = 0; gi < n_grp; ++gi) {
+                const u32 j0 = 1 + 6 * gi;
+                Cols6 mn;
+                coop_reb_load(mn, W, gi + 1 < n_grp ? j0 + 6 : j0, l);
+                fe_wide w; fe_wide_zero(w);
+#pragma unroll
+                for (u32 jj = 0; jj < 6; ++jj) fe_wide_mac(w, m.a[jj], coop_get(L.xs, j0 + jj < 17 ? j0 + jj : 17));
+                a = fe_add(a, fe_wide_reduce(w));
+                m = mn;
+            }
+            if (n_grp > 1) a = fe_mul(a, one);                          // up to three groups: < 6r -> < 2r
+            acc = fe_pick(l >= CO_XL0, a, acc);
+        }
+        // CO_RENORM rounds, then every lane's running value back below 2r.  (An `if` on the round number inside one loop is
+        // turned into a product that always runs.)  x_{r+1} is read before that: < 2 + 5 x 1.05 < 7.3r, fine for the S-box.
+#pragma unroll 1
+        for (u32 r = b; r < e;) {
+            const u32 n = e - r < CO_RENORM ? e - r : CO_RENORM;
+#pragma unroll 1
+            for (u32 k = 0; k < n; ++k, ++r) {
+                const fe cf = coef, c = cnext;
+                const u32 rn = r + 1 < e ? r + 1 : r;                   // a round ahead; the last one re-reads its own
+                coef = load_lanes(P.coef + (size_t)rn * NR * 64, l);
+                cnext = load_words(RC + (size_t)rn * NR);
+                fe y = xr;
+                pow5(y);
+#pragma unroll
+                for (int q = 0; q < NR; ++q) y.l[q] += c.l[q];          // limbs < 2^30: fe_mul_acc takes them as they are
+                acc = fe_mul_acc(cf, y, acc);
+                xr = wave_bcast(acc, CO_XL0 + (r - b));                 // x_{r+1}
+            }
+            acc = fe_mul(acc, one);
+        }
     }
-    pow5(x);
-    return coop_matmul(P.m, x, xs, l, t);
+    coop_cols_load(m, P.m, l, t);
+    x = fe_pick(l == 0, xr, acc);                                       // word layout again: x < 7.3r, st[k] < 2r
+#pragma unroll 1
+    for (u32 r = 0; r < 4; ++r) {
+        const fe c = r < 3 ? P.c[5 * t + P.n_rp + r * t + lc] : fe_zero();
+        if (r) coop_cols_load(m, P.m, l, t);
+        pow5(x); x = fe_add(x, c);
+        x = coop_matmul(m, x, L, l, t);
+    }
+    return fe_mul(x, one);                                              // < 2r for the callers (digests chained into the next sponge step)
+}
+// the sparse rounds' cooperative tables for one t (see above); one thread per (round, lane) and per (phase, word, lane)
+__global__ void coop_tables_kernel(Params P, u32* __restrict__ coef, u32* __restrict__ rebw) {
+    const u32 t = P.t, n_rp = P.n_rp, b1 = co_phase1(n_rp);
+    const u32 id = blockIdx.x * blockDim.x + threadIdx.x, lane = id & 63, idx = id >> 6;
+    const fe one = fe_one();
+    if (idx < n_rp) {
+        const u32 r = idx, b = r >= b1 ? b1 : 0, e = r >= b1 ? n_rp : b1;
+        const fe* __restrict__ Sr = P.s + (size_t)(2 * t - 1) * r;
+        fe v = fe_zero();
+        if (lane >= 1 && lane < t) v = Sr[t + lane - 1];
+        else if (lane >= CO_XL0 && b + (lane - 16) <= e) {
+            const u32 rho = b + (lane - 16);
+            const fe* __restrict__ Sw = P.s + (size_t)(2 * t - 1) * (rho - 1);
+            if (r == rho - 1) v = Sw[0];
+            else if (r < rho - 1) {
+                for (u32 j = 1; j < t; ++j) v = fe_mul(fe_add(v, fe_mul(Sw[j], Sr[t + j - 1])), one);   // < 4r -> < 2r
+            }
+        }
+        v = fe_canon(fe_mul(v, one));
+        for (int k = 0; k < NR; ++k) coef[((size_t)r * NR + k) * 64 + lane] = v.l[k];
+    } else if (idx < n_rp + 32) {
+        const u32 q = idx - n_rp, ph = q >> 4, j = (q & 15) + 1, b = ph ? b1 : 0, e = ph ? n_rp : b1;
+        fe v = fe_zero();
+        if (j < t && lane >= CO_XL0 && b + (lane - 16) <= e) v = P.s[(size_t)(2 * t - 1) * (b + (lane - 16) - 1) + j];
+        for (int k = 0; k < NR; ++k) rebw[((size_t)(ph * 16 + (j - 1)) * NR + k) * 64 + lane] = v.l[k];
+    }
 }
 __global__ __launch_bounds__(64) void bn128_level_coop_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
-    __shared__ u32 xs_all[2][17 * NR];
-    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-    u32* xs = xs_all[g];
-    const u64 i = (u64)blockIdx.x * 2 + g;
-    const u64 ic = i < n_ops ? i : n_ops - 1;                   // an idle group shadows the last parent
+    __shared__ CoopLds L;
+    const u32 l = threadIdx.x;
+    const u64 i = blockIdx.x;
     fe x = fe_zero();
-    if (l >= 1 && l <= 16) x = load_raw(in + (ic * 16 + (l - 1)) * 4);
-    x = coop_poseidon_fr(x, xs, 17);
-    if (i < n_ops && l == FH_OUT_IDX) store_raw(x, out + 4 * i);
+    if (l >= 1 && l <= 16) x = load_raw(in + (i * 16 + (l - 1)) * 4);
+    x = coop_poseidon_fr(x, L, 17);
+    if (l == FH_OUT_IDX) store_raw(x, out + 4 * i);
 }
 // LinearHash of a few, possibly very wide rows (the FRI trees of a large fold: final.starkStruct.*.json commits 2^7 rows of 3072
-// words): one lane per row would run 64 sponge steps of 1.2 M instructions each on 128 lanes.  32 lanes per row instead, the
-// sponge steps of linearhash_bn128.rs:105-131 in order, the digest handed from lane FH_OUT_IDX to lane 0 through LDS.
+// words): one lane per row would run 64 sponge steps of 1.2 M instructions each on 128 lanes.  One wave per row instead, the
+// sponge steps of linearhash_bn128.rs:105-131 in order, the digest handed from lane FH_OUT_IDX to lane 0.
 __global__ __launch_bounds__(64) void bn128_leaf_coop_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
-    __shared__ u32 xs_all[2][17 * NR];
-    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-    u32* xs = xs_all[g];
-    const u64 i = (u64)blockIdx.x * 2 + g;
-    const u64 ic = i < height ? i : height - 1;                 // an idle group shadows the last row
-    const u64* __restrict__ v = rows + ic * width;
+    __shared__ CoopLds L;
+    const u32 l = threadIdx.x;
+    const u64 i = blockIdx.x;
+    const u64* __restrict__ v = rows + i * width;
     const u32 nb = (width - 1) / 3 + 1;
     fe digest = fe_zero();
     for (u32 b = 0; b < nb; b += 16) {
         const u32 sz = nb - b < 16 ? nb - b : 16;
         fe x = fe_zero();
         if (l == 0) x = digest;
-        else if ((u32)l <= sz) {
+        else if (l <= sz) {
             const u32 at = 3 * (b + l - 1), len = width - at < 3 ? width - at : 3;
             x = words_to_fe(v + at, len);
         }
-        x = coop_poseidon_fr(x, xs, sz + 1);
-        __syncthreads();
-        if (l == FH_OUT_IDX) coop_put(xs, 0, 1, x);
-        __syncthreads();
-        digest = coop_get(xs, 0);
+        x = coop_poseidon_fr(x, L, sz + 1);
+        digest = wave_bcast(x, FH_OUT_IDX);
     }
-    if (i < height && l == 0) store_raw(digest, digests + 4 * i);
+    if (l == 0) store_raw(digest, digests + 4 * i);
 }
-// Poseidon::hash_ex for a handful of permutations (the transcript: one sponge step at a time): 32 lanes each
+// Poseidon::hash_ex for a handful of permutations (the transcript: one sponge step at a time): one wave each
 __global__ __launch_bounds__(64) void bn128_poseidon_coop_kernel(const u64* __restrict__ inp, u64 n, u32 n_in, const u64* __restrict__ init,
                                                                  u32 n_out, u64* __restrict__ out) {
-    __shared__ u32 xs_all[2][17 * NR];
-    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-    u32* xs = xs_all[g];
-    const u64 i = (u64)blockIdx.x * 2 + g;
-    const u64 ic = i < n ? i : n - 1;
+    __shared__ CoopLds L;
+    const u32 l = threadIdx.x;
+    const u64 i = blockIdx.x;
     fe x = fe_zero();
     if (l == 0) x = load_raw(init);
-    else if ((u32)l <= n_in) x = load_raw(inp + (ic * n_in + (l - 1)) * 4);
-    x = coop_poseidon_fr(x, xs, n_in + 1);
-    if (i < n && (u32)l < n_out) store_raw(x, out + (i * n_out + l) * 4);
+    else if (l <= n_in) x = load_raw(inp + (i * n_in + (l - 1)) * 4);
+    x = coop_poseidon_fr(x, L, n_in + 1);
+    if (l < n_out) store_raw(x, out + (i * n_out + l) * 4);
 }
 
 struct DeviceTables { fe* all = nullptr; bool ready = false; };
@@ -452,7 +561,19 @@ void FH_FN(load_constants)(const char* path) {
     hipLaunchKernelGGL(bn128_convert_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, nullptr, (const u32*)d_canon.p, (u64)count, d_all);
     ZK_HIP(hipGetLastError());
     Params prm[16];
-    for (int k = 0; k < 16; ++k) prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s};
+    size_t n_coop = 0;
+    for (int k = 0; k < 16; ++k) n_coop += ((size_t)NRP[k] + 32) * NR * 64;
+    u32* d_coop = nullptr;
+    ZK_HIP(hipMalloc((void**)&d_coop, n_coop * sizeof(u32)));
+    size_t at = 0;
+    for (int k = 0; k < 16; ++k) {
+        ZK_REQUIRE(co_phase1(NRP[k]) <= CO_XLANES && NRP[k] - co_phase1(NRP[k]) <= CO_XLANES, "too many sparse rounds for the cooperative form");
+        u32* coef = d_coop + at; u32* rebw = coef + (size_t)NRP[k] * NR * 64;
+        at += ((size_t)NRP[k] + 32) * NR * 64;
+        prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s, coef, rebw, co_phase1(NRP[k])};
+        hipLaunchKernelGGL(coop_tables_kernel, dim3(NRP[k] + 32), dim3(64), 0, nullptr, prm[k], coef, rebw);
+        ZK_HIP(hipGetLastError());
+    }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_prm), prm, sizeof(prm)));
     ZK_HIP(hipDeviceSynchronize());
     g_tables[dev].all = d_all; g_tables[dev].ready = true;
@@ -464,7 +585,7 @@ void FH_FN(poseidon_dev)(const u64* d_inp, uint64_t n, uint32_t n_in, const u64*
     ZK_REQUIRE(n_out >= 1 && n_out <= n_in + 1, "Wrong output length");
     if (n == 0) return;
     if (n <= 4096)  // latency-bound
-        hipLaunchKernelGGL(bn128_poseidon_coop_kernel, dim3((unsigned)((n + 1) / 2)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
+        hipLaunchKernelGGL(bn128_poseidon_coop_kernel, dim3((unsigned)n), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
     else
         hipLaunchKernelGGL(bn128_poseidon_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_inp, n, n_in, d_init, n_out, d_out);
     ZK_HIP(hipGetLastError());
@@ -485,11 +606,11 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
     const dim3 grid((unsigned)((height + 63) / 64)), blk(64);
     const u32 nb = width ? (width - 1) / 3 + 1 : 0;
     if (width > 4 && height <= 4096) {   // latency-bound: 32 lanes per row
-        hipLaunchKernelGGL(bn128_leaf_coop_kernel, dim3((unsigned)((height + 1) / 2)), blk, 0, st, d_rows, width, height, d_digests);
+        hipLaunchKernelGGL(bn128_leaf_coop_kernel, dim3((unsigned)height), blk, 0, st, d_rows, width, height, d_digests);
         ZK_HIP(hipGetLastError());
         return;
     }
-    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 8;   // tuning knob: largest block count that takes the register kernels
+    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 16;   // tuning knob: largest block count that takes the register kernels
     switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
         case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
         case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
@@ -498,6 +619,14 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
         case 6: hipLaunchKernelGGL(bn128_leaf_reg_kernel<6>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
         case 7: hipLaunchKernelGGL(bn128_leaf_reg_kernel<7>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
         case 8: hipLaunchKernelGGL(bn128_leaf_reg_kernel<8>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 9: hipLaunchKernelGGL(bn128_leaf_reg_kernel<9>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 10: hipLaunchKernelGGL(bn128_leaf_reg_kernel<10>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 11: hipLaunchKernelGGL(bn128_leaf_reg_kernel<11>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 12: hipLaunchKernelGGL(bn128_leaf_reg_kernel<12>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 13: hipLaunchKernelGGL(bn128_leaf_reg_kernel<13>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 14: hipLaunchKernelGGL(bn128_leaf_reg_kernel<14>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 15: hipLaunchKernelGGL(bn128_leaf_reg_kernel<15>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 16: hipLaunchKernelGGL(bn128_leaf_reg_kernel<16>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
         default: hipLaunchKernelGGL(bn128_leaf_kernel, grid, blk, 0, st, d_rows, width, height, d_digests);
     }
     ZK_HIP(hipGetLastError());
@@ -512,9 +641,12 @@ void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u6
     if (width) FH_FN(linearhash_rows_dev)(d_rows, width, height, d_nodes, st);
     uint64_t n = height, next = (n - 1) / 16 + 1, p_in = 0, p_out = next * 16;
     while (n > 1) {
+        static const bool level_reg = !getenv("ZK_FR_LEVEL_REG") || atoi(getenv("ZK_FR_LEVEL_REG"));   // tuning knob: 0 = the generic one-lane kernel
         static const u64 coop_upto = getenv("ZK_FR_LEVEL_COOP") ? strtoull(getenv("ZK_FR_LEVEL_COOP"), nullptr, 10) : 16384;
         if (next <= coop_upto)  // latency-bound: 32 lanes per parent
-            hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)((next + 1) / 2)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+            hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)next), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        else if (level_reg)
+            hipLaunchKernelGGL(bn128_level_reg_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else
             hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         ZK_HIP(hipGetLastError());

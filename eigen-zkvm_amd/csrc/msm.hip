@@ -18,6 +18,10 @@
 // Integer-ALU bound (about 10 Fq products per point and window); HBM traffic is 96 B per point.
 #include "zk_internal.h"
 
+// fe29_impl.hip.h: the sums keep squaring as fe_mul(a, a).  The dedicated squaring of the scalar-field hashes was measured here
+// (tools/gpu_sqr_ab.sh, profiles/r05/sqr_ab_raw.txt): G1 +-1 %, BN254 G2 3 % slower -- the accumulation kernels sit at a register edge.
+#define ZK_FE_SQR_PLAIN 1
+
 namespace zk {
 
 namespace bn254 {

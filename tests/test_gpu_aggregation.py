@@ -54,6 +54,10 @@ def test_aggregate_on_one_rank_equals_the_work_done_by_hand(zk):
     assert j["a_root1"] == r1s[0]["root1"] and j["b_root1"] == r1s[1]["root1"] and j["rootC"] == r1s[0]["rootC"]
     pub = r1s[0]["publics"]
     assert j["publics"] == (pub[:-4] if len(pub) >= 4 else pub) and list(j) == sorted(j)      # zkin_join.rs:29-37
+    # keep_proofs: the pool kept the join_zkin text of every join whose children it proved itself (here: both joins)
+    assert len(pool.join_inputs) == 2
+    first = json.loads(pool.join_inputs[0][1])
+    assert first["a_root1"] == r1s[0]["root1"] and first["b_root1"] == r1s[1]["root1"] and "b_finalPol" in first
     for kind, z in pool.proofs:                                               # every proof the pool made verifies against its circuit's setup
         assert sets[kind].verify(z) is True
     E.free(); pool.free()

@@ -148,6 +148,8 @@ def stark_aggregate(a):
         ws = pathlib.Path(a.workspace); ws.mkdir(parents=True, exist_ok=True)
         for i, (kind, z) in enumerate(pool.proofs):
             (ws / ("rank%d_%03d_%s.zkin.json" % (ex.rank, i, kind))).write_bytes(z)
+        for i, (_node, text) in enumerate(pool.join_inputs):                 # what `zkit join_zkin` writes in front of every recursive2 step (children proved on this rank)
+            (ws / ("rank%d_join%03d_input.zkin.json" % (ex.rank, i))).write_text(text)
     pool.free()
     ex.barrier()
 
