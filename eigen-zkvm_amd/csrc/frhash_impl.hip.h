@@ -514,6 +514,125 @@ __global__ __launch_bounds__(64) void bn128_poseidon_coop_kernel(const u64* __re
     if (l < n_out) store_raw(x, out + (i * n_out + l) * 4);
 }
 
+// ---- L lanes per permutation, for tree levels of a few thousand parents: too many for one wave each (every SIMD would run
+// ---- several 153 us permutations one after the other), too few for one lane each (a t = 17 permutation is a 2.5 ms chain and
+// ---- 8192 of them fill an eighth of the SIMDs).  Lane q of a group keeps the words q, q + L, q + 2L (S = ceil(17 / L) slots) in
+// ---- registers; words meet through LDS for the dense products, the matrices M and P are staged in LDS once per block.  A sparse
+// ---- round: x broadcast to the group, x^5 in every lane, each lane's S products of the row, reduced, canonical, summed over the
+// ---- group (< L r: the next S-box takes it as it is for L <= 8), and S fused product-accumulates for the column.
+// ---- Bounds as in the cooperative form: running words grow by < 1.05 r a round and are renormalised every CO_RENORM rounds.
+template <int L, int S>
+__device__ __forceinline__ void grp_matmul(fe (&st)[S], const u32 (&wd)[S], const u32* __restrict__ mat /* LDS */, u32* __restrict__ xg /* LDS, this group's words */, u32 q) {
+    constexpr int T = 17;                                                        // st < 3r in, < 6r out
+    __syncthreads();
+    fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; if (sl * L + q < (u32)T) coop_put(xg, sl * L + q, st[sl]); });
+    __syncthreads();
+    fh_static_for<0, S>([&](auto SI) { st[decltype(SI)::value] = fe_zero(); });
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 j0 = 0; j0 < 18; j0 += 6) {
+        fe_wide w[S];
+        fh_static_for<0, S>([&](auto SI) { fe_wide_zero(w[decltype(SI)::value]); });
+#pragma unroll 2
+        for (u32 jj = 0; jj < 6; ++jj) {
+            const u32 j = j0 + jj;
+            if (j < (u32)T) {
+                const fe xj = coop_get(xg, j);
+                fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; fe_wide_mac(w[sl], coop_get(mat, j * T + wd[sl]), xj); });
+            }
+        }
+        fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; st[sl] = fe_add(st[sl], fe_wide_reduce(w[sl])); });
+    }
+}
+template <int S>
+__device__ __forceinline__ void grp_sbox_layer(fe (&st)[S], const u32 (&wd)[S], const fe* __restrict__ c) {   // x^5 + the next constants (c may be null)
+    fe cc[S];
+    fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; cc[sl] = c ? c[wd[sl]] : fe_zero(); });
+    fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; pow5(st[sl]); st[sl] = fe_add(st[sl], cc[sl]); });
+}
+template <int L>
+__global__ __launch_bounds__(64) void bn128_level_grp_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    constexpr int T = 17, S = (T + L - 1) / L, G = 64 / L;
+    static_assert(L == 8 || L == 4, "group sums below are bounded for L <= 8");
+    static_assert((u32)L * (u32)L <= FH_AB_LIMIT, "a sum of L canonical values must fit the S-box square");
+    __shared__ u32 mats[2][T * T * NR];
+    __shared__ u32 xs[G][T * NR];
+    const Params P = g_prm[T - 2];
+    const u32 q = threadIdx.x % L, g = threadIdx.x / L;
+    {   // both matrices into LDS (289 x 9 words each)
+        const u32* __restrict__ m0 = (const u32*)P.m; const u32* __restrict__ m1 = (const u32*)P.p;
+        for (u32 k = threadIdx.x; k < T * T * NR; k += 64) { mats[0][k] = m0[k]; mats[1][k] = m1[k]; }
+    }
+    const u64 i = (u64)blockIdx.x * G + g, ic = i < n_ops ? i : n_ops - 1;      // an idle group shadows the last parent
+    const fe one = fe_one();
+    fe st[S];
+    u32 wd[S];                                                                  // this lane's words; slots past the state work on word 0's constants and are never read back
+    fh_static_for<0, S>([&](auto SI) {
+        constexpr int sl = decltype(SI)::value;
+        const u32 w = sl * L + q;
+        wd[sl] = w < T ? w : 0;
+        st[sl] = fe_zero();
+        if (w >= 1 && w < T) st[sl] = load_raw(in + (ic * 16 + (w - 1)) * 4);
+        st[sl] = fe_add(st[sl], P.c[wd[sl]]);
+    });
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 r = 0; r < 4; ++r) {
+        grp_sbox_layer<S>(st, wd, P.c + (r + 1) * T);
+        grp_matmul<L, S>(st, wd, r < 3 ? mats[0] : mats[1], xs[g], q);
+    }
+    // sparse rounds: word 0 lives in slot 0 of lane 0 of the group.  CO_RENORM rounds, then every running word back below 2r.
+    const u32 src0 = threadIdx.x - q;
+    const bool is0 = q == 0;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 r = 0; r < P.n_rp;) {
+        const u32 n = P.n_rp - r < CO_RENORM ? P.n_rp - r : CO_RENORM;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (u32 k = 0; k < n; ++k, ++r) {
+            const fe* __restrict__ Sr = P.s + (size_t)(2 * T - 1) * r;
+            fe wv[S], vv[S];
+            fh_static_for<0, S>([&](auto SI) {                                  // requested in front of the S-box
+                constexpr int sl = decltype(SI)::value;
+                wv[sl] = load_words((const u32*)(Sr + wd[sl]));
+                vv[sl] = load_words((const u32*)(Sr + T + (wd[sl] ? wd[sl] : 1) - 1));
+            });
+            const fe c = load_words((const u32*)(P.c + 5 * T + r));
+            fe y;
+#pragma unroll
+            for (int e = 0; e < NR; ++e) y.l[e] = (u32)__shfl((int)st[0].l[e], (int)src0, 64);
+            pow5(y);
+#pragma unroll
+            for (int e = 0; e < NR; ++e) y.l[e] += c.l[e];                      // limbs < 2^30, value < 3r
+            fe_wide w; fe_wide_zero(w);
+            fh_static_for<0, S>([&](auto SI) {
+                constexpr int sl = decltype(SI)::value;
+                const bool live = sl * L + q < (u32)T;
+                fe_wide_mac(w, fe_pick(live, wv[sl], fe_zero()), fe_pick(sl == 0 && is0, y, st[sl]));   // <= 3 products of < 7.3r (word 0: < 3r) by < r
+            });
+            fe p = fe_canon(fe_wide_reduce(w));
+#pragma unroll
+            for (int m = 1; m < L; m <<= 1) {
+                fe o;
+#pragma unroll
+                for (int e = 0; e < NR; ++e) o.l[e] = (u32)__shfl_xor((int)p.l[e], m, 64);
+#pragma unroll
+                for (int e = 0; e < NR; ++e) p.l[e] += o.l[e];
+                if (m == 2 || m * 2 >= L) fe_norm_u(p);                         // at most four summands per limb between two carry passes
+            }
+            fh_static_for<0, S>([&](auto SI) {
+                constexpr int sl = decltype(SI)::value;
+                const fe upd = fe_mul_acc(vv[sl], y, st[sl]);
+                st[sl] = fe_pick(sl == 0 && is0, p, upd);                       // word 0 <- the row's sum (< L r)
+            });
+        }
+        fh_static_for<0, S>([&](auto SI) { constexpr int sl = decltype(SI)::value; st[sl] = fe_pick(sl == 0 && is0, st[sl], fe_mul(st[sl], one)); });
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 r = 0; r < 4; ++r) {
+        grp_sbox_layer<S>(st, wd, r < 3 ? P.c + 5 * T + P.n_rp + r * T : nullptr);
+        grp_matmul<L, S>(st, wd, mats[0], xs[g], q);
+    }
+    if (i < n_ops && q == FH_OUT_IDX) store_raw(st[0], out + 4 * i);
+}
+
 struct DeviceTables { fe* all = nullptr; bool ready = false; };
 DeviceTables g_tables[64];
 const u32 NRP[16] = {FH_NRP};
@@ -643,7 +762,11 @@ void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u6
     while (n > 1) {
         static const bool level_reg = !getenv("ZK_FR_LEVEL_REG") || atoi(getenv("ZK_FR_LEVEL_REG"));   // tuning knob: 0 = the generic one-lane kernel
         static const u64 coop_upto = getenv("ZK_FR_LEVEL_COOP") ? strtoull(getenv("ZK_FR_LEVEL_COOP"), nullptr, 10) : 16384;
-        if (next <= coop_upto)  // latency-bound: 32 lanes per parent
+        static const u64 grp_from = getenv("ZK_FR_LEVEL_GRP_FROM") ? strtoull(getenv("ZK_FR_LEVEL_GRP_FROM"), nullptr, 10) : 2561;    // tuning knobs: parents from .. upto take
+        static const u64 grp_upto = getenv("ZK_FR_LEVEL_GRP_UPTO") ? strtoull(getenv("ZK_FR_LEVEL_GRP_UPTO"), nullptr, 10) : 32768;   // eight lanes each (0 upto = never)
+        if (next >= grp_from && next <= grp_upto)
+            hipLaunchKernelGGL(bn128_level_grp_kernel<8>, dim3((unsigned)((next + 7) / 8)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+        else if (next <= coop_upto)  // latency-bound: one wave per parent
             hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)next), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else if (level_reg)
             hipLaunchKernelGGL(bn128_level_reg_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
