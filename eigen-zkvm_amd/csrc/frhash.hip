@@ -6,12 +6,13 @@
 // A digest (ElementDigest<4, Fr>) holds the RAW limbs of an Fr, i.e. its Montgomery form a*2^256 mod r
 // (digest.rs:45-53); that is the format of every node buffer here.
 //
-// Mapping: one lane = one permutation; the state (t <= 17 elements of 9 x 29-bit limbs) lives in the lane's
-// private segment, the parameter tables (24 060 constants, converted once per device to the internal
-// Montgomery form) in global memory behind wave-uniform addresses.  Integer-ALU bound: 5 457 Fr products per
-// t = 17 permutation, 225 instructions each (fe29_impl.hip.h).  Value bounds: round-boundary state < 2r; a
-// column of the dense products sums 17 products (< 34r) and is brought back below 2r by one product with
-// R' mod r; the sparse rounds' running columns are renormalised every 16 rounds (< 34r in between).
+// Mapping, by how many permutations a launch holds (frhash_impl.hip.h): one lane per permutation with the state
+// (t <= 17 elements of 9 x 29-bit limbs) in registers where throughput binds (leaves of one sponge step, levels above 32 768 parents),
+// eight lanes per permutation for levels of 2 561..32 768 parents, one wave per permutation (sparse rounds as a linear recurrence over
+// the lanes) where a chain's latency binds (small levels, few wide rows, the transcript).  The parameter tables (24 060 constants,
+// converted once per device to the internal Montgomery form, plus the cooperative form's coefficient tables built from them on the
+// device) live in global memory.  Integer-ALU bound: 5 457 Fr products per one-lane t = 17 permutation, 190-230 instructions each
+// (fe29_impl.hip.h).  Value bounds are stated where the sums are formed.
 #include "zk_internal.h"
 #include <cstdio>
 #include <cstdlib>
