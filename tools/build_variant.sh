@@ -8,7 +8,7 @@ mkdir -p ../variants /tmp/zkvar
 obj=/tmp/zkvar/${name}_${src%.hip}.o
 extra=""; [ "$src" = msm.hip ] && extra="--gpu-max-threads-per-block=64"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-pass-failed $extra $flags -c $src -o $obj
-objs=""; for o in ntt poseidon frhash stark expr_jit msm stark_prover stark_verify starkinfo_gen groth16 compressor12 capi; do
+objs=""; for o in ntt poseidon frhash frhash_bls12381 stark expr_jit msm stark_prover stark_verify starkinfo_gen groth16 compressor12 capi; do
   if [ "$o.hip" = "$src" ]; then objs="$objs $obj"; else objs="$objs $o.o"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libzkgpu_${name}.so $objs -L/opt/rocm/lib -lhiprtc
 echo built ../variants/libzkgpu_${name}.so
