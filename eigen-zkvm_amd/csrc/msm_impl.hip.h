@@ -637,37 +637,62 @@ void fq_mont_to_canon_dev(void* d, uint64_t n, hipStream_t st) {
 
 // ---- bucket reduction for window tables.  All 16 windows carry the same weight there, so buckets of equal digit merge
 // ---- (M_d = sum_w B_{w,d}) and sum_d d M_d = sum_b 2^b T_b with T_b = the plain sum of the M_d whose digit has bit b
-// ---- set: 16 independent tree sums (5 levels of 8) and a 16-step Horner -- 86 dependent point operations instead of
-// ---- the ~230 of the weighted hierarchy + window Horner, which is what a sum costs when n is small.
-__global__ __launch_bounds__(64) void msm_merge_windows_kernel(const xyzz* __restrict__ buckets, xyzz* __restrict__ merged) {
-    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;                        // < N_BUCKET
-    xyzz acc = buckets[d];
-    for (int w = 1; w < N_WIN; ++w) acc = pt_add(acc, buckets[(u32)w * N_BUCKET + d]);
-    merged[d] = acc;
+// ---- set.  When n is small this tail IS the sum (2^18 points: 2 ms of accumulation, 4.3 ms of tail on G1, 3.2 + 7.9 on G2 of
+// ---- BLS12-381): every stage is a chain of point additions on lanes that have a SIMD to themselves, ~47 us each (G1, 14 limbs).
+// ---- Round 5 cuts the chain from 96 point operations to 46: the merge on two lanes per digit (8 deep instead of 15), the T_b as trees
+// ---- inside a workgroup (7 + 6 deep for 512 digits, then 6 for the 64 partial sums of a bit; were 8 + 4 x 7), and 2^b T_b by b
+// ---- doublings in lane b followed by a 4-level tree (15 doublings + 4 additions; the Horner walk was 15 of each).
+constexpr u32 BT_K = 8;                                                        // digits a lane sums before the workgroup's tree
+constexpr u32 BT_CHUNKS = (N_BUCKET / 2) / (64 * BT_K);                        // partial sums per bit after the first level: 64
+static_assert(BT_CHUNKS == 64 && C_BITS == 16, "the second level is one workgroup of 64 lanes per bit; the last one lane per bit");
+// sum over the workgroup's 64 lanes, result in lane 0 (6 dependent additions); every lane must call
+__device__ __forceinline__ xyzz wg_tree_sum(xyzz acc, xyzz* sh, u32 l, u32 width) {
+    for (u32 s = width >> 1; s >= 1; s >>= 1) {
+        __syncthreads();
+        if (l >= s && l < 2 * s) sh[l] = acc;
+        __syncthreads();
+        if (l < s) acc = pt_add(acc, sh[l + s]);
+    }
+    return acc;
 }
-// lane (b, g): the 8 digits number 8 g .. 8 g + 7 among those with bit b set (k-th such digit: a 1 spliced into k at bit b)
-__global__ __launch_bounds__(64) void msm_bit_partials_kernel(const xyzz* __restrict__ merged, xyzz* __restrict__ out /* [16][4096] */) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;                        // < 16 * 4096
-    const u32 b = t >> 12, g = t & 4095;
+__global__ __launch_bounds__(64) void msm_merge_windows_kernel(const xyzz* __restrict__ buckets, xyzz* __restrict__ merged) {
+    __shared__ xyzz sh[32];
+    constexpr u32 HW = N_WIN / 2;                                               // lane (digit, half): windows HW h .. HW h + HW - 1
+    const u32 l = threadIdx.x, h = l >> 5, d = blockIdx.x * 32 + (l & 31);
+    xyzz acc = buckets[(u32)(HW * h) * N_BUCKET + d];
+    for (u32 w = 1; w < HW; ++w) acc = pt_add(acc, buckets[(u32)(HW * h + w) * N_BUCKET + d]);
+    if (h) sh[l & 31] = acc;
+    __syncthreads();
+    if (!h) merged[d] = pt_add(acc, sh[l]);
+}
+static_assert(N_WIN % 2 == 0, "two halves of the windows");
+// block (chunk, b): the 512 digits number 512 chunk .. among those with bit b set (k-th such digit: a 1 spliced into k at bit b)
+__global__ __launch_bounds__(64) void msm_bit_tree_kernel(const xyzz* __restrict__ merged, xyzz* __restrict__ out /* [16][64] */) {
+    __shared__ xyzz sh[64];
+    const u32 l = threadIdx.x, b = blockIdx.y, k0 = (blockIdx.x * 64 + l) * BT_K;
     xyzz acc = pt_inf();
-    for (u32 j = 0; j < 8; ++j) {
-        const u32 k = g * 8 + j;
+    for (u32 j = 0; j < BT_K; ++j) {
+        const u32 k = k0 + j;
         const u32 d = ((k >> b) << (b + 1)) | (1u << b) | (k & ((1u << b) - 1));
         acc = pt_add(acc, merged[d]);
     }
-    out[t] = acc;
+    acc = wg_tree_sum(acc, sh, l, 64);
+    if (l == 0) out[b * BT_CHUNKS + blockIdx.x] = acc;
 }
-__global__ __launch_bounds__(64) void msm_sum8_kernel(const xyzz* __restrict__ in, xyzz* __restrict__ out, u32 n_out) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_out) return;
-    xyzz acc = in[(u64)t * 8];
-    for (u32 j = 1; j < 8; ++j) acc = pt_add(acc, in[(u64)t * 8 + j]);
-    out[t] = acc;
+__global__ __launch_bounds__(64) void msm_bit_sum_kernel(const xyzz* __restrict__ in /* [16][64] */, xyzz* __restrict__ T /* [16] */) {
+    __shared__ xyzz sh[64];
+    const u32 l = threadIdx.x, b = blockIdx.x;
+    const xyzz acc = wg_tree_sum(in[b * BT_CHUNKS + l], sh, l, 64);
+    if (l == 0) T[b] = acc;
 }
 __global__ __launch_bounds__(64) void msm_final_bits_kernel(const xyzz* __restrict__ T /* [16] */, u32* __restrict__ out) {
-    if (threadIdx.x | blockIdx.x) return;
-    xyzz acc = T[C_BITS - 1];
-    for (int b = C_BITS - 2; b >= 0; --b) { acc = pt_dbl(acc); acc = pt_add(acc, T[b]); }
+    __shared__ xyzz sh[64];
+    const u32 l = threadIdx.x;
+    xyzz acc = l < (u32)C_BITS ? T[l] : pt_inf();
+    for (u32 k = 0; k < (u32)C_BITS - 1; ++k)
+        if (k < l && l < (u32)C_BITS) acc = pt_dbl(acc);                      // lane b: 2^b T_b
+    acc = wg_tree_sum(acc, sh, l, 16);
+    if (l) return;
     if (pt_is_inf(acc)) { for (int i = 0; i < 2 * CW_STD; ++i) out[i] = 0; out[2 * CW_STD] = 1; return; }
     u32 x[CW_STD], y[CW_STD];
     pt_to_std(acc, x, y);
@@ -824,17 +849,13 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     // `st` has waited for the side stream's last event: everything it did is ordered before what follows on `st`, so the pool may forget
     // it (frees are stamped on `st` alone again, and a process that only ever used the null stream is back on the event-free fast path)
     if (n_chunks > 1) forget_stream(ss);
-    if (d_table) {   // equal window weights: merge, 16 bit-partial tree sums, 16-step Horner
+    if (d_table) {   // equal window weights: merge, 16 trees over the digits with a bit set, 2^b T_b in lane b and a last tree
         xyzz* merged = (xyzz*)S0.p;                       // N_BUCKET items fit: S0 holds n_keys / 16 = N_BUCKET
-        xyzz* pa = (xyzz*)A0.p; xyzz* pb = (xyzz*)S1.p;   // 16 * 4096 = N_BUCKET items, then 1/8 of it per level
-        hipLaunchKernelGGL(msm_merge_windows_kernel, dim3(N_BUCKET / 64), dim3(64), 0, st, (const xyzz*)buckets.p, merged);
-        hipLaunchKernelGGL(msm_bit_partials_kernel, dim3(C_BITS * 4096 / 64), dim3(64), 0, st, (const xyzz*)merged, pa);
-        u32 n_out = C_BITS * 512;
-        for (int level = 0; level < 4; ++level, n_out /= 8) {   // 4096 -> 512 -> 64 -> 8 -> 1 per bit
-            hipLaunchKernelGGL(msm_sum8_kernel, dim3((n_out + 63) / 64), dim3(64), 0, st, (const xyzz*)pa, pb, n_out);
-            std::swap(pa, pb);
-        }
-        hipLaunchKernelGGL(msm_final_bits_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)pa, (u32*)d_out);
+        xyzz* pa = (xyzz*)A0.p; xyzz* pb = (xyzz*)S1.p;   // 16 x 64 partial sums, then the 16 T_b
+        hipLaunchKernelGGL(msm_merge_windows_kernel, dim3(N_BUCKET / 32), dim3(64), 0, st, (const xyzz*)buckets.p, merged);
+        hipLaunchKernelGGL(msm_bit_tree_kernel, dim3(BT_CHUNKS, C_BITS), dim3(64), 0, st, (const xyzz*)merged, pa);
+        hipLaunchKernelGGL(msm_bit_sum_kernel, dim3(C_BITS), dim3(64), 0, st, (const xyzz*)pa, pb);
+        hipLaunchKernelGGL(msm_final_bits_kernel, dim3(1), dim3(64), 0, st, (const xyzz*)pb, (u32*)d_out);
         ZK_HIP(hipGetLastError());
         return;
     }
