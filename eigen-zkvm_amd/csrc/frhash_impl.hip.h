@@ -37,6 +37,7 @@ __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_s
 // Sums of products with deferred reduction (fe29_impl.hip.h fe_wide): the tables are canonical (< r), so a group of g
 // products with operands < B r needs g B <= FH_AB_LIMIT (168 for BN254's r, 68 for BLS12-381's).
 constexpr u32 DOT_DENSE = FE_WIDE_MAX;                                       // dense products: state < 3r (6 x 3 = 18)
+constexpr u32 CO_RENORM = 5;                                                 // fused product-accumulates between two renormalisations (register and cooperative forms)
 constexpr u32 PR_RENORM = 8;                                                 // sparse rounds: running columns renormalised every 8 rounds,
 constexpr u32 DOT_SPARSE = FH_AB_LIMIT / 18 < FE_WIDE_MAX ? FH_AB_LIMIT / 18 : FE_WIDE_MAX;   // < 2r + 8 * 2r = 18r in between
 // sum_{j < n} a[j * stride] * x[j] in groups of `grp`; n > grp: partial results (< 2r each) are added and renormalised
@@ -160,7 +161,7 @@ __device__ __forceinline__ void reg_rotate_in(fe (&a)[T], const fe& last) {
     fh_static_for<0, T - 1>([&](auto I) { a[decltype(I)::value] = a[decltype(I)::value + 1]; });
     a[T - 1] = last;
 }
-template <int T>
+template <int T, bool RENORM>
 __device__ __forceinline__ fe reg_dot(const fe* __restrict__ a, u32 stride, const fe (&x)[T], u32 grp) {
     fe_wide w; fe_wide_zero(w);
     fe acc = fe_zero();
@@ -170,38 +171,62 @@ __device__ __forceinline__ fe reg_dot(const fe* __restrict__ a, u32 stride, cons
         fe_wide_mac(w, a[(size_t)j * stride], x[j]);
         if (++cnt == grp || j + 1 == T) { acc = fe_add(acc, fe_wide_reduce(w)); cnt = 0; fe_wide_zero(w); }
     });
-    return (u32)T > grp ? fe_renorm(acc) : acc;
+    return RENORM && (u32)T > grp ? fe_renorm(acc) : acc;                    // up to three groups: < 6r without
+}
+template <int T>
+__device__ __forceinline__ void reg_renorm_tail(fe (&st)[T]) {               // st[1..T) < 2r, one rolled product
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int k = 1; k < T; ++k) {
+        const fe v = fe_renorm(st[1]);
+        fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
+        st[T - 1] = v;
+    }
 }
 // (The rolled loops carry interleave(disable) besides unroll(disable): with an even trip count the loop vectoriser otherwise
 // interleaves two trips, doubling the live state -- T = 8 took 512 registers, T = 10 and up spilled to scratch.)
+// Bounds (units of r).  Dense rounds: S-box output < 2, + constant < 3, a column of <= 3 groups of 6 products < 6 (no
+// renormalisation: the next S-box squares it, 36 <= FH_AB_LIMIT).  Sparse rounds: the words 1..T-1 enter below 2 (one pass of
+// products by one), each round adds S'[k] y to them inside the product's own reduction (fe_mul_acc: + < 1.05 a round), and after
+// every CO_RENORM rounds they come back below 2 -- in a loop of its own: written as `if (r % 8 == 7)` inside the column loop
+// the renormalising product was if-converted and ran every time (a quarter of the kernel).  The row product takes groups of
+// 6 x 7.3 <= FH_AB_LIMIT.  The column update is unrolled: rolled, rotating the state cost 122 moves per 212-instruction product.
+constexpr u32 DOT_SPARSE_REG = FH_AB_LIMIT / 8 < FE_WIDE_MAX ? FH_AB_LIMIT / 8 : FE_WIDE_MAX;
+static_assert(2 + CO_RENORM * 21 / 20 + 1 <= 8, "running words must stay below 8r between renormalisations");
+// The permutation's tables c | m | p | s (contiguous in that order in global memory, load_constants) are staged in LDS by the block
+// (reg_tables_to_lds): with one or two waves per SIMD nothing hides a global load, and once the sparse rounds were down to their
+// products the kernels ran at the latency of 60 table reads a round instead of at their instruction count.
+__host__ __device__ constexpr u32 fh_nrp(int t) { constexpr u32 v[16] = {FH_NRP}; return v[t - 2]; }
+template <int T> constexpr u32 REG_TAB_WORDS = (8 * T + fh_nrp(T) + 2 * T * T + (2 * T - 1) * fh_nrp(T)) * NR;
+static_assert(REG_TAB_WORDS<17> * 4 <= 120 * 1024, "the t = 17 tables must leave room in the 160 KiB of LDS");
 template <int T>
-__device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
-    const Params P = g_prm[T - 2];
+__device__ __forceinline__ const fe* reg_tables_to_lds(u32* lds) {            // every thread of the block
+    const u32* __restrict__ src = (const u32*)g_prm[T - 2].c;
+    for (u32 k = threadIdx.x; k < REG_TAB_WORDS<T>; k += blockDim.x) lds[k] = src[k];
+    __syncthreads();
+    return (const fe*)lds;
+}
+template <int T>
+__device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restrict__ tab /* LDS */) {
+    struct { u32 n_rp; const fe* c; const fe* m; const fe* p; const fe* s; } P;
+    P.n_rp = fh_nrp(T); P.c = tab; P.m = tab + 8 * T + fh_nrp(T); P.p = P.m + T * T; P.s = P.p + T * T;
     fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = fe_add(st[decltype(I)::value], P.c[decltype(I)::value]); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 fr = 0; fr < 8; ++fr) {
         if (fr == 4) {
+            reg_renorm_tail<T>(st);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (u32 r = 0; r < P.n_rp; ++r) {
-                pow5(st[0]);
-                st[0] = fe_add(st[0], P.c[5 * T + r]);
-                const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
-                const fe s0 = reg_dot<T>(S, 1, st, DOT_SPARSE);
-                const bool renorm = r % PR_RENORM == PR_RENORM - 1;
+            for (u32 r = 0; r < P.n_rp;) {
+                const u32 n = P.n_rp - r < CO_RENORM ? P.n_rp - r : CO_RENORM;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-                for (int k = 1; k < T; ++k) {                       // word 1 is updated, then the tail st[1..T) rotates
-                    fe v = fe_add(st[1], fe_mul(S[T + k - 1], st[0]));
-                    if (renorm) v = fe_renorm(v);
-                    fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
-                    st[T - 1] = v;
+                for (u32 q = 0; q < n; ++q, ++r) {
+                    pow5(st[0]);
+                    st[0] = fe_add(st[0], P.c[5 * T + r]);
+                    const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
+                    const fe s0 = reg_dot<T, true>(S, 1, st, DOT_SPARSE_REG);
+                    fh_static_for<1, T>([&](auto K) { constexpr int k = decltype(K)::value; st[k] = fe_mul_acc(S[T + k - 1], st[0], st[k]); });
+                    st[0] = s0;
                 }
-                st[0] = s0;
-            }
-#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (int k = 1; k < T; ++k) {
-                const fe v = fe_renorm(st[1]);
-                fh_static_for<1, T - 1>([&](auto I) { st[decltype(I)::value] = st[decltype(I)::value + 1]; });
-                st[T - 1] = v;
+                reg_renorm_tail<T>(st);
             }
         }
         // S-boxes + round constants of the next linear layer (none after the last S-box layer)
@@ -218,13 +243,15 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T]) {
         fe out[T];
         fh_static_for<0, T>([&](auto I) { out[decltype(I)::value] = fe_zero(); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (int i = 0; i < T; ++i) reg_rotate_in<T>(out, reg_dot<T>(mat + i, T, st, DOT_DENSE));
+        for (int i = 0; i < T; ++i) reg_rotate_in<T>(out, reg_dot<T, false>(mat + i, T, st, DOT_DENSE));
         fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = out[decltype(I)::value]; });
     }
 }
 // LinearHashBN128::hash_element_array for rows of 5 <= width <= 24 columns: one sponge step of t = NB + 1
 template <int NB>
-__global__ __launch_bounds__(64) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+__global__ __launch_bounds__(256) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    __shared__ u32 lds[REG_TAB_WORDS<NB + 1>];
+    const fe* tab = reg_tables_to_lds<NB + 1>(lds);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= height) return;
     const u64* __restrict__ v = rows + i * width;
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(64) void bn128_leaf_reg_kernel(const u64* __restric
         const u32 at = 3 * k, len = width - at < 3 ? width - at : 3;
         st[k + 1] = words_to_fe(v + at, len);
     });
-    poseidon_fr_reg<NB + 1>(st);
+    poseidon_fr_reg<NB + 1>(st, tab);
     store_raw(st[FH_OUT_IDX], digests + 4 * i);
 }
 
@@ -251,13 +278,15 @@ __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__
 }
 
 // the same with the 17 words in registers (poseidon_fr_reg<17>: no scratch arrays behind run-time indices)
-__global__ __launch_bounds__(64) void bn128_level_reg_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+__global__ __launch_bounds__(256) void bn128_level_reg_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    __shared__ u32 lds[REG_TAB_WORDS<17>];
+    const fe* tab = reg_tables_to_lds<17>(lds);
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_ops) return;
     fe st[17];
     st[0] = fe_zero();
     fh_static_for<0, 16>([&](auto K) { st[decltype(K)::value + 1] = load_raw(in + (i * 16 + decltype(K)::value) * 4); });
-    poseidon_fr_reg<17>(st);
+    poseidon_fr_reg<17>(st, tab);
     store_raw(st[FH_OUT_IDX], out + 4 * i);
 }
 
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(64) void bn128_level_reg_kernel(const u64* __restri
 //    its rounds sum_k w[k] st_b[k] (16 products).  The coefficient tables are built on the device from S when the constants load.
 // Bounds (units of r): dense inputs < 3, thirds < 2, sums < 6 -> S-box (36 <= FH_AB_LIMIT); running values start < 2 and grow by
 // < 1.05 a round, renormalised every CO_RENORM = 5 rounds (< 7.3: the S-box's square stays <= 54 <= FH_AB_LIMIT).
-constexpr u32 CO_RENORM = 5, CO_XL0 = 17, CO_XLANES = 47;
+constexpr u32 CO_XL0 = 17, CO_XLANES = 47;
 static_assert((2 + CO_RENORM * 21 / 20 + 1) * (2 + CO_RENORM * 21 / 20 + 1) <= FH_AB_LIMIT, "running values too large for the S-box square");
 __host__ __device__ constexpr u32 co_phase1(u32 n_rp) { return (n_rp + 1) / 2; }   // first round of the second phase; both halves <= CO_XLANES
 struct CoopLds { u32 xs[18 * NR]; u32 xp[64 * NR]; };
@@ -635,7 +664,7 @@ __global__ __launch_bounds__(64) void bn128_level_grp_kernel(const u64* __restri
 
 struct DeviceTables { fe* all = nullptr; bool ready = false; };
 DeviceTables g_tables[64];
-const u32 NRP[16] = {FH_NRP};
+const u32 NRP[16] = {FH_NRP};   // = fh_nrp(t) for t = 2..17
 
 void require_tables() {
     int dev; ZK_HIP(hipGetDevice(&dev));
@@ -722,7 +751,7 @@ uint64_t FH_FN(merkle_n_nodes)(uint64_t n_) {  // merklehash_bn128.rs:26-39
 void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     require_tables();
     if (height == 0) return;
-    const dim3 grid((unsigned)((height + 63) / 64)), blk(64);
+    const dim3 grid((unsigned)((height + 63) / 64)), blk(64), grid_reg((unsigned)((height + 255) / 256));
     const u32 nb = width ? (width - 1) / 3 + 1 : 0;
     if (width > 4 && height <= 4096) {   // latency-bound: 32 lanes per row
         hipLaunchKernelGGL(bn128_leaf_coop_kernel, dim3((unsigned)height), blk, 0, st, d_rows, width, height, d_digests);
@@ -731,21 +760,21 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
     }
     static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 16;   // tuning knob: largest block count that takes the register kernels
     switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
-        case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 4: hipLaunchKernelGGL(bn128_leaf_reg_kernel<4>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 5: hipLaunchKernelGGL(bn128_leaf_reg_kernel<5>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 6: hipLaunchKernelGGL(bn128_leaf_reg_kernel<6>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 7: hipLaunchKernelGGL(bn128_leaf_reg_kernel<7>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 8: hipLaunchKernelGGL(bn128_leaf_reg_kernel<8>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 9: hipLaunchKernelGGL(bn128_leaf_reg_kernel<9>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 10: hipLaunchKernelGGL(bn128_leaf_reg_kernel<10>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 11: hipLaunchKernelGGL(bn128_leaf_reg_kernel<11>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 12: hipLaunchKernelGGL(bn128_leaf_reg_kernel<12>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 13: hipLaunchKernelGGL(bn128_leaf_reg_kernel<13>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 14: hipLaunchKernelGGL(bn128_leaf_reg_kernel<14>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 15: hipLaunchKernelGGL(bn128_leaf_reg_kernel<15>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
-        case 16: hipLaunchKernelGGL(bn128_leaf_reg_kernel<16>, grid, blk, 0, st, d_rows, width, height, d_digests); break;
+        case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 4: hipLaunchKernelGGL(bn128_leaf_reg_kernel<4>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 5: hipLaunchKernelGGL(bn128_leaf_reg_kernel<5>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 6: hipLaunchKernelGGL(bn128_leaf_reg_kernel<6>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 7: hipLaunchKernelGGL(bn128_leaf_reg_kernel<7>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 8: hipLaunchKernelGGL(bn128_leaf_reg_kernel<8>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 9: hipLaunchKernelGGL(bn128_leaf_reg_kernel<9>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 10: hipLaunchKernelGGL(bn128_leaf_reg_kernel<10>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 11: hipLaunchKernelGGL(bn128_leaf_reg_kernel<11>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 12: hipLaunchKernelGGL(bn128_leaf_reg_kernel<12>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 13: hipLaunchKernelGGL(bn128_leaf_reg_kernel<13>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 14: hipLaunchKernelGGL(bn128_leaf_reg_kernel<14>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 15: hipLaunchKernelGGL(bn128_leaf_reg_kernel<15>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
+        case 16: hipLaunchKernelGGL(bn128_leaf_reg_kernel<16>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
         default: hipLaunchKernelGGL(bn128_leaf_kernel, grid, blk, 0, st, d_rows, width, height, d_digests);
     }
     ZK_HIP(hipGetLastError());
@@ -769,7 +798,7 @@ void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u6
         else if (next <= coop_upto)  // latency-bound: one wave per parent
             hipLaunchKernelGGL(bn128_level_coop_kernel, dim3((unsigned)next), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else if (level_reg)
-            hipLaunchKernelGGL(bn128_level_reg_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+            hipLaunchKernelGGL(bn128_level_reg_kernel, dim3((unsigned)((next + 255) / 256)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else
             hipLaunchKernelGGL(bn128_level_kernel, dim3((unsigned)((next + 63) / 64)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         ZK_HIP(hipGetLastError());
