@@ -17,6 +17,7 @@
 #include "poseidon_gl_constants.h"
 #include "ntt_reg.hip.h"   // static_for
 #include "acc6.hip.h"
+#include "poseidon_mfma.hip.h"
 #include <mutex>
 
 namespace zk {
@@ -33,13 +34,69 @@ constexpr int T_PT = T_PC + 24;      // [12 i][12 j] split: P[j][i]
 constexpr int T_SR = T_PT + 288;     // [22][12] split: S[23r + j], j < 12
 constexpr int T_DD = T_SR + 528;     // [2 blocks][m (m - 1) / 2 + i] split: D[r][r0 + i], r = r0 + m (partial rounds, below)
 constexpr int T_SCS = T_DD + 220;    // [2 blocks][11 k][11 m] split: S[23 (r0 + m) + 12 + k], the column entries regrouped by state word
-constexpr int T_CD = T_SCS + 484;    // [2 blocks][11 m][16 l] split: what u_(r0 + m) weighs in lane l of a cooperative permutation (coop_partial_rounds)
-constexpr int T_K0 = T_CD + 704;     // [4]: C[8 + i]^7 + (round 0's constant of word 8 + i): what a zero capacity word is after the first S-box
-constexpr int T_WORDS = T_K0 + 4;    // 2360 words = 18.4 KB
+constexpr int T_K0 = T_SCS + 484;    // [4]: C[8 + i]^7 + (round 0's constant of word 8 + i): what a zero capacity word is after the first S-box
+constexpr int T_CD = T_K0 + 4;       // [2 blocks][11 m][16 l] split: what u_(r0 + m) weighs in lane l of a cooperative permutation (coop_partial_rounds)
+constexpr int T_WORDS = T_CD + 704;  // 2360 words = 18.4 KB
+constexpr int T_ONE = T_CD;          // what a one-lane permutation reads: 1656 words = 12.9 KB
 constexpr int PR_B = 11;             // partial rounds per block
 static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0 && T_CD % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
+
+// Round 6: the dense 64-bit products of a ONE-LANE permutation on the matrix pipe (poseidon_mfma.hip.h).  Bit 0: the pre-sparse
+// matrix P; bit 1: the column update at the end of a block of partial rounds; bit 2: the row products at its start.
+#ifndef ZK_POSEIDON_MFMA
+#define ZK_POSEIDON_MFMA 0
+#endif
+#ifndef ZK_LH_WAVES
+#define ZK_LH_WAVES 4
+#endif
+#ifndef ZK_LH_ROWS_WAVES
+#define ZK_LH_ROWS_WAVES 3
+#endif
+constexpr int MF = ZK_POSEIDON_MFMA;
+static_assert(MF == 0 || (MF & 7) == 7, "the three dense products go to the matrix pipe together; bit 3 adds the MDS of the full rounds");
+// LDS image of a one-lane kernel in that mode (g_mtab): the constants the vector pipe still reads, then one table per product
+constexpr int TM_C0 = T_C0, TM_FC = T_FC, TM_PC = T_PC;            // as in g_tab
+constexpr int TM_S0 = T_PT;                                        // [22] split: S_r[0]
+constexpr int TM_DD = TM_S0 + 44;                                  // as T_DD
+constexpr int TM_K0 = TM_DD + 220;                                 // as T_K0
+constexpr int TM_HDR = TM_K0 + 4;                                  // 400 words
+constexpr int MT_P = 0, MT_BS = 1, MT_BE = 3, MT_MDS = 5, MT_N = 6;   // tables: P, block starts 0 / 1, block ends 0 / 1, the MDS
+constexpr int TM_WORDS = TM_HDR + MT_N * pmfma::TAB_WORDS;          // 7456 words = 58.3 KB
+static_assert(TM_C0 == 0 && TM_FC == 12 && TM_PC == 108 && TM_HDR % 2 == 0 && TM_WORDS * 8 <= 65536, "one-lane tables: 16-byte aligned, inside 64 KB");
+__host__ __device__ constexpr int tm_table(int k) { return TM_HDR + k * pmfma::TAB_WORDS; }
+constexpr int T_ONE_WORDS = MF ? TM_WORDS : T_ONE;
+__device__ u64 g_mtab[TM_WORDS];
+// ... and their shape: with the matrix-pipe tables (59 KB) two workgroups of six waves fill a CU's three waves per SIMD
+#ifndef ZK_ONE_THREADS
+#define ZK_ONE_THREADS (ZK_POSEIDON_MFMA ? 384 : 256)
+#endif
+constexpr int ONE_THREADS = ZK_ONE_THREADS;
+#ifndef ZK_ONE_WAVES
+#define ZK_ONE_WAVES 3
+#endif
+constexpr int ONE_WAVES_LH = MF ? ZK_ONE_WAVES : ZK_LH_WAVES;
+constexpr int ONE_WAVES_ROWS = MF ? ZK_ONE_WAVES : ZK_LH_ROWS_WAVES;
+#if ZK_POSEIDON_MFMA
+#define ZK_LEVEL_BOUNDS __launch_bounds__(ZK_ONE_THREADS, ZK_ONE_WAVES)
+#else
+#define ZK_LEVEL_BOUNDS __launch_bounds__(256)
+#endif
+#define ZK_POSEIDON_LDS_ONE __shared__ __attribute__((aligned(16))) u64 tab[T_ONE_WORDS]
+static_assert(T_ONE % 2 == 0 && TM_WORDS % 2 == 0, "tables are copied 16 bytes at a time");
+__device__ __forceinline__ void load_tables_one(u64* __restrict__ tab) {
+    const ulonglong2* __restrict__ src = reinterpret_cast<const ulonglong2*>(MF ? g_mtab : g_tab);
+    for (int i = threadIdx.x; i < T_ONE_WORDS / 2; i += blockDim.x) reinterpret_cast<ulonglong2*>(tab)[i] = src[i];
+    __syncthreads();
+}
+// The one-lane kernels are resident: a grid of as many workgroups as the chip holds, each walking its share of the items with the tables
+// loaded once (round 6: with the matrix-pipe tables a workgroup's LDS image is 59 KB).  Every lane of a wave stays in the loop together.
+template <class F>
+__device__ __forceinline__ void one_lane_items(u64 n_items, F&& f) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 base = (u64)blockIdx.x * blockDim.x; base < n_items; base += stride) f(base + threadIdx.x);
+}
 
 __device__ __forceinline__ void load_tables(u64* __restrict__ tab) {
     for (int i = threadIdx.x; i < T_WORDS; i += blockDim.x) tab[i] = g_tab[i];
@@ -130,6 +187,21 @@ __device__ __forceinline__ void mat_full(const u64* __restrict__ PT /* LDS */, u
     }
 }
 
+// the same product on the matrix pipe (poseidon_mfma.hip.h); every lane of the wave must be here
+__device__ __forceinline__ void mat_full_mfma(const u64* __restrict__ mt /* LDS: table MT_P */, u64 (&st)[12]) {
+    pmfma::BOps B;
+    pmfma::make_b<12>(B, [&](int j) { return st[j]; });
+    pmfma::product<3>(B, mt, [&](int o, u64 v) { st[o] = v; });
+}
+// mds_small on the matrix pipe: the entries are below 2^6, the table does not care
+template <bool CANON, int N_OUT = 12>
+__device__ __forceinline__ void mds_mfma(const u64* __restrict__ mt /* LDS: table MT_MDS */, u64 (&st)[12]) {
+    static_assert(N_OUT == 12 || N_OUT == 4, "whole tiles");
+    pmfma::BOps B;
+    pmfma::make_b<12>(B, [&](int j) { return st[j]; });
+    pmfma::product<N_OUT / 4>(B, mt, [&](int o, u64 v) { st[o] = (CANON && v >= GL_P) ? v - GL_P : v; });
+}
+
 // The 22 partial rounds (poseidon_opt.rs:140-163) in two blocks of 11 without a reduction per state word and round.
 // In round r only st[0] passes the S-box: u_r = st[0]^7 + c_r, st[0] <- S_r[0] u_r + sum_k S_r[k] st[k], st[k] += SC_r[k] u_r.
 // The words k >= 1 are linear in the u's, so inside a block that starts at round r0 with words s_k
@@ -166,35 +238,77 @@ __device__ __forceinline__ void partial_rounds(u64 (&st)[12], const u64* __restr
     }
 }
 
+// partial_rounds() with the two dense products of a block on the matrix pipe: G[m] = sum_k S_(r0 + m)[k] s_k for the block's eleven
+// rounds before the first S-box, and s_k += sum_m SC_m[k] u_m after the last; the S-box chain, S_r[0] u_r and the D[r][i] u_i
+// terms -- what depends on the previous round -- stay on the vector pipe.  tab = the TM_ image.
+__device__ __forceinline__ void partial_rounds_mfma(u64 (&st)[12], const u64* __restrict__ tab) {
+#pragma unroll 1
+    for (int b = 0; b < 22 / PR_B; ++b) {
+        const u64* __restrict__ S0 = tab + TM_S0 + 2 * PR_B * b;
+        const u64* __restrict__ DD = tab + TM_DD + 2 * (PR_B * (PR_B - 1) / 2) * b;
+        const u64* __restrict__ PC = tab + TM_PC + PR_B * b;
+        u32 u0[PR_B], u1[PR_B];
+        u64 G[PR_B];
+        {
+            pmfma::BOps B;
+            pmfma::make_b<11>(B, [&](int j) { return st[j + 1]; });
+            pmfma::product<3>(B, tab + tm_table(MT_BS + b), [&](int o, u64 v) { if (o < PR_B) G[o] = v; });
+        }
+        u64 s0 = st[0];
+        static_for<0, PR_B>([&](auto MI) {
+            constexpr int m = decltype(MI)::value;
+            const u64 u = pow7_add(s0, PC[m]);
+            u0[m] = (u32)u; u1[m] = (u32)(u >> 32);
+            Acc6 A;
+            acc_word(A, G[m]);
+            acc_mac(A, S0 + 2 * m, u0[m], u1[m]);
+            if constexpr (m > 0) acc_dot<m>(A, DD + 2 * (m * (m - 1) / 2), [&](int i, u32& a, u32& c) { a = u0[i]; c = u1[i]; });
+            s0 = acc_finish(A);
+        });
+        st[0] = s0;
+        pmfma::BOps B;
+        pmfma::make_b<11>(B, [&](int j) { return gl::mk64(u0[j], u1[j]); });
+        pmfma::product_add<3>(B, tab + tm_table(MT_BE + b), [&](int o) { return st[o < PR_B ? o + 1 : 1]; },
+                              [&](int o, u64 v) { if (o < PR_B) st[o + 1] = v; });
+    }
+}
+
 // in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables.
 // Two things every LinearHash and every tree node allow (round 3):
 //   * zero_cap (wave-uniform): the capacity words are zero -- the first block of a sponge and every node of a tree.  After the
 //     first constants they are C[8..12) whatever the input, so their first S-boxes are four table words (T_K0), not 16 products;
 //   * FULL_OUT = false: only st[0..4) is read afterwards (a digest, or the capacity of the next block): the last MDS computes
 //     four of its twelve outputs.  st[4..12) are then NOT the permutation's words.
-template <bool FULL_OUT = false>
+// BITS: which dense products go to the matrix pipe (MF above); 0 in the kernels where not every lane of a wave runs a permutation.
+template <bool FULL_OUT = false, int BITS = 0>
 __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab, bool zero_cap) {
+    constexpr int K0 = BITS ? TM_K0 : T_K0;
+    auto mds = [&](auto CANON, auto N_OUT) {
+        if constexpr (BITS & 8) mds_mfma<decltype(CANON)::value, decltype(N_OUT)::value>(tab + tm_table(MT_MDS), st);
+        else mds_small<decltype(CANON)::value, decltype(N_OUT)::value>(st);
+    };
+    using std::integral_constant;
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
     if (zero_cap) {
 #pragma unroll
-        for (int i = 8; i < 12; ++i) st[i] = tab[T_K0 + i - 8];
+        for (int i = 8; i < 12; ++i) st[i] = tab[K0 + i - 8];
     } else {
 #pragma unroll
         for (int i = 8; i < 12; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
     }
-    mds_small<false>(st);
+    mds(integral_constant<bool, false>{}, integral_constant<int, 12>{});
 #pragma unroll 1
     for (int R = 1; R < 7; ++R) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = pow7_add(st[i], tab[T_FC + R * 12 + i]);
-        if (R != 3) { mds_small<false>(st); continue; }
-        mat_full(tab + T_PT, st);
-        partial_rounds(st, tab);
+        if (R != 3) { mds(integral_constant<bool, false>{}, integral_constant<int, 12>{}); continue; }
+        if constexpr (BITS & 7) { mat_full_mfma(tab + tm_table(MT_P), st); partial_rounds_mfma(st, tab); }
+        else { mat_full(tab + T_PT, st); partial_rounds(st, tab); }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) st[i] = pow7(st[i]);
-    mds_small<true, FULL_OUT ? 12 : 4>(st);
+    mds(integral_constant<bool, true>{}, integral_constant<int, FULL_OUT ? 12 : 4>{});
 }
 
 
@@ -329,6 +443,7 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
 // capacity carried, tail zero-padded; a batch of <= 4 words is its own zero-padded digest -- only
 // the last batch can be that short); more than one batch digest -> _hash over the digests.
 // All control flow depends on w only, i.e. is wave-uniform.
+template <int BITS = 0>
 __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 w, u64 (&out)[4], const u64* __restrict__ tab) {
     if (w <= 4) {
 #pragma unroll
@@ -355,7 +470,7 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = second ? h[8 + i] : h[i];
         }
-        poseidon_perm(st, tab, cz);
+        poseidon_perm<false, BITS>(st, tab, cz);
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
             off += 8;
@@ -401,76 +516,80 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
     for (int i = 0; i < 4; ++i) out[i] = st[i];
 }
 
-#ifndef ZK_LH_WAVES
-#define ZK_LH_WAVES 4
-#endif
-#ifndef ZK_LH_ROWS_WAVES
-#define ZK_LH_ROWS_WAVES 3
-#endif
 // The same digest in two launches for trees of middling height: one lane per (row, batch) hashes its batch, then one lane per
 // row sponges the batch digests.  A row of 37 words is 4 batches of 2 permutations and a final sponge of 2: four
 // permutations deep instead of ten -- what counts while there are too few rows to fill the chip (2^15-row proof 5.47 -> 5.36 ms,
 // 2^18-row proof 11.64 -> 11.41 ms; from 2^19 rows on the one-launch kernel is the faster one).
-__global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_batch_kernel(const u64* __restrict__ rows, u32 w, u64 height, u32 bs, u32 hsz,
+// (one lane per HASHED batch: a last batch of <= 4 words is its own digest -- linearhash.rs:121-126 -- and is written by the lane of the batch
+// before it; every lane of a wave runs the same number of permutations, the matrix pipe's condition: a shorter last batch idles a trip)
+__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_batch_kernel(const u64* __restrict__ rows, u32 w, u64 height, u32 bs, u32 hsz, u32 n_hashed,
                                                                             u64* __restrict__ h /* [height][hsz][4] */) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 r = t / hsz;
-    const u32 b = (u32)(t - r * hsz);
-    if (r >= height) return;
-    const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    one_lane_items(height * n_hashed, [&](u64 t_) {
+    const bool live = t_ < height * n_hashed;
+    const u64 t = live ? t_ : height * n_hashed - 1;                   // idle lanes shadow the last batch
+    const u64 r = t / n_hashed;
+    const u32 b = (u32)(t - r * n_hashed);
+    const u32 len = (w - b * bs < bs) ? w - b * bs : bs;               // > 4
     const u64* __restrict__ v = rows + r * w + (u64)b * bs;
-    u64 st[12];
-    if (len <= 4) {                                                   // short last batch: identity padding, no permutation (linearhash.rs:121-126)
+    u64 st[12], keep[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st[i] = (u32)i < len ? v[i] : 0;
-    } else {
+    for (int i = 8; i < 12; ++i) st[i] = 0;
+    for (u32 off = 0; off < bs; off += 8) {
+        const bool act = off < len;
 #pragma unroll
-        for (int i = 8; i < 12; ++i) st[i] = 0;
-        for (u32 off = 0; off < len; off += 8) {
+        for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[off + i] : 0;
+        poseidon_perm<false, MF>(st, tab, off == 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[off + i] : 0;
-            poseidon_perm(st, tab, off == 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st[8 + i] = st[i];            // the capacity carries the digest so far
-        }
+        for (int i = 0; i < 4; ++i) { if (act) keep[i] = st[i]; st[8 + i] = st[i]; }   // the capacity carries the digest so far
     }
+    if (!live) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[t * 4 + i] = st[i];
+    for (int i = 0; i < 4; ++i) h[(r * hsz + b) * 4 + i] = keep[i];
+    if (b + 1 == n_hashed && n_hashed < hsz) {
+        const u32 len2 = w - hsz * bs + bs;                             // the short last batch
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[(r * hsz + hsz - 1) * 4 + i] = (u32)i < len2 ? v[bs + i] : 0;
+    }
+    });
 }
-__global__ __launch_bounds__(256, ZK_LH_WAVES) void linearhash_final_kernel(const u64* __restrict__ h, u32 hsz, u64 height, u64* __restrict__ digests) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= height) return;
+__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_final_kernel(const u64* __restrict__ h, u32 hsz, u64 height, u64* __restrict__ digests) {
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    one_lane_items(height, [&](u64 r_) {
+    const u64 r = r_ < height ? r_ : height - 1;
     const u64* __restrict__ v = h + r * hsz * 4;
     u64 st[12];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = (u32)i < 4 * hsz ? v[i] : 0;
 #pragma unroll
     for (int i = 8; i < 12; ++i) st[i] = 0;
-    poseidon_perm(st, tab, true);
+    poseidon_perm<false, MF>(st, tab, true);
     if (hsz > 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = 8 + (u32)i < 4 * hsz ? v[8 + i] : 0;
-        poseidon_perm(st, tab, false);
+        poseidon_perm<false, MF>(st, tab, false);
     }
+    if (r_ >= height) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = st[i];
+    });
 }
 // (three waves per SIMD: 168 registers keep the block-lazy partial rounds out of the private segment; four spill, 2-4 % slower)
-__global__ __launch_bounds__(256, ZK_LH_ROWS_WAVES) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= height) return;
+__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_ROWS) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    one_lane_items(height, [&](u64 r_) {
+    const u64 r = r_ < height ? r_ : height - 1;                       // idle lanes shadow the last row: the matrix pipe wants whole waves
     u64 d[4];
-    linearhash_row(rows + r * width, width, d, tab);
+    linearhash_row<MF>(rows + r * width, width, d, tab);
+    if (r_ >= height) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = d[i];
+    });
 }
 
 // The same LinearHash with 16 lanes per row (coop_perm): lane l < 12 owns state word l, lanes 0..3 keep the batch digests.
@@ -577,19 +696,21 @@ __global__ __launch_bounds__(256) void linearhash_rows_wave_kernel(const u64* __
 }
 
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
-__global__ __launch_bounds__(256) void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_ops) return;
+__global__ ZK_LEVEL_BOUNDS void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    one_lane_items(n_ops, [&](u64 i_) {
+    const u64 i = i_ < n_ops ? i_ : n_ops - 1;
     u64 st[12];
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = in[8 * i + k];
 #pragma unroll
     for (int k = 8; k < 12; ++k) st[k] = 0;
-    poseidon_perm(st, tab, true);
+    poseidon_perm<false, MF>(st, tab, true);
+    if (i_ >= n_ops) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
+    });
 }
 
 // the same for small levels: 16 lanes per parent (coop_perm), 16 parents per block
@@ -852,6 +973,31 @@ void ensure_constants() {
             for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
         }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
+    {   // LDS image of the one-lane kernels with the dense products on the matrix pipe (poseidon_mfma.hip.h)
+        static u64 mt[TM_WORDS];
+        for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                   // C0, FC, PC
+        for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }
+        for (int i = 0; i < 220; ++i) mt[TM_DD + i] = tab[T_DD + i];
+        for (int i = 0; i < 4; ++i) mt[TM_K0 + i] = tab[T_K0 + i];
+        u64 coef[144];
+        bool ok = true;
+        for (int o = 0; o < 12; ++o)
+            for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_P[12 * j + o];                   // out[o] = sum_j P[j][o] st[j]
+        ok = ok && pmfma::build_tables(coef, 12, 12, nullptr, mt + tm_table(MT_P));
+        for (int o = 0; o < 12; ++o)
+            for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_M[12 * j + o];                   // out[o] = sum_j M[j][o] st[j]
+        ok = ok && pmfma::build_tables(coef, 12, 12, nullptr, mt + tm_table(MT_MDS));
+        for (int b = 0; b < 22 / PR_B; ++b) {
+            for (int m = 0; m < PR_B; ++m)                                                                // G[m] = sum_(k >= 1) S_(r0 + m)[k] st[k]
+                for (int j = 0; j < 11; ++j) coef[m * 11 + j] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 1 + j];
+            ok = ok && pmfma::build_tables(coef, PR_B, 11, nullptr, mt + tm_table(MT_BS + b));
+            for (int o = 0; o < 11; ++o)                                                                  // st[o + 1] += sum_m SC_(r0 + m)[o + 1] u_m
+                for (int m = 0; m < PR_B; ++m) coef[o * PR_B + m] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 12 + o];
+            ok = ok && pmfma::build_tables(coef, 11, PR_B, nullptr, mt + tm_table(MT_BE + b));
+        }
+        ZK_REQUIRE(ok, "Poseidon matrix-pipe tables: a digit column exceeds its bound");
+        ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mtab), mt, sizeof(mt)));
+    }
     g_consts_loaded[dev] = true;
 }
 
@@ -889,6 +1035,18 @@ void poseidon_dev(const u64* d_in8, const u64* d_cap4, u64* d_out, int n_out, hi
     ZK_HIP(hipGetLastError());
 }
 
+// grid of a resident one-lane kernel: what the chip holds at `waves` waves per SIMD, or fewer when the items do not fill it
+static u32 one_lane_grid(u64 n_items, int waves) {
+    static int cus[64] = {};
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    if (!cus[dev]) { hipDeviceProp_t pr; ZK_HIP(hipGetDeviceProperties(&pr, dev)); cus[dev] = pr.multiProcessorCount; }
+    static const u64 factor = getenv("ZK_ONE_RESIDENT") ? strtoull(getenv("ZK_ONE_RESIDENT"), nullptr, 10) : 1;   // 0: one workgroup per chunk (as through round 5)
+    const u64 chunks = (n_items + ONE_THREADS - 1) / ONE_THREADS;
+    if (!factor) return (u32)chunks;
+    const u64 resident = (u64)cus[dev] * (u64)std::max(1, waves * 4 * 64 / ONE_THREADS) * factor;
+    return (u32)std::min(chunks, resident);
+}
+
 void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     ensure_constants();
     if (height == 0) return;
@@ -904,12 +1062,12 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
         hipLaunchKernelGGL(linearhash_rows_coop_kernel, dim3((u32)((height + 15) / 16)), dim3(256), 0, st, d_rows, width, height, d_digests);
     } else if (hsz > 1 && height <= batch_upto) {   // too few rows to fill the chip: the batches of a row side by side
         DevBuf h; h.reserve(height * hsz * 32);
-        hipLaunchKernelGGL(linearhash_batch_kernel, dim3((u32)((height * hsz + 255) / 256)), dim3(256), 0, st, d_rows, width, height, bs, hsz, h.u());
+        const u32 n_hashed = width - (hsz - 1) * bs <= 4 ? hsz - 1 : hsz;
+        hipLaunchKernelGGL(linearhash_batch_kernel, dim3(one_lane_grid(height * n_hashed, ONE_WAVES_LH)), dim3(ONE_THREADS), 0, st, d_rows, width, height, bs, hsz, n_hashed, h.u());
         ZK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(linearhash_final_kernel, dim3((u32)((height + 255) / 256)), dim3(256), 0, st, (const u64*)h.u(), hsz, height, d_digests);
+        hipLaunchKernelGGL(linearhash_final_kernel, dim3(one_lane_grid(height, ONE_WAVES_LH)), dim3(ONE_THREADS), 0, st, (const u64*)h.u(), hsz, height, d_digests);
     } else {
-        const u64 blocks = (height + 255) / 256;
-        hipLaunchKernelGGL(linearhash_rows_kernel, dim3((u32)blocks), dim3(256), 0, st, d_rows, width, height, d_digests);
+        hipLaunchKernelGGL(linearhash_rows_kernel, dim3(one_lane_grid(height, ONE_WAVES_ROWS)), dim3(ONE_THREADS), 0, st, d_rows, width, height, d_digests);
     }
     ZK_HIP(hipGetLastError());
 }
@@ -981,8 +1139,7 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
         if (next <= coop_upto) {  // few parents: latency-bound, 16 lanes per permutation
             hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((u32)((next + 15) / 16)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         } else {
-            const u64 blocks = (next + 255) / 256;
-            hipLaunchKernelGGL(merkle_level_kernel, dim3((u32)blocks), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+            hipLaunchKernelGGL(merkle_level_kernel, dim3(one_lane_grid(next, MF ? ZK_ONE_WAVES : 3)), dim3(ONE_THREADS), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         }
         ZK_HIP(hipGetLastError());
         n64 = next; next = (n64 - 1) / 2 + 1; p_in = p_out; p_out = p_in + next * 2;

@@ -569,6 +569,28 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     const u64 N = 1ull << S->nbits, Next = 1ull << S->nbits_ext, nc = S->n_constants;
     ZK_REQUIRE(n_words == nc * N, "const trace size mismatch");
     const clk::time_point t_parsed = clk::now();
+    const JitStats j0 = jit_stats();
+    const JVal& P = S->prog;
+    // Every step program on a host thread of its own, each thread handing its text to a compiler process of its own: hipRTC takes
+    // seconds per program, the programs are independent, and inside one process hipRTC compiles them one after the other whatever
+    // the threads (serially the three of PoseidonG were 8.0 of an 8.4 s cold setup; the code-object cache keeps one compilation per text).
+    // Round 6: they start HERE, before the constants are uploaded, extended and merkelized -- the compilers are other processes on
+    // host cores, the constants are copies and kernels: 0.6 s of a 2^24-row cold setup that used to stand in front of the 2.1 s of hipRTC.
+    // (The futures block in their destructors: an exception below still waits for the threads that read S.)
+    const zk_stark_setup* Sc = S.get();
+    const std::launch how = getenv("ZK_JIT_SERIAL") ? std::launch::deferred : std::launch::async;   // (ZK_JIT_SERIAL: one after the other, for measurements)
+    const bool spawn = how == std::launch::async && !getenv("ZK_JIT_INPROCESS");   // side by side really means one compiler process each (expr_jit.hip)
+    auto start = [Sc, how, spawn](const JVal& seg, bool ext, bool ret) {
+        return std::async(how, [Sc, &seg, ext, ret, spawn] {
+            jit_prefer_spawn(spawn && seg.at("first").size() >= 32);            // (a handful of instructions compiles faster than a process starts)
+            struct Off { ~Off() { jit_prefer_spawn(false); } } off;
+            return Sc->compile_segment(seg, ext, ret);
+        });
+    };
+    std::future<ProgramPtr> f2 = start(P.at("step2prev"), false, false), f3p = start(P.at("step3prev"), false, false), f3 = start(P.at("step3"), false, false),
+                            f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
+    std::vector<std::future<ProgramPtr>> fp;
+    for (const JVal& seg : P.at("publics_code").arr) fp.push_back(start(seg, false, true));
     S->const_n.reserve(std::max<u64>(1, nc * N) * 8); S->const_2ns.reserve(std::max<u64>(1, nc * Next) * 8);
     if (nc) {
         h2d_sync(S->const_n.p, const_pols, nc * N * 8);
@@ -596,25 +618,7 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         h2d_sync(S->d_pub_pos.p, pos.data(), pos.size() * 8);
     }
     const clk::time_point t_tree = clk::now();
-    const JitStats j0 = jit_stats();
-    const JVal& P = S->prog;
-    {   // every step program on a host thread of its own, each thread handing its text to a compiler process of its own: hipRTC takes
-        // seconds per program, the programs are independent, and inside one process hipRTC compiles them one after the other whatever
-        // the threads (serially the three of PoseidonG were 8.0 of an 8.4 s cold setup; the code-object cache keeps one compilation per text)
-        const zk_stark_setup* Sc = S.get();
-        const std::launch how = getenv("ZK_JIT_SERIAL") ? std::launch::deferred : std::launch::async;   // (ZK_JIT_SERIAL: one after the other, for measurements)
-        const bool spawn = how == std::launch::async && !getenv("ZK_JIT_INPROCESS");   // side by side really means one compiler process each (expr_jit.hip)
-        auto start = [Sc, how, spawn](const JVal& seg, bool ext, bool ret) {
-            return std::async(how, [Sc, &seg, ext, ret, spawn] {
-                jit_prefer_spawn(spawn && seg.at("first").size() >= 32);            // (a handful of instructions compiles faster than a process starts)
-                struct Off { ~Off() { jit_prefer_spawn(false); } } off;
-                return Sc->compile_segment(seg, ext, ret);
-            });
-        };
-        std::future<ProgramPtr> f2 = start(P.at("step2prev"), false, false), f3p = start(P.at("step3prev"), false, false), f3 = start(P.at("step3"), false, false),
-                                f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
-        std::vector<std::future<ProgramPtr>> fp;
-        for (const JVal& seg : P.at("publics_code").arr) fp.push_back(start(seg, false, true));
+    {   // the step programs were started before the constants went up (above): collect them
         std::exception_ptr err;                           // wait for all of them before an error leaves this scope (they read S)
         auto take = [&](std::future<ProgramPtr>& f) -> ProgramPtr { try { return f.get(); } catch (...) { if (!err) err = std::current_exception(); return ProgramPtr(); } };
         S->step2prev = take(f2); S->step3prev = take(f3p); S->step3 = take(f3); S->step42ns = take(f4); S->step52ns = take(f5);
@@ -626,7 +630,8 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         const clk::time_point t_jit = clk::now();
         const JitStats j1 = jit_stats();
         std::ostringstream o; o.setf(std::ios::fixed); o.precision(3);
-        o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_tree, t_jit)
+        o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_parsed, t_jit)
+          << ",\"programs_wait_after_constants_ms\":" << ms(t_tree, t_jit)
           << ",\"hiprtc_compiled\":" << (j1.compiled - j0.compiled) << ",\"hiprtc_processes\":" << (j1.spawned - j0.spawned) << ",\"code_cache_disk_hits\":" << (j1.disk_hits - j0.disk_hits)
           << ",\"code_cache_mem_hits\":" << (j1.mem_hits - j0.mem_hits) << ",\"total_ms\":" << ms(t_begin, t_jit) << "}";
         S->setup_timing = o.str();

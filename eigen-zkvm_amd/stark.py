@@ -452,7 +452,11 @@ class StagedProof:
 
     def __init__(self, setup, cm_n, stream=None):
         self._setup = setup                                                          # (keeps the setup alive)
+        self._cm = None
         if isinstance(cm_n, DevArray):
+            # the context BORROWS d_cm_pols until zk_stark_free (zkgpu.h): the step programs, evals() and an early stage 3 read it after
+            # this constructor returns -- keep the array (a temporary's __del__ would hand the block back to the pool mid-proof)
+            self._cm = cm_n
             self._h = lib().zk_stark_new(setup._h, None, cm_n.ptr, cm_n.n, stream)
         else:
             c = _np(cm_n)
@@ -511,6 +515,7 @@ class StagedProof:
     def free(self):
         if self._h:
             lib().zk_stark_free(self._h); self._h = None
+        self._cm = None                                                              # only now may the trace go back to the pool
 
     def __del__(self):
         try:

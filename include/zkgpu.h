@@ -333,7 +333,9 @@ char* zk_stark_gen_dev_on(zk_stark_setup_t* s, const uint64_t* d_cm_pols, uint64
  *   new -> commit 1 -> challenge 0, 1 -> eval 2PREV -> calculate_h1h2 -> commit 2 -> challenge 2, 3 -> eval 3PREV -> calculate_z ->
  *   eval 3 -> commit 3 -> challenge 4 -> eval 42NS -> commit 4 -> challenge 7 -> evals -> challenge 5, 6 -> eval 52NS -> fri_prove -> finish.
  * zk_stark_gen* is exactly this sequence; a proof driven through the stages is byte-equal to zk_stark_gen's (tests/cabi/zkgpu_cabi_test.c).
- *   zk_stark_new            the trace in host memory (cm_pols) or in HBM (d_cm_pols), the other NULL; sections allocated, publics computed and absorbed
+ *   zk_stark_new            the trace in host memory (cm_pols) or in HBM (d_cm_pols), the other NULL; sections allocated, publics computed and absorbed.
+ *                           d_cm_pols is BORROWED for the life of the context: every later stage reads it; it must stay allocated and unchanged
+ *                           until zk_stark_free (a host trace is copied, the caller may release it when zk_stark_new returns)
  *   zk_stark_commit_stage   stage 1..3: LDE + Merkle tree of cm<stage>; stage 4: Q split (inverse NTT, split, NTT) + tree 4; the root is absorbed by the
  *                           context's transcript and copied to root[4] when non-NULL (GL words, or the raw Montgomery limbs of a scalar-field digest)
  *   zk_stark_challenge      challenge i <- the context's transcript (copied to out[3] when non-NULL); i: 0 u, 1 defVal, 2 gamma, 3 beta, 4 vc, 5 v1, 6 v2, 7 xi

@@ -53,6 +53,34 @@ def test_staged_proof_of_poseidong_with_early_stage3(zk):
     ns.free()
 
 
+def test_a_staged_proof_keeps_its_device_trace_alive(zk):
+    """zk_stark_new borrows d_cm_pols until zk_stark_free (zkgpu.h).  The Python mirror must hold the DevArray it was given: a temporary's
+    __del__ hands the block back to the size-keyed pool, and the next reservation of that very size -- made here on purpose, and overwritten
+    -- would be the trace the later stages read (advisor finding, round 5)."""
+    stark, ns, cm = _setup(zk, "fibonacci_imP", _struct())
+    want = ns.gen_bytes(cm)
+    p = ns.staged(zk.DevArray.from_host(cm))                                  # a temporary: only the StagedProof keeps it
+    import gc; gc.collect()
+    junk = [zk.DevArray(cm.size, zero=True) for _ in range(4)]                # same size as the trace: would reuse its block if it had been freed
+    p.commit_stage(1)
+    more = [zk.DevArray(cm.size, zero=True) for _ in range(4)]
+    p.challenge(0); p.challenge(1)
+    p.eval(stark.STEP_2PREV); p.calculate_h1h2()
+    p.commit_stage(2); p.challenge(2); p.challenge(3)
+    p.eval(stark.STEP_3PREV); p.calculate_z(); p.eval(stark.STEP_3)
+    p.commit_stage(3); p.challenge(4)
+    p.eval(stark.STEP_42NS)
+    p.commit_stage(4); p.challenge(7)
+    p.evals(); p.challenge(5); p.challenge(6)
+    p.eval(stark.STEP_52NS)
+    p.fri_prove()
+    assert p.finish() == want
+    p.free()
+    assert p._cm is None                                                      # released with the context, not before
+    del junk, more
+    ns.free()
+
+
 def test_stages_are_accepted_in_the_references_order_only(zk):
     stark, ns, cm = _setup(zk, "fibonacci_imP", _struct())
     p = ns.staged(cm)
