@@ -11,8 +11,10 @@
 //   * the dense MDS has entries < 2^6, known at compile time: they become instruction immediates,
 //     and each output word is two chains of 12 v_mad_u64_u32 over the 32-bit halves of the state
 //     (no carries: 12 * 2^6 * 2^32 < 2^42) and ONE reduction instead of 12 modular multiplications;
-//   * the 64-bit round constants, the pre-sparse matrix P and the sparse rows S sit in LDS (6.3 KB
-//     per block, broadcast reads) -- as scalar loads their 288+ SGPRs spilled into VGPR lanes.
+//   * round 6: the products by full-width constants -- the pre-sparse matrix P and the two dense products of each lazy block
+//     of partial rounds, 628 of a permutation's terms -- run on the MATRIX pipe as byte-limb i8 GEMMs over the wave's 64 states
+//     (poseidon_mfma.hip.h): 3.4 k of 17.3 k vector instructions per permutation gone, the S-boxes are what is left;
+//   * the 64-bit round constants and the matrix-pipe tables sit in LDS (49 KB per workgroup of 256 lanes).
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
 #include "ntt_reg.hip.h"   // static_for
@@ -37,65 +39,37 @@ constexpr int T_SCS = T_DD + 220;    // [2 blocks][11 k][11 m] split: S[23 (r0 +
 constexpr int T_K0 = T_SCS + 484;    // [4]: C[8 + i]^7 + (round 0's constant of word 8 + i): what a zero capacity word is after the first S-box
 constexpr int T_CD = T_K0 + 4;       // [2 blocks][11 m][16 l] split: what u_(r0 + m) weighs in lane l of a cooperative permutation (coop_partial_rounds)
 constexpr int T_WORDS = T_CD + 704;  // 2360 words = 18.4 KB
-constexpr int T_ONE = T_CD;          // what a one-lane permutation reads: 1656 words = 12.9 KB
 constexpr int PR_B = 11;             // partial rounds per block
 static_assert(T_PT % 2 == 0 && T_SR % 2 == 0 && T_DD % 2 == 0 && T_SCS % 2 == 0 && T_CD % 2 == 0, "split constants are read as 16-byte pairs");
 __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
 
-// Round 6: the dense 64-bit products of a ONE-LANE permutation on the matrix pipe (poseidon_mfma.hip.h).  Bit 0: the pre-sparse
-// matrix P; bit 1: the column update at the end of a block of partial rounds; bit 2: the row products at its start.
-#ifndef ZK_POSEIDON_MFMA
-#define ZK_POSEIDON_MFMA 0
-#endif
-#ifndef ZK_LH_WAVES
-#define ZK_LH_WAVES 4
-#endif
-#ifndef ZK_LH_ROWS_WAVES
-#define ZK_LH_ROWS_WAVES 3
-#endif
-constexpr int MF = ZK_POSEIDON_MFMA;
-static_assert(MF == 0 || (MF & 7) == 7, "the three dense products go to the matrix pipe together; bit 3 adds the MDS of the full rounds");
-// LDS image of a one-lane kernel in that mode (g_mtab): the constants the vector pipe still reads, then one table per product
-constexpr int TM_C0 = T_C0, TM_FC = T_FC, TM_PC = T_PC;            // as in g_tab
-constexpr int TM_S0 = T_PT;                                        // [22] split: S_r[0]
+// LDS image of the ONE-LANE kernels (g_mtab; round 6): the constants their vector instructions still read, then one matrix-pipe table
+// (poseidon_mfma.hip.h) per dense product.
+constexpr int TM_S0 = T_PT;                                        // [22] split: S_r[0]   (C0, FC, PC in front of it as in g_tab)
 constexpr int TM_DD = TM_S0 + 44;                                  // as T_DD
 constexpr int TM_K0 = TM_DD + 220;                                 // as T_K0
 constexpr int TM_HDR = TM_K0 + 4;                                  // 400 words
-constexpr int MT_P = 0, MT_BS = 1, MT_BE = 3, MT_MDS = 5, MT_N = 6;   // tables: P, block starts 0 / 1, block ends 0 / 1, the MDS
-constexpr int TM_WORDS = TM_HDR + MT_N * pmfma::TAB_WORDS;          // 7456 words = 58.3 KB
-static_assert(TM_C0 == 0 && TM_FC == 12 && TM_PC == 108 && TM_HDR % 2 == 0 && TM_WORDS * 8 <= 65536, "one-lane tables: 16-byte aligned, inside 64 KB");
+constexpr int MT_P = 0, MT_BS = 1, MT_BE = 3, MT_N = 5;            // tables: P, block starts 0 / 1, block ends 0 / 1
+constexpr int TM_WORDS = TM_HDR + MT_N * pmfma::TAB_WORDS;          // 6280 words = 49 KB
+static_assert(TM_HDR % 2 == 0 && TM_WORDS % 2 == 0 && TM_WORDS * 8 <= 65536, "one-lane tables: 16-byte aligned, inside 64 KB");
 __host__ __device__ constexpr int tm_table(int k) { return TM_HDR + k * pmfma::TAB_WORDS; }
-constexpr int T_ONE_WORDS = MF ? TM_WORDS : T_ONE;
 __device__ u64 g_mtab[TM_WORDS];
-// ... and their shape: with the matrix-pipe tables (59 KB) two workgroups of six waves fill a CU's three waves per SIMD
+// Shape of the one-lane kernels: 256 lanes per workgroup, launch bounds of two waves per SIMD -- up to 256 registers keep a permutation's
+// S-boxes, the eleven u's of a block and a product's accumulators out of the private segment (the kernels take 126-160, so three
+// workgroups and their 3 x 49 KB of tables share a CU), and a wave that waits for the matrix pipe has partners filling the vector
+// pipe.  Measured on 2^22 x 19 trees (profiles/r06/poseidon_mfma.md): 256 lanes 7.25 ms, 512 lanes 7.5, 384 lanes 9.2 (six-wave
+// workgroups do not tile four SIMDs); bounds of three waves (168 registers) 8.2-9.5; resident grids (tables loaded once per CU)
+// lose 5-10 % to one workgroup per chunk of rows -- workgroups that start together run their phases together.
 #ifndef ZK_ONE_THREADS
-#define ZK_ONE_THREADS (ZK_POSEIDON_MFMA ? 384 : 256)
+#define ZK_ONE_THREADS 256
 #endif
 constexpr int ONE_THREADS = ZK_ONE_THREADS;
-#ifndef ZK_ONE_WAVES
-#define ZK_ONE_WAVES 3
-#endif
-constexpr int ONE_WAVES_LH = MF ? ZK_ONE_WAVES : ZK_LH_WAVES;
-constexpr int ONE_WAVES_ROWS = MF ? ZK_ONE_WAVES : ZK_LH_ROWS_WAVES;
-#if ZK_POSEIDON_MFMA
-#define ZK_LEVEL_BOUNDS __launch_bounds__(ZK_ONE_THREADS, ZK_ONE_WAVES)
-#else
-#define ZK_LEVEL_BOUNDS __launch_bounds__(256)
-#endif
-#define ZK_POSEIDON_LDS_ONE __shared__ __attribute__((aligned(16))) u64 tab[T_ONE_WORDS]
-static_assert(T_ONE % 2 == 0 && TM_WORDS % 2 == 0, "tables are copied 16 bytes at a time");
+#define ZK_ONE_BOUNDS __launch_bounds__(ZK_ONE_THREADS, 2)
+#define ZK_POSEIDON_LDS_ONE __shared__ __attribute__((aligned(16))) u64 tab[TM_WORDS]
 __device__ __forceinline__ void load_tables_one(u64* __restrict__ tab) {
-    const ulonglong2* __restrict__ src = reinterpret_cast<const ulonglong2*>(MF ? g_mtab : g_tab);
-    for (int i = threadIdx.x; i < T_ONE_WORDS / 2; i += blockDim.x) reinterpret_cast<ulonglong2*>(tab)[i] = src[i];
+    for (int i = threadIdx.x; i < TM_WORDS / 2; i += blockDim.x) reinterpret_cast<ulonglong2*>(tab)[i] = reinterpret_cast<const ulonglong2*>(g_mtab)[i];
     __syncthreads();
-}
-// The one-lane kernels are resident: a grid of as many workgroups as the chip holds, each walking its share of the items with the tables
-// loaded once (round 6: with the matrix-pipe tables a workgroup's LDS image is 59 KB).  Every lane of a wave stays in the loop together.
-template <class F>
-__device__ __forceinline__ void one_lane_items(u64 n_items, F&& f) {
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 base = (u64)blockIdx.x * blockDim.x; base < n_items; base += stride) f(base + threadIdx.x);
 }
 
 __device__ __forceinline__ void load_tables(u64* __restrict__ tab) {
@@ -172,81 +146,30 @@ __device__ __forceinline__ void mds_small(u64 (&st)[12]) {
     }
 }
 
-// st <- sum_j P[j][i] * st[j]: twelve batched dot products against the transposed, split P in LDS
-__device__ __forceinline__ void mat_full(const u64* __restrict__ PT /* LDS */, u64 (&st)[12]) {
-    u32 x0[12], x1[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) { x0[j] = (u32)st[j]; x1[j] = (u32)(st[j] >> 32); }
-    // one output per (not unrolled) trip, shifted in at the top: only one dot product's constants are in flight
-#pragma unroll 1
-    for (int i = 0; i < 12; ++i) {
-        const u64 d = dot12(PT + 24 * i, x0, x1);
-#pragma unroll
-        for (int k = 0; k < 11; ++k) st[k] = st[k + 1];
-        st[11] = d;
-    }
-}
-
-// the same product on the matrix pipe (poseidon_mfma.hip.h); every lane of the wave must be here
-__device__ __forceinline__ void mat_full_mfma(const u64* __restrict__ mt /* LDS: table MT_P */, u64 (&st)[12]) {
+// st <- sum_j P[j][i] * st[j]  (poseidon_opt.rs:121-131) on the matrix pipe; every lane of the wave must be here
+__device__ __forceinline__ void mat_full(const u64* __restrict__ mt /* LDS: table MT_P */, u64 (&st)[12]) {
     pmfma::BOps B;
     pmfma::make_b<12>(B, [&](int j) { return st[j]; });
     pmfma::product<3>(B, mt, [&](int o, u64 v) { st[o] = v; });
-}
-// mds_small on the matrix pipe: the entries are below 2^6, the table does not care
-template <bool CANON, int N_OUT = 12>
-__device__ __forceinline__ void mds_mfma(const u64* __restrict__ mt /* LDS: table MT_MDS */, u64 (&st)[12]) {
-    static_assert(N_OUT == 12 || N_OUT == 4, "whole tiles");
-    pmfma::BOps B;
-    pmfma::make_b<12>(B, [&](int j) { return st[j]; });
-    pmfma::product<N_OUT / 4>(B, mt, [&](int o, u64 v) { st[o] = (CANON && v >= GL_P) ? v - GL_P : v; });
 }
 
 // The 22 partial rounds (poseidon_opt.rs:140-163) in two blocks of 11 without a reduction per state word and round.
 // In round r only st[0] passes the S-box: u_r = st[0]^7 + c_r, st[0] <- S_r[0] u_r + sum_k S_r[k] st[k], st[k] += SC_r[k] u_r.
 // The words k >= 1 are linear in the u's, so inside a block that starts at round r0 with words s_k
-//     st[0] after round r  =  S_r[0] u_r + sum_k S_r[k] s_k + sum_{r0 <= i < r} D[r][i] u_i,   D[r][i] = sum_k S_r[k] SC_i[k]
-// (D precomputed on the host), one batched dot product of 12 + (r - r0) terms, and at the end of the block
-//     s_k <- s_k + sum_i SC_i[k] u_i,
-// eleven batched dot products of 11 terms: 44 reductions per permutation where the round-by-round form has 22 + 242.
-// Blocks of 11 minimise multiply-adds + reductions (616 terms; one block of 22 would need 737, four of 5-6 have 66 reductions).
+//     st[0] after round r  =  S_r[0] u_r + G[r] + sum_{r0 <= i < r} D[r][i] u_i,   G[r] = sum_k S_r[k] s_k,  D[r][i] = sum_k S_r[k] SC_i[k]
+// (D precomputed on the host), and at the end of the block
+//     s_k <- s_k + sum_i SC_i[k] u_i.
+// Round 6: the block's two dense products -- the eleven G[r] before the first S-box, the eleven column updates after the last --
+// are matrix-pipe products over the wave's 64 states (11 x 11 full-width constants each); what depends on the previous round -- the
+// S-box chain, S_r[0] u_r and the D terms, batched dot products in 22/22/20-bit limbs with one recombination per round (acc6.hip.h) --
+// stays on the vector pipe.  Blocks of 11 minimise the D terms + products (four blocks of 5-6 save 60 terms and cost four more products).
+// tab = the TM_ image.
 __device__ __forceinline__ void partial_rounds(u64 (&st)[12], const u64* __restrict__ tab) {
-#pragma unroll 1
-    for (int b = 0; b < 22 / PR_B; ++b) {
-        const u64* __restrict__ SR = tab + T_SR + 24 * PR_B * b;
-        const u64* __restrict__ DD = tab + T_DD + 2 * (PR_B * (PR_B - 1) / 2) * b;
-        const u64* __restrict__ SCS = tab + T_SCS + 2 * 11 * PR_B * b;
-        const u64* __restrict__ PC = tab + T_PC + PR_B * b;
-        u32 u0[PR_B], u1[PR_B];
-        u64 s0 = st[0];
-        static_for<0, PR_B>([&](auto MI) {
-            constexpr int m = decltype(MI)::value;
-            const u64 u = pow7_add(s0, PC[m]);
-            u0[m] = (u32)u; u1[m] = (u32)(u >> 32);
-            Acc6 A; acc_zero(A);
-            acc_dot<12>(A, SR + 24 * m, [&](int k, u32& a, u32& c) { a = k ? (u32)st[k] : u0[m]; c = k ? (u32)(st[k] >> 32) : u1[m]; });
-            if constexpr (m > 0) acc_dot<m>(A, DD + 2 * (m * (m - 1) / 2), [&](int i, u32& a, u32& c) { a = u0[i]; c = u1[i]; });
-            s0 = acc_finish(A);
-        });
-        st[0] = s0;
-#pragma unroll
-        for (int k = 1; k < 12; ++k) {
-            Acc6 A; acc_word(A, st[k]);
-            acc_dot<PR_B>(A, SCS + 2 * (PR_B * (k - 1)), [&](int m, u32& a, u32& c) { a = u0[m]; c = u1[m]; });
-            st[k] = acc_finish(A);
-        }
-    }
-}
-
-// partial_rounds() with the two dense products of a block on the matrix pipe: G[m] = sum_k S_(r0 + m)[k] s_k for the block's eleven
-// rounds before the first S-box, and s_k += sum_m SC_m[k] u_m after the last; the S-box chain, S_r[0] u_r and the D[r][i] u_i
-// terms -- what depends on the previous round -- stay on the vector pipe.  tab = the TM_ image.
-__device__ __forceinline__ void partial_rounds_mfma(u64 (&st)[12], const u64* __restrict__ tab) {
 #pragma unroll 1
     for (int b = 0; b < 22 / PR_B; ++b) {
         const u64* __restrict__ S0 = tab + TM_S0 + 2 * PR_B * b;
         const u64* __restrict__ DD = tab + TM_DD + 2 * (PR_B * (PR_B - 1) / 2) * b;
-        const u64* __restrict__ PC = tab + TM_PC + PR_B * b;
+        const u64* __restrict__ PC = tab + T_PC + PR_B * b;
         u32 u0[PR_B], u1[PR_B];
         u64 G[PR_B];
         {
@@ -273,42 +196,36 @@ __device__ __forceinline__ void partial_rounds_mfma(u64 (&st)[12], const u64* __
     }
 }
 
-// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = LDS tables.
+// in-place permutation of st = in[8] || cap[4]   (poseidon_opt.rs:98-199); tab = the one-lane LDS image (TM_).  EVERY LANE OF THE
+// WAVE must call it together (the matrix pipe works on the wave's 64 states at once): kernels keep idle lanes on a shadow input.
 // Two things every LinearHash and every tree node allow (round 3):
 //   * zero_cap (wave-uniform): the capacity words are zero -- the first block of a sponge and every node of a tree.  After the
-//     first constants they are C[8..12) whatever the input, so their first S-boxes are four table words (T_K0), not 16 products;
+//     first constants they are C[8..12) whatever the input, so their first S-boxes are four table words (TM_K0), not 16 products;
 //   * FULL_OUT = false: only st[0..4) is read afterwards (a digest, or the capacity of the next block): the last MDS computes
 //     four of its twelve outputs.  st[4..12) are then NOT the permutation's words.
-// BITS: which dense products go to the matrix pipe (MF above); 0 in the kernels where not every lane of a wave runs a permutation.
-template <bool FULL_OUT = false, int BITS = 0>
+template <bool FULL_OUT = false>
 __device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab, bool zero_cap) {
-    constexpr int K0 = BITS ? TM_K0 : T_K0;
-    auto mds = [&](auto CANON, auto N_OUT) {
-        if constexpr (BITS & 8) mds_mfma<decltype(CANON)::value, decltype(N_OUT)::value>(tab + tm_table(MT_MDS), st);
-        else mds_small<decltype(CANON)::value, decltype(N_OUT)::value>(st);
-    };
-    using std::integral_constant;
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
     if (zero_cap) {
 #pragma unroll
-        for (int i = 8; i < 12; ++i) st[i] = tab[K0 + i - 8];
+        for (int i = 8; i < 12; ++i) st[i] = tab[TM_K0 + i - 8];
     } else {
 #pragma unroll
         for (int i = 8; i < 12; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
     }
-    mds(integral_constant<bool, false>{}, integral_constant<int, 12>{});
+    mds_small<false>(st);
 #pragma unroll 1
     for (int R = 1; R < 7; ++R) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) st[i] = pow7_add(st[i], tab[T_FC + R * 12 + i]);
-        if (R != 3) { mds(integral_constant<bool, false>{}, integral_constant<int, 12>{}); continue; }
-        if constexpr (BITS & 7) { mat_full_mfma(tab + tm_table(MT_P), st); partial_rounds_mfma(st, tab); }
-        else { mat_full(tab + T_PT, st); partial_rounds(st, tab); }
+        if (R != 3) { mds_small<false>(st); continue; }
+        mat_full(tab + tm_table(MT_P), st);
+        partial_rounds(st, tab);
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) st[i] = pow7(st[i]);
-    mds(integral_constant<bool, true>{}, integral_constant<int, FULL_OUT ? 12 : 4>{});
+    mds_small<true, FULL_OUT ? 12 : 4>(st);
 }
 
 
@@ -443,7 +360,6 @@ __device__ __forceinline__ u64 coop_perm(u64 x, const u64* __restrict__ tab) {
 // capacity carried, tail zero-padded; a batch of <= 4 words is its own zero-padded digest -- only
 // the last batch can be that short); more than one batch digest -> _hash over the digests.
 // All control flow depends on w only, i.e. is wave-uniform.
-template <int BITS = 0>
 __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 w, u64 (&out)[4], const u64* __restrict__ tab) {
     if (w <= 4) {
 #pragma unroll
@@ -470,7 +386,7 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = second ? h[8 + i] : h[i];
         }
-        poseidon_perm<false, BITS>(st, tab, cz);
+        poseidon_perm(st, tab, cz);
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
             off += 8;
@@ -520,13 +436,13 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
 // row sponges the batch digests.  A row of 37 words is 4 batches of 2 permutations and a final sponge of 2: four
 // permutations deep instead of ten -- what counts while there are too few rows to fill the chip (2^15-row proof 5.47 -> 5.36 ms,
 // 2^18-row proof 11.64 -> 11.41 ms; from 2^19 rows on the one-launch kernel is the faster one).
-// (one lane per HASHED batch: a last batch of <= 4 words is its own digest -- linearhash.rs:121-126 -- and is written by the lane of the batch
-// before it; every lane of a wave runs the same number of permutations, the matrix pipe's condition: a shorter last batch idles a trip)
-__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_batch_kernel(const u64* __restrict__ rows, u32 w, u64 height, u32 bs, u32 hsz, u32 n_hashed,
-                                                                            u64* __restrict__ h /* [height][hsz][4] */) {
+// One lane per HASHED batch: a last batch of <= 4 words is its own digest (linearhash.rs:121-126) and is written by the lane of the batch
+// before it; every lane of a wave runs the same number of permutations (the matrix pipe's condition): a shorter last batch idles a trip.
+__global__ ZK_ONE_BOUNDS void linearhash_batch_kernel(const u64* __restrict__ rows, u32 w, u64 height, u32 bs, u32 hsz, u32 n_hashed,
+                                                      u64* __restrict__ h /* [height][hsz][4] */) {
     ZK_POSEIDON_LDS_ONE;
     load_tables_one(tab);
-    one_lane_items(height * n_hashed, [&](u64 t_) {
+    const u64 t_ = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = t_ < height * n_hashed;
     const u64 t = live ? t_ : height * n_hashed - 1;                   // idle lanes shadow the last batch
     const u64 r = t / n_hashed;
@@ -540,7 +456,7 @@ __global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_batch_ke
         const bool act = off < len;
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[off + i] : 0;
-        poseidon_perm<false, MF>(st, tab, off == 0);
+        poseidon_perm(st, tab, off == 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { if (act) keep[i] = st[i]; st[8 + i] = st[i]; }   // the capacity carries the digest so far
     }
@@ -552,44 +468,40 @@ __global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_batch_ke
 #pragma unroll
         for (int i = 0; i < 4; ++i) h[(r * hsz + hsz - 1) * 4 + i] = (u32)i < len2 ? v[bs + i] : 0;
     }
-    });
 }
-__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_LH) void linearhash_final_kernel(const u64* __restrict__ h, u32 hsz, u64 height, u64* __restrict__ digests) {
+__global__ ZK_ONE_BOUNDS void linearhash_final_kernel(const u64* __restrict__ h, u32 hsz, u64 height, u64* __restrict__ digests) {
     ZK_POSEIDON_LDS_ONE;
     load_tables_one(tab);
-    one_lane_items(height, [&](u64 r_) {
-    const u64 r = r_ < height ? r_ : height - 1;
+    const u64 r_ = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 r = r_ < height ? r_ : height - 1;                       // idle lanes shadow the last row
     const u64* __restrict__ v = h + r * hsz * 4;
     u64 st[12];
 #pragma unroll
     for (int i = 0; i < 8; ++i) st[i] = (u32)i < 4 * hsz ? v[i] : 0;
 #pragma unroll
     for (int i = 8; i < 12; ++i) st[i] = 0;
-    poseidon_perm<false, MF>(st, tab, true);
+    poseidon_perm(st, tab, true);
     if (hsz > 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = 8 + (u32)i < 4 * hsz ? v[8 + i] : 0;
-        poseidon_perm<false, MF>(st, tab, false);
+        poseidon_perm(st, tab, false);
     }
     if (r_ >= height) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = st[i];
-    });
 }
-// (three waves per SIMD: 168 registers keep the block-lazy partial rounds out of the private segment; four spill, 2-4 % slower)
-__global__ __launch_bounds__(ONE_THREADS, ONE_WAVES_ROWS) void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+__global__ ZK_ONE_BOUNDS void linearhash_rows_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
     ZK_POSEIDON_LDS_ONE;
     load_tables_one(tab);
-    one_lane_items(height, [&](u64 r_) {
+    const u64 r_ = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 r = r_ < height ? r_ : height - 1;                       // idle lanes shadow the last row: the matrix pipe wants whole waves
     u64 d[4];
-    linearhash_row<MF>(rows + r * width, width, d, tab);
+    linearhash_row(rows + r * width, width, d, tab);
     if (r_ >= height) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) digests[4 * r + i] = d[i];
-    });
 }
 
 // The same LinearHash with 16 lanes per row (coop_perm): lane l < 12 owns state word l, lanes 0..3 keep the batch digests.
@@ -696,21 +608,20 @@ __global__ __launch_bounds__(256) void linearhash_rows_wave_kernel(const u64* __
 }
 
 // merklehash.rs:110-134 do_merklize_level: parent i = Poseidon(node[2i] || node[2i+1], cap 0)
-__global__ ZK_LEVEL_BOUNDS void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
+__global__ ZK_ONE_BOUNDS void merkle_level_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
     ZK_POSEIDON_LDS_ONE;
     load_tables_one(tab);
-    one_lane_items(n_ops, [&](u64 i_) {
-    const u64 i = i_ < n_ops ? i_ : n_ops - 1;
+    const u64 i_ = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i = i_ < n_ops ? i_ : n_ops - 1;                         // idle lanes shadow the last parent
     u64 st[12];
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = in[8 * i + k];
 #pragma unroll
     for (int k = 8; k < 12; ++k) st[k] = 0;
-    poseidon_perm<false, MF>(st, tab, true);
+    poseidon_perm(st, tab, true);
     if (i_ >= n_ops) return;
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[4 * i + k] = st[k];
-    });
 }
 
 // the same for small levels: 16 lanes per parent (coop_perm), 16 parents per block
@@ -780,16 +691,16 @@ __global__ __launch_bounds__(64) void merkle_root_from_path_kernel(const u64* __
 // stark_gen.rs:311,359) has all-zero leaves, so every node of a level holds the same digest:
 // one permutation per level instead of one per node.
 __global__ __launch_bounds__(64) void zero_tree_chain_kernel(u32 levels, u64* __restrict__ h /* [levels + 1][4] */) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    if (threadIdx.x | blockIdx.x) return;
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    const bool w = threadIdx.x == 0 && blockIdx.x == 0;              // (all 64 lanes run the same permutation: the matrix pipe wants the whole wave)
     u64 cur[4] = {0, 0, 0, 0};
-    for (int k = 0; k < 4; ++k) h[k] = 0;
+    if (w) for (int k = 0; k < 4; ++k) h[k] = 0;
     for (u32 l = 0; l < levels; ++l) {
         u64 st[12];
         for (int k = 0; k < 4; ++k) { st[k] = cur[k]; st[4 + k] = cur[k]; st[8 + k] = 0; }
         poseidon_perm(st, tab, true);
-        for (int k = 0; k < 4; ++k) { cur[k] = st[k]; h[4 * (l + 1) + k] = st[k]; }
+        for (int k = 0; k < 4; ++k) { cur[k] = st[k]; if (w) h[4 * (l + 1) + k] = st[k]; }
     }
 }
 __global__ void fill_digest_kernel(u64* __restrict__ nodes, u64 n, const u64* __restrict__ h) {
@@ -798,15 +709,15 @@ __global__ void fill_digest_kernel(u64* __restrict__ nodes, u64 n, const u64* __
 }
 
 __global__ __launch_bounds__(64) void poseidon_one_kernel(const u64* in8, const u64* cap4, u64* out, int n_out) {
-    ZK_POSEIDON_LDS;
-    load_tables(tab);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 st[12];
+    ZK_POSEIDON_LDS_ONE;
+    load_tables_one(tab);
+    u64 st[12];                                                       // (all 64 lanes run the same permutation, lane 0 writes)
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = in8[k] >= GL_P ? in8[k] - GL_P : in8[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) st[8 + k] = cap4[k] >= GL_P ? cap4[k] - GL_P : cap4[k];
     poseidon_perm<true>(st, tab, false);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
 #pragma unroll
     for (int k = 0; k < 12; ++k) if (k < n_out) out[k] = st[k];
 }
@@ -973,7 +884,7 @@ void ensure_constants() {
             for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
         }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
-    {   // LDS image of the one-lane kernels with the dense products on the matrix pipe (poseidon_mfma.hip.h)
+    {   // LDS image of the one-lane kernels: their dense products run on the matrix pipe (poseidon_mfma.hip.h)
         static u64 mt[TM_WORDS];
         for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                   // C0, FC, PC
         for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }
@@ -984,9 +895,6 @@ void ensure_constants() {
         for (int o = 0; o < 12; ++o)
             for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_P[12 * j + o];                   // out[o] = sum_j P[j][o] st[j]
         ok = ok && pmfma::build_tables(coef, 12, 12, nullptr, mt + tm_table(MT_P));
-        for (int o = 0; o < 12; ++o)
-            for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_M[12 * j + o];                   // out[o] = sum_j M[j][o] st[j]
-        ok = ok && pmfma::build_tables(coef, 12, 12, nullptr, mt + tm_table(MT_MDS));
         for (int b = 0; b < 22 / PR_B; ++b) {
             for (int m = 0; m < PR_B; ++m)                                                                // G[m] = sum_(k >= 1) S_(r0 + m)[k] st[k]
                 for (int j = 0; j < 11; ++j) coef[m * 11 + j] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 1 + j];
@@ -1035,18 +943,6 @@ void poseidon_dev(const u64* d_in8, const u64* d_cap4, u64* d_out, int n_out, hi
     ZK_HIP(hipGetLastError());
 }
 
-// grid of a resident one-lane kernel: what the chip holds at `waves` waves per SIMD, or fewer when the items do not fill it
-static u32 one_lane_grid(u64 n_items, int waves) {
-    static int cus[64] = {};
-    int dev; ZK_HIP(hipGetDevice(&dev));
-    if (!cus[dev]) { hipDeviceProp_t pr; ZK_HIP(hipGetDeviceProperties(&pr, dev)); cus[dev] = pr.multiProcessorCount; }
-    static const u64 factor = getenv("ZK_ONE_RESIDENT") ? strtoull(getenv("ZK_ONE_RESIDENT"), nullptr, 10) : 1;   // 0: one workgroup per chunk (as through round 5)
-    const u64 chunks = (n_items + ONE_THREADS - 1) / ONE_THREADS;
-    if (!factor) return (u32)chunks;
-    const u64 resident = (u64)cus[dev] * (u64)std::max(1, waves * 4 * 64 / ONE_THREADS) * factor;
-    return (u32)std::min(chunks, resident);
-}
-
 void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st) {
     ensure_constants();
     if (height == 0) return;
@@ -1063,11 +959,11 @@ void linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64
     } else if (hsz > 1 && height <= batch_upto) {   // too few rows to fill the chip: the batches of a row side by side
         DevBuf h; h.reserve(height * hsz * 32);
         const u32 n_hashed = width - (hsz - 1) * bs <= 4 ? hsz - 1 : hsz;
-        hipLaunchKernelGGL(linearhash_batch_kernel, dim3(one_lane_grid(height * n_hashed, ONE_WAVES_LH)), dim3(ONE_THREADS), 0, st, d_rows, width, height, bs, hsz, n_hashed, h.u());
+        hipLaunchKernelGGL(linearhash_batch_kernel, dim3((u32)((height * n_hashed + ONE_THREADS - 1) / ONE_THREADS)), dim3(ONE_THREADS), 0, st, d_rows, width, height, bs, hsz, n_hashed, h.u());
         ZK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(linearhash_final_kernel, dim3(one_lane_grid(height, ONE_WAVES_LH)), dim3(ONE_THREADS), 0, st, (const u64*)h.u(), hsz, height, d_digests);
+        hipLaunchKernelGGL(linearhash_final_kernel, dim3((u32)((height + ONE_THREADS - 1) / ONE_THREADS)), dim3(ONE_THREADS), 0, st, (const u64*)h.u(), hsz, height, d_digests);
     } else {
-        hipLaunchKernelGGL(linearhash_rows_kernel, dim3(one_lane_grid(height, ONE_WAVES_ROWS)), dim3(ONE_THREADS), 0, st, d_rows, width, height, d_digests);
+        hipLaunchKernelGGL(linearhash_rows_kernel, dim3((u32)((height + ONE_THREADS - 1) / ONE_THREADS)), dim3(ONE_THREADS), 0, st, d_rows, width, height, d_digests);
     }
     ZK_HIP(hipGetLastError());
 }
@@ -1139,7 +1035,7 @@ void merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_no
         if (next <= coop_upto) {  // few parents: latency-bound, 16 lanes per permutation
             hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((u32)((next + 15) / 16)), dim3(256), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         } else {
-            hipLaunchKernelGGL(merkle_level_kernel, dim3(one_lane_grid(next, MF ? ZK_ONE_WAVES : 3)), dim3(ONE_THREADS), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
+            hipLaunchKernelGGL(merkle_level_kernel, dim3((u32)((next + ONE_THREADS - 1) / ONE_THREADS)), dim3(ONE_THREADS), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         }
         ZK_HIP(hipGetLastError());
         n64 = next; next = (n64 - 1) / 2 + 1; p_in = p_out; p_out = p_in + next * 2;
