@@ -51,9 +51,11 @@ def test_aggregation_leg_control_flow_two_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # each rank proves its own tasks once after one warm-up of its first task, nobody else's; then its first task alone (task_latency_s)
-    # ... and once more in the end-to-end pass (one clock over tasks + joins)
-    assert res[0][1] == [0, 0, 2, 4, 6, 0, 0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5, 1, 1, 3, 5]
+    # each rank proves its own tasks once after one warm-up of its first task, nobody else's; then its first task alone (task_latency_s),
+    # then seven tasks of its OWN for the weak-scaling number (tasks 7 (rank + 1) + k: no other rank's, none of the fixed set)
+    # ... and the fixed set once more in the end-to-end pass (one clock over tasks + joins)
+    assert res[0][1] == [0, 0, 2, 4, 6, 0] + list(range(7, 14)) + [0, 2, 4, 6] and res[1][1] == [1, 1, 3, 5, 1] + list(range(14, 21)) + [1, 3, 5]
+    assert all(r[2]["weak"]["tasks"] == 14 and r[2]["weak"]["tasks_per_s"] > 0 and r[2]["weak"]["scaling"].startswith("weak") for r in res)
     assert all(r[2]["task_latency_s"] is not None for r in res)
     # the join tree over 7 leaves: 3 + 2 + 1 joins in 3 levels, shared between the ranks, same root everywhere and equal
     # to the tree computed in one process
@@ -98,7 +100,9 @@ def test_aggregation_leg_eight_ranks_one_task_each():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [[k, k, k, k] for k in range(8)]        # warm-up, the timed proof, the latency probe, the end-to-end pass: its own task only
+    # warm-up, the timed proof, the latency probe, eight tasks of its own for the weak-scaling number, the end-to-end pass: never another rank's task
+    assert [r[1] for r in res] == [[k, k, k] + list(range(8 * (k + 1), 8 * (k + 2))) + [k] for k in range(8)]
+    assert all(r[2]["weak"]["tasks"] == 64 for r in res)
     assert [r[3] for r in res] == [6, 4, 2, 2, 0, 0, 0, 0]                # join j of a level on rank j (phase clock + end-to-end pass)
     st = StubProver()
     lvl = [st.prove(u)[2] for u in range(8)]
@@ -115,7 +119,8 @@ def test_aggregation_leg_single_rank():
     import bench
     pr = StubProver()
     out = bench.aggregation_leg(pr, _ex(None))
-    assert pr.proved == [0] + list(range(8)) + [0] + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+    assert pr.proved == [0] + list(range(8)) + [0] + list(range(8)) + list(range(8)) and out["tasks_gathered"] == list(range(8)) and out["distinct_roots"] == 8
+    assert out["weak"]["tasks"] == 8                                       # one rank: the weak pass proves the fixed set again
     assert (out["join_tree"]["levels"], out["join_tree"]["joins"], pr.joined) == (3, 7, 14)
     assert out["end_to_end"]["includes_final_wrap"] is False and out["end_to_end"]["root_equals_phase_run"]
 

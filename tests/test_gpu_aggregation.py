@@ -162,6 +162,11 @@ def test_bench_two_ranks_control_flow_on_one_gpu(tmp_path):
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1
     b = json.loads(lines[0])
+    assert list(b)[-1] == "headline" and b["headline"]["ranks_seen"] == 2 and b["headline"]["ntt_gelems"] == b["value"] and len(lines[0]) < 4000
+    assert b["legs"]["aggregation"]["tasks_per_s"] > 0
+    # the one stdout line is compact (round 6); the legs' detail is one line on stderr, prefixed "bench_detail: " (and gpurun_out/bench_detail.json)
+    (detail,) = [l for l in outs[0][1].splitlines() if l.startswith("bench_detail: ")]
+    b = json.loads(detail[len("bench_detail: "):])
     assert b["n_gpus"] == 2 and b["steps"] == 3 and b["warmup"] == 1 and b["scaling"] == "weak" and b["higher_is_better"] is True
     assert b["metric"].startswith("Goldilocks NTT GElems/s") and b["config"]["parallelism"] == "replicas x2" and b["value"] > 0
     assert "roofline" in b and b["roofline"]["bound"] == "hbm"
@@ -186,6 +191,9 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
     b = json.loads(lines[0])
+    assert list(b)[-1] == "headline" and b["headline"]["ranks_seen"] == 2 and b["headline"]["ntt_gelems"] == b["value"] and len(lines[0]) < 4000
+    (detail,) = [l for l in r.stderr.splitlines() if "bench_detail: " in l]      # the launcher relays rank 0's stderr with a "[rank 0] " prefix
+    assert json.loads(detail[detail.index("bench_detail: ") + len("bench_detail: "):])["headline"] == b["headline"]
     assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["value"] > 0 and b["config"]["parallelism"] == "replicas x2"
 
 

@@ -48,13 +48,18 @@ def _zk():
 
 def stark_prove(a):
     import importlib
+    import time
+    t_start = time.perf_counter()
     import numpy as np
     zk = _zk()
     stark = importlib.import_module("eigen_zkvm_amd.stark")
+    t_init = time.perf_counter()
     ss = json.load(open(a.stark_struct))
     pil = json.load(open(a.piljson))
-    const = np.fromfile(a.const_pols, dtype="<u8")                       # polsarray.rs:137-217: headerless LE u64, row-major
-    cm = np.fromfile(a.cm_pols, dtype="<u8")
+    # polsarray.rs:137-217: headerless LE u64, row-major.  Mapped, not read: the library's upload is the one pass over the bytes
+    # (np.fromfile would copy 5 GB at 2^24 rows before the first of them moves to the GPU)
+    const = np.memmap(a.const_pols, dtype="<u8", mode="r")
+    cm = np.memmap(a.cm_pols, dtype="<u8", mode="r")
     n = 1 << ss["nBits"]
     if const.size != n * pil["nConstants"] or cm.size != n * pil["nCommitments"]:
         raise SystemExit("zkgpu_prove: %s / %s do not hold 2^%d rows of %d / %d columns"
@@ -65,15 +70,23 @@ def stark_prove(a):
         program_json = stark.generate_program(json.dumps(pil), json.dumps(ss))
     else:
         raise SystemExit("zkgpu_prove: --program FILE is required (this build has no code generator)")
+    t_gen = time.perf_counter()
     setup = stark.NativeStarkSetup(const, program_json, json.dumps(ss), prover_addr=a.prover_addr if ss.get("verificationHashType") != "GL" else None,
                                    self_check=not a.no_verify)                 # prove.rs:124-132: assert!(stark_verify(..)) before anything is written
+    t_setup = time.perf_counter()
     zkin = setup.gen_json(cm)
+    t_prove = time.perf_counter()
     with open(a.zkin, "w") as f:
         f.write(zkin)
+    split = {"init_s": round(t_init - t_start, 3), "inputs_and_starkinfo_s": round(t_gen - t_init, 3), "setup_s": round(t_setup - t_gen, 3),
+             "prove_s": round(t_prove - t_setup, 3), "write_s": round(time.perf_counter() - t_prove, 3), "total_s": round(time.perf_counter() - t_start, 3),
+             "setup_split": setup.setup_timing(), "self_check": not a.no_verify}
     setup.free()
-    # prove.rs:134-150 always renders the circom verifier into -c; pil2circom is out of scope here: say so, loudly
-    print("zkgpu_prove: warning: no circom verifier is written to %s (pil2circom is out of scope of this backend; "
-          "the reference's stark_prove writes it)" % a.circom_file, file=sys.stderr)
+    # prove.rs:134-150 always renders the circom verifier into -c; pil2circom is out of scope here: say so when the flag was given
+    if a.circom_file:
+        print("zkgpu_prove: warning: no circom verifier is written to %s (pil2circom is out of scope of this backend; "
+              "the reference's stark_prove writes it)" % a.circom_file, file=sys.stderr)
+    print("zkgpu_prove: timing %s" % json.dumps(split), file=sys.stderr)        # prove.rs:95 #[time_profiler("stark_prove")] has the one number
     print("zkgpu_prove: proof of 2^%d rows %swritten to %s (rootC %s)" % (ss["nBits"], "" if a.no_verify else "verified and ", a.zkin, json.loads(zkin)["rootC"]))
 
 
@@ -184,7 +197,7 @@ def main(argv=None):
     s.add_argument("-a", "--agg_stage", action="store_true")
     s.add_argument("--o", dest="const_pols", default="pols.const")
     s.add_argument("--m", dest="cm_pols", default="pols.cm")
-    s.add_argument("-c", "--circom", dest="circom_file", default="stark_verfier.circom")
+    s.add_argument("-c", "--circom", dest="circom_file", default=None, help="accepted for zkit compatibility; nothing is written (warned)")
     s.add_argument("--i", dest="zkin", default="zkin.json")
     s.add_argument("--prover_addr", default="273030697313060285579891744179749754319274977764")
     s.add_argument("--program", help='{"starkinfo", "program"} JSON of the code generator (extension, see the module text)')
