@@ -1,27 +1,31 @@
-// Dense 64-bit linear layers of Poseidon-Goldilocks on the matrix pipe (round 6).
+// Products of a constant matrix of full-width Goldilocks constants with a vector of field elements PER LANE, on the matrix pipe (round 6).
 //
-// out[o] = sum_j c[o][j] x[j] mod p for up to 12 x 12 full-width constants, ONE PERMUTATION PER LANE (the mapping of
-// poseidon.hip): the pre-sparse matrix P (poseidon_opt.rs:121-131) and the two dense products of each lazy block of partial rounds
-// (poseidon.hip partial_rounds, which regroups poseidon_opt.rs:140-163).  On the vector pipe a term costs six v_mad_u64_u32 and an
-// output a 25-instruction recombination; here the 64 lanes' states are the B operand of v_mfma_i32_32x32x32_i8 and the constants the A
-// operand:
-//   * a state word is 8 bytes x_b; c x = sum_b x_b (c 2^(8 b) mod p), and each (c 2^(8 b) mod p) is written in eight balanced base-256
+// out[o] = sum_j c[o][j] x[j] mod p for up to 4 TL x 4 KS constants c, where every lane of a wave holds its own x[] in registers and
+// all lanes share c: the dense linear layers of Poseidon-Goldilocks (poseidon.hip: the pre-sparse matrix P of poseidon_opt.rs:121-131 and
+// the two dense products of each lazy block of partial rounds, 12 x 12: KS = TL = 3).  The shapes are template parameters because the
+// same form was measured for the radix-16 butterfly networks of an NTT pass (a 16-point DFT over a lane's sixteen points IS such a
+// product, 16 x 16: KS = TL = 4) -- bit-exact and NOT faster there: tools/experiments/ntt_mfma.patch, profiles/r06/ntt_mfma.md.
+// On the vector pipe a term costs six v_mad_u64_u32 and an output a 25-instruction recombination; here the
+// 64 lanes' vectors are the B operand of v_mfma_i32_32x32x32_i8 and the constants the A operand:
+//   * a word is 8 bytes x_b; c x = sum_b x_b (c 2^(8 b) mod p), and each (c 2^(8 b) mod p) is written in eight balanced base-256
 //     digits a_d in [-128, 127] (its representative in (-p/2, p/2) always fits).  Row (o, d) of A holds digit d of every (j, b): the
-//     product's row is the d-th byte column of the output, eight i32 columns per output (|column| < 2^21), NOT the fifteen of a plain
+//     product's row is the d-th byte column of the output, eight i32 columns per output (|column| <= 2^21), NOT the fifteen of a plain
 //     byte-limb product -- the reduction mod p happened in the table;
 //   * B wants signed bytes: x_b xor 0x80 = x_b - 128; the missing 128 sum(a) is a constant per output and rides, with a bias that makes
 //     everything positive, on the two 64-bit addends of the recombination (K below);
-//   * one 32 x 32 x 32 tile = 4 outputs x 8 digits against 4 words x 8 bytes for 32 permutations.  The rows are ordered so that the
-//     sixteen accumulators of a lane are the 2 x 8 digit columns of two outputs of one permutation; the wave's 64 permutations are
+//   * one 32 x 32 x 32 tile = 4 outputs x 8 digits against 4 words x 8 bytes for 32 lanes' vectors.  The rows are ordered so that the
+//     sixteen accumulators of a lane are the 2 x 8 digit columns of two outputs of one vector; the wave's 64 vectors are
 //     two column tiles, lanes l and l + 32 trade words by v_permlane32_swap on the way in (each supplies half of the K range) and
 //     on the way out (each recombines two of a tile's four outputs for both of them).
 // Per 12 x 12 product: 18 MFMAs (32 cycles each on the SIMD's matrix pipe, beside the other waves' vector work), 9 LDS fragment
-// reads, 24 xors, 24 swaps and 12 recombinations of ~14 vector instructions.
+// reads, 24 xors, 24 swaps and 12 recombinations of ~14 vector instructions; per 16 x 16 product 32 MFMAs and 16 recombinations.
 #pragma once
 #include "gl.hip.h"
 #include "acc6.hip.h"
+#include "ntt_reg.hip.h"   // static_for
 #include <vector>
 #include <cstring>
+#include <type_traits>
 
 namespace zk {
 namespace pmfma {
@@ -29,20 +33,24 @@ namespace pmfma {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int FRAG_WORDS = 3 * 3 * 64 * 2;   // u64 words of one product's A fragments: [tile][kstep][lane] x 16 bytes = 9 KB
-constexpr int K_WORDS = 12 * 2;              // (KL, KH) per output
-constexpr int TAB_WORDS = FRAG_WORDS + K_WORDS;
+// table of one product with KS k-steps (4 input words each) and TL tiles (4 outputs each), u64 words: the A fragments
+// [tile][kstep][lane] x 16 bytes, then (KL, KH) per output
+__host__ __device__ constexpr int frag_words(int KS, int TL) { return TL * KS * 64 * 2; }
+__host__ __device__ constexpr int tab_words(int KS, int TL) { return frag_words(KS, TL) + 4 * TL * 2; }
+constexpr int FRAG_WORDS = frag_words(3, 3);   // the 12 x 12 products of Poseidon: 9 KB
+constexpr int TAB_WORDS = tab_words(3, 3);
 
 // ---- host: the tables of one product -------------------------------------------------------------------------------------------
-// coef[o * n_in + j] canonical, n_out, n_in <= 12; addend[o] (may be null): a canonical constant added to output o for free.
+// coef[o * n_in + j] canonical, n_out <= 4 TL, n_in <= 4 KS; addend[o] (may be null): a canonical constant added to output o for free.
 // Returns false if a column could exceed the bound the recombination assumes.
-inline bool build_tables(const u64* coef, int n_out, int n_in, const u64* addend, u64* tab /* TAB_WORDS */) {
+inline bool build_tables(const u64* coef, int n_out, int n_in, const u64* addend, u64* tab /* tab_words(KS, TL) */, int KS = 3, int TL = 3) {
     typedef unsigned __int128 u128;
     typedef __int128 i128;
-    std::memset(tab, 0, sizeof(u64) * TAB_WORDS);
+    if (n_out > 4 * TL || n_in > 4 * KS || KS > 4 || TL > 4) return false;
+    std::memset(tab, 0, sizeof(u64) * tab_words(KS, TL));
     signed char* fr = reinterpret_cast<signed char*>(tab);
-    static signed char dig[12][12][8][8];      // [o][j][b][d]
-    std::memset(dig, 0, sizeof(dig));
+    std::vector<signed char> digv(16 * 16 * 64, 0);
+    auto dig = [&](int o, int j, int b, int d) -> signed char& { return digv[((o * 16 + j) * 8 + b) * 8 + d]; };   // [o][j][b][d]
     const i128 P = (i128)GL_P;
     const i128 S = (i128)(~0ull) / 255;        // (256^8 - 1) / 255
     for (int o = 0; o < n_out; ++o)
@@ -55,7 +63,7 @@ inline bool build_tables(const u64* coef, int n_out, int n_in, const u64* addend
                 for (int d = 0; d < 8; ++d) {
                     int lowb = (int)(((s % 256) + 256) % 256);
                     int dg = lowb >= 128 ? lowb - 256 : lowb;
-                    dig[o][j][b][d] = (signed char)dg;
+                    dig(o, j, b, d) = (signed char)dg;
                     s = (s - dg) / 256;
                 }
                 if (s != 0) return false;
@@ -63,36 +71,36 @@ inline bool build_tables(const u64* coef, int n_out, int n_in, const u64* addend
             }
         }
     // fragments: tile t, k-step s, lane l, byte i  <-  row m = l & 31, K slot (l >> 5, i)
-    for (int t = 0; t < 3; ++t)
-        for (int s = 0; s < 3; ++s)
+    for (int t = 0; t < TL; ++t)
+        for (int s = 0; s < KS; ++s)
             for (int l = 0; l < 64; ++l) {
                 const int m = l & 31, H = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
                 const int o = 4 * t + 2 * H + (r >> 3), d = r & 7, h = l >> 5;
                 for (int i = 0; i < 16; ++i) {
                     const int j = 4 * s + 2 * h + (i >> 3), b = i & 7;
-                    fr[((t * 3 + s) * 64 + l) * 16 + i] = (o < n_out && j < n_in) ? dig[o][j][b][d] : 0;
+                    fr[((t * KS + s) * 64 + l) * 16 + i] = (o < n_out && j < n_in) ? dig(o, j, b, d) : 0;
                 }
             }
     // K: the bytes reach the matrix pipe as x_b - 128; what is missing is 128 * (sum of the row's digits) per column, a constant.
-    for (int o = 0; o < 12; ++o) {
+    for (int o = 0; o < 4 * TL; ++o) {
         i128 corr = 0;
         long long worst = 0;
         if (o < n_out)
             for (int d = 0; d < 8; ++d) {
                 long long sa = 0, sabs = 0;
                 for (int j = 0; j < n_in; ++j)
-                    for (int b = 0; b < 8; ++b) { sa += dig[o][j][b][d]; sabs += dig[o][j][b][d] < 0 ? -dig[o][j][b][d] : dig[o][j][b][d]; }
+                    for (int b = 0; b < 8; ++b) { sa += dig(o, j, b, d); sabs += dig(o, j, b, d) < 0 ? -dig(o, j, b, d) : dig(o, j, b, d); }
                 corr += ((i128)(128 * sa)) << (8 * d);
                 if (128 * sabs > worst) worst = 128 * sabs;
             }
-        if (worst >= (1ll << 21)) return false;
+        if (worst > (1ll << 21)) return false;
         i128 c = corr % P; if (c < 0) c += P;
         if (addend && o < n_out) c = (c + (i128)(addend[o] % GL_P)) % P;
         // KL + 2^32 KH = c (mod p), both in [2^47, 2^47 + 2^32)
         i128 tau = (c - ((i128)1 << 47) - (((i128)1 << 79) % P)) % P; if (tau < 0) tau += P;
         const u64 tv = (u64)tau;
-        tab[FRAG_WORDS + 2 * o] = (1ull << 47) + (tv & 0xFFFFFFFFull);
-        tab[FRAG_WORDS + 2 * o + 1] = (1ull << 47) + (tv >> 32);
+        tab[frag_words(KS, TL) + 2 * o] = (1ull << 47) + (tv & 0xFFFFFFFFull);
+        tab[frag_words(KS, TL) + 2 * o + 1] = (1ull << 47) + (tv >> 32);
     }
     return true;
 }
@@ -133,11 +141,12 @@ __device__ __forceinline__ u64 recombine_add(int c0, int c1, int c2, int c3, int
     const u32 r2 = __builtin_addc((u32)(q >> 32), 0u, cb, &cc);
     return gl::mad_eps_nc(r2, gl::mk64(x0, x1));
 }
-// The B operands of a product: the wave's 64 states as signed bytes, 3 k-steps x 2 column tiles x 4 registers.
-struct BOps { v4i b[3][2]; };
-template <int N_IN = 12, class X>
-__device__ __forceinline__ void make_b(BOps& B, X&& x /* x(j) -> u64, any representative */) {
-    static_for<0, 3>([&](auto SI) {
+// The B operands of a product: the wave's 64 vectors as signed bytes, KS k-steps x 2 column tiles x 4 registers.
+template <int KS> struct BOpsT { v4i b[KS][2]; };
+using BOps = BOpsT<3>;
+template <int N_IN, int KS, class X>
+__device__ __forceinline__ void make_b(BOpsT<KS>& B, X&& x /* x(j) -> u64, any representative */) {
+    static_for<0, KS>([&](auto SI) {
         constexpr int s = decltype(SI)::value;
         u32 va[4], vb[4];
 #pragma unroll
@@ -149,69 +158,60 @@ __device__ __forceinline__ void make_b(BOps& B, X&& x /* x(j) -> u64, any repres
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) swap32(va[r], vb[r]);   // va: lanes < 32 keep their own first half, lanes >= 32 get the partner's second half ...
-        B.b[s][0] = v4i{(int)va[0], (int)va[1], (int)va[2], (int)va[3]};   // column tile 0 = permutations of lanes 0..31
-        B.b[s][1] = v4i{(int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};   // column tile 1 = permutations of lanes 32..63
+        B.b[s][0] = v4i{(int)va[0], (int)va[1], (int)va[2], (int)va[3]};   // column tile 0 = the vectors of lanes 0..31
+        B.b[s][1] = v4i{(int)vb[0], (int)vb[1], (int)vb[2], (int)vb[3]};   // column tile 1 = the vectors of lanes 32..63
     });
 }
-// out[o] for this lane's permutation, o < 4 * N_TILES; tab = the product's table in LDS.  Every lane of the wave must be here.
-template <int N_TILES = 3, class OUT>
-__device__ __forceinline__ void product(const BOps& B, const u64* __restrict__ tab, OUT&& out /* out(o, value) */) {
-    const int lane = threadIdx.x & 63;
-    const v4i* __restrict__ fr = reinterpret_cast<const v4i*>(tab) + lane;
-    const ulonglong2* __restrict__ Kt = reinterpret_cast<const ulonglong2*>(tab + FRAG_WORDS) + 2 * (lane >> 5);
-    int one = 1, s16 = 65536;
-    asm volatile("" : "+v"(one), "+v"(s16));
-    static_for<0, N_TILES>([&](auto TI) {
-        constexpr int t = decltype(TI)::value;
-        v16i acc0 = {}, acc1 = {};
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const v4i a = fr[(t * 3 + s) * 64];
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B.b[s][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B.b[s][1], acc1, 0, 0, 0);
-        }
-        const ulonglong2 K0 = Kt[4 * t], K1 = Kt[4 * t + 1];
-        u64 r00 = recombine(acc0[0], acc0[1], acc0[2], acc0[3], acc0[4], acc0[5], acc0[6], acc0[7], K0, one, s16);
-        u64 r01 = recombine(acc0[8], acc0[9], acc0[10], acc0[11], acc0[12], acc0[13], acc0[14], acc0[15], K1, one, s16);
-        u64 r10 = recombine(acc1[0], acc1[1], acc1[2], acc1[3], acc1[4], acc1[5], acc1[6], acc1[7], K0, one, s16);
-        u64 r11 = recombine(acc1[8], acc1[9], acc1[10], acc1[11], acc1[12], acc1[13], acc1[14], acc1[15], K1, one, s16);
-        swap64(r00, r10);                                  // r00: output 4 t of the lane's own permutation, r10: output 4 t + 2
-        swap64(r01, r11);
-        out(4 * t, r00); out(4 * t + 1, r01); out(4 * t + 2, r10); out(4 * t + 3, r11);
-    });
-}
+template <int N_IN = 12, class X>
+__device__ __forceinline__ void make_b(BOps& B, X&& x) { make_b<N_IN, 3>(B, x); }
 
-// out[o] + add(o): add(o) is the lane's OWN word o (any u64); it travels to the lane that recombines output o of this permutation
-// the way the result travels back
-template <int N_TILES = 3, class ADD, class OUT>
-__device__ __forceinline__ void product_add(const BOps& B, const u64* __restrict__ tab, ADD&& add, OUT&& out) {
+// out[o] for this lane's vector, o < 4 * N_TILES (N_TILES <= TL, the table's); tab = the product's table (LDS, or global memory that
+// stays in cache).  Every lane of the wave must be here.  add(o): the lane's OWN word o (any u64) to be added to output o, or nothing.
+struct NoAdd {};
+template <int N_TILES, int KS, int TL, class ADD, class OUT>
+__device__ __forceinline__ void product_t(const BOpsT<KS>& B, const u64* __restrict__ tab, ADD&& add, OUT&& out /* out(o, value) */) {
+    constexpr bool ADDS = !std::is_same<std::decay_t<ADD>, NoAdd>::value;
     const int lane = threadIdx.x & 63;
     const v4i* __restrict__ fr = reinterpret_cast<const v4i*>(tab) + lane;
-    const ulonglong2* __restrict__ Kt = reinterpret_cast<const ulonglong2*>(tab + FRAG_WORDS) + 2 * (lane >> 5);
+    const ulonglong2* __restrict__ Kt = reinterpret_cast<const ulonglong2*>(tab + frag_words(KS, TL)) + 2 * (lane >> 5);
     int one = 1, s16 = 65536;
     asm volatile("" : "+v"(one), "+v"(s16));
     static_for<0, N_TILES>([&](auto TI) {
         constexpr int t = decltype(TI)::value;
         v16i acc0 = {}, acc1 = {};
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const v4i a = fr[(t * 3 + s) * 64];
+        for (int s = 0; s < KS; ++s) {
+            const v4i a = fr[(t * KS + s) * 64];
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B.b[s][0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B.b[s][1], acc1, 0, 0, 0);
         }
-        u64 a00 = add(4 * t), a01 = add(4 * t + 1), a10 = add(4 * t + 2), a11 = add(4 * t + 3);
-        swap64(a00, a10);                                  // a00: word 4 t + 2 H of the permutation in column tile 0, a10: of the one in tile 1
-        swap64(a01, a11);
         const ulonglong2 K0 = Kt[4 * t], K1 = Kt[4 * t + 1];
-        u64 r00 = recombine_add(acc0[0], acc0[1], acc0[2], acc0[3], acc0[4], acc0[5], acc0[6], acc0[7], K0, one, s16, a00);
-        u64 r01 = recombine_add(acc0[8], acc0[9], acc0[10], acc0[11], acc0[12], acc0[13], acc0[14], acc0[15], K1, one, s16, a01);
-        u64 r10 = recombine_add(acc1[0], acc1[1], acc1[2], acc1[3], acc1[4], acc1[5], acc1[6], acc1[7], K0, one, s16, a10);
-        u64 r11 = recombine_add(acc1[8], acc1[9], acc1[10], acc1[11], acc1[12], acc1[13], acc1[14], acc1[15], K1, one, s16, a11);
-        swap64(r00, r10);
+        u64 r00, r01, r10, r11;
+        if constexpr (ADDS) {
+            // the addend travels to the lane that recombines output o of this vector the way the result travels back
+            u64 a00 = add(4 * t), a01 = add(4 * t + 1), a10 = add(4 * t + 2), a11 = add(4 * t + 3);
+            swap64(a00, a10);                              // a00: word 4 t + 2 H of the vector in column tile 0, a10: of the one in tile 1
+            swap64(a01, a11);
+            r00 = recombine_add(acc0[0], acc0[1], acc0[2], acc0[3], acc0[4], acc0[5], acc0[6], acc0[7], K0, one, s16, a00);
+            r01 = recombine_add(acc0[8], acc0[9], acc0[10], acc0[11], acc0[12], acc0[13], acc0[14], acc0[15], K1, one, s16, a01);
+            r10 = recombine_add(acc1[0], acc1[1], acc1[2], acc1[3], acc1[4], acc1[5], acc1[6], acc1[7], K0, one, s16, a10);
+            r11 = recombine_add(acc1[8], acc1[9], acc1[10], acc1[11], acc1[12], acc1[13], acc1[14], acc1[15], K1, one, s16, a11);
+        } else {
+            r00 = recombine(acc0[0], acc0[1], acc0[2], acc0[3], acc0[4], acc0[5], acc0[6], acc0[7], K0, one, s16);
+            r01 = recombine(acc0[8], acc0[9], acc0[10], acc0[11], acc0[12], acc0[13], acc0[14], acc0[15], K1, one, s16);
+            r10 = recombine(acc1[0], acc1[1], acc1[2], acc1[3], acc1[4], acc1[5], acc1[6], acc1[7], K0, one, s16);
+            r11 = recombine(acc1[8], acc1[9], acc1[10], acc1[11], acc1[12], acc1[13], acc1[14], acc1[15], K1, one, s16);
+        }
+        swap64(r00, r10);                                  // r00: output 4 t of the lane's own vector, r10: output 4 t + 2
         swap64(r01, r11);
         out(4 * t, r00); out(4 * t + 1, r01); out(4 * t + 2, r10); out(4 * t + 3, r11);
     });
 }
+// the 12 x 12 shapes of Poseidon
+template <int N_TILES = 3, class OUT>
+__device__ __forceinline__ void product(const BOps& B, const u64* __restrict__ tab, OUT&& out) { product_t<N_TILES, 3, 3>(B, tab, NoAdd{}, out); }
+template <int N_TILES = 3, class ADD, class OUT>
+__device__ __forceinline__ void product_add(const BOps& B, const u64* __restrict__ tab, ADD&& add, OUT&& out) { product_t<N_TILES, 3, 3>(B, tab, add, out); }
 
 }  // namespace pmfma
 }  // namespace zk

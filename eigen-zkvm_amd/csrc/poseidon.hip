@@ -13,13 +13,13 @@
 //     (no carries: 12 * 2^6 * 2^32 < 2^42) and ONE reduction instead of 12 modular multiplications;
 //   * round 6: the products by full-width constants -- the pre-sparse matrix P and the two dense products of each lazy block
 //     of partial rounds, 628 of a permutation's terms -- run on the MATRIX pipe as byte-limb i8 GEMMs over the wave's 64 states
-//     (poseidon_mfma.hip.h): 3.4 k of 17.3 k vector instructions per permutation gone, the S-boxes are what is left;
+//     (gl_mfma.hip.h): 3.4 k of 17.3 k vector instructions per permutation gone, the S-boxes are what is left;
 //   * the 64-bit round constants and the matrix-pipe tables sit in LDS (49 KB per workgroup of 256 lanes).
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
 #include "ntt_reg.hip.h"   // static_for
 #include "acc6.hip.h"
-#include "poseidon_mfma.hip.h"
+#include "gl_mfma.hip.h"
 #include <mutex>
 
 namespace zk {
@@ -45,7 +45,7 @@ __device__ u64 g_tab[T_WORDS];
 #define ZK_POSEIDON_LDS __shared__ __attribute__((aligned(16))) u64 tab[T_WORDS]
 
 // LDS image of the ONE-LANE kernels (g_mtab; round 6): the constants their vector instructions still read, then one matrix-pipe table
-// (poseidon_mfma.hip.h) per dense product.
+// (gl_mfma.hip.h) per dense product.
 constexpr int TM_S0 = T_PT;                                        // [22] split: S_r[0]   (C0, FC, PC in front of it as in g_tab)
 constexpr int TM_DD = TM_S0 + 44;                                  // as T_DD
 constexpr int TM_K0 = TM_DD + 220;                                 // as T_K0
@@ -884,7 +884,7 @@ void ensure_constants() {
             for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
         }
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
-    {   // LDS image of the one-lane kernels: their dense products run on the matrix pipe (poseidon_mfma.hip.h)
+    {   // LDS image of the one-lane kernels: their dense products run on the matrix pipe (gl_mfma.hip.h)
         static u64 mt[TM_WORDS];
         for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                   // C0, FC, PC
         for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }

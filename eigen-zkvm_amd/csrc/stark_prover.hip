@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <array>
 #include <cstring>
+#include <atomic>
 #include <future>
 #include <map>
 #include <memory>
@@ -257,6 +258,7 @@ struct zk_stark_setup {
     // in stage 3 depends on a challenge: no plookup / permutation / connection columns and no challenge or
     // expression-section operand in step3 itself.  The transcript order is untouched (stark_gen below).
     bool early_stage3 = false;
+    std::atomic<int> early_ctx_live{0};    // contexts that currently use side_stream / ev_inputs / ev_stage3 (at most one)
     hipStream_t side_stream = nullptr;     // memory-bound stage-3 work beside the ALU-bound hashing of tree 1
     hipEvent_t ev_inputs = nullptr, ev_stage3 = nullptr;
     std::string setup_timing;              // JSON: where StarkSetup::new's time went (zk_stark_setup_timing)
@@ -746,6 +748,14 @@ struct zk_stark_ctx {
     int committed = 0;                                    // trees 1..committed exist
     bool ran[5] = {false, false, false, false, false};
     bool h1h2_done = false, z_done = false, evals_done = false;
+    u32 chal_have = 0;                                    // bit i: challenge i was drawn from the transcript or set by the caller
+    void need_challenges(u32 mask, const char* who) const {
+        if ((chal_have & mask) == mask) return;
+        char buf[16]; snprintf(buf, sizeof buf, "0x%02x", mask & ~chal_have);
+        throw Error(std::string(who) + ": its challenges come first (zk_stark_challenge or zk_stark_set_challenge; bit i of the mask = challenge i: "
+                    "0 u, 1 defVal, 2 gamma, 3 beta, 4 vc, 5 v1, 6 v2, 7 xi); missing " + buf);
+    }
+    bool holds_early = false;                             // this context owns the setup's side stream and its two events
 
     zk_stark_ctx(zk_stark_setup& s, const uint64_t* cm_pols, const u64* d_cm, uint64_t n_words, hipStream_t stream)
         : S(s), st(stream), T((on_stream(stream), stream)), I(s.info), nbits(s.nbits), nbits_ext(s.nbits_ext), ext(s.nbits_ext - s.nbits),
@@ -832,8 +842,19 @@ struct zk_stark_ctx {
         tr.reset(new AnyTranscript(bn128));
         tr->put_words_dev(d_pub.u(), n_pub, st);
         T.mark("inputs_publics");
-        stage3_early = S.early_stage3;
+        // the early stage 3 runs on the SETUP's side stream and is ordered by the setup's two events: one live context at a time may use them
+        // (advisor finding, round 5); a second context on the same setup takes stage 3 in order on its own stream -- the same proof
+        if (S.early_stage3) {
+            if (S.early_ctx_live.fetch_add(1) == 0) holds_early = true; else S.early_ctx_live.fetch_sub(1);
+        }
+        stage3_early = holds_early;
         n_cm = S.n_cm1;
+    }
+    ~zk_stark_ctx() {
+        if (holds_early) {
+            if (stage3_started) (void)hipStreamSynchronize(S.side_stream);          // nothing of this proof is left on the shared stream
+            S.early_ctx_live.fetch_sub(1);
+        }
     }
     zk_stark_ctx(const zk_stark_ctx&) = delete; zk_stark_ctx& operator=(const zk_stark_ctx&) = delete;
 
@@ -881,11 +902,26 @@ struct zk_stark_ctx {
     }
     // transcript.get_field() -> challenge i (u, defVal, gamma, beta, vc, v1, v2, xi: constant.rs:39-50), kept in HBM for the step programs
     // (count consecutive challenges in one launch, together with the root absorbed just before)
-    void challenge(int i, int count = 1) { ZK_REQUIRE(i >= 0 && count >= 1 && i + count <= 8, "challenge index"); tr->get_fields_dev(d_chal.u() + 3 * i, (u32)count, st); }
+    // The transcript must hold what the reference has absorbed when it draws challenge i (stark_gen.rs:285-294, 313-321, 362-369, 407-414, 474-479):
+    // u, defVal after root 1; gamma, beta after root 2; vc after root 3; xi after root 4; v1, v2 after the evaluations.
+    void challenge_allowed(int i, int count) const {
+        ZK_REQUIRE(i >= 0 && count >= 1 && i + count <= 8, "challenge index");
+        for (int k = i; k < i + count; ++k) {
+            const int need = k <= 1 ? 1 : k <= 3 ? 2 : k == 4 ? 3 : 4;
+            ZK_REQUIRE(committed >= need, "challenge: the commitment it is drawn after comes first (u, defVal: 1; gamma, beta: 2; vc: 3; xi, v1, v2: 4)");
+            if (k == 5 || k == 6) ZK_REQUIRE(evals_done, "challenge v1 / v2: the evaluations are absorbed first (stark_gen.rs:472-479)");
+        }
+    }
+    void challenge(int i, int count = 1) {
+        challenge_allowed(i, count);
+        tr->get_fields_dev(d_chal.u() + 3 * i, (u32)count, st);
+        chal_have |= ((1u << count) - 1) << i;
+    }
     void set_challenge(int i, const u64 v[3]) {                                    // a caller with its own transcript
-        ZK_REQUIRE(i >= 0 && i < 8, "challenge index");
+        challenge_allowed(i, 1);
         ZK_HIP(hipMemcpyAsync(d_chal.u() + 3 * i, v, 24, hipMemcpyHostToDevice, st));
         ZK_HIP(hipStreamSynchronize(st));                                          // (v is the caller's)
+        chal_have |= 1u << i;
     }
     void get_challenge(int i, u64 out[3]) {
         ZK_REQUIRE(i >= 0 && i < 8, "challenge index");
@@ -951,13 +987,16 @@ struct zk_stark_ctx {
     // calculate_exps_parallel(ctx, starkinfo, segment, domain, step) (stark_gen.rs:786-792) for one of the five step programs
     void eval(int step) {
         ZK_REQUIRE(step >= 0 && step <= 4, "eval: step id");
+        ZK_REQUIRE(!ran[step], "eval: every step program runs once per proof");
         on_stream(st);
         switch (step) {
             case STEP_2PREV:
                 ZK_REQUIRE(committed >= 1, "step2prev follows the first commitment and the challenges u, defVal");
+                need_challenges(0x03, "step2prev");
                 run(S.step2prev, false); break;
             case STEP_3PREV:
                 ZK_REQUIRE(committed >= 2, "step3prev follows the second commitment and the challenges gamma, beta");
+                need_challenges(0x0c, "step3prev");
                 zero(B[S_TMPEXP_N], sN[S_TMPEXP_N] * N, st);                       // an output-only section starts from zero (stark_gen.rs:944-951)
                 run(S.step3prev, false); break;
             case STEP_3:
@@ -966,9 +1005,11 @@ struct zk_stark_ctx {
                 break;
             case STEP_42NS:
                 ZK_REQUIRE(committed >= 3, "step42ns follows the third commitment and the challenge vc");
+                need_challenges(0x10, "step42ns");
                 run(S.step42ns, true); break;
             default:
                 ZK_REQUIRE(evals_done, "step52ns follows the evaluations and the challenges v1, v2");
+                need_challenges(0xe0, "step52ns");
                 xdiv.reserve(3 * Next * 8); xdivw.reserve(3 * Next * 8);            // stark_gen.rs:481-522
                 xdivxsub2_dev(d_chal.u() + 3 * 7, 1, gl::hroot(nbits), nbits_ext, xdiv.u(), xdivw.u(), st);   // both tables, one launch
                 T.mark("xDivXSubXi");
@@ -1020,6 +1061,7 @@ struct zk_stark_ctx {
     // xi is sum_i qq2_i (xi / shift)^i -- the weights of the coefficients are the powers the reference feeds its ifft.)
     void evals() {
         ZK_REQUIRE(committed == 4 && !evals_done, "the evaluations follow the fourth commitment and the challenge xi, once");
+        need_challenges(0x80, "evals");
         on_stream(st);
         const u64* d_xi = d_chal.u() + 3 * 7;
         DevBuf LEv, LpEv, pw, pwp, lt1, lt1p, lt2;
@@ -1412,9 +1454,9 @@ char* zk_fri_prove_dev(zk_transcript_t* transcript, const uint64_t* d_pol, uint3
             ZK_REQUIRE(nbits_ext <= 32 && steps[0] <= nbits_ext, "zk_fri_prove_dev: the first step cannot exceed the polynomial's size");
             hipStream_t st = (hipStream_t)stream;
             on_stream(st);
-            AnyTranscript tr(transcript);
             const std::vector<u32> sv(steps, steps + n_steps);
-            FriState F;
+            FriState F;                                    // declared BEFORE the borrowed transcript: on an exception the transcript goes first and
+            AnyTranscript tr(transcript);                  // flushes its deferred put while the buffers it points into (F's) still exist
             F.commit(tr, nullptr, K(d_pol), nbits_ext, sv, n_queries, st, nullptr);
             std::vector<std::unique_ptr<AnyTree>> borrowed;
             std::vector<const AnyTree*> all_trees; std::vector<u64> all_mask;

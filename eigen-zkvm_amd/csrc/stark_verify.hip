@@ -280,7 +280,7 @@ F3 execute_code(const JVal& code, const ExecCtx& c) {
 // value carried up (the leaf digest first), then idx >>= 4 -- every honest proof passes, and proofs the reference would wave through
 // with forged rows are rejected.  g_reference_compat (zk_stark_verify_set_reference_compat) restores the reference's behaviour for the
 // parity tests against the restated verifier.
-std::atomic<int> g_reference_compat{0};
+thread_local int g_reference_compat = 0;   // per calling thread: a parity test on one thread must not weaken verifications running on others (advisor finding, round 5)
 struct PathRef { const Opening* o; u64 idx; const u64* want; const char* what; };
 void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths of one tree share the row width */) {
     size_t n = 0; u32 max_depth = 1;
@@ -326,7 +326,7 @@ void check_paths(Hash h, const std::vector<std::vector<PathRef>>& trees /* paths
         leaves.resize(4 * n); d2h_sync(leaves.data(), d_leaves.p, n * 32);
     }
     d2h_sync(got.data(), d_roots.p, (h == H_GL ? n : levels) * stride * 8);
-    const bool strict = g_reference_compat.load() == 0;
+    const bool strict = g_reference_compat == 0;
     k = 0; lv = 0;
     for (auto& t : trees)
         for (auto& p : t) {
@@ -490,7 +490,8 @@ int stark_verify_impl(const JVal& info, const JVal& prog, const JVal& ss, const 
 }  // namespace zk
 
 extern "C" int zk_stark_verify_set_reference_compat(int on) {
-    const int old = g_reference_compat.exchange(on ? 1 : 0);
+    const int old = g_reference_compat;
+    g_reference_compat = on ? 1 : 0;
     return old;
 }
 

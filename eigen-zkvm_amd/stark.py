@@ -500,7 +500,12 @@ class StagedProof:
 
     def run_all(self):
         """stark_gen.rs:279-545, in order -> zkin bytes"""
-        self.commit_stage(1); self.challenge(0); self.challenge(1)
+        self.commit_stage(1)
+        return self.run_all_from_stage1()
+
+    def run_all_from_stage1(self):
+        """the rest of run_all() once commit_stage(1) has been called"""
+        self.challenge(0); self.challenge(1)
         self.eval(STEP_2PREV); self.calculate_h1h2()
         self.commit_stage(2); self.challenge(2); self.challenge(3)
         self.eval(STEP_3PREV); self.calculate_z(); self.eval(STEP_3)

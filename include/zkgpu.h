@@ -286,7 +286,7 @@ int zk_stark_setup_set_prover_addr(zk_stark_setup_t* s, const char* prover_addr)
  * than the reference where the reference is loose: scalar-field (16-ary) Merkle paths are walked level by level -- the node at position
  * idx & 15 of every level must be the value carried up, starting from the row's digest -- whereas merklehash_bn128.rs:108-128 binds only
  * the last level to the root (rows unbound); finalPol must hold exactly 2^steps.last values and every path must have the depth its tree
- * implies.  Honest proofs pass either way.  zk_stark_verify_set_reference_compat(1) switches the process to the reference's lenient path
+ * implies.  Honest proofs pass either way.  zk_stark_verify_set_reference_compat(1) switches the CALLING THREAD to the reference's lenient path
  * check (for parity tests against a verifier that follows the reference to the letter); it returns the previous setting.
  *   zk_stark_verify       against a prover's setup (its StarkInfo / Program / StarkStruct and the root of its constants)
  *   zk_stark_verify_with  without one: the same JSON texts zk_stark_setup_new takes + const_root (GL words, or the raw

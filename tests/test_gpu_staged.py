@@ -81,6 +81,25 @@ def test_a_staged_proof_keeps_its_device_trace_alive(zk):
     ns.free()
 
 
+def test_two_live_contexts_on_one_setup(zk):
+    """PoseidonG's setup runs stage 3 early on the SETUP's side stream: a second context on the same setup must not share that stream's
+    events (advisor finding, round 5) -- it takes stage 3 in order; both proofs equal the one-call proof"""
+    import poseidong as PG
+    zk.init(0)
+    stark = importlib.import_module("eigen_zkvm_amd.stark")
+    nbits = 12
+    ns = stark.NativeStarkSetup(PG.consts(nbits), json.dumps(PG.program(nbits)), json.dumps(PG.stark_struct(nbits)))
+    d_cm = zk.DevArray.from_host(PG.trace(nbits, None, PG.FIRST_ZERO, seed=nbits))
+    want = ns.gen_bytes(d_cm)
+    a, b = ns.staged(d_cm), ns.staged(d_cm)
+    a.commit_stage(1); b.commit_stage(1)                                      # a's early stage 3 is in flight on the side stream while b commits
+    assert b.run_all_from_stage1() == want
+    assert a.run_all_from_stage1() == want
+    a.free(); b.free()
+    assert ns.staged(d_cm).run_all() == want                                  # the side stream is free again
+    ns.free()
+
+
 def test_stages_are_accepted_in_the_references_order_only(zk):
     stark, ns, cm = _setup(zk, "fibonacci_imP", _struct())
     p = ns.staged(cm)
@@ -88,9 +107,19 @@ def test_stages_are_accepted_in_the_references_order_only(zk):
         p.commit_stage(2)
     with pytest.raises(zk.ZkError, match="first commitment"):
         p.eval(stark.STEP_2PREV)
-    p.commit_stage(1); p.challenge(0); p.challenge(1)
+    with pytest.raises(zk.ZkError, match="commitment it is drawn after"):
+        p.challenge(0)                                                        # u is drawn from a transcript that holds root 1
+    p.commit_stage(1)
+    with pytest.raises(zk.ZkError, match="its challenges come first"):
+        p.eval(stark.STEP_2PREV)                                              # u, defVal neither drawn nor set: would run on zeros (advisor finding, round 5)
+    with pytest.raises(zk.ZkError, match="commitment it is drawn after"):
+        p.set_challenge(2, [1, 2, 3])                                         # gamma belongs behind root 2
+    p.challenge(0); p.challenge(1)
     with pytest.raises(zk.ZkError, match="calculate_H1H2"):
         p.commit_stage(2)
+    p.eval(stark.STEP_2PREV)
+    with pytest.raises(zk.ZkError, match="runs once"):
+        p.eval(stark.STEP_2PREV)
     with pytest.raises(zk.ZkError, match="FRI::prove"):
         p.finish()
     with pytest.raises(zk.ZkError, match="challenge index"):

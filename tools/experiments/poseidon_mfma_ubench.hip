@@ -1,5 +1,5 @@
 // Stage A of the round-6 experiment: Poseidon-GL's dense 12 x 12 product (the pre-sparse matrix P) on the vector pipe (mat_full, as shipped
-// through round 5) against the matrix-pipe form (csrc/poseidon_mfma.hip.h), one permutation per lane, three waves per SIMD.
+// through round 5) against the matrix-pipe form (csrc/gl_mfma.hip.h), one permutation per lane, three waves per SIMD.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I eigen-zkvm_amd/csrc tools/experiments/poseidon_mfma_ubench.hip -o tools/experiments/poseidon_mfma_ubench \
 //         -L eigen-zkvm_amd -l:libzkgpu.so -Wl,-rpath,'$ORIGIN/../../eigen-zkvm_amd'
 // Prints: layout probe, equality of both forms with the host's 128-bit arithmetic, time per product.  SQ_INSTS_VALU: run under
