@@ -50,7 +50,7 @@ PADD_PRODUCTS = 11
 def pmc_traffic(nbits):
     """roofline.traffic: HBM bytes per ntt_pass_kernel launch from the PMC counters -- rocprofv3 --pmc FETCH_SIZE and --pmc
     WRITE_SIZE in separate passes with the gfx950 fetch correction calibrated on a 1 GiB copy of the same run
-    (tools/gpu_pmc.sh -> tools/pmc_summarize.py -> profiles/rNN/pmc_hbm_traffic.json).  Counters cannot be read by the
+    (tools/gpu_round.sh profiles -> tools/pmc_summarize.py -> profiles/rNN/pmc_hbm_traffic.json).  Counters cannot be read by the
     run that is being timed, so the number is taken from the newest committed profile and only if that profile was
     collected on the kernel sources this build has (src_sha16); otherwise null."""
     sys.path.insert(0, str(ROOT / "tools"))

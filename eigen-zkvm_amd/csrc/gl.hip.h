@@ -177,13 +177,7 @@ __device__ __forceinline__ u64 mad_eps_nc(u32 r2, u64 t) {          // t + r2*(2
     u64 u; u32 m;
     asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
                  : "=&v"(u), "=v"(m) : "v"(r2), "v"(t) : "vcc");
-#ifdef ZK_GL_EPS_MAD
-    u64 d, carry;                                                    // u + m as ONE multiply-add (m * 1 + u): no zero-extending move for the addend
-    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(carry) : "v"(m), "v"(u));
-    return d;
-#else
     return u + m;                                                    // carried: += 2^32 - 1 (cannot carry again)
-#endif
 }
 __device__ __forceinline__ u64 reduce_words_nc(u32 w0, u32 w1, u32 r2, u32 r3) { return mad_eps_nc(r2, sub_word_fold(w0, w1, r3)); }
 // acc + x for a 32-bit word x as ONE multiply-add (x * 1 + acc) instead of a zero-extending move and a 64-bit addition
@@ -201,10 +195,6 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {                // any u64 
     const u64 p3 = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
     return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
 }
-#ifdef ZK_GL_NO_SQR3
-__device__ __forceinline__ u64 sqr_nc(u64 a) { return mul_nc(a, a); }
-#endif
-#ifndef ZK_GL_NO_SQR3
 // A squaring with the cross product a0 a1 taken once (round 4): three multiply-adds instead of four, the second use of the cross
 // product a 64-bit addition.  The same number of instructions as the plain product, a cheaper mix: 2^22 x 19 tree 9.39-9.44 ms against
 // 9.54-9.70 (profiles/r04/poseidon_variants.md).  Half of the S-box's products are squarings (x^2, x^6).
@@ -218,8 +208,6 @@ __device__ __forceinline__ u64 sqr_nc(u64 a) {
     const u64 p3 = (u64)a1 * a1 + (p1 >> 32) + (p2 >> 32);
     return reduce_words_nc((u32)p0, (u32)p2, (u32)p3, (u32)(p3 >> 32));
 }
-#else
-#endif
 __device__ __forceinline__ u64 mul_add_nc(u64 a, u64 b, u64 c) {     // a*b + c, any u64 in, nc out
     GL_OPAQUE(a); GL_OPAQUE(b); GL_OPAQUE(c);
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);

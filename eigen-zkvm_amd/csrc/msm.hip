@@ -120,10 +120,6 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 // Fq2 product (fe_mul2) a BN254 addition is ~70 KB: the Fq2 products are inlined into the point formulas, the hot
 // mixed addition into the accumulate kernel, and the cold formulas (pt_add, pt_dbl, pt_dbl_aff) stay real functions.
 // BLS12-381 (14 limbs, 2.4 x the code) keeps cf_mul / cf_sqr as functions.
-#ifdef ZK_G2_FQ_NOINLINE
-#undef FQ_MUL_ATTR
-#define FQ_MUL_ATTR __noinline__
-#endif
 #define MSM_G2_INLINE_CF   // 9 x 29-bit limbs: the Fq2 products are small enough to inline; the rare point formulas stay out of line
 #define MSM_G2
 namespace {
@@ -230,10 +226,6 @@ __host__ __device__ constexpr u32 GEN_Y(int i) {
 // Fq2 product (fe_mul2) a BN254 addition is ~70 KB: the Fq2 products are inlined into the point formulas, the hot
 // mixed addition into the accumulate kernel, and the cold formulas (pt_add, pt_dbl, pt_dbl_aff) stay real functions.
 // BLS12-381 (14 limbs, 2.4 x the code) keeps cf_mul / cf_sqr as functions.
-#ifdef ZK_G2_FQ_NOINLINE
-#undef FQ_MUL_ATTR
-#define FQ_MUL_ATTR __noinline__
-#endif
 #define MSM_G2
 namespace {
 #include "msm_impl.hip.h"
@@ -248,15 +240,6 @@ namespace {
 void msm_g1_bn254_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
     bn254::g1::msm_g1_dev(d_bases, d_scalars, n, d_out, st);
 }
-#ifdef ZK_MSM_UBENCH
-}  // namespace zk
-// variant builds only (tools/build_variant.sh ... "-DZK_MSM_UBENCH"): msm_impl.hip.h's cost probe of batched-affine additions
-extern "C" int zk_msm_ubench_affine(const void* d_bases_std, uint64_t n_lanes, uint32_t K, int mode) {
-    try { zk::bn254::g1half::ubench_affine_dev(d_bases_std, n_lanes, K, mode, nullptr); return 0; }
-    catch (const std::exception& e) { fprintf(stderr, "ubench: %s\n", e.what()); return -1; }
-}
-namespace zk {
-#endif
 void g1_bn254_mul_generator_dev(const u64* d_k, uint64_t n, void* d_bases, hipStream_t st) {
     bn254::g1::g1_mul_generator_dev(d_k, n, d_bases, st);
 }

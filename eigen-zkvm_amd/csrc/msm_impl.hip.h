@@ -491,11 +491,7 @@ __global__ __launch_bounds__(256) void balance_scatter_kernel(const u32* __restr
 // wave issues at most every ~6.5 cycles even with independent instructions at hand (profiles/r05/ubench_lat.txt).  ZK_MSM_G2_WAVES=2 (variant
 // builds: tools/build_variant.sh) caps the kernel at 256 registers for two waves per SIMD.
 #undef MSM_ACC_BOUNDS
-#if defined(MSM_G2) && defined(ZK_MSM_G2_WAVES)
-#define MSM_ACC_BOUNDS __launch_bounds__(64, ZK_MSM_G2_WAVES)
-#else
 #define MSM_ACC_BOUNDS __launch_bounds__(64)
-#endif
 template <bool FIRST>
 __global__ MSM_ACC_BOUNDS void msm_accumulate_kernel(const u32* __restrict__ conv, const u32* __restrict__ offsets,
                                                             const u32* __restrict__ counts, const u32* __restrict__ idx,
@@ -503,9 +499,6 @@ __global__ MSM_ACC_BOUNDS void msm_accumulate_kernel(const u32* __restrict__ con
     const u32 key = order[blockIdx.x * blockDim.x + threadIdx.x];  // window * 2^16 + digit, heaviest first
     xyzz acc = FIRST ? pt_inf() : buckets[key];
     const u32 n = counts[key], off = offsets[key];
-#ifdef ZK_MSM_NO_PREFETCH
-    for (u32 k = 0; k < n; ++k) acc = pt_madd(acc, load_aff(conv, idx[off + k]));
-#else
     // the next point's coordinates (and the index after it) are requested before the current addition starts: the gather's
     // two dependent loads (index, then 2 x NR words at a random address) fly during ~2 500 instructions of arithmetic
     u32 i_next = n > 1 ? idx[off + 1] : 0;
@@ -517,7 +510,6 @@ __global__ MSM_ACC_BOUNDS void msm_accumulate_kernel(const u32* __restrict__ con
         acc = pt_madd(acc, cur);
         cur = nxt;
     }
-#endif
     buckets[key] = acc;
 }
 // One level of the radix-R hierarchy (R = 2^RLOG) that computes sum_k k*B_k per window.  An item (S, A) stands
@@ -735,11 +727,8 @@ static hipStream_t msm_side_stream() {
     if (!ss[dev]) ZK_HIP(hipStreamCreateWithFlags(&ss[dev], hipStreamNonBlocking));
     return ss[dev];
 }
-// produce(ctx, first, count, stream): optional -- makes the points / scalars [first, first + count) of a pre-converted sum on `stream` just before
-// that chunk is sorted there (the endomorphism split of the outer sum: chunk c + 1's split then runs beside chunk c's accumulation, like its sort)
-typedef void (*msm_chunk_producer)(void* ctx, uint64_t first, uint64_t count, hipStream_t stream);
 static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n, uint64_t base_off, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st,
-                     const void* d_preconv = nullptr, msm_chunk_producer produce = nullptr, void* produce_ctx = nullptr) {
+                     const void* d_preconv = nullptr) {
     ZK_REQUIRE(n >= 1 && n < (1ull << 28), "msm: n out of range");
     ZK_REQUIRE(!d_table || (n < (1ull << 24) && base_off + n <= table_n && table_n < (1ull << 24)), "msm table: range out of bounds");
     const size_t n_keys = (size_t)N_WIN * N_BUCKET;
@@ -801,7 +790,6 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
         const u32* sc = (const u32*)d_scalars + c0 * MSM_SC_WORDS;
         u32 *counts_p = (u32*)CH[c].counts.p, *offsets_p = (u32*)CH[c].offsets.p, *idx_p = (u32*)CH[c].idx.p, *order_p = (u32*)CH[c].order.p;
         const u64 total = nc * N_WIN;
-        if (produce && nc) { produce(produce_ctx, c0, nc, ss); ZK_HIP(hipGetLastError()); }
         if (nc == 0) { ZK_HIP(hipMemsetAsync(counts_p, 0, n_keys * 4, ss)); ZK_HIP(hipMemsetAsync(offsets_p, 0, n_keys * 4, ss)); }
         else if (lds_sort) {  // LDS-histogram partition (no device-scope atomics)
             const u32 n_blocks = (u32)((nc + SORT_PTS - 1) / SORT_PTS);
@@ -883,80 +871,7 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     ZK_HIP(hipGetLastError());
 }   // the pooled scratch above is released here, stream-ordered: the sum is asynchronous on `st` like every other _dev entry point
 
-#if defined(ZK_MSM_UBENCH) && !defined(MSM_G2) && !defined(MSM_GLV)
-// ---- micro-benchmark (variant builds only, tools/msm_affine_ubench.py): what would batched-affine bucket additions cost?
-// A: the shipped accumulation -- a lane adds K resident affine points into one XYZZ accumulator (pt_madd, 10 products each).
-// B: K independent affine additions P_i + Q_i per lane with ONE inversion for all of them (Montgomery's trick inside the lane):
-//    sweep 1: d_i = x(Q_i) - x(P_i), prefix products kept in a global scratch row; Fermat inversion of the lane's product;
-//    sweep 2, backwards: 1/d_i from the running inverse and the stored prefix, lambda, x3, y3 (2 products + 1 square) --
-//    6 products per addition + 300 / K for the inversion + 36 B written and read per addition for the prefix.
-// Both read their points from a [lane][K] array (the same words), so the loads are the same.  No special cases (the inputs are
-// distinct multiples of G): this measures the arithmetic and the scratch traffic, not a usable kernel.
-__global__ __launch_bounds__(64) void ubench_madd_kernel(const u32* __restrict__ pts, u32 K, xyzz* __restrict__ out) {
-    const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    xyzz acc = pt_inf();
-    for (u32 k = 0; k < K; ++k) acc = pt_madd(acc, load_aff(pts, (u32)(lane * K + k)));
-    out[lane] = acc;
-}
-__global__ __launch_bounds__(64) void ubench_affine_kernel(const u32* __restrict__ pts, u32 K, u32* __restrict__ scratch /* [lanes][K][NR] */,
-                                                           u32* __restrict__ out /* [lanes][K/2][PTW] */) {
-    const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u32 m = K / 2;                                                  // pairs (2 i, 2 i + 1) of the lane's points
-    u32* __restrict__ sc = scratch + lane * (u64)m * NR;
-    cf run = cf_one();
-    for (u32 i = 0; i < m; ++i) {
-        const aff P = load_aff(pts, (u32)(lane * K + 2 * i)), Q = load_aff(pts, (u32)(lane * K + 2 * i + 1));
-        run = cf_mul(run, cf_sub<2>(Q.x, P.x));
-#pragma unroll
-        for (int l = 0; l < NR; ++l) sc[(u64)i * NR + l] = run.l[l];
-    }
-    cf inv = cf_inv(run);
-    for (u32 i = m; i-- > 0;) {
-        const aff P = load_aff(pts, (u32)(lane * K + 2 * i)), Q = load_aff(pts, (u32)(lane * K + 2 * i + 1));
-        cf pre = cf_one();
-        if (i) {
-#pragma unroll
-            for (int l = 0; l < NR; ++l) pre.l[l] = sc[(u64)(i - 1) * NR + l];
-        }
-        const cf d = cf_sub<2>(Q.x, P.x);
-        const cf inv_d = cf_mul(inv, pre);
-        inv = cf_mul(inv, d);
-        const cf lam = cf_mul(cf_sub<2>(Q.y, P.y), inv_d);
-        const cf x3 = cf_sub<2>(cf_sub<2>(cf_sqr(lam), P.x), Q.x);         // < 6q
-        const cf y3 = cf_sub<2>(cf_mul(lam, cf_sub<8>(P.x, x3)), P.y);      // < 4q
-        u32* o = out + (lane * (u64)m + i) * PTW;
-#pragma unroll
-        for (int l = 0; l < NR; ++l) { o[l] = x3.l[l]; o[NR + l] = y3.l[l]; }
-    }
-}
-// both on `st`; returns nothing: the caller times it.  pts: n_lanes * K converted points (msm_convert_kernel's layout)
-void ubench_affine_dev(const void* d_bases_std, uint64_t n_lanes, uint32_t K, int mode, hipStream_t st) {
-    DevBuf conv, scratch, out;
-    const u64 n = n_lanes * K;
-    conv.reserve((size_t)n * PTW * 4);
-    hipLaunchKernelGGL(msm_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases_std, n, (u32*)conv.p);
-    ZK_HIP(hipStreamSynchronize(st));
-    hipEvent_t a, b; ZK_HIP(hipEventCreate(&a)); ZK_HIP(hipEventCreate(&b));
-    float best = 1e30f;
-    if (mode == 0) out.reserve(n_lanes * sizeof(xyzz));
-    else { scratch.reserve((size_t)n_lanes * (K / 2) * NR * 4); out.reserve((size_t)n_lanes * (K / 2) * PTW * 4); }
-    for (int rep = 0; rep < 3; ++rep) {
-        ZK_HIP(hipEventRecord(a, st));
-        if (mode == 0) hipLaunchKernelGGL(ubench_madd_kernel, dim3((unsigned)(n_lanes / 64)), dim3(64), 0, st, (const u32*)conv.p, K, (xyzz*)out.p);
-        else hipLaunchKernelGGL(ubench_affine_kernel, dim3((unsigned)(n_lanes / 64)), dim3(64), 0, st, (const u32*)conv.p, K, (u32*)scratch.p, (u32*)out.p);
-        ZK_HIP(hipEventRecord(b, st)); ZK_HIP(hipEventSynchronize(b));
-        float ms; ZK_HIP(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
-    }
-    const u64 adds = mode == 0 ? n : n / 2;
-    printf("%s: %llu lanes x K = %u: %.3f ms, %llu additions, %.3f ns per addition (whole device)\n", mode == 0 ? "xyzz madd      " : "batched affine ",
-           (unsigned long long)n_lanes, K, best, (unsigned long long)adds, best * 1e6 / adds);
-    ZK_HIP(hipEventDestroy(a)); ZK_HIP(hipEventDestroy(b));
-}
-#endif
 void msm_preconv_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points); }
-void msm_preconv_chunked_dev(const void* d_points, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st, msm_chunk_producer produce, void* ctx) {
-    msm_core(nullptr, nullptr, 0, 0, d_scalars, n, d_out, st, d_points, produce, ctx);
-}
 #ifdef MSM_GLV
 // ---- the curve's endomorphism phi(x, y) = (beta x, y) = [lambda](x, y): k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128, so a sum
 // over n points with 254-bit scalars becomes a sum over 2n points with 128-bit scalars: the same number of bucket additions, half
@@ -1053,30 +968,14 @@ __global__ __launch_bounds__(256) void glv_split_kernel(const u32* __restrict__ 
     cf_store_int(bx, o + PTW); cf_store_int(n2 ? ny : y, o + PTW + CW_INT);
 }
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) {
-    static const bool off = getenv("ZK_MSM_NO_GLV") != nullptr;
-    if (off || n < 4096 || n >= (1ull << 27)) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); return; }
+    if (n < 4096 || n >= (1ull << 27)) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); return; }
     DevBuf conv2, sc2;
     conv2.reserve((size_t)2 * n * PTW * 4); sc2.reserve((size_t)2 * n * 16);
-    static const bool chunked = getenv("ZK_MSM_SPLIT_CHUNKED") != nullptr;
-    if (!chunked) {                                                       // the default: the split of all points in front of the sum
-        hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
-        ZK_HIP(hipGetLastError());
-        MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);
-        return;
-    }
-    // Round 5, measured and NOT the default (ZK_MSM_SPLIT_CHUNKED=1): the split (a 256-bit division by lambda and an Fq product per point: 0.37 ms of an
-    // 8 ms sum at 2^22 points) made chunk by chunk on the stream the chunk is sorted on, so that only the first chunk's quarter stands in front of the
-    // sum.  BN254 2^22: 8.04-8.13 ms against 8.03-8.10; 2^23: 15.0 against 14.6-14.7 (profiles/r05/msm_ab_raw.txt) -- the split is integer work like
-    // the accumulation it would run beside (the sort, which does overlap, is memory-bound): nothing to hide it behind.
-    struct SplitCtx { const u32* bases; const u32* scalars; u64 n; u32* conv2; u32* sc2; } ctx{(const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p};
-    auto split_chunk = [](void* c_, uint64_t first, uint64_t count, hipStream_t s) {
-        const SplitCtx* c = (const SplitCtx*)c_;
-        const u64 i0 = first / 2, i1 = std::min<u64>(c->n, (first + count + 1) / 2);      // pairs (2 i, 2 i + 1) belong to point i; chunk boundaries are even
-        if (i1 <= i0) return;
-        hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((i1 - i0 + 255) / 256)), dim3(256), 0, s, c->bases + i0 * (2 * CW_STD), c->scalars + i0 * 8, i1 - i0,
-                           c->conv2 + 2 * i0 * PTW, c->sc2 + 2 * i0 * 4);
-    };
-    MSM_GLV::msm_preconv_chunked_dev(conv2.p, sc2.p, 2 * n, d_out, st, split_chunk, &ctx);     // asynchronous: conv2 / sc2 go back to the pool with the sum still in flight; pool_free's events order their reuse
+    // the split of all points in front of the sum (made chunk by chunk beside the accumulation it gains nothing: the split is integer work
+    // like the accumulation -- round 5, tools/experiments/rejected_switches_r02_r05.patch, profiles/r05/msm_ab_raw.txt)
+    hipLaunchKernelGGL(glv_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const u32*)d_bases, (const u32*)d_scalars, n, (u32*)conv2.p, (u32*)sc2.p);
+    ZK_HIP(hipGetLastError());
+    MSM_GLV::msm_preconv_dev(conv2.p, sc2.p, 2 * n, d_out, st);     // asynchronous: conv2 / sc2 go back to the pool with the sum still in flight; pool_free's events order their reuse
 }
 #else
 void msm_g1_dev(const void* d_bases, const void* d_scalars, uint64_t n, void* d_out, hipStream_t st) { msm_core(d_bases, nullptr, 0, 0, d_scalars, n, d_out, st); }

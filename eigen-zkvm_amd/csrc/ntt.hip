@@ -30,14 +30,9 @@ namespace zk {
 
 namespace {
 
-#ifndef ZK_NTT_WAVES
-#define ZK_NTT_WAVES
-#endif
-// elements per tile (a workgroup of ZK_NTT_TILE / 16 lanes, 8 bytes of LDS per element).  4096 ships; 2048 and 1024 exist for the
-// tile-granularity measurements of profiles/r05/ntt_bound.md (tools/build_variant.sh ... "-DZK_NTT_TILE=2048")
-#ifndef ZK_NTT_TILE
-#define ZK_NTT_TILE 4096
-#endif
+// elements per tile (a workgroup of NTT_TILE / 16 lanes, 8 bytes of LDS per element); tiles of 2048 and 1024 measured 24 % / 77 % slower
+// (profiles/r05/ntt_bound.md; the switches of those runs: tools/experiments/rejected_switches_r02_r05.patch)
+constexpr int NTT_TILE = 4096;
 constexpr int TW_LO_BITS = 12;
 constexpr int TW_LO = 1 << TW_LO_BITS;
 
@@ -60,8 +55,6 @@ struct PassParams {
     u32 np;
     u32 log_s;
     u32 has_tw;        // L > R (not the last pass)
-    u32 out_mul;       // last pass only: output row r lands in row r * out_mul + out_off (1, 0 = plain; 2, b = coset b of an extension)
-    u32 out_off;
 };
 
 __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e) {
@@ -69,19 +62,15 @@ __device__ __forceinline__ u64 tab2(const u64* __restrict__ lo, const u64* __res
 }
 
 template <int LOGA, int LOGB, bool KMODE, bool INV>
-__global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel(const PassParams P) {
+__global__ __launch_bounds__(NTT_TILE / 16) void ntt_pass_kernel(const PassParams P) {
     constexpr int LOGR = LOGA + LOGB, R = 1 << LOGR, RA = 1 << LOGA, RB = 1 << LOGB;
-    constexpr int C = ZK_NTT_TILE / R;         // lanes per tile
+    constexpr int C = NTT_TILE / R;         // lanes per tile
     constexpr int GA = 16 / RA, GB = 16 / RB;  // independent sub-transforms per thread
     constexpr int TG = R / 16;                 // threads along the transform axis
     constexpr int PAD = KMODE ? 512 / R : 0;   // words; spreads kappa_a rows over banks (KMODE reads)
     constexpr int ROW = RB * C + PAD;
     static_assert(LOGR >= 4 && LOGR <= 8 && LOGA <= 4 && LOGB <= 4, "tile shape");
-#ifdef ZK_NTT_LDSPAD
-    __shared__ u64 lds[RA * ROW + ZK_NTT_LDSPAD];
-#else
     __shared__ u64 lds[RA * ROW];
-#endif
 
     const int t = threadIdx.x;
     const u64 u0 = (u64)blockIdx.x * C;
@@ -113,11 +102,8 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
                     x[g][ja] = ok ? v : 0;
                 }
         }
-#ifndef ZK_NTT_NOMATH
 #pragma unroll
         for (int g = 0; g < GA; ++g) ntt_reg<LOGA, INV>(x[g]);
-#endif
-#if !defined(ZK_NTT_NOMATH) && !defined(ZK_NTT_NO_SHIFT_TW)
         // Passes of <= 6 bits: w_R is a power of two (w_64 = 2^39, ntt_reg.hip.h), so the twiddle w_R^(jb ka) between the two halves is a
         // shift like the butterflies' own -- once jb is a compile-time number.  jb = ta GA + g and ta = t / C with C = 4096 / R >= 64
         // lanes: the same in every lane of a wave, so a switch over ta (R / 16 <= 4 cases) costs no divergence and turns the 15 general
@@ -140,7 +126,6 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
                 }
             });
         } else
-#endif
         {
 #pragma unroll
             for (int g = 0; g < GA; ++g) {
@@ -148,10 +133,8 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
 #pragma unroll
                 for (int ka = 0; ka < RA; ++ka) {
                     u64 v = x[g][bitrev_c(ka, LOGA)];
-#ifndef ZK_NTT_NOMATH
                     if (LOGB > 0 && ka > 0) v = gl::mul(v, P.w256[(jb * ka) << (8 - LOGR)]);
                     else if (P.pre_scale != 1) v = gl::mul(v, P.pre_scale);
-#endif
                     lds[ka * ROW + jb * C + c] = v;
                 }
             }
@@ -173,11 +156,9 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
         // p = uc / (s n_pols): a shift for one column; a 32-bit division when the matrix has fewer than 2^32 words per transform-axis
         // index (every size in use); the 64-bit division otherwise -- uniform branches, the general case cost ~100 instructions per lane
         u64 p, rem;
-#ifndef ZK_NTT_DIV64
         if (P.np == 1) { p = uc >> P.log_s; rem = uc & (((u64)1 << P.log_s) - 1); }
         else if ((P.inner >> 32) == 0) { const u32 p32 = (u32)uc / (u32)P.s_np; p = p32; rem = (u32)uc - p32 * (u32)P.s_np; }
         else
-#endif
         { p = uc / P.s_np; rem = uc - p * P.s_np; }
         u64 tw[GB][RB];
         if (P.tw_mid) {  // L <= 2^16: every twiddle w_L^(p*kappa) is one load from the 512 KB table (L2), no chain;
@@ -191,19 +172,13 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
         }
         // (a uniform run-time branch on purpose: as `if constexpr` the compiler sinks these loads below the
         // butterflies to save registers and the L2 latency lands on the critical path again)
-#ifndef ZK_NTT_NOMATH
 #pragma unroll
         for (int g = 0; g < GB; ++g) ntt_reg<LOGB, INV>(y[g]);
-#endif
         if (u >= P.inner) return;
 
         u64* __restrict__ outp = P.out + p * R * P.s_np + rem;
-        u64 kstride = P.s_np;                          // words between the outputs kappa and kappa + 1 of a lane
-        const u64 row_q = !(P.sc_lo || P.out_mul > 1) ? 0 : P.np == 1 ? rem : (P.inner >> 32) == 0 ? (u64)((u32)rem / P.np) : rem / P.np;  // output row = kappa*s + row_q (last pass: p == 0)
-        if (P.out_mul > 1) {                           // rows interleaved with another transform's: row r -> r * out_mul + out_off
-            outp = P.out + ((row_q * P.out_mul + P.out_off) * P.np + (rem - row_q * P.np));
-            kstride = P.s_np * P.out_mul;
-        }
+        const u64 kstride = P.s_np;                    // words between the outputs kappa and kappa + 1 of a lane
+        const u64 row_q = !P.sc_lo ? 0 : P.np == 1 ? rem : (P.inner >> 32) == 0 ? (u64)((u32)rem / P.np) : rem / P.np;  // output row = kappa*s + row_q (last pass: p == 0)
         if (P.tw_mid) {
 #pragma unroll
             for (int g = 0; g < GB; ++g) {
@@ -211,9 +186,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
 #pragma unroll
                 for (int kb = 0; kb < RB; ++kb) {
                     u64 v = y[g][bitrev_c(kb, LOGB)];
-#ifndef ZK_NTT_NOMATH
                     v = gl::mul(v, tw[g][kb]);
-#endif
                     outp[(u64)(RA * kb + ka) * kstride] = v;
                 }
             }
@@ -232,11 +205,7 @@ __global__ __launch_bounds__(ZK_NTT_TILE / 16) ZK_NTT_WAVES void ntt_pass_kernel
 #pragma unroll
             for (int kb = 0; kb < RB; ++kb) {
                 u64 v = y[g][bitrev_c(kb, LOGB)];
-#ifdef ZK_NTT_NOMATH
-                if (false) {
-#else
                 if (scaled) {
-#endif
                     v = gl::mul(v, f);
                     if (kb + 1 < RB) f = gl::mul(f, fstep);
                 }
@@ -331,10 +300,10 @@ ScaleTables get_scale(u32 nbits, u64 g, u64 cst) {  // cst * g^k, k < 2^nbits
 
 template <int LOGA, int LOGB>
 void launch_pass(const PassParams& P, bool kmode, bool inverse, hipStream_t st) {
-    constexpr int C = ZK_NTT_TILE >> (LOGA + LOGB);
+    constexpr int C = NTT_TILE >> (LOGA + LOGB);
     const u64 blocks = (P.inner + C - 1) / C;
     ZK_REQUIRE(blocks < (1ull << 31), "ntt: grid too large");
-    const dim3 g((u32)blocks), b(ZK_NTT_TILE / 16);
+    const dim3 g((u32)blocks), b(NTT_TILE / 16);
     const int variant = (kmode ? 2 : 0) | (inverse ? 1 : 0);
 #define ZK_PASS(K, I) hipLaunchKernelGGL((ntt_pass_kernel<LOGA, LOGB, K, I>), g, b, 0, st, P)
     switch (variant) {
@@ -371,12 +340,8 @@ std::vector<int> plan(u32 nbits) {
 // bufs.back() = output.  scale: optional (g, cst) output scaling cst*g^row; out_scale: constant.
 struct Scale { bool on = false; u64 g = 1, cst = 1; };
 
-// first_pass / n_run: run only passes [first_pass, first_pass + n_run) of the plan (n_run < 0: all of them); `in` is then the
-// input of pass first_pass and the passes write a / b alternately so that the LAST pass run lands in `a`.  out_mul / out_off:
-// the transform's last pass interleaves its output rows (PassParams).
 void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land in `a` */
-                   u32 n_pols, u32 nbits, u64 valid_rows, bool inverse, Scale sc, u64 out_scale, hipStream_t st,
-                   int first_pass = 0, int n_run = -1, u32 out_mul = 1, u32 out_off = 0) {
+                   u32 n_pols, u32 nbits, u64 valid_rows, bool inverse, Scale sc, u64 out_scale, hipStream_t st) {
     const u64 n = 1ull << nbits;
     if (nbits < 4) {
         u64 w = gl::hroot(nbits);
@@ -396,12 +361,9 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
     if (sc.on) S = get_scale(nbits, sc.g, sc.cst);
     u32 log_s = 0;
     const u64* cur = in;
-    const int end_pass = n_run < 0 ? np : first_pass + n_run;
-    ZK_REQUIRE(first_pass >= 0 && end_pass <= np && first_pass <= end_pass, "ntt: pass range");
-    for (int i = 0; i < first_pass; ++i) log_s += radices[i];
-    for (int i = first_pass; i < end_pass; ++i) {
+    for (int i = 0; i < np; ++i) {
         const int logr = radices[i];
-        u64* dstbuf = ((end_pass - 1 - i) % 2 == 0) ? a : b;
+        u64* dstbuf = ((np - 1 - i) % 2 == 0) ? a : b;
         const bool last = (i == np - 1);
         PassParams P{};
         P.in = cur; P.out = dstbuf;
@@ -422,7 +384,6 @@ void run_transform(const u64* in, u64* a, u64* b, /* ping-pong, result must land
         P.np = n_pols;
         P.log_s = log_s;
         P.has_tw = last ? 0 : 1;
-        P.out_mul = last ? out_mul : 1; P.out_off = last ? out_off : 0;
         P.dshift = T.dshift;
         P.tw_mid = (!last && log_s >= T.dshift) ? T.mid : nullptr;  // L = N >> log_s <= 2^16
         const bool kmode = P.s_np < 16;
@@ -451,40 +412,8 @@ void lde_dev(const u64* d_src, u64* d_dst, u64* d_tmp, uint32_t n_pols, uint32_t
     if (n_pols == 0) return;  // fft_p.rs:262-264
     ZK_REQUIRE(d_src != d_dst, "lde: dst may not alias src");
     const u64 n = 1ull << nbits;
-    static const bool coset = getenv("ZK_LDE_COSET") != nullptr;
-    if (nbits_ext == nbits + 1 && nbits >= 9 && coset) {
-        // NOT the default -- measured slower (round 3, 2^24 -> 2^25: 18.7 vs 15.2 ms for 19 columns, 32.3 vs 28.5 ms for 36; bit-exact,
-        // tests/test_gpu_parity.py passes with ZK_LDE_COSET=1): the duplicated inverse pass and two 24-level transforms are 80
-        // N-levels of butterflies against the 74 of the plan below, and a pass costs what its butterflies cost.  Kept as the record.
-        // Blow-up 2 (every StarkStruct of the reference): the extension's even rows are the size-N transform of the coefficients
-        // scaled by 49^k, its odd rows the one of the coefficients scaled by (49 w_ext)^k -- the two cosets 49 <w> and 49 w_ext <w>
-        // of 49 <w_ext>.  Two N-point transforms (3 passes at 2^24, the 8-bit kernel) instead of one 2N-point transform over a
-        // half-zero input (4 passes of 6-7 bits over twice the rows): 10 N-pass-equivalents instead of 11, no butterfly on zeros.
-        //   inverse: its last pass runs twice, with the scale tables of g = 49 and g = 49 w_ext  -> c0, c1
-        //   forward: c0 and c1 separately; the last passes write rows 2k and 2k + 1 of dst.
-        // Buffers (N n_pols words each): dst = [D0 | D1], tmp = [T0 | T1].  With m = passes - 1: m even -> c0, c1 live in T0, T1 and
-        // ping-pong with D0, D1 (an even number of steps ends where it began); m odd -> they live in D0, D1 and end in T0, T1.
-        // Either way the last forward passes read tmp and write dst, and the inverse's earlier passes use the other pair.
-        const int np = ntt_num_passes(nbits), m = np - 1;
-        const u64 half = n * n_pols;
-        u64 *D0 = d_dst, *D1 = d_dst + half, *T0 = d_tmp, *T1 = d_tmp + half;
-        u64 *C0 = (m % 2 == 0) ? T0 : D0, *C1 = (m % 2 == 0) ? T1 : D1;          // where the coefficients go
-        u64 *P0 = (m % 2 == 0) ? D0 : T0, *P1 = (m % 2 == 0) ? D1 : T1;          // the other pair
-        const u64 ninv = gl::hinv(n % GL_P), w_ext = gl::hroot(nbits_ext);
-        Scale s0; s0.on = true; s0.g = 49; s0.cst = ninv;
-        Scale s1; s1.on = true; s1.g = gl::hmul(49, w_ext); s1.cst = ninv;
-        const u64* last_in = d_src;
-        if (m > 0) { run_transform(d_src, P0, P1, n_pols, nbits, n, true, Scale{}, 1, st, 0, m); last_in = P0; }   // lands in P0
-        run_transform(last_in, C0, nullptr, n_pols, nbits, n, true, s0, 1, st, m, 1);
-        run_transform(last_in, C1, nullptr, n_pols, nbits, n, true, s1, 1, st, m, 1);
-        if (m > 0) {
-            run_transform(C0, (m % 2 == 0) ? C0 : P0, (m % 2 == 0) ? P0 : C0, n_pols, nbits, n, false, Scale{}, 1, st, 0, m);   // ends in tmp
-            run_transform(C1, (m % 2 == 0) ? C1 : P1, (m % 2 == 0) ? P1 : C1, n_pols, nbits, n, false, Scale{}, 1, st, 0, m);
-        }
-        run_transform(T0, d_dst, nullptr, n_pols, nbits, n, false, Scale{}, 1, st, m, 1, 2, 0);
-        run_transform(T1, d_dst, nullptr, n_pols, nbits, n, false, Scale{}, 1, st, m, 1, 2, 1);
-        return;
-    }
+    // (Blow-up 2 as two size-N coset transforms with interleaved output rows instead of one 2N-point transform over a half-zero input was
+    // measured in round 3: bit-exact, 18.7 against 15.2 ms for 19 columns at 2^24 -- tools/experiments/rejected_switches_r02_r05.patch.)
     // coefficients * 49^i / N  (fft_p.rs:144-172): the inverse transform's last pass applies it.
     Scale sc; sc.on = true; sc.g = 49; sc.cst = gl::hinv(n % GL_P);
     const int fwd_passes = ntt_num_passes(nbits_ext);

@@ -38,19 +38,9 @@ __device__ __forceinline__ void ntt_reg(u64 (&x)[1 << LOG]) {
 #pragma unroll
             for (int blk = 0; blk < n; blk += 2 * half) {
                 const u64 a = x[blk + j], b = x[blk + j + half];
-#if defined(ZK_NTT_FAKE)      /* timing experiments only (wrong values): what would flag-free arithmetic buy? */
-                x[blk + j] = a + b;
-#if ZK_NTT_FAKE >= 2
-                x[blk + j + half] = (a - b) << (e & 31);
-#else
-                if constexpr (e >= 96) x[blk + j + half] = gl::mul_pow2<e - 96>(b - a);
-                else                   x[blk + j + half] = gl::mul_pow2<e>(a - b);
-#endif
-#else
                 x[blk + j] = gl::add(a, b);
                 if constexpr (e >= 96) x[blk + j + half] = gl::mul_pow2<e - 96>(gl::sub(b, a));
                 else                   x[blk + j + half] = gl::mul_pow2<e>(gl::sub(a, b));
-#endif
             }
         });
     });

@@ -61,11 +61,8 @@ __device__ u64 g_mtab[TM_WORDS];
 // pipe.  Measured on 2^22 x 19 trees (profiles/r06/poseidon_mfma.md): 256 lanes 7.25 ms, 512 lanes 7.5, 384 lanes 9.2 (six-wave
 // workgroups do not tile four SIMDs); bounds of three waves (168 registers) 8.2-9.5; resident grids (tables loaded once per CU)
 // lose 5-10 % to one workgroup per chunk of rows -- workgroups that start together run their phases together.
-#ifndef ZK_ONE_THREADS
-#define ZK_ONE_THREADS 256
-#endif
-constexpr int ONE_THREADS = ZK_ONE_THREADS;
-#define ZK_ONE_BOUNDS __launch_bounds__(ZK_ONE_THREADS, 2)
+constexpr int ONE_THREADS = 256;
+#define ZK_ONE_BOUNDS __launch_bounds__(256, 2)
 #define ZK_POSEIDON_LDS_ONE __shared__ __attribute__((aligned(16))) u64 tab[TM_WORDS]
 __device__ __forceinline__ void load_tables_one(u64* __restrict__ tab) {
     for (int i = threadIdx.x; i < TM_WORDS / 2; i += blockDim.x) reinterpret_cast<ulonglong2*>(tab)[i] = reinterpret_cast<const ulonglong2*>(g_mtab)[i];

@@ -580,10 +580,9 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
     // host cores, the constants are copies and kernels: 0.6 s of a 2^24-row cold setup that used to stand in front of the 2.1 s of hipRTC.
     // (The futures block in their destructors: an exception below still waits for the threads that read S.)
     const zk_stark_setup* Sc = S.get();
-    const std::launch how = getenv("ZK_JIT_SERIAL") ? std::launch::deferred : std::launch::async;   // (ZK_JIT_SERIAL: one after the other, for measurements)
-    const bool spawn = how == std::launch::async && !getenv("ZK_JIT_INPROCESS");   // side by side really means one compiler process each (expr_jit.hip)
-    auto start = [Sc, how, spawn](const JVal& seg, bool ext, bool ret) {
-        return std::async(how, [Sc, &seg, ext, ret, spawn] {
+    const bool spawn = !getenv("ZK_JIT_INPROCESS");        // side by side really means one compiler process each (expr_jit.hip); the switch keeps hipRTC in this process
+    auto start = [Sc, spawn](const JVal& seg, bool ext, bool ret) {
+        return std::async(std::launch::async, [Sc, &seg, ext, ret, spawn] {
             jit_prefer_spawn(spawn && seg.at("first").size() >= 32);            // (a handful of instructions compiles faster than a process starts)
             struct Off { ~Off() { jit_prefer_spawn(false); } } off;
             return Sc->compile_segment(seg, ext, ret);

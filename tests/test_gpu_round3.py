@@ -1,6 +1,6 @@
 """Round-3 additions to the boundary, each against the oracle or a host restatement:
 stage timers and setup timing (the reference's `#[time_profiler]` spans, stark_gen.rs:192,624,709,734,785, fri.rs:83,
-stark_setup.rs:26), zk_dev_fill_splitmix, and the coset form of the extension kept behind ZK_LDE_COSET."""
+stark_setup.rs:26) and zk_dev_fill_splitmix."""
 import json, os, pathlib, subprocess, sys
 import numpy as np
 import pytest
@@ -63,28 +63,6 @@ def test_stage_timers_and_setup_timing(zk, orc):
     assert s2["hiprtc_compiled"] == 0 and s2["code_cache_mem_hits"] >= 3
     assert second.gen(cm) == plain
     second.free(); setup.free()
-
-
-_COSET = r'''
-import sys, pathlib
-import numpy as np
-ROOT = pathlib.Path(sys.argv[1]); sys.path.insert(0, str(ROOT / "tests"))
-import zkgpu_loader, oracle_lib
-zk = zkgpu_loader.load(); zk.init(0); orc = oracle_lib.load()
-rng = np.random.default_rng(5)
-for nbits, w in [(9, 1), (9, 5), (12, 3), (13, 19), (16, 2), (17, 7)]:          # 2 and 3 passes, odd and even pass counts
-    x = rng.integers(0, zk.P, size=(1 << nbits) * w, dtype=np.uint64)
-    assert np.array_equal(zk.interpolate(x, w, nbits, nbits + 1), orc.lde(x, w, nbits, nbits + 1)), (nbits, w)
-print("coset lde ok")
-'''
-
-
-def test_coset_form_of_the_extension_is_bit_exact():
-    """ZK_LDE_COSET=1 (csrc/ntt.hip lde_dev: two size-N transforms with interleaved output rows; slower, kept as the record of
-    the experiment) gives the oracle's extension"""
-    env = dict(os.environ, ZK_LDE_COSET="1")
-    r = subprocess.run([sys.executable, "-c", _COSET, str(ROOT)], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0 and "coset lde ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_threads_prove_on_the_device_of_zk_init(zk):

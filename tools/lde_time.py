@@ -1,4 +1,4 @@
-"""LDE timing: python tools/lde_time.py nbits np [np ...]   (the shipped plan is inverse + one 2N-point forward transform over a half-zero input; ZK_LDE_COSET=1 opts into the two size-N coset transforms measured and dropped in round 3)"""
+"""LDE timing: python tools/lde_time.py nbits np [np ...]   (the plan is inverse + one 2N-point forward transform over a half-zero input)"""
 import sys, time, pathlib, ctypes
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))

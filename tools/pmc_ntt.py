@@ -1,4 +1,4 @@
-"""Workload for tools/gpu_pmc.sh: calibration copy (1 GiB read + 1 GiB write) then 2^24 NTT fwd+inv x4,
+"""Workload for tools/gpu_round.sh profiles / sq: calibration copy (1 GiB read + 1 GiB write) then 2^24 NTT fwd+inv x4,
 and one 20-column 2^20 -> 2^21 LDE + Merkle tree (the prover's stage-1 shape)."""
 import sys, pathlib
 import numpy as np, torch

@@ -1,4 +1,4 @@
-"""Per-kernel averages of the FETCH_SIZE / WRITE_SIZE passes written by tools/gpu_pmc.sh, as text and as the JSON that
+"""Per-kernel averages of the FETCH_SIZE / WRITE_SIZE passes written by tools/gpu_round.sh profiles, as text and as the JSON that
 bench.py's `roofline.traffic` is read from (profiles/rNN/pmc_hbm_traffic.json).
 
 Counter units are KiB.  The 1 GiB device copy of the same run calibrates them: FETCH_SIZE reports half of a wide streaming
