@@ -19,7 +19,7 @@ P = 0xFFFFFFFF00000001
 
 EXPORTS = [
     "zk_init", "zk_last_error", "zk_device_count", "zk_gl_modulus", "zk_gl_root_of_unity",
-    "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download", "zk_dev_sync", "zk_dev_memset", "zk_dev_fill_splitmix", "zk_dev_trim",
+    "zk_gl_poseidon_selfcheck", "zk_dev_alloc", "zk_dev_free", "zk_dev_upload", "zk_dev_download", "zk_dev_sync", "zk_dev_memset", "zk_dev_fill_splitmix", "zk_dev_trim",
     "zk_gl_ntt", "zk_gl_lde", "zk_gl_ntt_dev", "zk_gl_lde_dev", "zk_gl_ntt_passes",
     "zk_gl_poseidon", "zk_gl_linearhash", "zk_gl_linearhash_rows_dev",
     "zk_merkle_n_nodes", "zk_gl_merkelize", "zk_gl_merkelize_dev", "zk_merkle_root", "zk_merkle_nodes", "zk_merkle_elements",
@@ -113,6 +113,7 @@ def _load():
         "zk_gl_lde_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp]),
         "zk_gl_ntt_passes": (C.c_int, [C.c_uint32]),
         "zk_gl_poseidon": (C.c_int, [vp, vp, vp, C.c_uint32]),
+        "zk_gl_poseidon_selfcheck": (C.c_int, []),
         "zk_gl_linearhash": (C.c_int, [vp, C.c_size_t, vp]),
         "zk_gl_linearhash_rows_dev": (C.c_int, [vp, C.c_uint32, C.c_uint64, vp, vp]),
         "zk_merkle_n_nodes": (C.c_uint64, [C.c_uint64]),

@@ -416,6 +416,15 @@ int zk_gl_lde(const uint64_t* src, uint32_t n_pols, uint32_t nbits, uint64_t* ds
     });
 }
 
+int zk_gl_poseidon_selfcheck(void) {                                   // host arithmetic only: no CallScope, no device
+    try {
+        const std::string why = poseidon_tables_selfcheck();
+        if (why.empty()) return 0;
+        set_error(why);
+    } catch (const std::exception& e) { set_error(e.what()); }
+    return -1;
+}
+
 int zk_gl_poseidon(const uint64_t in[8], const uint64_t cap[4], uint64_t* out, uint32_t n_out) {
     return guard([&] {
         // poseidon_opt.rs:81-96 rejects wrong input/capacity lengths; with fixed-size C arrays the

@@ -24,6 +24,7 @@
 #include "acc6.hip.h"
 #include "ntt_reg.hip.h"   // static_for
 #include <vector>
+#include <string>
 #include <cstring>
 #include <type_traits>
 
@@ -103,6 +104,66 @@ inline bool build_tables(const u64* coef, int n_out, int n_in, const u64* addend
         tab[frag_words(KS, TL) + 2 * o + 1] = (1ull << 47) + (tv >> 32);
     }
     return true;
+}
+
+// Host-side check of a table against the coefficients it was built from (no GPU): every row's digits spell (c 2^(8 b) mod p) or its
+// negative-side representative, the fragments sit where product_t() reads them, and the two addends of every output are in range and
+// congruent to 128 * (sum of the row's digits, weighted) + addend + the bias.  Returns "" or what is wrong.
+inline std::string check_tables(const u64* coef, int n_out, int n_in, const u64* addend, const u64* tab, int KS = 3, int TL = 3) {
+    typedef __int128 i128;
+    const signed char* fr = reinterpret_cast<const signed char*>(tab);
+    const i128 P = (i128)GL_P;
+    auto frag = [&](int o, int d, int j, int b) -> int {   // the byte product_t() multiplies word j's byte b with for output o's digit column d
+        const int t = o / 4, H = (o % 4) / 2, r = 8 * (o % 2) + d, m = (r & 3) + 8 * (r >> 2) + 4 * H;
+        const int s = j / 4, h = (j % 4) / 2, i = 8 * (j % 2) + b;
+        return fr[((t * KS + s) * 64 + (32 * h + m)) * 16 + i];
+    };
+    for (int o = 0; o < 4 * TL; ++o) {
+        i128 corr = 0;
+        for (int j = 0; j < 4 * KS; ++j)
+            for (int b = 0; b < 8; ++b) {
+                i128 v = 0;
+                for (int d = 7; d >= 0; --d) v = v * 256 + frag(o, d, j, b);
+                corr += 128 * v;
+                i128 want = 0;
+                if (o < n_out && j < n_in) { want = (i128)(coef[o * n_in + j] % GL_P); for (int k = 0; k < b; ++k) want = (want << 8) % P; }
+                i128 got = v % P; if (got < 0) got += P;
+                if (got != want) return "digits of output " + std::to_string(o) + ", word " + std::to_string(j) + ", byte " + std::to_string(b) + " do not spell c 2^(8 b) mod p";
+            }
+        const u64 KL = tab[frag_words(KS, TL) + 2 * o], KH = tab[frag_words(KS, TL) + 2 * o + 1];
+        if (KL < (1ull << 47) || KL >= (1ull << 47) + (1ull << 32) || KH < (1ull << 47) || KH >= (1ull << 47) + (1ull << 32)) return "addends of output " + std::to_string(o) + " out of range";
+        i128 want = corr % P; if (want < 0) want += P;
+        if (addend && o < n_out) want = (want + (i128)(addend[o] % GL_P)) % P;
+        const i128 got = ((i128)KL + (((i128)KH << 32) % P)) % P;
+        if (got != want) return "addends of output " + std::to_string(o) + " are not congruent to the bias correction";
+    }
+    return "";
+}
+
+// What the device computes from a table, step by step on the host (the i32 columns, the two biased 64-bit sums, the fold): out[o] mod p
+// for a vector x of ANY u64 words.  With check_tables() and the known-answer tests on the device this pins the form on both sides.
+inline void emulate_product(const u64* tab, const u64* x, int n_words, u64* out, int KS = 3, int TL = 3) {
+    typedef unsigned __int128 u128;
+    const signed char* fr = reinterpret_cast<const signed char*>(tab);
+    for (int o = 0; o < 4 * TL; ++o) {
+        long long col[8];
+        for (int d = 0; d < 8; ++d) {
+            long long c = 0;
+            for (int j = 0; j < 4 * KS; ++j)
+                for (int b = 0; b < 8; ++b) {
+                    const int t = o / 4, H = (o % 4) / 2, r = 8 * (o % 2) + d, m = (r & 3) + 8 * (r >> 2) + 4 * H;
+                    const int s = j / 4, h = (j % 4) / 2, i = 8 * (j % 2) + b;
+                    const int a = fr[((t * KS + s) * 64 + (32 * h + m)) * 16 + i];
+                    const int xb = (int)(signed char)((unsigned char)((j < n_words ? x[j] : 0) >> (8 * b)) ^ 0x80);
+                    c += (long long)a * xb;
+                }
+            col[d] = c;                                        // |c| <= 2^21: fits the pipe's i32
+        }
+        const u64 KL = tab[frag_words(KS, TL) + 2 * o], KH = tab[frag_words(KS, TL) + 2 * o + 1];
+        const u64 lo = (u64)((long long)KL + col[0] + (col[1] << 8) + (col[2] << 16) + (col[3] << 24));
+        const u64 hi = (u64)((long long)KH + col[4] + (col[5] << 8) + (col[6] << 16) + (col[7] << 24));
+        out[o] = (u64)(((u128)lo + ((u128)hi << 32)) % GL_P);
+    }
 }
 
 // ---- device --------------------------------------------------------------------------------------------------------------------

@@ -839,17 +839,46 @@ __global__ __launch_bounds__(64) void tr_put_get_kernel(TranscriptState* t, cons
     tr_store(t, &ts);
 }
 
+// the coefficient matrix of one matrix-pipe product of the permutation (row-major [n_out][n_in]); which: MT_P, MT_BS + b, MT_BE + b
+void mfma_coefficients(int which, u64 (&coef)[144], int& n_out, int& n_in) {
+    if (which == MT_P) {
+        n_out = n_in = 12;
+        for (int o = 0; o < 12; ++o)
+            for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_P[12 * j + o];                   // out[o] = sum_j P[j][o] st[j]
+    } else if (which < MT_BE) {
+        const int b = which - MT_BS; n_out = PR_B; n_in = 11;
+        for (int m = 0; m < PR_B; ++m)                                                                    // G[m] = sum_(k >= 1) S_(r0 + m)[k] st[k]
+            for (int j = 0; j < 11; ++j) coef[m * 11 + j] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 1 + j];
+    } else {
+        const int b = which - MT_BE; n_out = 11; n_in = PR_B;
+        for (int o = 0; o < 11; ++o)                                                                      // st[o + 1] += sum_m SC_(r0 + m)[o + 1] u_m
+            for (int m = 0; m < PR_B; ++m) coef[o * PR_B + m] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 12 + o];
+    }
+}
+// g_tab's image -> the one-lane kernels' image; "" or what went wrong.  Host only (also behind zk_poseidon_tables_selfcheck, no GPU needed).
+std::string build_one_lane_image(const u64* tab, u64* mt) {
+    for (int i = 0; i < TM_WORDS; ++i) mt[i] = 0;
+    for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                       // C0, FC, PC
+    for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }
+    for (int i = 0; i < 220; ++i) mt[TM_DD + i] = tab[T_DD + i];
+    for (int i = 0; i < 4; ++i) mt[TM_K0 + i] = tab[T_K0 + i];
+    for (int which = 0; which < MT_N; ++which) {
+        u64 coef[144]; int n_out, n_in;
+        mfma_coefficients(which, coef, n_out, n_in);
+        if (!pmfma::build_tables(coef, n_out, n_in, nullptr, mt + tm_table(which))) return "a digit column of product " + std::to_string(which) + " exceeds its bound";
+        const std::string why = pmfma::check_tables(coef, n_out, n_in, nullptr, mt + tm_table(which));
+        if (!why.empty()) return "product " + std::to_string(which) + ": " + why;
+    }
+    return "";
+}
+
 bool g_consts_loaded[64] = {};
 
 std::mutex g_consts_mu;
-void ensure_constants() {
-    int dev; ZK_HIP(hipGetDevice(&dev));
-    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-    std::lock_guard<std::mutex> lk(g_consts_mu);          // provers on several host threads
-    if (g_consts_loaded[dev]) return;
+// the cooperative kernels' LDS image (the T_ layout) from the constants of poseidon_gl_constants.h; host only
+void build_coop_image(u64* tab) {
     // regroup C[118] by use (poseidon_opt.rs:98-199): initial add, post-S-box constants of the 8 full
     // rounds (C[12(R+1)+i] for R < 4, C[82+12(R-4)+i] for R = 4..6, none for the last), partial rounds
-    static u64 tab[T_WORDS];
     for (int i = 0; i < T_WORDS; ++i) tab[i] = 0;
     for (int i = 0; i < 12; ++i) tab[T_C0 + i] = ZK_POSEIDON_C[i];
     for (int R = 0; R < 7; ++R)
@@ -880,33 +909,52 @@ void ensure_constants() {
             split(T_CD + 2 * (16 * r + m), ZK_POSEIDON_S[23 * r]);   // ... and in lane m of its own round: S_r[0]
             for (int k = 1; k < 12; ++k) split(T_SCS + 2 * (11 * PR_B * b + PR_B * (k - 1) + m), ZK_POSEIDON_S[23 * r + 11 + k]);
         }
+}
+void ensure_constants() {
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_consts_mu);          // provers on several host threads
+    if (g_consts_loaded[dev]) return;
+    static u64 tab[T_WORDS];
+    build_coop_image(tab);
     ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tab), tab, sizeof(tab)));
     {   // LDS image of the one-lane kernels: their dense products run on the matrix pipe (gl_mfma.hip.h)
         static u64 mt[TM_WORDS];
-        for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                   // C0, FC, PC
-        for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }
-        for (int i = 0; i < 220; ++i) mt[TM_DD + i] = tab[T_DD + i];
-        for (int i = 0; i < 4; ++i) mt[TM_K0 + i] = tab[T_K0 + i];
-        u64 coef[144];
-        bool ok = true;
-        for (int o = 0; o < 12; ++o)
-            for (int j = 0; j < 12; ++j) coef[o * 12 + j] = ZK_POSEIDON_P[12 * j + o];                   // out[o] = sum_j P[j][o] st[j]
-        ok = ok && pmfma::build_tables(coef, 12, 12, nullptr, mt + tm_table(MT_P));
-        for (int b = 0; b < 22 / PR_B; ++b) {
-            for (int m = 0; m < PR_B; ++m)                                                                // G[m] = sum_(k >= 1) S_(r0 + m)[k] st[k]
-                for (int j = 0; j < 11; ++j) coef[m * 11 + j] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 1 + j];
-            ok = ok && pmfma::build_tables(coef, PR_B, 11, nullptr, mt + tm_table(MT_BS + b));
-            for (int o = 0; o < 11; ++o)                                                                  // st[o + 1] += sum_m SC_(r0 + m)[o + 1] u_m
-                for (int m = 0; m < PR_B; ++m) coef[o * PR_B + m] = ZK_POSEIDON_S[23 * (PR_B * b + m) + 12 + o];
-            ok = ok && pmfma::build_tables(coef, 11, PR_B, nullptr, mt + tm_table(MT_BE + b));
-        }
-        ZK_REQUIRE(ok, "Poseidon matrix-pipe tables: a digit column exceeds its bound");
+        const std::string why = build_one_lane_image(tab, mt);
+        ZK_REQUIRE(why.empty(), "Poseidon matrix-pipe tables: " + why);
         ZK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mtab), mt, sizeof(mt)));
     }
     g_consts_loaded[dev] = true;
 }
 
 }  // namespace
+
+// Host-side self check of the one-lane kernels' tables (no GPU): the digit tables against their coefficients, and the matrix-pipe
+// arithmetic step by step (gl_mfma.hip.h emulate_product) against 128-bit arithmetic on random and extreme vectors.  "" or what is wrong.
+std::string poseidon_tables_selfcheck() {
+    static u64 tab[T_WORDS], mt[TM_WORDS];
+    build_coop_image(tab);
+    const std::string why = build_one_lane_image(tab, mt);
+    if (!why.empty()) return why;
+    u64 seed = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&] { seed += 0x9E3779B97F4A7C15ull; u64 z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    for (int which = 0; which < MT_N; ++which) {
+        u64 coef[144]; int n_out, n_in;
+        mfma_coefficients(which, coef, n_out, n_in);
+        for (int trial = 0; trial < 64; ++trial) {
+            u64 x[12], got[12];
+            for (int j = 0; j < 12; ++j)
+                x[j] = trial == 0 ? 0 : trial == 1 ? ~0ull : trial == 2 ? GL_P - 1 : trial == 3 ? 0x8080808080808080ull : trial == 4 ? 0x7F7F7F7F7F7F7F7Full : rnd();
+            pmfma::emulate_product(mt + tm_table(which), x, n_in, got);
+            for (int o = 0; o < n_out; ++o) {
+                unsigned __int128 want = 0;
+                for (int j = 0; j < n_in; ++j) want = (want + (unsigned __int128)(coef[o * n_in + j] % GL_P) * (x[j] % GL_P)) % GL_P;
+                if (got[o] != (u64)want) return "product " + std::to_string(which) + ", output " + std::to_string(o) + ", trial " + std::to_string(trial) + ": the matrix-pipe arithmetic disagrees with 128-bit arithmetic";
+            }
+        }
+    }
+    return "";
+}
 
 size_t transcript_state_bytes() { return sizeof(TranscriptState); }
 void transcript_init_dev(void* d_t, hipStream_t st) {

@@ -95,6 +95,7 @@ void merkle_roots_from_paths_dev(const u64* d_leaves, const u64* d_paths, const 
 
 // ---- device-resident transcript (poseidon.hip; transcript.rs:8-103) ----
 size_t transcript_state_bytes();
+std::string poseidon_tables_selfcheck();   // host only: the one-lane kernels' matrix-pipe tables and arithmetic against 128-bit arithmetic ("" = fine)
 void transcript_init_dev(void* d_t, hipStream_t st);
 void transcript_put_dev(void* d_t, const u64* d_src, uint64_t n, hipStream_t st);
 void transcript_get_dev(void* d_t, u64* d_dst, uint32_t n_words, hipStream_t st);

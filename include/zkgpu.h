@@ -76,6 +76,10 @@ int zk_gl_ntt_passes(uint32_t nbits); /* HBM passes a 2^nbits transform takes (b
  * replaces Poseidon::hash(inp, init_state, out) (starky/src/poseidon_opt.rs:76-200):
  * in[8] || cap[4] -> first n_out (1..12) state words.                                        */
 int zk_gl_poseidon(const uint64_t in[8], const uint64_t cap[4], uint64_t* out, uint32_t n_out);
+/* Host-only self check (NO GPU needed): the tables behind the kernels' matrix-pipe products -- the pre-sparse matrix P and the dense products
+ * of the lazy partial-round blocks (poseidon_opt.rs:121-163) as balanced base-256 digit rows -- against their coefficients, and the
+ * matrix-pipe arithmetic replayed step by step on the host against 128-bit arithmetic.  0 = fine, -1 = zk_last_error() says what is wrong. */
+int zk_gl_poseidon_selfcheck(void);
 /* replaces LinearHash::hash(flatvals, 0) (starky/src/linearhash.rs:79-110)                   */
 int zk_gl_linearhash(const uint64_t* v, size_t n, uint64_t out[4]);
 /* one digest per row of a device-resident [height][width] matrix -> d_digests[height][4]     */

@@ -102,3 +102,13 @@ def test_stark_verify_rejects_malformed_input_before_touching_a_device(zk):
         assert lib.zk_last_error()
     assert lib.zk_stark_verify_with(None, ss.encode(), root, b"{}") == -1 and b"null" in lib.zk_last_error()
     assert lib.zk_stark_verify(None, b"{}") == -1
+
+
+def test_poseidon_matrix_pipe_tables_selfcheck():
+    """Round 6: the one-lane Poseidon kernels compute their dense 64-bit products on the matrix pipe from digit tables built on the host
+    (csrc/gl_mfma.hip.h).  zk_gl_poseidon_selfcheck needs no GPU: every table row must spell c 2^(8 b) mod p, the fragments must sit where the
+    kernel reads them, and the pipe's arithmetic -- i32 columns of (byte - 128) x digit, two biased 64-bit sums, the fold -- replayed on the host
+    must equal 128-bit arithmetic for P and the four block products on random and extreme vectors (0, 2^64 - 1, p - 1, 0x80..80, 0x7F..7F)."""
+    import zkgpu_loader
+    zk = zkgpu_loader.load()
+    assert zk.lib().zk_gl_poseidon_selfcheck() == 0, zk.lib().zk_last_error().decode()

@@ -22,13 +22,13 @@ SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_C
 do_tests() { timeout 3300 python -m pytest "${@:-tests}" -m gpu -x -q --durations=8 > gpurun_out/pytest_gpu.log 2>&1; echo "rc=$?" >> gpurun_out/pytest_gpu.log; tail -15 gpurun_out/pytest_gpu.log; }
 do_bench() { timeout 1500 python bench.py "$@" > gpurun_out/bench_stdout.txt 2> gpurun_out/bench_stderr.txt; echo "rc=$?"; tail -c 1500 gpurun_out/bench_stdout.txt; grep -v '^bench_detail' gpurun_out/bench_stderr.txt | tail -5; }
 do_sq() {
-  O=gpurun_out/profiles/sq; rm -rf $O; mkdir -p $O
+  local O=gpurun_out/profiles/sq; rm -rf $O; mkdir -p $O
   timeout 400 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O -o sq -- python3 tools/pmc_ntt.py > $O.log 2>&1
   { echo "# rocprofv3 --pmc SQ_* over tools/pmc_ntt.py (2^24 NTT x8, 2^20->2^21 x20 LDE + Merkle)"; python3 tools/pmc_sq_summarize.py $O; } > gpurun_out/profiles/pmc_sq.txt
   head -20 gpurun_out/profiles/pmc_sq.txt | cut -c1-250; clean $O
 }
 do_icache() {
-  O=gpurun_out/pmc_ic; rm -rf $O; mkdir -p $O; : > gpurun_out/pmc_icache.txt
+  local O=gpurun_out/pmc_ic; rm -rf $O; mkdir -p $O; : > gpurun_out/pmc_icache.txt
   for spec in "msm_bn:tools/msm_bench.py bn254 g1 20" "msm_bls:tools/msm_bench.py bls12_381 g1 20" "g16:tools/groth16_bench.py BLS12381 18" "fs:tools/final_stark_probe.py 2"; do
     n=${spec%%:*}; c=${spec#*:}
     timeout 600 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$n -o ic -- python3 $c > $O/$n.log 2>&1
@@ -36,9 +36,9 @@ do_icache() {
   done
   cut -c1-260 gpurun_out/pmc_icache.txt; clean $O
 }
-do_prof() { n=$1; shift; O=gpurun_out/prof_$n; rm -rf $O; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o $n -- "$@" > $O.log 2>&1; tail -3 $O.log; stats $O 24; }
+do_prof() { local n=$1; shift; local O=gpurun_out/prof_$n; rm -rf $O; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o $n -- "$@" > $O.log 2>&1; tail -3 $O.log; stats $O 24; }
 do_profiles() {
-  O=gpurun_out/profiles; rm -rf $O; mkdir -p $O
+  local O=gpurun_out/profiles; rm -rf $O; mkdir -p $O
   timeout 1500 python bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 800 $O/bench.json; cp gpurun_out/bench_detail.json $O/bench_detail.json
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ntt -o ntt -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-prove --no-msm --no-bn128 --no-groth16 --no-poseidon --no-agg > $O/ntt.log 2>&1
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prove -o prove -- python3 tools/prove_bench.py --nbits 24 --reps 3 > $O/prove.log 2>&1; tail -1 $O/prove.log | cut -c1-400
