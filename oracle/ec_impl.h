@@ -151,7 +151,7 @@ int EC_X(scalar_mul)(const uint64_t *p, const uint64_t k[4], uint64_t *out) {
 void EC_X(make_bases)(uint64_t n, uint64_t a, uint64_t b, uint64_t *out /* n * PTW */) {
     uint64_t g[PTW], tmp[PTW], ka[4] = {a, 0, 0, 0}, kb[4] = {b, 0, 0, 0};
     EC_X(generator)(g);
-    aff_t step; EC_X(scalar_mul)(g, kb, tmp); step.x = fq_load(tmp); step.y = fq_load(tmp + EC_NL); step.inf = 0;
+    aff_t step; EC_X(scalar_mul)(g, kb, tmp); step.x = fq_load(tmp); step.y = fq_load(tmp + EC_NL); step.inf = b == 0;   /* b = 0: [0]G is the point at infinity, every base is [a]G (round 6: the fuzz drew b = 0 and got garbage bases) */
     aff_t first; EC_X(scalar_mul)(g, ka, tmp); first.x = fq_load(tmp); first.y = fq_load(tmp + EC_NL); first.inf = 0;
     jac_t cur; cur.x = first.x; cur.y = first.y; cur.z = R1;
     jac_t *pts = (jac_t *)malloc(n * sizeof(jac_t));
@@ -339,7 +339,7 @@ int EC_X(g2_scalar_mul)(const uint64_t *p, const uint64_t k[4], uint64_t *out) {
 void EC_X(g2_make_bases)(uint64_t n, uint64_t a, uint64_t b, uint64_t *out /* n * PT2W */) {
     uint64_t g[PT2W], tmp[PT2W], ka[4] = {a, 0, 0, 0}, kb[4] = {b, 0, 0, 0};
     EC_X(g2_generator)(g);
-    EC_X(g2_scalar_mul)(g, kb, tmp); aff2_t step = aff2_load(tmp);
+    EC_X(g2_scalar_mul)(g, kb, tmp); aff2_t step = aff2_load(tmp); if (b == 0) step.inf = 1;
     EC_X(g2_scalar_mul)(g, ka, tmp); aff2_t first = aff2_load(tmp);
     jac2_t cur; cur.x = first.x; cur.y = first.y; cur.z = f2_one();
     for (uint64_t i = 0; i < n; ++i) {              /* sizes used in tests are small: one inversion per point */

@@ -104,6 +104,26 @@ def test_msm_cancellation_and_duplicates(zk, orc):
     assert inf == einf and np.array_equal(got, exp)
 
 
+def test_msm_every_base_the_same_point_with_window_boundary_scalars(zk, orc):
+    """The sum the round-6 fuzz campaign stumbled over (seed 671: 169 bases made with step 0).  The failure was the GENERATOR's -- the oracle's
+    make_bases took [0]G, the point at infinity, for a finite step and produced garbage bases; fixed in oracle/ec_impl.h -- but the shape is
+    worth keeping: every base is [748]G, the scalars are random 252-bit words with 0, 1, r - 1, 2^(16 k) - 1 and 2^(16 k) every seventh place,
+    so every bucket addition is a doubling or meets its own multiple.  Oracle, closed form and device must agree."""
+    n, a = 169, 748
+    bases = orc.bn254_make_bases(n, a, 0)
+    assert all(np.array_equal(bases[8 * i:8 * i + 8], bases[:8]) for i in range(n))      # b = 0: [a]G every time
+    rng = np.random.default_rng(671)
+    raw = rng.integers(0, 2**64, size=(n, 4), dtype=np.uint64); raw[:, 3] &= np.uint64((1 << 60) - 1)
+    for k in range(0, n, 7):
+        v = [0, 1, R - 1, (1 << (16 * int(rng.integers(1, 15)))) - 1, 1 << (16 * int(rng.integers(1, 15)))][int(rng.integers(0, 5))]
+        raw[k] = [(v >> (64 * j)) & (2**64 - 1) for j in range(4)]
+    vals = [sum(int(raw[i, j]) << (64 * j) for j in range(4)) for i in range(n)]
+    got, inf = zk.msm_g1_bn254(bases, raw.reshape(-1))
+    exp, einf = orc.bn254_msm(bases, raw.reshape(-1), 8)
+    closed, cinf = orc.bn254_scalar_mul(orc.bn254_generator(), words(a * sum(vals) % R))
+    assert not inf and inf == einf == cinf and np.array_equal(got, exp) and np.array_equal(got, closed)
+
+
 def test_msm_same_bucket_pressure(zk, orc):
     """All scalars share their window digits except the lowest: one bucket per window gets n points."""
     n = 5000

@@ -135,3 +135,13 @@ def test_transcript_matches_manual_sponge(orc):
     words = [int(e2[3]), int(e2[4])]
     bits = [(words[i // 63] >> (i % 63)) & 1 for i in range(88)]
     assert [int(v) for v in perms] == [sum(bits[q * 11 + j] << j for j in range(11)) for q in range(8)]
+
+
+def test_make_bases_with_step_zero_repeats_the_first_point():
+    """oracle/ec_impl.h make_bases(n, a, 0): [0]G is the point at infinity, so every base is [a]G (round 6: the fuzz drew a step of 0, the
+    generator treated infinity as a finite point and the "mismatch" it reported was garbage in, garbage out)"""
+    import oracle_lib
+    orc = oracle_lib.load()
+    b = orc.bn254_make_bases(5, 7, 0)
+    one, inf = orc.bn254_scalar_mul(orc.bn254_generator(), np.array([7, 0, 0, 0], dtype=np.uint64))
+    assert not inf and all(np.array_equal(b[8 * i:8 * i + 8], one) for i in range(5))

@@ -1,7 +1,7 @@
 """One-off fuzz of the primitives against the oracle at random shapes (beyond the fixed parametrisations of tests/test_gpu_parity.py):
 NTT / iNTT / LDE (any blow-up), LinearHash rows, Merkle trees of any height (odd levels) with openings walked back to the root by the
 device's own path kernel (zk_stark_verify's), FRI folds.  python tools/fuzz_primitives.py SEED ROUNDS  (needs a GPU)"""
-import pathlib, sys, time
+import os, pathlib, sys, time
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests"), str(ROOT / "oracle")]
 import numpy as np
@@ -67,7 +67,10 @@ def run(seed, rounds, verbose=True):
             raw[k] = [(v >> (64 * j)) & (2**64 - 1) for j in range(4)]
         got, inf = zk.msm_g1_bn254(bases, raw.reshape(-1))
         exp, einf = orc.bn254_msm(bases, raw.reshape(-1), 8)
-        check("msm_bn254", inf == einf and np.array_equal(got, exp), n)
+        ok = inf == einf and np.array_equal(got, exp)
+        if not ok and os.environ.get("ZK_FUZZ_DUMP"):                       # keep a failing sum for the bench (tools/msm_fail_probe.py)
+            np.savez(os.path.join(os.environ["ZK_FUZZ_DUMP"], "msm_fail_%d_%d.npz" % (seed, n)), bases=bases, scalars=raw.reshape(-1), got=got, exp=exp, inf=inf, einf=einf, a=a, d=d)
+        check("msm_bn254", ok, n)
     if verbose:
         print("fuzz primitives seed %d: %d cases in %.0f s, mismatches: %s" % (seed, n_cases, time.time() - t0, bad), flush=True)
     return bad
