@@ -226,65 +226,31 @@ __device__ __forceinline__ fe fe_canon(const fe& a) {
     for (int i = 0; i < NR; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
     return r;
 }
-// a^-1 in Montgomery form (0 -> 0).  Round 6: the binary extended Euclid on the plain value instead of a^(q - 2): an inversion is always the
-// work of ONE lane at the end of a chain (a sum's conversion to affine, a table's seed), and a lone wave pays 8.3 cycles per dependent
-// instruction -- Fermat's 254 / 381 squarings + ~half as many products at 225 / 500 instructions each were 0.3 / 1.0 ms (70 % of
-// msm_final_bits_kernel); at most 2 x 254 / 2 x 381 halvings and subtractions of ~50 / ~75 instructions are a fifth of that.
-//   plain = a / R' (one product by the integer 1), canonical;  invariants  x1 plain = u R',  x2 plain = v R'  (mod q)  with x1 = R', x2 = 0
-//   at the start, so that the x belonging to u = 1 (or v = 1) is  plain^-1 R'  -- the Montgomery form of a^-1 -- with no other constant.
-__device__ __forceinline__ bool fe_bn_is_one(const fe& a) {
-    u32 z = a.l[0] ^ 1u;
-#pragma unroll
-    for (int i = 1; i < NR; ++i) z |= a.l[i];
-    return z == 0;
+// a^(q - 2).  (Round 6 measured the binary extended Euclid in its place -- at most 2 log2 q halvings and subtractions of ~100 dependent
+// instructions against ~1.5 log2 q products of 225 / 500 instructions -- and lost: msm_final_kernel 543 -> 677 us, msm_final_bits_kernel
+// 1192 -> 1225 us, g1_mul_generator_kernel 42.7 -> 63.8 ms.  A product's 2 x 81 multiply-adds are independent and issue every 4.2 cycles even
+// on a lone wave; Euclid's compare / borrow chains are dependent and pay the lone wave's 8.3 cycles each.  tools/experiments/fe_inv_euclid.patch)
+__host__ __device__ constexpr u32 fe_qm2_limb(int i) {   // limb i of q - 2 (the borrow may run past limb 0: BLS12-381's r = 1 mod 2^29)
+    long long borrow = 2;
+    u32 out = 0;
+    for (int k = 0; k <= i; ++k) {
+        long long v = (long long)Q29(k) - borrow;
+        borrow = 0;
+        if (v < 0) { v += (1ll << LB); borrow = 1; }
+        out = (u32)v;
+    }
+    return out;
 }
-__device__ __forceinline__ bool fe_bn_geq(const fe& a, const fe& b) {          // canonical limbs
-    bool gt = false, lt = false;
-#pragma unroll
+__device__ fe fe_inv(const fe& a) {  // a^(q-2)
+    fe r = fe_one();
     for (int i = NR - 1; i >= 0; --i) {
-        const bool g = a.l[i] > b.l[i], l = a.l[i] < b.l[i];
-        if (!gt && !lt) { gt = g; lt = l; }
+        const u32 w = fe_qm2_limb(i);
+        for (int b = LB - 1; b >= 0; --b) {
+            r = fe_sqr(r);
+            if ((w >> b) & 1) r = fe_mul(r, a);
+        }
     }
-    return !lt;
-}
-__device__ __forceinline__ void fe_bn_sub(fe& a, const fe& b) {               // a -= b, a >= b, limbs stay below 2^29
-    u32 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { const u32 d = a.l[i] - b.l[i] - borrow; borrow = d >> 31; a.l[i] = d & LMASK; }
-}
-__device__ __forceinline__ void fe_bn_addq(fe& a) {                            // a += q (a < q: the sum fits the limbs)
-    u32 carry = 0;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { const u32 d = a.l[i] + Q29(i) + carry; carry = i + 1 < NR ? d >> LB : 0; a.l[i] = i + 1 < NR ? d & LMASK : d; }
-}
-__device__ __forceinline__ void fe_bn_shr1(fe& a) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) a.l[i] = (a.l[i] >> 1) | (i + 1 < NR ? (a.l[i + 1] & 1u) << (LB - 1) : 0u);
-}
-__device__ __forceinline__ void fe_bn_halve_mod(fe& x) { if (x.l[0] & 1u) fe_bn_addq(x); fe_bn_shr1(x); }   // x / 2 mod q
-__device__ __forceinline__ void fe_bn_sub_mod(fe& x, const fe& y) {             // x = x - y mod q, both < q
-    if (!fe_bn_geq(x, y)) fe_bn_addq(x);
-    fe_bn_sub(x, y);
-}
-__device__ fe fe_inv(const fe& a) {
-    fe pl = fe_zero(); pl.l[0] = 1;
-    fe u = fe_canon(fe_mul(a, pl));                                           // the plain value a / R'
-    u32 nz = 0;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) nz |= u.l[i];
-    if (!nz) return fe_zero();
-    fe v, x1 = fe_canon(fe_one()), x2 = fe_zero();
-#pragma unroll
-    for (int i = 0; i < NR; ++i) v.l[i] = Q29(i);
-#pragma unroll 1
-    for (int it = 0; it < 4 * LB * NR; ++it) {                                // (at most 2 log2 q + 2 trips; the bound keeps a corrupted input from spinning)
-        if (fe_bn_is_one(u) || fe_bn_is_one(v)) break;
-        if (!(u.l[0] & 1u)) { fe_bn_shr1(u); fe_bn_halve_mod(x1); }
-        else if (!(v.l[0] & 1u)) { fe_bn_shr1(v); fe_bn_halve_mod(x2); }
-        else if (fe_bn_geq(u, v)) { fe_bn_sub(u, v); fe_bn_sub_mod(x1, x2); }
-        else { fe_bn_sub(v, u); fe_bn_sub_mod(x2, x1); }
-    }
-    return fe_bn_is_one(u) ? x1 : x2;
+    return r;
 }
 // external layout (NL x 32-bit words, Montgomery R) <-> internal (NR x 29-bit limbs, Montgomery R')
 __device__ __forceinline__ fe fe_from_std(const u32 (&w)[NL]) {

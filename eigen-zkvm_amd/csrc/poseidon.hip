@@ -48,10 +48,10 @@ __device__ u64 g_tab[T_WORDS];
 // (gl_mfma.hip.h) per dense product.
 constexpr int TM_S0 = T_PT;                                        // [22] split: S_r[0]   (C0, FC, PC in front of it as in g_tab)
 constexpr int TM_DD = TM_S0 + 44;                                  // as T_DD
-constexpr int TM_K0 = TM_DD + 220;                                 // as T_K0
-constexpr int TM_HDR = TM_K0 + 4;                                  // 400 words
+constexpr int TM_K0 = TM_DD + 220;                                 // [12]: C[i]^7 + (round 0's constant of word i): what a ZERO input word is after the first S-box
+constexpr int TM_HDR = TM_K0 + 12;                                 // 408 words
 constexpr int MT_P = 0, MT_BS = 1, MT_BE = 3, MT_N = 5;            // tables: P, block starts 0 / 1, block ends 0 / 1
-constexpr int TM_WORDS = TM_HDR + MT_N * pmfma::TAB_WORDS;          // 6280 words = 49 KB
+constexpr int TM_WORDS = TM_HDR + MT_N * pmfma::TAB_WORDS;          // 6288 words = 49 KB
 static_assert(TM_HDR % 2 == 0 && TM_WORDS % 2 == 0 && TM_WORDS * 8 <= 65536, "one-lane tables: 16-byte aligned, inside 64 KB");
 __host__ __device__ constexpr int tm_table(int k) { return TM_HDR + k * pmfma::TAB_WORDS; }
 __device__ u64 g_mtab[TM_WORDS];
@@ -200,13 +200,19 @@ __device__ __forceinline__ void partial_rounds(u64 (&st)[12], const u64* __restr
 //     first constants they are C[8..12) whatever the input, so their first S-boxes are four table words (TM_K0), not 16 products;
 //   * FULL_OUT = false: only st[0..4) is read afterwards (a digest, or the capacity of the next block): the last MDS computes
 //     four of its twelve outputs.  st[4..12) are then NOT the permutation's words.
+//   * n_in (wave-uniform, round 6): only st[0..n_in) hold input, the rest of the rate is the sponge's zero padding (the last block of a
+//     batch whose length is not a multiple of 8, the second half of the digests' sponge): their first S-boxes are table words too.
+//     A row of 36 columns absorbs four such blocks of ONE word each.
 template <bool FULL_OUT = false>
-__device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab, bool zero_cap) {
+__device__ __forceinline__ void poseidon_perm(u64 (&st)[12], const u64* __restrict__ tab, bool zero_cap, u32 n_in = 8) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
+    for (int i = 0; i < 8; ++i) {
+        if ((u32)i < n_in) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
+        else st[i] = tab[TM_K0 + i];
+    }
     if (zero_cap) {
 #pragma unroll
-        for (int i = 8; i < 12; ++i) st[i] = tab[TM_K0 + i - 8];
+        for (int i = 8; i < 12; ++i) st[i] = tab[TM_K0 + i];
     } else {
 #pragma unroll
         for (int i = 8; i < 12; ++i) st[i] = pow7_add(gl::add_nc(st[i], tab[T_C0 + i]), tab[T_FC + i]);
@@ -374,16 +380,19 @@ __device__ __forceinline__ void linearhash_row(const u64* __restrict__ row, u32 
     u32 b = 0, off = 0;
     bool final_sponge = false, second = false, cz = true;   // cz: the capacity words are zero (first block of a sponge)
     for (;;) {
+        u32 n_in;                                              // how many words of the rate hold input (the rest is the sponge's zero padding)
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
             const u64* __restrict__ v = row + (u64)b * bs + off;
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = (off + i < len) ? v[i] : 0;
+            n_in = len - off < 8 ? len - off : 8;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) st[i] = second ? h[8 + i] : h[i];
+            n_in = second ? 4 * hsz - 8 : (4 * hsz < 8 ? 4 * hsz : 8);
         }
-        poseidon_perm(st, tab, cz);
+        poseidon_perm(st, tab, cz, n_in);
         if (!final_sponge) {
             const u32 len = (w - b * bs < bs) ? w - b * bs : bs;
             off += 8;
@@ -477,13 +486,13 @@ __global__ ZK_ONE_BOUNDS void linearhash_final_kernel(const u64* __restrict__ h,
     for (int i = 0; i < 8; ++i) st[i] = (u32)i < 4 * hsz ? v[i] : 0;
 #pragma unroll
     for (int i = 8; i < 12; ++i) st[i] = 0;
-    poseidon_perm(st, tab, true);
+    poseidon_perm(st, tab, true, 4 * hsz < 8 ? 4 * hsz : 8);
     if (hsz > 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[8 + i] = st[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = 8 + (u32)i < 4 * hsz ? v[8 + i] : 0;
-        poseidon_perm(st, tab, false);
+        poseidon_perm(st, tab, false, 4 * hsz - 8);
     }
     if (r_ >= height) return;
 #pragma unroll
@@ -861,7 +870,10 @@ std::string build_one_lane_image(const u64* tab, u64* mt) {
     for (int i = 0; i < TM_S0; ++i) mt[i] = tab[i];                                                       // C0, FC, PC
     for (int r = 0; r < 22; ++r) { mt[TM_S0 + 2 * r] = tab[T_SR + 24 * r]; mt[TM_S0 + 2 * r + 1] = tab[T_SR + 24 * r + 1]; }
     for (int i = 0; i < 220; ++i) mt[TM_DD + i] = tab[T_DD + i];
-    for (int i = 0; i < 4; ++i) mt[TM_K0 + i] = tab[T_K0 + i];
+    for (int i = 0; i < 12; ++i) {                                                                        // a zero word after round 0's S-box: C[i]^7 + C[12 + i]
+        const u64 c = ZK_POSEIDON_C[i], c2 = gl::hmul(c, c), c3 = gl::hmul(c2, c), c7 = gl::hmul(gl::hmul(c3, c3), c), k = ZK_POSEIDON_C[12 + i];
+        mt[TM_K0 + i] = c7 + k >= GL_P || c7 + k < c7 ? c7 + k - GL_P : c7 + k;
+    }
     for (int which = 0; which < MT_N; ++which) {
         u64 coef[144]; int n_out, n_in;
         mfma_coefficients(which, coef, n_out, n_in);
