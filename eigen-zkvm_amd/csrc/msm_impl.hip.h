@@ -752,6 +752,9 @@ static void msm_core(const void* d_bases, const void* d_table, uint64_t table_n,
     // Round 4: sums of 2^24 and more pairs go through the same chunks -- of 2^22 pairs each, so that every chunk takes the LDS-histogram
     // sort (its point indices are chunk-relative, 24 bits) instead of ONE sort with device-scope atomics over all pairs:
     // 2^24 points (2^25 pairs) 48.1 -> see profiles/r04/msm_large.txt.
+    // Round 6: chunks that GROW (2^18, 2^19, ... pairs, so that the first sort, which nothing hides, is short) were measured and are slower:
+    // BN254 2^22 points 8.17-8.28 ms against 7.97-8.08 with four equal chunks, BLS12-381 16.75-16.86 against 16.59-16.68 -- every
+    // accumulation launch walks all 2^19 buckets, and a chunk that leaves 0-4 points per bucket pays the walk for nothing.
     int n_chunks = 1;
     if (!d_table && chunks_env > 1) {
         if (n >= (1ull << 23) && n < (1ull << 24)) n_chunks = std::min(chunks_env, 8);
