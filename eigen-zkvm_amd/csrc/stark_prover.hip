@@ -592,6 +592,37 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
                             f4 = start(P.at("step42ns"), true, false), f5 = start(P.at("step52ns"), true, false);
     std::vector<std::future<ProgramPtr>> fp;
     for (const JVal& seg : P.at("publics_code").arr) fp.push_back(start(seg, false, true));
+    // Round 6 (round-5 verdict, 3b): pre-size the pool.  A proof's large buffers -- the sections, the extensions' workspaces, the trees, the
+    // quotient's and the evaluations' buffers: their sizes follow from map_sectionsN -- are taken from the driver HERE, on a helper thread,
+    // beside the compilers and the constants, and parked in the size-keyed pool.  VRAM that any process handed back is cleared by the driver
+    // when it is allocated again (~30-90 ms per GB: DESIGN.md 3.5): without this the first stark_gen of a process pays it stage by stage
+    // (1.0-1.5 s at 2^24 rows on a box that is not fresh, 4 x the steady state).
+    std::future<void> prewarm;
+    {
+        std::vector<size_t> sizes;
+        const u64 nodes_bytes = S->fr ? 0 : merkle_n_nodes(Next) * 32;                   // GL trees; the scalar-field trees size themselves
+        auto sec = [&](u64 words) { if (words * 8 >= (64u << 20)) sizes.push_back(words * 8); };
+        for (int k : {S_CM2_N, S_CM3_N, S_TMPEXP_N}) sec(S->sN[k] * N);
+        for (int k : {S_CM1_2NS, S_CM2_2NS, S_CM3_2NS}) { sec(S->sN[k] * Next); sec(S->sN[k] * Next); }   // the section and its extension's workspace
+        sec(S->sN[S_CM4_2NS] * Next); sec((u64)S->q_dim * Next); sec(3 * Next); sec(3 * Next);              // cm4, q, f, scratch
+        sec((u64)S->q_dim * Next); sec((u64)S->q_dim * Next);                                              // the quotient's coefficients + workspace
+        if (S->q_deg) { sec((u64)S->q_dim * S->q_deg * Next); sec((u64)S->q_dim * S->q_deg * Next); }     // ... split, + the forward transform's workspace
+        sec(3 * Next); sec(3 * Next);                                                                      // x / (x - xi), x / (x - xi w)
+        for (int k = 0; k < 5; ++k) sec(3 * N);                                                            // the evaluations' tables (LEv, LpEv and their transforms)
+        const int n_trees = (S->sN[S_CM1_N] > 0) + (S->sN[S_CM2_N] > 0) + (S->sN[S_CM3_N] > 0) + 1;        // an empty section shares the setup's zero tree
+        for (int k = 0; k < n_trees && nodes_bytes >= (64u << 20); ++k) sizes.push_back(nodes_bytes);
+        size_t total = 0; for (size_t b : sizes) total += b;
+        const char* pw = getenv("ZK_STARK_PREWARM");
+        if (total >= (1ull << 30) && !(pw && !strcmp(pw, "0"))) {
+            int dev = 0; ZK_HIP(hipGetDevice(&dev));
+            prewarm = std::async(std::launch::async, [sizes, dev] {
+                if (hipSetDevice(dev) != hipSuccess) return;
+                std::vector<void*> held;
+                try { for (size_t b : sizes) held.push_back(pool_alloc(b)); } catch (...) {}       // out of memory: what fits is parked, the proof asks for the rest
+                for (void* q : held) pool_free(q);
+            });
+        }
+    }
     S->const_n.reserve(std::max<u64>(1, nc * N) * 8); S->const_2ns.reserve(std::max<u64>(1, nc * Next) * 8);
     if (nc) {
         h2d_sync(S->const_n.p, const_pols, nc * N * 8);
@@ -626,13 +657,15 @@ zk_stark_setup* setup_new(const char* json, const char* ss_json, const uint64_t*
         for (auto& f : fp) S->public_programs.push_back(take(f));
         if (err) std::rethrow_exception(err);
     }
+    const clk::time_point t_programs = clk::now();
+    if (prewarm.valid()) prewarm.get();                   // the pool holds a proof's large buffers when the setup is handed out
     {   // where the time went (stark_setup.rs:26 `#[time_profiler("stark_setup")]` has one number; a caller deciding whether to keep a
         // setup alive wants the split): JSON parsing, upload + extension + tree of the constants, kernel generation / compilation
-        const clk::time_point t_jit = clk::now();
+        const clk::time_point t_jit = clk::now();         // (includes the wait for the pool's pre-sizing, reported on its own)
         const JitStats j1 = jit_stats();
         std::ostringstream o; o.setf(std::ios::fixed); o.precision(3);
-        o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_parsed, t_jit)
-          << ",\"programs_wait_after_constants_ms\":" << ms(t_tree, t_jit)
+        o << "{\"json_parse_ms\":" << ms(t_begin, t_parsed) << ",\"const_lde_merkle_ms\":" << ms(t_parsed, t_tree) << ",\"programs_ms\":" << ms(t_parsed, t_programs)
+          << ",\"programs_wait_after_constants_ms\":" << ms(t_tree, t_programs) << ",\"pool_prewarm_wait_ms\":" << ms(t_programs, t_jit)
           << ",\"hiprtc_compiled\":" << (j1.compiled - j0.compiled) << ",\"hiprtc_processes\":" << (j1.spawned - j0.spawned) << ",\"code_cache_disk_hits\":" << (j1.disk_hits - j0.disk_hits)
           << ",\"code_cache_mem_hits\":" << (j1.mem_hits - j0.mem_hits) << ",\"total_ms\":" << ms(t_begin, t_jit) << "}";
         S->setup_timing = o.str();
