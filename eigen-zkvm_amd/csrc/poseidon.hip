@@ -13,7 +13,7 @@
 //     (no carries: 12 * 2^6 * 2^32 < 2^42) and ONE reduction instead of 12 modular multiplications;
 //   * round 6: the products by full-width constants -- the pre-sparse matrix P and the two dense products of each lazy block
 //     of partial rounds, 628 of a permutation's terms -- run on the MATRIX pipe as byte-limb i8 GEMMs over the wave's 64 states
-//     (gl_mfma.hip.h): 3.4 k of 17.3 k vector instructions per permutation gone, the S-boxes are what is left;
+//     (gl_mfma.hip.h): 3.9 k of 17.3 k vector instructions per permutation gone (SQ counters: 13.4 k), the S-boxes are what is left;
 //   * the 64-bit round constants and the matrix-pipe tables sit in LDS (49 KB per workgroup of 256 lanes).
 #include "zk_internal.h"
 #include "poseidon_gl_constants.h"
