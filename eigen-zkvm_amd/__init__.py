@@ -36,12 +36,12 @@ EXPORTS = [
     "zk_msm_g1_bls12_381", "zk_msm_g1_bls12_381_dev", "zk_g1_bls12_381_mul_generator_dev",
     "zk_msm_g2_bn254", "zk_msm_g2_bn254_dev", "zk_g2_bn254_mul_generator_dev",
     "zk_msm_g2_bls12_381", "zk_msm_g2_bls12_381_dev", "zk_g2_bls12_381_mul_generator_dev",
-    "zk_bn128_load_constants", "zk_bn128_poseidon", "zk_bn128_poseidon_dev", "zk_bn128_linearhash",
+    "zk_bn128_load_constants", "zk_bn128_poseidon_selfcheck", "zk_bn128_poseidon", "zk_bn128_poseidon_dev", "zk_bn128_linearhash",
     "zk_bn128_merkle_n_nodes", "zk_bn128_merkelize", "zk_bn128_merkelize_dev", "zk_bn128_merkle_root", "zk_bn128_merkle_nodes",
     "zk_bn128_merkle_depth", "zk_bn128_merkle_group_proof", "zk_bn128_merkle_group_proofs", "zk_bn128_merkle_free",
     "zk_bn128_transcript_new", "zk_bn128_transcript_put", "zk_bn128_transcript_get_fields1", "zk_bn128_transcript_get_field",
     "zk_bn128_transcript_get_permutations", "zk_bn128_transcript_free",
-    "zk_bls12381_load_constants", "zk_bls12381_poseidon", "zk_bls12381_poseidon_dev", "zk_bls12381_linearhash",
+    "zk_bls12381_load_constants", "zk_bls12381_poseidon_selfcheck", "zk_bls12381_poseidon", "zk_bls12381_poseidon_dev", "zk_bls12381_linearhash",
     "zk_bls12381_merkle_n_nodes", "zk_bls12381_merkelize", "zk_bls12381_merkelize_dev", "zk_bls12381_merkle_root", "zk_bls12381_merkle_nodes",
     "zk_bls12381_merkle_depth", "zk_bls12381_merkle_group_proof", "zk_bls12381_merkle_group_proofs", "zk_bls12381_merkle_free",
     "zk_bls12381_transcript_new", "zk_bls12381_transcript_put", "zk_bls12381_transcript_get_fields1", "zk_bls12381_transcript_get_field",
@@ -145,6 +145,7 @@ def _load():
         "zk_stark_evals_dev": (C.c_int, [C.POINTER(EvalDesc), C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp]),
         "zk_stark_qsplit_dev": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]),
         "zk_bn128_load_constants": (C.c_int, [C.c_char_p]),
+        "zk_bn128_poseidon_selfcheck": (C.c_int, [C.c_char_p]),
         "zk_bn128_poseidon": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
         "zk_bn128_poseidon_dev": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp]),
         "zk_bn128_linearhash": (C.c_int, [vp, C.c_size_t, vp]),
@@ -164,6 +165,7 @@ def _load():
         "zk_bn128_transcript_get_permutations": (C.c_int, [vp, C.c_uint32, C.c_uint32, vp]),
         "zk_bn128_transcript_free": (C.c_int, [vp]),
         "zk_bls12381_load_constants": (C.c_int, [C.c_char_p]),
+        "zk_bls12381_poseidon_selfcheck": (C.c_int, [C.c_char_p]),
         "zk_bls12381_poseidon": (C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp]),
         "zk_bls12381_poseidon_dev": (C.c_int, [vp, C.c_uint64, C.c_uint32, vp, C.c_uint32, vp, vp]),
         "zk_bls12381_linearhash": (C.c_int, [vp, C.c_size_t, vp]),
@@ -592,6 +594,13 @@ def _fr(name, field):
     if field not in ("bn128", "bls12381"):
         raise ZkError("unknown scalar field " + str(field))
     return getattr(lib(), "zk_%s_%s" % (field, name))
+
+
+def bn128_tables_selfcheck(path=None, field="bn128"):
+    """host-only check of the matrix-pipe tables of `field`'s Poseidon (zk_<field>_poseidon_selfcheck); raises ZkError naming the difference"""
+    import pathlib
+    p = path or str(pathlib.Path(__file__).resolve().parent / "data" / ("poseidon_%s_constants.bin" % field))
+    _check(_fr("poseidon_selfcheck", field)(str(p).encode()))
 
 
 def bn128_init(path=None, field="bn128"):

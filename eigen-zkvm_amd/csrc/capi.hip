@@ -779,6 +779,7 @@ struct FrOps {   // one scalar field: device entry points (frhash.hip) + the hos
     const char* name;
     uint64_t R[4], R2[4], INV;     // modulus, 2^512 mod r, -r^-1 mod 2^64
     void (*load)(const char*);
+    std::string (*selfcheck)(const char*);
     void (*poseidon_dev)(const u64*, uint64_t, uint32_t, const u64*, uint32_t, u64*, hipStream_t);
     uint64_t (*n_nodes)(uint64_t);
     void (*linearhash_rows_dev)(const u64*, uint32_t, uint64_t, u64*, hipStream_t);
@@ -787,11 +788,11 @@ struct FrOps {   // one scalar field: device entry points (frhash.hip) + the hos
 const FrOps FR_BN128 = {"bn128",
     {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
     {1997599621687373223ULL, 6052339484930628067ULL, 10108755138030829701ULL, 150537098327114917ULL}, 0xc2e1f593efffffffULL,
-    bn128_load_constants, bn128_poseidon_dev, bn128_merkle_n_nodes, bn128_linearhash_rows_dev, bn128_merkelize_dev};
+    bn128_load_constants, bn128_tables_selfcheck, bn128_poseidon_dev, bn128_merkle_n_nodes, bn128_linearhash_rows_dev, bn128_merkelize_dev};
 const FrOps FR_BLS12381 = {"bls12381",
     {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL},
     {14526898881837571181ULL, 3129137299524312099ULL, 419701826671360399ULL, 524908885293268753ULL}, 0xfffffffeffffffffULL,
-    bls12381_load_constants, bls12381_poseidon_dev, bls12381_merkle_n_nodes, bls12381_linearhash_rows_dev, bls12381_merkelize_dev};
+    bls12381_load_constants, bls12381_tables_selfcheck, bls12381_poseidon_dev, bls12381_merkle_n_nodes, bls12381_linearhash_rows_dev, bls12381_merkelize_dev};
 
 struct FrMerkle {
     const FrOps* F = nullptr;
@@ -1039,6 +1040,15 @@ struct zk_bls12381_transcript : FrTranscript {};
 extern "C" {
 #define ZK_FRHASH_CAPI(P, OPS)                                                                                          \
     int zk_##P##_load_constants(const char* path) { return guard([&] { ZK_REQUIRE(path, "null path"); OPS.load(path); }); } \
+    int zk_##P##_poseidon_selfcheck(const char* path) {                  /* host arithmetic only: no CallScope, no device */ \
+        try {                                                                                                           \
+            if (!path) { set_error("null path"); return -1; }                                                           \
+            const std::string why = OPS.selfcheck(path);                                                                \
+            if (why.empty()) return 0;                                                                                  \
+            set_error(why);                                                                                             \
+        } catch (const std::exception& e) { set_error(e.what()); }                                                      \
+        return -1;                                                                                                      \
+    }                                                                                                                   \
     int zk_##P##_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out) { \
         return fr_poseidon(OPS, inp, n_in, init_state, n_out, out);                                                     \
     }                                                                                                                   \

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
 
 namespace zk {
 namespace bn128fr {
@@ -40,6 +41,7 @@ namespace bn128fr {
 // the host entry points live in the field namespace; zk_internal.h declares them in zk::.  (The BLS12-381 twin is a translation unit
 // of its own, frhash_bls12381.hip: the two take over a minute each to compile.)
 void bn128_load_constants(const char* path) { bn128fr::bn128_load_constants(path); }
+std::string bn128_tables_selfcheck(const char* path) { return bn128fr::bn128_tables_selfcheck(path); }
 void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st) { bn128fr::bn128_poseidon_dev(d_inp, n, n_in, d_init, n_out, d_out, st); }
 uint64_t bn128_merkle_n_nodes(uint64_t h) { return bn128fr::bn128_merkle_n_nodes(h); }
 void bn128_linearhash_rows_dev(const u64* r, uint32_t w, uint64_t h, u64* d, hipStream_t st) { bn128fr::bn128_linearhash_rows_dev(r, w, h, d, st); }

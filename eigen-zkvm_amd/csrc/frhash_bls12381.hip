@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
 
 namespace zk {
 // ---- BLS12-381 scalar field: poseidon_bls12381_opt.rs (hash() returns state[1], :94-103), linearhash_bls12381.rs,
@@ -22,6 +23,7 @@ namespace bls12381fr {
 }  // namespace bls12381fr
 
 void bls12381_load_constants(const char* path) { bls12381fr::bls12381_load_constants(path); }
+std::string bls12381_tables_selfcheck(const char* path) { return bls12381fr::bls12381_tables_selfcheck(path); }
 void bls12381_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st) { bls12381fr::bls12381_poseidon_dev(d_inp, n, n_in, d_init, n_out, d_out, st); }
 uint64_t bls12381_merkle_n_nodes(uint64_t h) { return bls12381fr::bls12381_merkle_n_nodes(h); }
 void bls12381_linearhash_rows_dev(const u64* r, uint32_t w, uint64_t h, u64* d, hipStream_t st) { bls12381fr::bls12381_linearhash_rows_dev(r, w, h, d, st); }

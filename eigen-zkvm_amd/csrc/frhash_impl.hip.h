@@ -29,7 +29,8 @@ __device__ __forceinline__ fe fe_renorm(const fe& a) { return fe_mul(a, fe_one()
 
 // ---- parameter tables: per t (index t-2) offsets into one array of fe --------------------------------
 struct Params { u32 t, n_rp; const fe* c; const fe* m; const fe* p; const fe* s;
-                const u32* coef; const u32* rebw; u32 b1; };   // cooperative form of the sparse rounds (coop_tables_kernel): [round][limb][lane], [phase][word - 1][limb][lane], first round of phase 1
+                const u32* coef; const u32* rebw; u32 b1;
+                const void* mf_m; const void* mf_p; const u64* mf_k; };   // matrix-pipe form of the dense layers (fr_mfma.hip.h): fragments of M and P, addends [8 layers][t][8]   // cooperative form of the sparse rounds (coop_tables_kernel): [round][limb][lane], [phase][word - 1][limb][lane], first round of phase 1
 __device__ Params g_prm[16];
 
 __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
@@ -156,6 +157,10 @@ template <int B, int E, class F>
 __device__ __forceinline__ void fh_static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); fh_static_for<B + 1, E>(f); }
 }
+#ifndef ZK_FR_MFMA_FROM
+#define ZK_FR_MFMA_FROM 3    // dense layers of t >= this on the matrix pipe (A/B knob; 18 = never)
+#endif
+#include "fr_mfma.hip.h"
 template <int T>
 __device__ __forceinline__ void reg_rotate_in(fe (&a)[T], const fe& last) {
     fh_static_for<0, T - 1>([&](auto I) { a[decltype(I)::value] = a[decltype(I)::value + 1]; });
@@ -196,19 +201,31 @@ static_assert(2 + CO_RENORM * 21 / 20 + 1 <= 8, "running words must stay below 8
 // (reg_tables_to_lds): with one or two waves per SIMD nothing hides a global load, and once the sparse rounds were down to their
 // products the kernels ran at the latency of 60 table reads a round instead of at their instruction count.
 __host__ __device__ constexpr u32 fh_nrp(int t) { constexpr u32 v[16] = {FH_NRP}; return v[t - 2]; }
-template <int T> constexpr u32 REG_TAB_WORDS = (8 * T + fh_nrp(T) + 2 * T * T + (2 * T - 1) * fh_nrp(T)) * NR;
-static_assert(REG_TAB_WORDS<17> * 4 <= 120 * 1024, "the t = 17 tables must leave room in the 160 KiB of LDS");
+template <int T> constexpr bool REG_MF = T >= ZK_FR_MFMA_FROM;             // dense layers on the matrix pipe: M and P are not staged (their fragments pass through LDS an output at a time)
+template <int T> constexpr u32 REG_TAB_WORDS = (8 * T + fh_nrp(T) + (REG_MF<T> ? 0 : 2 * T * T) + (2 * T - 1) * fh_nrp(T)) * NR;
+template <int T> constexpr u32 REG_ABUF_AT = (REG_TAB_WORDS<T> + 3) & ~3u;                                          // 16-byte aligned
+template <int T> constexpr u32 REG_LDS_WORDS = REG_ABUF_AT<T> + (REG_MF<T> ? 2 * T * 64 * 4 : 0);                   // + two outputs' fragments (fr_mfma.hip.h)
+static_assert(REG_LDS_WORDS<17> * 4 <= 128 * 1024, "the t = 17 tables must leave room in the 160 KiB of LDS");
 template <int T>
 __device__ __forceinline__ const fe* reg_tables_to_lds(u32* lds) {            // every thread of the block
     const u32* __restrict__ src = (const u32*)g_prm[T - 2].c;
-    for (u32 k = threadIdx.x; k < REG_TAB_WORDS<T>; k += blockDim.x) lds[k] = src[k];
+    constexpr u32 NC = (8 * T + fh_nrp(T)) * NR, NM = 2 * T * T * NR, NS = (2 * T - 1) * fh_nrp(T) * NR;
+    if constexpr (REG_MF<T>) {
+        for (u32 k = threadIdx.x; k < NC; k += blockDim.x) lds[k] = src[k];
+        for (u32 k = threadIdx.x; k < NS; k += blockDim.x) lds[NC + k] = src[NC + NM + k];
+    } else {
+        for (u32 k = threadIdx.x; k < NC + NM + NS; k += blockDim.x) lds[k] = src[k];
+    }
     __syncthreads();
     return (const fe*)lds;
 }
 template <int T>
 __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restrict__ tab /* LDS */) {
+    constexpr bool MF = REG_MF<T>;
     struct { u32 n_rp; const fe* c; const fe* m; const fe* p; const fe* s; } P;
-    P.n_rp = fh_nrp(T); P.c = tab; P.m = tab + 8 * T + fh_nrp(T); P.p = P.m + T * T; P.s = P.p + T * T;
+    P.n_rp = fh_nrp(T); P.c = tab; P.m = tab + 8 * T + fh_nrp(T); P.p = P.m + T * T; P.s = MF ? P.m : P.p + T * T;
+    const mf_v4i* mf_m = nullptr; const mf_v4i* mf_p = nullptr; const u64* mf_k = nullptr;
+    if constexpr (MF) { mf_m = (const mf_v4i*)g_prm[T - 2].mf_m; mf_p = (const mf_v4i*)g_prm[T - 2].mf_p; mf_k = g_prm[T - 2].mf_k; }
     fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = fe_add(st[decltype(I)::value], P.c[decltype(I)::value]); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 fr = 0; fr < 8; ++fr) {
@@ -219,11 +236,22 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
                 const u32 n = P.n_rp - r < CO_RENORM ? P.n_rp - r : CO_RENORM;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (u32 q = 0; q < n; ++q, ++r) {
+#if ZK_MF_DBG == 4
+                    continue;
+#endif
+#if ZK_MF_DBG != 8
                     pow5(st[0]);
+#endif
                     st[0] = fe_add(st[0], P.c[5 * T + r]);
                     const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
+#if ZK_MF_DBG == 7
+                    const fe s0 = fe_add(st[0], S[0]);
+#else
                     const fe s0 = reg_dot<T, true>(S, 1, st, DOT_SPARSE_REG);
+#endif
+#if ZK_MF_DBG != 6
                     fh_static_for<1, T>([&](auto K) { constexpr int k = decltype(K)::value; st[k] = fe_mul_acc(S[T + k - 1], st[0], st[k]); });
+#endif
                     st[0] = s0;
                 }
                 reg_renorm_tail<T>(st);
@@ -235,10 +263,13 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int i = 0; i < T; ++i) {
             fe x = st[0];
+#if ZK_MF_DBG != 5
             pow5(x);
-            if (has_c) x = fe_add(x, c[i]);
+#endif
+            if (!MF && has_c) x = fe_add(x, c[i]);                          // matrix pipe: the constants' image rides on the layer's addends
             reg_rotate_in<T>(st, x);
         }
+        if constexpr (MF) { mf_dense<T>(st, fr == 3 ? mf_p : mf_m, mf_k + (size_t)fr * T * 8, (mf_v4i*)((u32*)tab + REG_ABUF_AT<T>)); continue; }
         const fe* __restrict__ mat = fr == 3 ? P.p : P.m;
         fe out[T];
         fh_static_for<0, T>([&](auto I) { out[decltype(I)::value] = fe_zero(); });
@@ -248,12 +279,12 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
     }
 }
 // LinearHashBN128::hash_element_array for rows of 5 <= width <= 24 columns: one sponge step of t = NB + 1
+// (waves per SIMD the register budget is held to: what the vector-pipe form of the same t reached -- left alone the matrix-pipe form of t = 5 took 254 registers)
 template <int NB>
-__global__ __launch_bounds__(256) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
-    __shared__ u32 lds[REG_TAB_WORDS<NB + 1>];
+__global__ __launch_bounds__(256, NB <= 4 ? 3 : NB <= 7 ? 2 : 1) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+    __shared__ __attribute__((aligned(16))) u32 lds[REG_LDS_WORDS<NB + 1>];
     const fe* tab = reg_tables_to_lds<NB + 1>(lds);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= height) return;
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = i0 < height ? i0 : height - 1;   // idle lanes shadow the last row: the matrix pipe wants whole waves
     const u64* __restrict__ v = rows + i * width;
     fe st[NB + 1];
     st[0] = fe_zero();
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(256) void bn128_leaf_reg_kernel(const u64* __restri
         st[k + 1] = words_to_fe(v + at, len);
     });
     poseidon_fr_reg<NB + 1>(st, tab);
-    store_raw(st[FH_OUT_IDX], digests + 4 * i);
+    if (i0 < height) store_raw(st[FH_OUT_IDX], digests + 4 * i);
 }
 
 // hash_node (linearhash_bn128.rs:93-103): parent i = Poseidon(16 digests, init 0)
@@ -279,15 +310,14 @@ __global__ __launch_bounds__(64) void bn128_level_kernel(const u64* __restrict__
 
 // the same with the 17 words in registers (poseidon_fr_reg<17>: no scratch arrays behind run-time indices)
 __global__ __launch_bounds__(256) void bn128_level_reg_kernel(const u64* __restrict__ in, u64 n_ops, u64* __restrict__ out) {
-    __shared__ u32 lds[REG_TAB_WORDS<17>];
+    __shared__ __attribute__((aligned(16))) u32 lds[REG_LDS_WORDS<17>];
     const fe* tab = reg_tables_to_lds<17>(lds);
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_ops) return;
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = i0 < n_ops ? i0 : n_ops - 1;
     fe st[17];
     st[0] = fe_zero();
     fh_static_for<0, 16>([&](auto K) { st[decltype(K)::value + 1] = load_raw(in + (i * 16 + decltype(K)::value) * 4); });
     poseidon_fr_reg<17>(st, tab);
-    store_raw(st[FH_OUT_IDX], out + 4 * i);
+    if (i0 < n_ops) store_raw(st[FH_OUT_IDX], out + 4 * i);
 }
 
 // ---- cooperative permutation for the latency-bound places (small tree levels, few wide rows, the transcript): ONE WAVE per
@@ -666,6 +696,37 @@ struct DeviceTables { fe* all = nullptr; bool ready = false; };
 DeviceTables g_tables[64];
 const u32 NRP[16] = {FH_NRP};   // = fh_nrp(t) for t = 2..17
 
+// The matrix-pipe tables of one t (fr_mfma.hip.h): fragments of M and P, and per dense layer the addends carrying the image of the round
+// constants that follow the layer's S-boxes (poseidon_fr_reg's order: layers 0..2 M, 3 P, 4..7 M; none after the last S-boxes).
+void mf_upload(const unsigned char* canon, size_t off_c, size_t off_m, size_t off_p, int T, u32 n_rp, Params& prm) {
+    const MfInt q = mf_modulus();
+    const size_t fb = (size_t)T * T * 1024;
+    std::vector<signed char> frag(2 * fb);
+    std::vector<MfInt> corr(2 * T);
+    std::string err = mf_build_matrix(canon + 32 * off_m, T, frag.data(), corr.data());
+    if (err.empty()) err = mf_build_matrix(canon + 32 * off_p, T, frag.data() + fb, corr.data() + T);
+    if (!err.empty()) throw Error(std::string(FH_NAME " Poseidon, matrix-pipe tables of t = ") + std::to_string(T) + ": " + err);
+    std::vector<u64> K((size_t)8 * T * 8);
+    std::vector<MfInt> cm(T);
+    for (int layer = 0; layer < 8; ++layer) {
+        const bool isp = layer == 3, has_c = layer < 7;
+        const size_t c_at = layer < 3 ? (size_t)(layer + 1) * T : layer == 3 ? (size_t)4 * T : (size_t)5 * T + n_rp + (size_t)(layer - 4) * T;
+        if (has_c) for (int j = 0; j < T; ++j) cm[j] = mf_shlmod(mf_from_bytes(canon + 32 * (off_c + c_at + j)), NR * LB + LB, q);   // internal form, times the step's 2^29
+        const unsigned char* mat = canon + 32 * (isp ? off_p : off_m);
+        for (int o = 0; o < T; ++o) {
+            MfInt add = mf_zero();
+            if (has_c) for (int j = 0; j < T; ++j) add = mf_addmod(add, mf_mulmod(cm[j], mf_from_bytes(mat + 32 * ((size_t)j * T + o)), q), q);
+            mf_addends(add, corr[(isp ? T : 0) + o], &K[((size_t)layer * T + o) * 8]);
+        }
+    }
+    void* d_frag = nullptr; u64* d_k = nullptr;
+    ZK_HIP(hipMalloc(&d_frag, 2 * fb));
+    ZK_HIP(hipMalloc((void**)&d_k, K.size() * 8));
+    ZK_HIP(hipMemcpy(d_frag, frag.data(), 2 * fb, hipMemcpyHostToDevice));
+    ZK_HIP(hipMemcpy(d_k, K.data(), K.size() * 8, hipMemcpyHostToDevice));
+    prm.mf_m = d_frag; prm.mf_p = (const char*)d_frag + fb; prm.mf_k = d_k;
+}
+
 void require_tables() {
     int dev; ZK_HIP(hipGetDevice(&dev));
     ZK_REQUIRE(dev >= 0 && dev < 64 && g_tables[dev].ready, FH_NAME " Poseidon constants not loaded (zk_" FH_NAME "_load_constants)");
@@ -674,10 +735,9 @@ void require_tables() {
 }  // namespace
 
 // file format: tools/gen_poseidon_bn128_constants.py
-void FH_FN(load_constants)(const char* path) {
-    int dev; ZK_HIP(hipGetDevice(&dev));
-    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-    if (g_tables[dev].ready) return;
+namespace {
+struct TabOff { size_t c, m, p, s; u32 t; };
+size_t read_constants(const char* path, std::vector<unsigned char>& canon /* all 32-byte values back to back */, TabOff (&off)[16]) {
     FILE* f = fopen(path, "rb");
     if (!f) throw Error(std::string("cannot open ") + path);
     std::vector<unsigned char> buf;
@@ -688,8 +748,6 @@ void FH_FN(load_constants)(const char* path) {
     ZK_REQUIRE(got == buf.size() && buf.size() >= 8 && !memcmp(buf.data(), "PBN1", 4), "bad Poseidon constants file");
     uint32_t nt; memcpy(&nt, buf.data() + 4, 4);
     ZK_REQUIRE(nt == 16, "bad Poseidon constants file (t range)");
-    std::vector<unsigned char> canon;   // all 32-byte values back to back
-    struct Off { size_t c, m, p, s; u32 t; } off[16];
     size_t pos = 8, count = 0;
     for (int k = 0; k < 16; ++k) {
         ZK_REQUIRE(pos + 12 <= buf.size(), "truncated Poseidon constants file");
@@ -702,6 +760,28 @@ void FH_FN(load_constants)(const char* path) {
         canon.insert(canon.end(), buf.begin() + pos, buf.begin() + pos + 32 * n);
         pos += 32 * n; count += n;
     }
+    return count;
+}
+}
+// host arithmetic only (no device): the matrix-pipe tables of every t against the constants they are built from; "" or what is wrong
+std::string FH_FN(tables_selfcheck)(const char* path) {
+    std::vector<unsigned char> canon; TabOff off[16];
+    read_constants(path, canon, off);
+    for (int k = 0; k < 16; ++k) {
+        if ((int)off[k].t < ZK_FR_MFMA_FROM) continue;
+        for (int which = 0; which < 2; ++which) {
+            const std::string why = mf_selfcheck(canon.data() + 32 * (which ? off[k].p : off[k].m), (int)off[k].t, 977 * k + which);
+            if (!why.empty()) return std::string(FH_NAME " Poseidon, matrix ") + (which ? "P" : "M") + ": " + why;
+        }
+    }
+    return "";
+}
+void FH_FN(load_constants)(const char* path) {
+    int dev; ZK_HIP(hipGetDevice(&dev));
+    ZK_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    if (g_tables[dev].ready) return;
+    std::vector<unsigned char> canon; TabOff off[16];
+    const size_t count = read_constants(path, canon, off);
     DevBuf d_canon; d_canon.reserve(canon.size());
     ZK_HIP(hipMemcpy(d_canon.p, canon.data(), canon.size(), hipMemcpyHostToDevice));
     fe* d_all = nullptr;
@@ -718,7 +798,8 @@ void FH_FN(load_constants)(const char* path) {
         ZK_REQUIRE(co_phase1(NRP[k]) <= CO_XLANES && NRP[k] - co_phase1(NRP[k]) <= CO_XLANES, "too many sparse rounds for the cooperative form");
         u32* coef = d_coop + at; u32* rebw = coef + (size_t)NRP[k] * NR * 64;
         at += ((size_t)NRP[k] + 32) * NR * 64;
-        prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s, coef, rebw, co_phase1(NRP[k])};
+        prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s, coef, rebw, co_phase1(NRP[k]), nullptr, nullptr, nullptr};
+        if ((int)off[k].t >= ZK_FR_MFMA_FROM) mf_upload(canon.data(), off[k].c, off[k].m, off[k].p, (int)off[k].t, NRP[k], prm[k]);
         hipLaunchKernelGGL(coop_tables_kernel, dim3(NRP[k] + 32), dim3(64), 0, nullptr, prm[k], coef, rebw);
         ZK_HIP(hipGetLastError());
     }

@@ -155,12 +155,14 @@ ZK_MSM_FIXED_DECL(g2_bls12_381)
 #undef ZK_MSM_FIXED_DECL
 // ---- BN128-field hashing (poseidon_bn128.hip); digests = 4 raw (Montgomery, R = 2^256) limbs
 void bn128_load_constants(const char* path);
+std::string bn128_tables_selfcheck(const char* path);   // host only: the matrix-pipe tables (fr_mfma.hip.h) against the constants; "" or what is wrong
 void bn128_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st);
 uint64_t bn128_merkle_n_nodes(uint64_t height);
 void bn128_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);
 void bn128_merkelize_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_nodes, hipStream_t st);
 // the same over the BLS12-381 scalar field (verificationHashType "BLS12381")
 void bls12381_load_constants(const char* path);
+std::string bls12381_tables_selfcheck(const char* path);
 void bls12381_poseidon_dev(const u64* d_inp, uint64_t n, uint32_t n_in, const u64* d_init, uint32_t n_out, u64* d_out, hipStream_t st);
 uint64_t bls12381_merkle_n_nodes(uint64_t height);
 void bls12381_linearhash_rows_dev(const u64* d_rows, uint32_t width, uint64_t height, u64* d_digests, hipStream_t st);

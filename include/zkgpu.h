@@ -201,6 +201,10 @@ int zk_g1_bn254_mul_generator_dev(const uint64_t* d_k, uint64_t n, void* d_bases
  * zk_bn128_load_constants reads the Poseidon parameter tables (t = 2..17; data/poseidon_bn128_constants.bin,
  * written by tools/gen_poseidon_bn128_constants.py from poseidon_bn128_constants_opt.rs) once per device.      */
 int zk_bn128_load_constants(const char* path);
+/* Host-only check (no GPU) of the matrix-pipe tables the dense layers of the one-lane kernels run on (csrc/fr_mfma.hip.h): built from
+ * the constants file, emulated the device's way on random and extreme vectors, compared with plain modular arithmetic.  0, or -1 with
+ * zk_last_error() naming the first difference.                                                                                      */
+int zk_bn128_poseidon_selfcheck(const char* path);
 /* Poseidon::hash_ex(inp, init_state, out) (poseidon_bn128_opt.rs:80-86, 98-224): n_in = 1..16 inputs, t = n_in + 1,
  * first n_out (<= t) state words.  Wrong lengths are errors, as the reference bails (:99-105).                   */
 int zk_bn128_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out);
@@ -237,6 +241,7 @@ int zk_bn128_transcript_free(zk_bn128_transcript_t* t);
 typedef struct zk_bls12381_merkle zk_bls12381_merkle_t;
 typedef struct zk_bls12381_transcript zk_bls12381_transcript_t;
 int zk_bls12381_load_constants(const char* path);
+int zk_bls12381_poseidon_selfcheck(const char* path);
 int zk_bls12381_poseidon(const uint64_t* inp, uint32_t n_in, const uint64_t init_state[4], uint32_t n_out, uint64_t* out);
 int zk_bls12381_poseidon_dev(const uint64_t* d_inp, uint64_t n, uint32_t n_in, const uint64_t* d_init_state, uint32_t n_out,
                           uint64_t* d_out, void* stream);

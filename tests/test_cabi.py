@@ -112,3 +112,16 @@ def test_poseidon_matrix_pipe_tables_selfcheck():
     import zkgpu_loader
     zk = zkgpu_loader.load()
     assert zk.lib().zk_gl_poseidon_selfcheck() == 0, zk.lib().zk_last_error().decode()
+
+
+@pytest.mark.parametrize("field", ["bn128", "bls12381"])
+def test_scalar_field_poseidon_matrix_pipe_tables_selfcheck(field):
+    """Round 6: the dense layers (M, P) of the one-lane scalar-field Poseidon kernels run on the matrix pipe from digit tables built on the
+    host when the constants are loaded (csrc/fr_mfma.hip.h).  zk_<field>_poseidon_selfcheck needs no GPU: for every t = 3..17 and both
+    matrices it builds the tables from the constants file and replays the device's arithmetic in host integers -- i32 columns of
+    (byte - 128) x digit, eight biased 64-bit words, the Montgomery step -- on random and extreme vectors (2^256 - 1, 0, 0x80..80, 0x7F..7F);
+    every output must be congruent to sum_j c x_j + addend, below 2r, with every intermediate inside the range the device code assumes."""
+    import zkgpu_loader
+    zk = zkgpu_loader.load()
+    zk.bn128_tables_selfcheck(field=field)
+

@@ -10,7 +10,7 @@
 #   sq | icache              the SQ instruction-mix counters / the instruction-cache counters alone
 #   small                    the three circuits of a recursion task under the profiler: busy / idle split and launch timelines
 #   prof NAME cmd...         rocprofv3 --kernel-trace --stats of any command -> gpurun_out/prof_NAME/, top of the kernel statistics printed
-#   ab trees|ntt|msm|prove LIB...   parity tests, then alternating timings of library variants (eigen-zkvm_amd/variants/libzkgpu_LIB.so built by
+#   ab trees|ntt|msm|prove|fr LIB...   parity tests, then alternating timings of library variants (eigen-zkvm_amd/variants/libzkgpu_LIB.so built by
 #                            tools/build_variant.sh; "shipped" = the library; LIB@ENV=VAL runs a variant under an environment switch)
 #   fuzz [seed]              a fuzz campaign (profiles/rNN/fuzz.txt)
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -71,7 +71,8 @@ do_ab() {
     ntt)   par="tests/test_gpu_parity.py -k ntt or lde or fft or interpolate or root"; run() { for sh in "24 1" "20 36" "16 12"; do timeout 300 python tools/ntt_time.py $sh; done; timeout 300 python tools/lde_time.py 24 19 36; } ;;
     msm)   par="tests/test_gpu_msm.py"; run() { for c in "bn254 g1 22" "bls12_381 g1 22" "bn254 g1 18"; do timeout 300 python tools/msm_bench.py $c 2>&1 | tail -2; done; timeout 300 python tools/groth16_bench.py BLS12381 18 2>&1 | tail -1; } ;;
     prove) par="tests/test_gpu_stark.py"; run() { timeout 600 python tools/prove_bench.py --nbits 20 24 --reps 3 2>&1 | cut -c1-260; timeout 200 python tools/small_proof_probe.py r1 20 2>&1 | tail -1; } ;;
-    *) echo "ab: trees|ntt|msm|prove"; exit 2 ;;
+    fr)    par="tests/test_gpu_bn128.py"; run() { for sh in "bn128 24 10 3" "bn128 22 5 3" "bn128 22 10 3" "bn128 22 13 3" "bn128 20 19 5" "bn128 20 24 5" "bn128 20 36 5" "bn128 20 48 5" "bn128 22 48 3" "bls12381 22 10 3" "bls12381 20 48 5"; do timeout 300 python tools/fr_merkle_time.py $sh 2>&1 | cut -c1-80; done; timeout 300 python tools/final_stark_probe.py 4 2>&1 | tail -1 | cut -c1-200; } ;;
+    *) echo "ab: trees|ntt|msm|prove|fr"; exit 2 ;;
   esac
   for a in "$@"; do sel $a; echo "== parity $a" >> $out; env $e timeout 900 python -m pytest $par -m gpu -x -q 2>&1 | tail -2 >> $out; done
   for r in 1 2; do for a in "$@"; do sel $a; echo "== $a (run $r)" >> $out; env $e bash -c "$(declare -f run); run" >> $out 2>&1; done; done
