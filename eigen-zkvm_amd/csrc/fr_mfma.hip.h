@@ -118,15 +118,22 @@ inline void mf_addends(const MfInt& add /* < r: 2^29 (M c) in the internal form,
 // What the device computes for output o from a table, step by step in host integers (the i32 columns, the eight biased words, the ten
 // limbs, the Montgomery step): x[j] any integers < 2^256.  With mf_selfcheck() and the known answers on the device this pins the form on
 // both sides.  ok = false if a column or a word leaves the range the device code assumes.
-inline MfInt mf_emulate(const signed char* frag, const u64* K8, int T, int o, const MfInt* x, bool& ok) {
+inline u64 mf_neg_inverse() {                                             // -r^-1 mod 2^64
+    const u64 r0 = mf_modulus().w[0];
+    u64 inv = 1;
+    for (int i = 0; i < 7; ++i) inv *= 2 - r0 * inv;
+    return (u64)0 - inv;
+}
+inline MfInt mf_emulate_gen(const signed char* const* frags /* per input word: its fragment for this output */, int n_in, const u64* K8, const MfInt* x,
+                            int shift /* the Montgomery step: 29 or 32 */, bool& ok) {
     long long col[32];
     for (int d = 0; d < 32; ++d) {
         const int H = d >> 4, idx = d & 15, m = (idx & 3) + 8 * (idx >> 2) + 4 * H;
         long long c = 0;
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < n_in; ++j)
             for (int b = 0; b < 32; ++b) {
                 const int h = b >> 4, i = b & 15;
-                const int a = frag[(((size_t)o * T + j) * 64 + (32 * h + m)) * 16 + i];
+                const int a = frags[j][(size_t)(32 * h + m) * 16 + i];
                 const int xb = (int)(signed char)((unsigned char)(x[j].w[b >> 3] >> (8 * (b & 7))) ^ 0x80);
                 c += (long long)a * xb;
             }
@@ -142,14 +149,19 @@ inline MfInt mf_emulate(const signed char* frag, const u64* K8, int T, int o, co
         MfInt ww = mf_zero(); ww.w[0] = (u64)w;
         V = mf_add(V, ww);
     }
-    const u32 m = ((u32)V.w[0] * QINV29) & LMASK;
+    const u64 mask = (1ull << shift) - 1, m = (V.w[0] * mf_neg_inverse()) & mask;
     MfInt mr = mf_zero();
     const MfInt q = mf_modulus();
-    for (int bit = 28; bit >= 0; --bit) { mr = mf_add(mr, mr); if ((m >> bit) & 1) mr = mf_add(mr, q); }
+    for (int bit = shift - 1; bit >= 0; --bit) { mr = mf_add(mr, mr); if ((m >> bit) & 1) mr = mf_add(mr, q); }
     V = mf_add(V, mr);
-    if (V.w[0] & LMASK) ok = false;
-    for (int i = 0; i < 5; ++i) V.w[i] = (V.w[i] >> LB) | (i + 1 < 5 ? V.w[i + 1] << (64 - LB) : 0);
+    if (V.w[0] & mask) ok = false;
+    for (int i = 0; i < 5; ++i) V.w[i] = (V.w[i] >> shift) | (i + 1 < 5 ? V.w[i + 1] << (64 - shift) : 0);
     return V;
+}
+inline MfInt mf_emulate(const signed char* frag, const u64* K8, int T, int o, const MfInt* x, bool& ok) {
+    std::vector<const signed char*> f(T);
+    for (int j = 0; j < T; ++j) f[j] = frag + ((size_t)o * T + j) * 1024;
+    return mf_emulate_gen(f.data(), T, K8, x, LB, ok);
 }
 // Host-only check of the tables of one matrix (no GPU): built from `mat`, every output of random and extreme vectors, emulated the
 // device's way, must be congruent to sum_j c x_j + A for a random addend A, below 2r, with every intermediate in range.
@@ -179,6 +191,105 @@ inline std::string mf_selfcheck(const unsigned char* mat, int T, u64 seed) {
             if (!mf_less(R, mf_add(q, q))) return "t = " + std::to_string(T) + ", output " + std::to_string(o) + ": result not below 2r";
             const MfInt Rr = reduce(R);
             for (int i = 0; i < 5; ++i) if (Rr.w[i] != want.w[i]) return "t = " + std::to_string(T) + ", output " + std::to_string(o) + ": not congruent to the product";
+        }
+    }
+    return "";
+}
+
+// ---- the sparse rounds (poseidon_bn128_opt.rs:133-188) ------------------------------------------------------------------------------
+// Round r: y = x_0^5 + c_r;  x_0' = sum_j S_r[j] x_j (x_0 = y);  x_k' = x_k + S'_r[k] y.  Every one of these is a product of the matrix
+// pipe's kind: the row against all t words, column k against (x_0^5, x_k) with the coefficient 1 for x_k -- so the running words never
+// leave the byte form the B operands want, come back below 2^241 + r every round (no renormalisation schedule), and the vector pipe is
+// left with the S-box and ~80 instructions per word and round.  Montgomery step 2^32 here (the outputs are wanted as eight 32-bit words).
+// Per round, contiguous: 2t - 1 fragments [row j = 0..t-1 | column k = 1..t-1], then t x 8 addends (c_r's images and the biases).
+constexpr int MF_SP_SHIFT = 32;
+inline size_t mf_sparse_round_bytes(int T) { return (size_t)(2 * T - 1) * 1024 + (size_t)T * 64; }
+// one fragment from a coefficient already multiplied by the step's power of two; adds to the output's corr and column sums
+inline bool mf_fragment(MfInt v, const MfInt& q, signed char* frag, MfInt& corr, long long* colabs) {
+    signed char dig[32 * 32];
+    for (int b = 0; b < 32; ++b) {
+        if (!mf_digits(v, q, dig + b * 32)) return false;
+        for (int d = 0; d < 32; ++d) colabs[d] += dig[b * 32 + d] < 0 ? -dig[b * 32 + d] : dig[b * 32 + d];
+        corr = mf_addmod(corr, mf_shlmod(v, 7, q), q);
+        v = mf_shlmod(v, 8, q);
+    }
+    for (int l = 0; l < 64; ++l) {
+        const int m = l & 31, H = (m >> 2) & 1, idx = (m & 3) + 4 * (m >> 3), d = 16 * H + idx, h = l >> 5;
+        for (int i = 0; i < 16; ++i) frag[(size_t)l * 16 + i] = dig[(16 * h + i) * 32 + d];
+    }
+    return true;
+}
+// S: n_rp x (2t - 1) canonical 32-byte integers (row t | column t - 1), c: the n_rp round constants; out: n_rp blocks of
+// mf_sparse_round_bytes(t), ident: the fragment of the coefficient 1.  "" or what is wrong.
+inline std::string mf_build_sparse(const unsigned char* S, const unsigned char* c, int T, int n_rp, unsigned char* out, signed char* ident) {
+    const MfInt q = mf_modulus();
+    MfInt one = mf_zero(); one.w[0] = 1;
+    MfInt corr_i = mf_zero(); long long abs_i[32] = {0};
+    if (!mf_fragment(mf_shlmod(one, MF_SP_SHIFT, q), q, ident, corr_i, abs_i)) return "the unit does not fit 32 balanced digits";
+    const size_t rb = mf_sparse_round_bytes(T);
+    for (int r = 0; r < n_rp; ++r) {
+        unsigned char* blk = out + rb * r;
+        u64* K = reinterpret_cast<u64*>(blk + (size_t)(2 * T - 1) * 1024);
+        const unsigned char* Sr = S + 32 * (size_t)(2 * T - 1) * r;
+        const MfInt cr = mf_shlmod(mf_from_bytes(c + 32 * (size_t)r), NR * LB + MF_SP_SHIFT, q);   // c_r in the internal form, times the step's 2^32
+        {   // the row
+            MfInt corr = mf_zero(); long long ab[32] = {0};
+            for (int j = 0; j < T; ++j)
+                if (!mf_fragment(mf_shlmod(mf_from_bytes(Sr + 32 * j), MF_SP_SHIFT, q), q, (signed char*)blk + (size_t)j * 1024, corr, ab)) return "a constant does not fit 32 balanced digits";
+            for (int d = 0; d < 32; ++d) if (128 * ab[d] >= (1ll << 23) - (1ll << 15)) return "a digit column could leave the range of the recombination";
+            mf_addends(mf_mulmod(cr, mf_from_bytes(Sr), q), corr, K);
+        }
+        for (int k = 1; k < T; ++k) {
+            MfInt corr = corr_i; long long ab[32];
+            for (int d = 0; d < 32; ++d) ab[d] = abs_i[d];
+            const MfInt sk = mf_from_bytes(Sr + 32 * (size_t)(T + k - 1));
+            if (!mf_fragment(mf_shlmod(sk, MF_SP_SHIFT, q), q, (signed char*)blk + (size_t)(T + k - 1) * 1024, corr, ab)) return "a constant does not fit 32 balanced digits";
+            for (int d = 0; d < 32; ++d) if (128 * ab[d] >= (1ll << 23) - (1ll << 15)) return "a digit column could leave the range of the recombination";
+            mf_addends(mf_mulmod(cr, sk, q), corr, K + 8 * k);
+        }
+    }
+    return "";
+}
+// Host-only check of the sparse rounds' tables: a few rounds replayed the device's way on random and extreme words against plain arithmetic.
+inline std::string mf_selfcheck_sparse(const unsigned char* S, const unsigned char* c, int T, int n_rp, u64 seed) {
+    const MfInt q = mf_modulus();
+    const size_t rb = mf_sparse_round_bytes(T);
+    std::vector<unsigned char> tab(rb * n_rp);
+    std::vector<signed char> ident(1024);
+    const std::string err = mf_build_sparse(S, c, T, n_rp, tab.data(), ident.data());
+    if (!err.empty()) return err;
+    auto rnd = [&]() { seed += 0x9E3779B97F4A7C15ull; u64 z = seed; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto reduce = [&](MfInt v) { while (!mf_less(v, q)) v = mf_sub(v, q); return v; };
+    std::vector<MfInt> x(T);
+    const int rounds[4] = {0, 1, n_rp / 2, n_rp - 1};
+    for (int t4 = 0; t4 < 4; ++t4) {
+        const int r = rounds[t4];
+        for (int j = 0; j < T; ++j) { x[j] = mf_zero(); for (int i = 0; i < 4; ++i) x[j].w[i] = t4 == 0 ? ~0ull : t4 == 1 ? 0x8080808080808080ull >> (j & 1) : rnd(); }
+        const unsigned char* blk = tab.data() + rb * r;
+        const u64* K = reinterpret_cast<const u64*>(blk + (size_t)(2 * T - 1) * 1024);
+        const unsigned char* Sr = S + 32 * (size_t)(2 * T - 1) * r;
+        const MfInt cr = mf_shlmod(mf_from_bytes(c + 32 * (size_t)r), NR * LB, q);                 // internal form
+        const MfInt y = mf_addmod(reduce(x[0]), cr, q);                                             // x[0] plays x_0^5
+        for (int o = 0; o < T; ++o) {
+            bool ok = true;
+            MfInt R, want;
+            if (o == 0) {
+                std::vector<const signed char*> f(T);
+                for (int j = 0; j < T; ++j) f[j] = (const signed char*)blk + (size_t)j * 1024;
+                R = mf_emulate_gen(f.data(), T, K, x.data(), MF_SP_SHIFT, ok);
+                want = mf_mulmod(y, mf_from_bytes(Sr), q);
+                for (int j = 1; j < T; ++j) want = mf_addmod(want, mf_mulmod(reduce(x[j]), mf_from_bytes(Sr + 32 * j), q), q);
+            } else {
+                const signed char* f[2] = {(const signed char*)blk + (size_t)(T + o - 1) * 1024, ident.data()};
+                const MfInt xx[2] = {x[0], x[o]};
+                R = mf_emulate_gen(f, 2, K + 8 * o, xx, MF_SP_SHIFT, ok);
+                want = mf_addmod(reduce(x[o]), mf_mulmod(y, mf_from_bytes(Sr + 32 * (size_t)(T + o - 1)), q), q);
+            }
+            const std::string at = "sparse round " + std::to_string(r) + " of t = " + std::to_string(T) + ", word " + std::to_string(o);
+            if (!ok) return at + ": an intermediate leaves its range";
+            if (R.w[4] || (R.w[3] >> 63) || !mf_less(R, mf_add(q, q))) return at + ": result not below 2r";
+            const MfInt Rr = reduce(R);
+            for (int i = 0; i < 5; ++i) if (Rr.w[i] != want.w[i]) return at + ": not congruent to the round's arithmetic";
         }
     }
     return "";
@@ -304,4 +415,142 @@ __device__ __forceinline__ void mf_dense(fe (&st)[T], const mf_v4i* __restrict__
 #endif
     });
     __syncthreads();                                                       // the next layer's first stash must not overtake this layer's last reads
+}
+
+// ---- device: the sparse rounds -------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr u32 mf_r32(int i) {                          // the modulus in 32-bit words
+    u64 acc = 0;
+    for (int k = 0; k < NR; ++k) {
+        const int bit = LB * k - 32 * i;
+        if (bit >= 0 && bit < 32) acc |= (u64)Q29(k) << bit;
+        else if (bit < 0 && bit > -LB) acc |= (u64)Q29(k) >> (-bit);
+    }
+    return (u32)acc;
+}
+__host__ __device__ constexpr u32 mf_rinv32() {                            // -r^-1 mod 2^32
+    u32 inv = 1;
+    for (int i = 0; i < 6; ++i) inv *= 2 - mf_r32(0) * inv;
+    return 0u - inv;
+}
+// eight words of weight 2^(32 q), each < 2^49, holding 2^32 * (the output) -> the output in eight 32-bit words, < 2^242 + r
+__device__ __forceinline__ void mf_reduce_words(const u64 (&W)[8], u32 (&out)[8]) {
+    u32 v[9];
+    u64 acc = W[0];
+    v[0] = (u32)acc;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { acc = W[q] + (acc >> 32); v[q] = (u32)acc; }
+    v[8] = (u32)(acc >> 32);
+    const u32 m = v[0] * mf_rinv32();
+    u64 t = (u64)m * mf_r32(0) + v[0];                                     // low word zero
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        t = (u64)m * mf_r32(q) + ((u64)v[q] + (t >> 32));                  // <= (2^32 - 1)^2 + 2 (2^32 - 1)
+        out[q - 1] = (u32)t;
+    }
+    out[7] = v[8] + (u32)(t >> 32);
+}
+__device__ __forceinline__ fe mf_words_to_fe(const u32 (&w)[8]) {           // value < 2^256 -> limbs, normalised
+    fe x;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int bit = LB * k, wi = bit >> 5, s = bit & 31;
+        u32 v = w[wi] >> s;
+        if (s > 32 - LB && wi + 1 < 8) v |= w[wi + 1] << (32 - s);
+        x.l[k] = v & LMASK;
+    }
+    return x;
+}
+__device__ __forceinline__ void mf_b_from_words(u32 (&w)[8], mf_v4i& b0, mf_v4i& b1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] ^= 0x80808080u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mf_swap32(w[i], w[4 + i]);
+    b0 = mf_v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    b1 = mf_v4i{(int)w[4], (int)w[5], (int)w[6], (int)w[7]};
+}
+__device__ __forceinline__ fe mf_fe_from_b(const mf_v4i& b0, const mf_v4i& b1) {   // the lane's own word back out of its two operands
+    u32 w[8] = {(u32)b0[0], (u32)b0[1], (u32)b0[2], (u32)b0[3], (u32)b1[0], (u32)b1[1], (u32)b1[2], (u32)b1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mf_swap32(w[i], w[4 + i]);                 // the swap is its own inverse
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] ^= 0x80808080u;
+    return mf_words_to_fe(w);
+}
+// two tiles' accumulators of one output -> the lane's own eight words of it
+__device__ __forceinline__ void mf_output_words(const mf_v16i& acc0, const mf_v16i& acc1, const u64* __restrict__ Ko, int one, int s16, u32 (&out)[8]) {
+    u64 Wa[4], Wb[4], W[8];
+    mf_words(acc0, Ko, one, s16, Wa);
+    mf_words(acc1, Ko, one, s16, Wb);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u32 a0 = (u32)Wa[g], a1 = (u32)(Wa[g] >> 32), b0 = (u32)Wb[g], b1 = (u32)(Wb[g] >> 32);
+        mf_swap32(a0, b0); mf_swap32(a1, b1);
+        W[g] = ((u64)a1 << 32) | a0; W[4 + g] = ((u64)b1 << 32) | b0;
+    }
+    mf_reduce_words(W, out);
+}
+// All n_rp sparse rounds on st (words < 2^256 in; < 2^242 + r out, limbs normalised).  tab: the rounds' blocks (mf_build_sparse, global
+// memory), ident: the unit's fragment, abuf: two blocks' worth of LDS.  The whole block of 256 threads must be here.
+template <int T>
+__device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict__ tab, const mf_v4i* __restrict__ ident, mf_v4i* abuf, u32 n_rp) {
+    constexpr int PER = (2 * T - 1) * 64 + 4 * T, NLD = (PER + 255) / 256;   // a round's block in 16-byte words
+    const int lane = threadIdx.x & 63, H = lane >> 5;
+    mf_v4i pf[NLD];
+    auto fetch = [&](u32 r) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int e = threadIdx.x + 256 * k; if (NLD * 256 == PER || e < PER) pf[k] = tab[(size_t)r * PER + e]; }
+    };
+    auto stash = [&](u32 r) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int e = threadIdx.x + 256 * k; if (NLD * 256 == PER || e < PER) abuf[(r & 1) * PER + e] = pf[k]; }
+    };
+    fetch(0);
+    const mf_v4i aI = ident[lane];
+    mf_v4i B0[T], B1[T];                                                   // [0] unused: word 0 goes through the S-box in limbs
+    fh_static_for<1, T>([&](auto J) { constexpr int j = decltype(J)::value; mf_make_b(st[j], B0[j], B1[j]); });
+    fe s0 = st[0];
+    stash(0);
+    __syncthreads();
+    int one = 1, s16 = 65536;
+    asm volatile("" : "+v"(one), "+v"(s16));
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 r = 0; r < n_rp; ++r) {
+        if (r + 1 < n_rp) fetch(r + 1);
+        pow5(s0);
+        mf_v4i P0, P1;
+        mf_make_b(s0, P0, P1);
+        const mf_v4i* __restrict__ fr = abuf + (r & 1) * PER + lane;
+        const u64* __restrict__ Kr = reinterpret_cast<const u64*>(abuf + (r & 1) * PER + (2 * T - 1) * 64) + 4 * H;
+        {   // the row: every word
+            mf_v16i acc0 = {}, acc1 = {};
+            const mf_v4i a0 = fr[0];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P1, acc1, 0, 0, 0);
+            fh_static_for<1, T>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const mf_v4i a = fr[j * 64];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], acc1, 0, 0, 0);
+            });
+            u32 w[8];
+            mf_output_words(acc0, acc1, Kr, one, s16, w);
+            s0 = mf_words_to_fe(w);
+        }
+        fh_static_for<1, T>([&](auto KK) {   // column k: S'[k] x_0^5 + x_k
+            constexpr int k = decltype(KK)::value;
+            mf_v16i acc0 = {}, acc1 = {};
+            const mf_v4i a = fr[(T + k - 1) * 64];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B0[k], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B1[k], acc1, 0, 0, 0);
+            u32 w[8];
+            mf_output_words(acc0, acc1, Kr + 8 * k, one, s16, w);
+            mf_b_from_words(w, B0[k], B1[k]);
+        });
+        if (r + 1 < n_rp) stash(r + 1);
+        __syncthreads();
+    }
+    st[0] = s0;
+    fh_static_for<1, T>([&](auto J) { constexpr int j = decltype(J)::value; st[j] = mf_fe_from_b(B0[j], B1[j]); });
 }

@@ -30,7 +30,8 @@ __device__ __forceinline__ fe fe_renorm(const fe& a) { return fe_mul(a, fe_one()
 // ---- parameter tables: per t (index t-2) offsets into one array of fe --------------------------------
 struct Params { u32 t, n_rp; const fe* c; const fe* m; const fe* p; const fe* s;
                 const u32* coef; const u32* rebw; u32 b1;
-                const void* mf_m; const void* mf_p; const u64* mf_k; };   // matrix-pipe form of the dense layers (fr_mfma.hip.h): fragments of M and P, addends [8 layers][t][8]   // cooperative form of the sparse rounds (coop_tables_kernel): [round][limb][lane], [phase][word - 1][limb][lane], first round of phase 1
+                const void* mf_m; const void* mf_p; const u64* mf_k;           // matrix-pipe form of the dense layers (fr_mfma.hip.h): fragments of M and P, addends [8 layers][t][8]
+                const void* mf_s; const void* mf_i; };                          // ... and of the sparse rounds: n_rp blocks of mf_sparse_round_bytes(t), the unit's fragment   // cooperative form of the sparse rounds (coop_tables_kernel): [round][limb][lane], [phase][word - 1][limb][lane], first round of phase 1
 __device__ Params g_prm[16];
 
 __device__ __forceinline__ void pow5(fe& x) { const fe x2 = fe_sqr(x), x4 = fe_sqr(x2); x = fe_mul(x4, x); }  // poseidon_bn128_opt.rs:88-94
@@ -202,9 +203,9 @@ static_assert(2 + CO_RENORM * 21 / 20 + 1 <= 8, "running words must stay below 8
 // products the kernels ran at the latency of 60 table reads a round instead of at their instruction count.
 __host__ __device__ constexpr u32 fh_nrp(int t) { constexpr u32 v[16] = {FH_NRP}; return v[t - 2]; }
 template <int T> constexpr bool REG_MF = T >= ZK_FR_MFMA_FROM;             // dense layers on the matrix pipe: M and P are not staged (their fragments pass through LDS an output at a time)
-template <int T> constexpr u32 REG_TAB_WORDS = (8 * T + fh_nrp(T) + (REG_MF<T> ? 0 : 2 * T * T) + (2 * T - 1) * fh_nrp(T)) * NR;
+template <int T> constexpr u32 REG_TAB_WORDS = (8 * T + fh_nrp(T) + (REG_MF<T> ? 0 : 2 * T * T + (2 * T - 1) * fh_nrp(T))) * NR;   // matrix pipe: the round constants alone
 template <int T> constexpr u32 REG_ABUF_AT = (REG_TAB_WORDS<T> + 3) & ~3u;                                          // 16-byte aligned
-template <int T> constexpr u32 REG_LDS_WORDS = REG_ABUF_AT<T> + (REG_MF<T> ? 2 * T * 64 * 4 : 0);                   // + two outputs' fragments (fr_mfma.hip.h)
+template <int T> constexpr u32 REG_LDS_WORDS = REG_ABUF_AT<T> + (REG_MF<T> ? 2 * ((2 * T - 1) * 64 + 4 * T) * 4 : 0);   // + two sparse rounds' blocks (fr_mfma.hip.h; a dense output's t fragments fit)
 static_assert(REG_LDS_WORDS<17> * 4 <= 128 * 1024, "the t = 17 tables must leave room in the 160 KiB of LDS");
 template <int T>
 __device__ __forceinline__ const fe* reg_tables_to_lds(u32* lds) {            // every thread of the block
@@ -212,7 +213,6 @@ __device__ __forceinline__ const fe* reg_tables_to_lds(u32* lds) {            //
     constexpr u32 NC = (8 * T + fh_nrp(T)) * NR, NM = 2 * T * T * NR, NS = (2 * T - 1) * fh_nrp(T) * NR;
     if constexpr (REG_MF<T>) {
         for (u32 k = threadIdx.x; k < NC; k += blockDim.x) lds[k] = src[k];
-        for (u32 k = threadIdx.x; k < NS; k += blockDim.x) lds[NC + k] = src[NC + NM + k];
     } else {
         for (u32 k = threadIdx.x; k < NC + NM + NS; k += blockDim.x) lds[k] = src[k];
     }
@@ -226,10 +226,12 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
     P.n_rp = fh_nrp(T); P.c = tab; P.m = tab + 8 * T + fh_nrp(T); P.p = P.m + T * T; P.s = MF ? P.m : P.p + T * T;
     const mf_v4i* mf_m = nullptr; const mf_v4i* mf_p = nullptr; const u64* mf_k = nullptr;
     if constexpr (MF) { mf_m = (const mf_v4i*)g_prm[T - 2].mf_m; mf_p = (const mf_v4i*)g_prm[T - 2].mf_p; mf_k = g_prm[T - 2].mf_k; }
+    mf_v4i* const abuf = (mf_v4i*)((u32*)tab + REG_ABUF_AT<T>);
     fh_static_for<0, T>([&](auto I) { st[decltype(I)::value] = fe_add(st[decltype(I)::value], P.c[decltype(I)::value]); });
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 fr = 0; fr < 8; ++fr) {
-        if (fr == 4) {
+        if (MF && fr == 4) mf_sparse<T>(st, (const mf_v4i*)g_prm[T - 2].mf_s, (const mf_v4i*)g_prm[T - 2].mf_i, abuf, P.n_rp);
+        if (!MF && fr == 4) {
             reg_renorm_tail<T>(st);
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (u32 r = 0; r < P.n_rp;) {
@@ -269,7 +271,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
             if (!MF && has_c) x = fe_add(x, c[i]);                          // matrix pipe: the constants' image rides on the layer's addends
             reg_rotate_in<T>(st, x);
         }
-        if constexpr (MF) { mf_dense<T>(st, fr == 3 ? mf_p : mf_m, mf_k + (size_t)fr * T * 8, (mf_v4i*)((u32*)tab + REG_ABUF_AT<T>)); continue; }
+        if constexpr (MF) { mf_dense<T>(st, fr == 3 ? mf_p : mf_m, mf_k + (size_t)fr * T * 8, abuf); continue; }
         const fe* __restrict__ mat = fr == 3 ? P.p : P.m;
         fe out[T];
         fh_static_for<0, T>([&](auto I) { out[decltype(I)::value] = fe_zero(); });
@@ -698,7 +700,7 @@ const u32 NRP[16] = {FH_NRP};   // = fh_nrp(t) for t = 2..17
 
 // The matrix-pipe tables of one t (fr_mfma.hip.h): fragments of M and P, and per dense layer the addends carrying the image of the round
 // constants that follow the layer's S-boxes (poseidon_fr_reg's order: layers 0..2 M, 3 P, 4..7 M; none after the last S-boxes).
-void mf_upload(const unsigned char* canon, size_t off_c, size_t off_m, size_t off_p, int T, u32 n_rp, Params& prm) {
+void mf_upload(const unsigned char* canon, size_t off_c, size_t off_m, size_t off_p, size_t off_s, int T, u32 n_rp, Params& prm) {
     const MfInt q = mf_modulus();
     const size_t fb = (size_t)T * T * 1024;
     std::vector<signed char> frag(2 * fb);
@@ -719,6 +721,14 @@ void mf_upload(const unsigned char* canon, size_t off_c, size_t off_m, size_t of
             mf_addends(add, corr[(isp ? T : 0) + o], &K[((size_t)layer * T + o) * 8]);
         }
     }
+    const size_t sb = mf_sparse_round_bytes(T) * n_rp;
+    std::vector<unsigned char> sp(sb + 1024);
+    err = mf_build_sparse(canon + 32 * off_s, canon + 32 * (off_c + (size_t)5 * T), T, (int)n_rp, sp.data(), (signed char*)sp.data() + sb);
+    if (!err.empty()) throw Error(std::string(FH_NAME " Poseidon, matrix-pipe tables of t = ") + std::to_string(T) + ": " + err);
+    void* d_sp = nullptr;
+    ZK_HIP(hipMalloc(&d_sp, sp.size()));
+    ZK_HIP(hipMemcpy(d_sp, sp.data(), sp.size(), hipMemcpyHostToDevice));
+    prm.mf_s = d_sp; prm.mf_i = (const char*)d_sp + sb;
     void* d_frag = nullptr; u64* d_k = nullptr;
     ZK_HIP(hipMalloc(&d_frag, 2 * fb));
     ZK_HIP(hipMalloc((void**)&d_k, K.size() * 8));
@@ -773,6 +783,8 @@ std::string FH_FN(tables_selfcheck)(const char* path) {
             const std::string why = mf_selfcheck(canon.data() + 32 * (which ? off[k].p : off[k].m), (int)off[k].t, 977 * k + which);
             if (!why.empty()) return std::string(FH_NAME " Poseidon, matrix ") + (which ? "P" : "M") + ": " + why;
         }
+        const std::string why = mf_selfcheck_sparse(canon.data() + 32 * off[k].s, canon.data() + 32 * (off[k].c + (size_t)5 * off[k].t), (int)off[k].t, (int)NRP[k], 31 * k);
+        if (!why.empty()) return std::string(FH_NAME " Poseidon: ") + why;
     }
     return "";
 }
@@ -798,8 +810,8 @@ void FH_FN(load_constants)(const char* path) {
         ZK_REQUIRE(co_phase1(NRP[k]) <= CO_XLANES && NRP[k] - co_phase1(NRP[k]) <= CO_XLANES, "too many sparse rounds for the cooperative form");
         u32* coef = d_coop + at; u32* rebw = coef + (size_t)NRP[k] * NR * 64;
         at += ((size_t)NRP[k] + 32) * NR * 64;
-        prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s, coef, rebw, co_phase1(NRP[k]), nullptr, nullptr, nullptr};
-        if ((int)off[k].t >= ZK_FR_MFMA_FROM) mf_upload(canon.data(), off[k].c, off[k].m, off[k].p, (int)off[k].t, NRP[k], prm[k]);
+        prm[k] = {off[k].t, NRP[k], d_all + off[k].c, d_all + off[k].m, d_all + off[k].p, d_all + off[k].s, coef, rebw, co_phase1(NRP[k]), nullptr, nullptr, nullptr, nullptr, nullptr};
+        if ((int)off[k].t >= ZK_FR_MFMA_FROM) mf_upload(canon.data(), off[k].c, off[k].m, off[k].p, off[k].s, (int)off[k].t, NRP[k], prm[k]);
         hipLaunchKernelGGL(coop_tables_kernel, dim3(NRP[k] + 32), dim3(64), 0, nullptr, prm[k], coef, rebw);
         ZK_HIP(hipGetLastError());
     }
