@@ -49,15 +49,35 @@ inline MfInt mf_modulus() {
 }
 inline MfInt mf_addmod(const MfInt& a, const MfInt& b, const MfInt& q) { MfInt s = mf_add(a, b); return mf_less(s, q) ? s : mf_sub(s, q); }
 inline MfInt mf_dblmod(const MfInt& a, const MfInt& q) { return mf_addmod(a, a, q); }
-inline MfInt mf_mulmod(const MfInt& a, const MfInt& b, const MfInt& q) {                            // a, b < q
+// t mod q for 0 <= t < 2^40 q: the quotient estimated from the top 128 bits (never too large, at most a few too small)
+inline MfInt mf_reduce_small(MfInt t, const MfInt& q) {
+    const unsigned __int128 th = ((unsigned __int128)t.w[4] << 64) | t.w[3];
+    const u64 k = (u64)(th / ((unsigned __int128)q.w[3] + 1));
+    MfInt kq = mf_zero(); unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (unsigned __int128)q.w[i] * k; kq.w[i] = (u64)c; c >>= 64; }
+    kq.w[4] = (u64)c;
+    t = mf_sub(t, kq);
+    while (!mf_less(t, q)) t = mf_sub(t, q);
+    return t;
+}
+inline MfInt mf_mulsmall(const MfInt& a, u64 k, const MfInt& q) {                                   // a k mod q, a < q, k < 2^40
+    MfInt t = mf_zero(); unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) { c += (unsigned __int128)a.w[i] * k; t.w[i] = (u64)c; c >>= 64; }
+    t.w[4] = (u64)c;
+    return mf_reduce_small(t, q);
+}
+inline MfInt mf_shlmod(MfInt a, int k, const MfInt& q) {                                            // a 2^k mod q
+    for (; k >= 32; k -= 32) a = mf_mulsmall(a, 1ull << 32, q);
+    return k ? mf_mulsmall(a, 1ull << k, q) : a;
+}
+inline MfInt mf_mulmod(const MfInt& a, const MfInt& b, const MfInt& q) {                            // a, b < q: Horner over b's 32-bit words
     MfInt r = mf_zero();
-    for (int bit = 255; bit >= 0; --bit) {
-        r = mf_dblmod(r, q);
-        if ((b.w[bit >> 6] >> (bit & 63)) & 1) r = mf_addmod(r, a, q);
+    for (int i = 7; i >= 0; --i) {
+        r = mf_mulsmall(r, 1ull << 32, q);
+        r = mf_addmod(r, mf_mulsmall(a, (u32)(b.w[i >> 1] >> (32 * (i & 1))), q), q);
     }
     return r;
 }
-inline MfInt mf_shlmod(MfInt a, int k, const MfInt& q) { while (k-- > 0) a = mf_dblmod(a, q); return a; }
 inline MfInt mf_from_bytes(const unsigned char* p) {                                                 // 32 bytes, little endian, < q
     MfInt r = mf_zero();
     for (int i = 0; i < 32; ++i) r.w[i >> 3] |= (u64)p[i] << (8 * (i & 7));
@@ -67,16 +87,13 @@ inline MfInt mf_from_bytes(const unsigned char* p) {                            
 inline bool mf_digits(const MfInt& v, const MfInt& q, signed char* dg) {
     MfInt s = v;
     if (mf_less(mf_sub(q, v), v)) s = mf_sub(v, q);                                                  // q - v < v: take v - q
-    for (int d = 0; d < 32; ++d) {
-        const int low = (int)(s.w[0] & 0xFF), g = low >= 128 ? low - 256 : low;
-        dg[d] = (signed char)g;
-        MfInt gg = mf_zero(); gg.w[0] = (u64)(long long)g; if (g < 0) for (int i = 1; i < 5; ++i) gg.w[i] = ~0ull;
-        s = mf_sub(s, gg);
-        const u64 sign = mf_negative(s) ? 0xFF00000000000000ull : 0;
-        for (int i = 0; i < 5; ++i) s.w[i] = (s.w[i] >> 8) | (i + 1 < 5 ? s.w[i + 1] << 56 : sign);
+    int carry = 0;
+    for (int d = 0; d < 32; ++d) {                                                                   // two's complement bytes, carry = 1 after a digit taken negative
+        const int t = (int)((s.w[d >> 3] >> (8 * (d & 7))) & 0xFF) + carry;
+        carry = t >= 128;
+        dg[d] = (signed char)(carry ? t - 256 : t);
     }
-    for (int i = 0; i < 5; ++i) if (s.w[i]) return false;
-    return true;
+    return carry ? s.w[4] == ~0ull : s.w[4] == 0;                                                    // what is left: the sign bytes + carry = 0
 }
 
 // One matrix: frag [T][T][64 lanes][16 bytes]; corr[o] = 128 * sum of the row's constants (mod r).  mat: T * T canonical 32-byte
@@ -92,7 +109,7 @@ inline std::string mf_build_matrix(const unsigned char* mat, int T, signed char*
             for (int b = 0; b < 32; ++b) {
                 if (!mf_digits(v, q, &dig[(size_t)b * 32])) return "a constant does not fit 32 balanced digits";
                 for (int d = 0; d < 32; ++d) colabs[d] += dig[(size_t)b * 32 + d] < 0 ? -dig[(size_t)b * 32 + d] : dig[(size_t)b * 32 + d];
-                corr[o] = mf_addmod(corr[o], mf_shlmod(v, 7, q), q);                                // 128 v
+                corr[o] = mf_addmod(corr[o], v, q);
                 v = mf_shlmod(v, 8, q);
             }
             // fragment (o, j): lane l -> row m = l & 31 = digit 16 H + idx, K half h = l >> 5 = bytes 16 h .. 16 h + 15
@@ -102,6 +119,7 @@ inline std::string mf_build_matrix(const unsigned char* mat, int T, signed char*
             }
         }
         for (int d = 0; d < 32; ++d) if (128 * colabs[d] >= (1ll << 23) - (1ll << 15)) return "a digit column could leave the range of the recombination";
+        corr[o] = mf_shlmod(corr[o], 7, q);                                                         // 128 x the sum of the row's constants
     }
     return "";
 }

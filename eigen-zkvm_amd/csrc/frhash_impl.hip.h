@@ -885,7 +885,7 @@ void FH_FN(merkelize_dev)(const u64* d_rows, uint32_t width, uint64_t height, u6
         static const bool level_reg = !getenv("ZK_FR_LEVEL_REG") || atoi(getenv("ZK_FR_LEVEL_REG"));   // tuning knob: 0 = the generic one-lane kernel
         static const u64 coop_upto = getenv("ZK_FR_LEVEL_COOP") ? strtoull(getenv("ZK_FR_LEVEL_COOP"), nullptr, 10) : 16384;
         static const u64 grp_from = getenv("ZK_FR_LEVEL_GRP_FROM") ? strtoull(getenv("ZK_FR_LEVEL_GRP_FROM"), nullptr, 10) : 2561;    // tuning knobs: parents from .. upto take
-        static const u64 grp_upto = getenv("ZK_FR_LEVEL_GRP_UPTO") ? strtoull(getenv("ZK_FR_LEVEL_GRP_UPTO"), nullptr, 10) : 32768;   // eight lanes each (0 upto = never)
+        static const u64 grp_upto = getenv("ZK_FR_LEVEL_GRP_UPTO") ? strtoull(getenv("ZK_FR_LEVEL_GRP_UPTO"), nullptr, 10) : 16384;   // eight lanes each (0 upto = never); round 6: 32768 -> 16384, the one-lane kernel on the matrix pipe takes 32 768 parents in 1.0 ms against 1.9
         if (next >= grp_from && next <= grp_upto)
             hipLaunchKernelGGL(bn128_level_grp_kernel<8>, dim3((unsigned)((next + 7) / 8)), dim3(64), 0, st, d_nodes + 4 * p_in, next, d_nodes + 4 * p_out);
         else if (next <= coop_upto)  // latency-bound: one wave per parent

@@ -78,7 +78,7 @@ def test_merkle_root_known_answer(zk, orc):
 @pytest.mark.parametrize("height,width", [(1, 5), (16, 3), (17, 50), (33, 6), (256, 9), (257, 12), (4096, 20), (5000, 1), (1000, 0),
                                           (128, 3072), (3, 49), (4097, 49), (4096, 145), (2, 7),    # few wide rows: one wave per row
                                           (4097, 27), (4100, 37), (4099, 48),                       # one sponge step of 9 / 13 / 16 blocks, state in registers
-                                          (45000, 3), (262160, 2), (524304, 2)])                    # levels of 2813 and 16385 parents (eight lanes each, ragged) and 32770 (one lane each, registers)
+                                          (45000, 3), (262144, 2), (262160, 2), (524304, 2)])       # levels of 2813 and 16384 parents (eight lanes each), 16385 and 32770 (one lane each, registers, ragged)
 def test_merkle_tree_matches_oracle(zk, orc, height, width):
     h = orc.bn128()
     rng = np.random.default_rng(height * 100 + width)
