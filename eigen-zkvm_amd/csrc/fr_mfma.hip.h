@@ -320,7 +320,7 @@ __device__ __forceinline__ u64 mf_mad_i64(int a, int b, u64 c) {          // a *
     return d;
 }
 __device__ __forceinline__ void mf_swap32(u32& a, u32& b) {                // a's lanes 32..63 <-> b's lanes 0..31
-    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);   // (as inline assembly the swap escaped the compiler's hazard handling: wrong digests at t = 17)
     a = r[0]; b = r[1];
 }
 // the 32 bytes of x (< 2^256, limbs normalised) as this lane's share of the two B operands
@@ -450,14 +450,18 @@ __host__ __device__ constexpr u32 mf_rinv32() {                            // -r
     for (int i = 0; i < 6; ++i) inv *= 2 - mf_r32(0) * inv;
     return 0u - inv;
 }
-// eight words of weight 2^(32 q), each < 2^49, holding 2^32 * (the output) -> the output in eight 32-bit words, < 2^242 + r
-__device__ __forceinline__ void mf_reduce_words(const u64 (&W)[8], u32 (&out)[8]) {
+// eight words of weight 2^(32 q), each < 2^49 (lo | hi halves), holding 2^32 * (the output) -> the output in eight 32-bit words, < 2^242 + r
+__device__ __forceinline__ void mf_reduce_words(const u32 (&lo)[8], const u32 (&hi)[8], u32 (&out)[8]) {
     u32 v[9];
-    u64 acc = W[0];
-    v[0] = (u32)acc;
+    v[0] = lo[0];
+    u32 c = hi[0];                                                         // what moves up a word: < 2^18
 #pragma unroll
-    for (int q = 1; q < 8; ++q) { acc = W[q] + (acc >> 32); v[q] = (u32)acc; }
-    v[8] = (u32)(acc >> 32);
+    for (int q = 1; q < 8; ++q) {
+        const u32 x = lo[q] + c;
+        c = hi[q] + (x < c ? 1u : 0u);
+        v[q] = x;
+    }
+    v[8] = c;
     const u32 m = v[0] * mf_rinv32();
     u64 t = (u64)m * mf_r32(0) + v[0];                                     // low word zero
 #pragma unroll
@@ -496,19 +500,24 @@ __device__ __forceinline__ fe mf_fe_from_b(const mf_v4i& b0, const mf_v4i& b1) {
 }
 // two tiles' accumulators of one output -> the lane's own eight words of it
 __device__ __forceinline__ void mf_output_words(const mf_v16i& acc0, const mf_v16i& acc1, const u64* __restrict__ Ko, int one, int s16, u32 (&out)[8]) {
-    u64 Wa[4], Wb[4], W[8];
+    u64 Wa[4], Wb[4];
     mf_words(acc0, Ko, one, s16, Wa);
     mf_words(acc1, Ko, one, s16, Wb);
+    u32 lo[8], hi[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        u32 a0 = (u32)Wa[g], a1 = (u32)(Wa[g] >> 32), b0 = (u32)Wb[g], b1 = (u32)(Wb[g] >> 32);
-        mf_swap32(a0, b0); mf_swap32(a1, b1);
-        W[g] = ((u64)a1 << 32) | a0; W[4 + g] = ((u64)b1 << 32) | b0;
+        lo[g] = (u32)Wa[g]; hi[g] = (u32)(Wa[g] >> 32); lo[4 + g] = (u32)Wb[g]; hi[4 + g] = (u32)(Wb[g] >> 32);
+        mf_swap32(lo[g], lo[4 + g]); mf_swap32(hi[g], hi[4 + g]);         // now [0..3] = the lane's own words 0..3, [4..7] = its own words 4..7, in both halves
     }
-    mf_reduce_words(W, out);
+    mf_reduce_words(lo, hi, out);
 }
 // All n_rp sparse rounds on st (words < 2^256 in; < 2^242 + r out, limbs normalised).  tab: the rounds' blocks (mf_build_sparse, global
 // memory), ident: the unit's fragment, abuf: two blocks' worth of LDS.  The whole block of 256 threads must be here.
+#if ZK_MF_DBG == 11
+#define MF_MFMA(a, b, c, x, y, z) ((c) + (a)[0] + (b)[1])
+#else
+#define MF_MFMA __builtin_amdgcn_mfma_i32_32x32x32_i8
+#endif
 template <int T>
 __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict__ tab, const mf_v4i* __restrict__ ident, mf_v4i* abuf, u32 n_rp) {
     constexpr int PER = (2 * T - 1) * 64 + 4 * T, NLD = (PER + 255) / 256;   // a round's block in 16-byte words
@@ -533,41 +542,58 @@ __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict_
     asm volatile("" : "+v"(one), "+v"(s16));
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 r = 0; r < n_rp; ++r) {
+#if ZK_MF_DBG != 13
         if (r + 1 < n_rp) fetch(r + 1);
-        pow5(s0);
-        mf_v4i P0, P1;
-        mf_make_b(s0, P0, P1);
+#endif
         const mf_v4i* __restrict__ fr = abuf + (r & 1) * PER + lane;
         const u64* __restrict__ Kr = reinterpret_cast<const u64*>(abuf + (r & 1) * PER + (2 * T - 1) * 64) + 4 * H;
-        {   // the row: every word
-            mf_v16i acc0 = {}, acc1 = {};
+        // the row's products with the words that do not pass the S-box go first: the matrix pipe works through them under the S-box
+        mf_v16i row0 = {}, row1 = {};
+        fh_static_for<1, T>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const mf_v4i a = fr[j * 64];
+            row0 = MF_MFMA(a, B0[j], row0, 0, 0, 0);
+            row1 = MF_MFMA(a, B1[j], row1, 0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+#if ZK_MF_DBG != 12
+        pow5(s0);
+#endif
+        mf_v4i P0, P1;
+        mf_make_b(s0, P0, P1);
+        {
             const mf_v4i a0 = fr[0];
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P1, acc1, 0, 0, 0);
-            fh_static_for<1, T>([&](auto J) {
-                constexpr int j = decltype(J)::value;
-                const mf_v4i a = fr[j * 64];
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], acc1, 0, 0, 0);
-            });
+            row0 = MF_MFMA(a0, P0, row0, 0, 0, 0);
+            row1 = MF_MFMA(a0, P1, row1, 0, 0, 0);
+        }
+        // columns k: S'[k] x_0^5 + x_k, the products of column k + 1 issued before column k is put together
+        mf_v16i ca0[2], ca1[2];
+        auto issue = [&](auto KK, int slot) {
+            constexpr int k = decltype(KK)::value;
+            const mf_v4i a = fr[(T + k - 1) * 64];
+            ca0[slot] = MF_MFMA(a, P0, (mf_v16i{}), 0, 0, 0);
+            ca1[slot] = MF_MFMA(a, P1, (mf_v16i{}), 0, 0, 0);
+            ca0[slot] = MF_MFMA(aI, B0[k], ca0[slot], 0, 0, 0);
+            ca1[slot] = MF_MFMA(aI, B1[k], ca1[slot], 0, 0, 0);
+        };
+        issue(std::integral_constant<int, 1>{}, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
             u32 w[8];
-            mf_output_words(acc0, acc1, Kr, one, s16, w);
+            mf_output_words(row0, row1, Kr, one, s16, w);
             s0 = mf_words_to_fe(w);
         }
-        fh_static_for<1, T>([&](auto KK) {   // column k: S'[k] x_0^5 + x_k
+        fh_static_for<1, T>([&](auto KK) {
             constexpr int k = decltype(KK)::value;
-            mf_v16i acc0 = {}, acc1 = {};
-            const mf_v4i a = fr[(T + k - 1) * 64];
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P1, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B0[k], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B1[k], acc1, 0, 0, 0);
+            if constexpr (k + 1 < T) { issue(std::integral_constant<int, k + 1>{}, (k + 1) & 1); __builtin_amdgcn_sched_barrier(0); }
             u32 w[8];
-            mf_output_words(acc0, acc1, Kr + 8 * k, one, s16, w);
+            mf_output_words(ca0[k & 1], ca1[k & 1], Kr + 8 * k, one, s16, w);
             mf_b_from_words(w, B0[k], B1[k]);
         });
+#if ZK_MF_DBG != 13
         if (r + 1 < n_rp) stash(r + 1);
         __syncthreads();
+#endif
     }
     st[0] = s0;
     fh_static_for<1, T>([&](auto J) { constexpr int j = decltype(J)::value; st[j] = mf_fe_from_b(B0[j], B1[j]); });
