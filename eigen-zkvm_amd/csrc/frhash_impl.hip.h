@@ -281,9 +281,16 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
     }
 }
 // LinearHashBN128::hash_element_array for rows of 5 <= width <= 24 columns: one sponge step of t = NB + 1
-// (waves per SIMD the register budget is held to: what the vector-pipe form of the same t reached -- left alone the matrix-pipe form of t = 5 took 254 registers)
+#ifndef ZK_LB3
+#define ZK_LB3 4
+#endif
+#ifndef ZK_LB2
+#define ZK_LB2 12
+#endif
+// (waves per SIMD the register budget is held to, measured per block count: three up to 4 blocks -- left alone t = 5 took 254 registers --, two up to 12
+// blocks: 2^20 x 24 9.4 -> 7.9 ms, x 33 11.5 -> 10.3; from 13 blocks on two waves spill: x 48 16.8 -> 22.5 ms)
 template <int NB>
-__global__ __launch_bounds__(256, NB <= 4 ? 3 : NB <= 7 ? 2 : 1) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+__global__ __launch_bounds__(256, NB <= ZK_LB3 ? 3 : NB <= ZK_LB2 ? 2 : 1) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
     __shared__ __attribute__((aligned(16))) u32 lds[REG_LDS_WORDS<NB + 1>];
     const fe* tab = reg_tables_to_lds<NB + 1>(lds);
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = i0 < height ? i0 : height - 1;   // idle lanes shadow the last row: the matrix pipe wants whole waves
