@@ -58,6 +58,19 @@ def run(seed, rounds, verbose=True):
             t = zk.MerkleTreeBN128(field=fld); t.merkelize(rows, w, h)
             check("merkle_" + fld, np.array_equal(t.nodes(), hb[fld].merkelize(rows, w, h)), h, w)
             t.free()
+        if r % 25 == 0:                                                         # the one-lane kernels (matrix pipe since round 6): one sponge step on more than 4096 rows,
+            for fld in ("bn128", "bls12381"):                                   # ragged heights, extreme words; every 100th round a level of more than 16 384 parents
+                big = r % 100 == 0
+                h = int(rng.integers(262145, 270000)) if big else int(rng.integers(4097, 9000))
+                w = int(rng.integers(1, 5)) if big else int(rng.integers(5, 49))
+                rows = R(h * w)
+                for k in range(int(rng.integers(0, 6))):
+                    rows[int(rng.integers(0, h * w))] = [0, P - 1, 0xFFFFFFFF, 0x8080808080808080 % P, 1][int(rng.integers(0, 5))]
+                if rng.integers(0, 2):
+                    rows[(h - 1) * w:] = P - 1                                  # the last row is the one idle lanes shadow
+                t = zk.MerkleTreeBN128(field=fld); t.merkelize(rows, w, h)
+                check("merkle_tall_" + fld, np.array_equal(t.nodes(), hb[fld].merkelize(rows, w, h)), h, w)
+                t.free()
         n = int(rng.integers(1, 300))
         a, d = int(rng.integers(1, 1000)), int(rng.integers(0, 1000))
         bases = orc.bn254_make_bases(n, a, d)
