@@ -16,9 +16,6 @@
 //     on the way out (each forms the low / high four words of both outputs).
 // Every lane of the wave must take part.
 
-#ifndef ZK_MF_DBG
-#define ZK_MF_DBG 0
-#endif
 typedef int mf_v4i __attribute__((ext_vector_type(4)));
 typedef int mf_v16i __attribute__((ext_vector_type(16)));
 
@@ -379,9 +376,6 @@ __device__ __forceinline__ fe mf_reduce(const u64 (&W)[8]) {
 template <int T>
 __device__ __forceinline__ void mf_dense(fe (&st)[T], const mf_v4i* __restrict__ frag, const u64* __restrict__ K, mf_v4i* abuf) {
     constexpr int PER = T * 64, NLD = (PER + 255) / 256;                   // fragments' 16-byte words per output; loads per thread (block of 256)
-#if ZK_MF_DBG == 1
-    return;
-#endif
     const int lane = threadIdx.x & 63, H = lane >> 5;
     mf_v4i pf[NLD];
     auto fetch = [&](int o) {
@@ -401,20 +395,14 @@ __device__ __forceinline__ void mf_dense(fe (&st)[T], const mf_v4i* __restrict__
     asm volatile("" : "+v"(one), "+v"(s16));
     fh_static_for<0, T>([&](auto O) {
         constexpr int o = decltype(O)::value;
-#if ZK_MF_DBG != 3
         if constexpr (o + 1 < T) fetch(o + 1);
-#endif
         const mf_v4i* __restrict__ fr = abuf + (o & 1) * PER + lane;
         mf_v16i acc0 = {}, acc1 = {};
         fh_static_for<0, T>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const mf_v4i a = fr[j * 64];
-#if ZK_MF_DBG == 2
-            acc0[j & 15] += a[0] + B0[j][0]; acc1[j & 15] += a[1] + B1[j][1];
-#else
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], acc1, 0, 0, 0);
-#endif
         });
         const u64* __restrict__ Ko = K + 8 * o + 4 * H;
         u64 Wa[4], Wb[4];
@@ -428,9 +416,7 @@ __device__ __forceinline__ void mf_dense(fe (&st)[T], const mf_v4i* __restrict__
             W[g] = ((u64)a1 << 32) | a0; W[4 + g] = ((u64)b1 << 32) | b0;
         }
         st[o] = mf_reduce(W);
-#if ZK_MF_DBG != 3
         if constexpr (o + 1 < T) { stash(o + 1); __syncthreads(); }        // the other buffer: its last readers passed the previous barrier
-#endif
     });
     __syncthreads();                                                       // the next layer's first stash must not overtake this layer's last reads
 }
@@ -513,11 +499,6 @@ __device__ __forceinline__ void mf_output_words(const mf_v16i& acc0, const mf_v1
 }
 // All n_rp sparse rounds on st (words < 2^256 in; < 2^242 + r out, limbs normalised).  tab: the rounds' blocks (mf_build_sparse, global
 // memory), ident: the unit's fragment, abuf: two blocks' worth of LDS.  The whole block of 256 threads must be here.
-#if ZK_MF_DBG == 11
-#define MF_MFMA(a, b, c, x, y, z) ((c) + (a)[0] + (b)[1])
-#else
-#define MF_MFMA __builtin_amdgcn_mfma_i32_32x32x32_i8
-#endif
 template <int T>
 __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict__ tab, const mf_v4i* __restrict__ ident, mf_v4i* abuf, u32 n_rp) {
     constexpr int PER = (2 * T - 1) * 64 + 4 * T, NLD = (PER + 255) / 256;   // a round's block in 16-byte words
@@ -542,9 +523,7 @@ __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict_
     asm volatile("" : "+v"(one), "+v"(s16));
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
     for (u32 r = 0; r < n_rp; ++r) {
-#if ZK_MF_DBG != 13
         if (r + 1 < n_rp) fetch(r + 1);
-#endif
         const mf_v4i* __restrict__ fr = abuf + (r & 1) * PER + lane;
         const u64* __restrict__ Kr = reinterpret_cast<const u64*>(abuf + (r & 1) * PER + (2 * T - 1) * 64) + 4 * H;
         // the row's products with the words that do not pass the S-box go first: the matrix pipe works through them under the S-box
@@ -552,29 +531,27 @@ __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict_
         fh_static_for<1, T>([&](auto J) {
             constexpr int j = decltype(J)::value;
             const mf_v4i a = fr[j * 64];
-            row0 = MF_MFMA(a, B0[j], row0, 0, 0, 0);
-            row1 = MF_MFMA(a, B1[j], row1, 0, 0, 0);
+            row0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B0[j], row0, 0, 0, 0);
+            row1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, B1[j], row1, 0, 0, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
-#if ZK_MF_DBG != 12
         pow5(s0);
-#endif
         mf_v4i P0, P1;
         mf_make_b(s0, P0, P1);
         {
             const mf_v4i a0 = fr[0];
-            row0 = MF_MFMA(a0, P0, row0, 0, 0, 0);
-            row1 = MF_MFMA(a0, P1, row1, 0, 0, 0);
+            row0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P0, row0, 0, 0, 0);
+            row1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, P1, row1, 0, 0, 0);
         }
         // columns k: S'[k] x_0^5 + x_k, the products of column k + 1 issued before column k is put together
         mf_v16i ca0[2], ca1[2];
         auto issue = [&](auto KK, int slot) {
             constexpr int k = decltype(KK)::value;
             const mf_v4i a = fr[(T + k - 1) * 64];
-            ca0[slot] = MF_MFMA(a, P0, (mf_v16i{}), 0, 0, 0);
-            ca1[slot] = MF_MFMA(a, P1, (mf_v16i{}), 0, 0, 0);
-            ca0[slot] = MF_MFMA(aI, B0[k], ca0[slot], 0, 0, 0);
-            ca1[slot] = MF_MFMA(aI, B1[k], ca1[slot], 0, 0, 0);
+            ca0[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P0, (mf_v16i{}), 0, 0, 0);
+            ca1[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, P1, (mf_v16i{}), 0, 0, 0);
+            ca0[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B0[k], ca0[slot], 0, 0, 0);
+            ca1[slot] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aI, B1[k], ca1[slot], 0, 0, 0);
         };
         issue(std::integral_constant<int, 1>{}, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -590,10 +567,8 @@ __device__ __forceinline__ void mf_sparse(fe (&st)[T], const mf_v4i* __restrict_
             mf_output_words(ca0[k & 1], ca1[k & 1], Kr + 8 * k, one, s16, w);
             mf_b_from_words(w, B0[k], B1[k]);
         });
-#if ZK_MF_DBG != 13
         if (r + 1 < n_rp) stash(r + 1);
         __syncthreads();
-#endif
     }
     st[0] = s0;
     fh_static_for<1, T>([&](auto J) { constexpr int j = decltype(J)::value; st[j] = mf_fe_from_b(B0[j], B1[j]); });

@@ -238,22 +238,11 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
                 const u32 n = P.n_rp - r < CO_RENORM ? P.n_rp - r : CO_RENORM;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (u32 q = 0; q < n; ++q, ++r) {
-#if ZK_MF_DBG == 4
-                    continue;
-#endif
-#if ZK_MF_DBG != 8
                     pow5(st[0]);
-#endif
                     st[0] = fe_add(st[0], P.c[5 * T + r]);
                     const fe* __restrict__ S = P.s + (size_t)(2 * T - 1) * r;
-#if ZK_MF_DBG == 7
-                    const fe s0 = fe_add(st[0], S[0]);
-#else
                     const fe s0 = reg_dot<T, true>(S, 1, st, DOT_SPARSE_REG);
-#endif
-#if ZK_MF_DBG != 6
                     fh_static_for<1, T>([&](auto K) { constexpr int k = decltype(K)::value; st[k] = fe_mul_acc(S[T + k - 1], st[0], st[k]); });
-#endif
                     st[0] = s0;
                 }
                 reg_renorm_tail<T>(st);
@@ -265,9 +254,7 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (int i = 0; i < T; ++i) {
             fe x = st[0];
-#if ZK_MF_DBG != 5
             pow5(x);
-#endif
             if (!MF && has_c) x = fe_add(x, c[i]);                          // matrix pipe: the constants' image rides on the layer's addends
             reg_rotate_in<T>(st, x);
         }
@@ -290,20 +277,43 @@ __device__ __forceinline__ void poseidon_fr_reg(fe (&st)[T], const fe* __restric
 // (waves per SIMD the register budget is held to, measured per block count: three up to 4 blocks -- left alone t = 5 took 254 registers --, two up to 12
 // blocks: 2^20 x 24 9.4 -> 7.9 ms, x 33 11.5 -> 10.3; from 13 blocks on two waves spill: x 48 16.8 -> 22.5 ms)
 template <int NB>
-__global__ __launch_bounds__(256, NB <= ZK_LB3 ? 3 : NB <= ZK_LB2 ? 2 : 1) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests) {
+__global__ __launch_bounds__(256, NB <= ZK_LB3 ? 3 : NB <= ZK_LB2 ? 2 : 1) void bn128_leaf_reg_kernel(const u64* __restrict__ rows, u32 width, u64 height, u64* __restrict__ digests,
+                                                                                                     u32 col0 /* first column of this, the row's last, sponge step */) {
     __shared__ __attribute__((aligned(16))) u32 lds[REG_LDS_WORDS<NB + 1>];
     const fe* tab = reg_tables_to_lds<NB + 1>(lds);
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = i0 < height ? i0 : height - 1;   // idle lanes shadow the last row: the matrix pipe wants whole waves
     const u64* __restrict__ v = rows + i * width;
     fe st[NB + 1];
-    st[0] = fe_zero();
+    st[0] = col0 ? load_raw(digests + 4 * i) : fe_zero();                   // the digest of the steps before (bn128_leaf_reg_steps_kernel)
     fh_static_for<0, NB>([&](auto K) {
         constexpr int k = decltype(K)::value;
-        const u32 at = 3 * k, len = width - at < 3 ? width - at : 3;
+        const u32 at = col0 + 3 * k, len = width - at < 3 ? width - at : 3;
         st[k + 1] = words_to_fe(v + at, len);
     });
     poseidon_fr_reg<NB + 1>(st, tab);
     if (i0 < height) store_raw(st[FH_OUT_IDX], digests + 4 * i);
+}
+// rows of more than 48 columns on tall trees: the full sponge steps (16 blocks each, t = 17) of a row one after the other in one lane; the
+// last, shorter step is bn128_leaf_reg_kernel<its blocks> on the digest left here.  (Through round 5 these rows took the generic kernel
+// with the state in scratch: 2^20 x 49 52.8 ms against 16.8 for 48 columns.)
+__global__ __launch_bounds__(256) void bn128_leaf_reg_steps_kernel(const u64* __restrict__ rows, u32 width, u64 height, u32 n_steps, u64* __restrict__ digests) {
+    __shared__ __attribute__((aligned(16))) u32 lds[REG_LDS_WORDS<17>];
+    const fe* tab = reg_tables_to_lds<17>(lds);
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x, i = i0 < height ? i0 : height - 1;
+    const u64* __restrict__ v = rows + i * width;
+    fe st[17];
+    st[0] = fe_zero();
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (u32 s = 0; s < n_steps; ++s) {
+        fh_static_for<0, 16>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const u32 at = 48 * s + 3 * k, len = width - at < 3 ? width - at : 3;
+            st[k + 1] = words_to_fe(v + at, len);
+        });
+        poseidon_fr_reg<17>(st, tab);
+        st[0] = st[FH_OUT_IDX];                                             // Poseidon::hash
+    }
+    if (i0 < height) store_raw(st[0], digests + 4 * i);
 }
 
 // hash_node (linearhash_bn128.rs:93-103): parent i = Poseidon(16 digests, init 0)
@@ -858,25 +868,24 @@ void FH_FN(linearhash_rows_dev)(const u64* d_rows, uint32_t width, uint64_t heig
         ZK_HIP(hipGetLastError());
         return;
     }
-    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 16;   // tuning knob: largest block count that takes the register kernels
-    switch (width > 4 && (int)nb <= reg_max ? nb : 0) {   // one sponge step with the state in registers; wider rows (and width <= 4: no hash) take the generic kernel
-        case 2: hipLaunchKernelGGL(bn128_leaf_reg_kernel<2>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 3: hipLaunchKernelGGL(bn128_leaf_reg_kernel<3>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 4: hipLaunchKernelGGL(bn128_leaf_reg_kernel<4>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 5: hipLaunchKernelGGL(bn128_leaf_reg_kernel<5>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 6: hipLaunchKernelGGL(bn128_leaf_reg_kernel<6>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 7: hipLaunchKernelGGL(bn128_leaf_reg_kernel<7>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 8: hipLaunchKernelGGL(bn128_leaf_reg_kernel<8>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 9: hipLaunchKernelGGL(bn128_leaf_reg_kernel<9>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 10: hipLaunchKernelGGL(bn128_leaf_reg_kernel<10>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 11: hipLaunchKernelGGL(bn128_leaf_reg_kernel<11>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 12: hipLaunchKernelGGL(bn128_leaf_reg_kernel<12>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 13: hipLaunchKernelGGL(bn128_leaf_reg_kernel<13>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 14: hipLaunchKernelGGL(bn128_leaf_reg_kernel<14>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 15: hipLaunchKernelGGL(bn128_leaf_reg_kernel<15>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        case 16: hipLaunchKernelGGL(bn128_leaf_reg_kernel<16>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests); break;
-        default: hipLaunchKernelGGL(bn128_leaf_kernel, grid, blk, 0, st, d_rows, width, height, d_digests);
+    static const int reg_max = getenv("ZK_FRHASH_REG_MAX") ? atoi(getenv("ZK_FRHASH_REG_MAX")) : 1 << 30;   // tuning knob: largest block count that takes the register kernels
+    if (width <= 4 || (int)nb > reg_max) {   // width <= 4: no hash
+        hipLaunchKernelGGL(bn128_leaf_kernel, grid, blk, 0, st, d_rows, width, height, d_digests);
+        ZK_HIP(hipGetLastError());
+        return;
     }
+    // one sponge step with the state in registers; rows of more than 16 blocks: their full steps first, the digest handed on through d_digests
+    const u32 n_steps = (nb - 1) / 16, last = nb - 16 * n_steps, col0 = 48 * n_steps;       // last = 1..16 blocks
+    if (n_steps) {
+        hipLaunchKernelGGL(bn128_leaf_reg_steps_kernel, grid_reg, dim3(256), 0, st, d_rows, width, height, n_steps, d_digests);
+        ZK_HIP(hipGetLastError());
+    }
+#define ZK_LEAF_REG(N) case N: hipLaunchKernelGGL(bn128_leaf_reg_kernel<N>, grid_reg, dim3(256), 0, st, d_rows, width, height, d_digests, col0); break;
+    switch (last) {
+        ZK_LEAF_REG(1) ZK_LEAF_REG(2) ZK_LEAF_REG(3) ZK_LEAF_REG(4) ZK_LEAF_REG(5) ZK_LEAF_REG(6) ZK_LEAF_REG(7) ZK_LEAF_REG(8)
+        ZK_LEAF_REG(9) ZK_LEAF_REG(10) ZK_LEAF_REG(11) ZK_LEAF_REG(12) ZK_LEAF_REG(13) ZK_LEAF_REG(14) ZK_LEAF_REG(15) ZK_LEAF_REG(16)
+    }
+#undef ZK_LEAF_REG
     ZK_HIP(hipGetLastError());
 }
 

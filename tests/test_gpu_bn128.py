@@ -78,6 +78,7 @@ def test_merkle_root_known_answer(zk, orc):
 @pytest.mark.parametrize("height,width", [(1, 5), (16, 3), (17, 50), (33, 6), (256, 9), (257, 12), (4096, 20), (5000, 1), (1000, 0),
                                           (128, 3072), (3, 49), (4097, 49), (4096, 145), (2, 7),    # few wide rows: one wave per row
                                           (4097, 27), (4100, 37), (4099, 48),                       # one sponge step of 9 / 13 / 16 blocks, state in registers
+                                          (4101, 96), (4098, 130), (4099, 52), (4100, 147),         # tall and wide: full steps in one kernel, the last (16 / 12 / 2 / 1 blocks) in another
                                           (45000, 3), (262144, 2), (262160, 2), (524304, 2)])       # levels of 2813 and 16384 parents (eight lanes each), 16385 and 32770 (one lane each, registers, ragged)
 def test_merkle_tree_matches_oracle(zk, orc, height, width):
     h = orc.bn128()
@@ -170,7 +171,7 @@ def test_bls12381_merkle_known_answer_and_oracle(zk, orc, bls):
     i, j = np.meshgrid(np.arange(4, dtype=np.uint64), np.arange(3, dtype=np.uint64), indexing="ij")
     t = zk.MerkleTreeBN128(field=bls); t.merkelize((i + j * np.uint64(10) + np.uint64(1)).reshape(-1), 3, 4)
     assert h.from_mont(t.root()) == 32227206116237215740162377531481191838063909532381497804787245624658969614932   # merklehash_bls12381.rs:274-300
-    for height, width in ((33, 6), (257, 12), (4096, 20), (5000, 1), (4100, 37), (45000, 3), (524304, 2)):   # the last three: as in test_merkle_tree_matches_oracle
+    for height, width in ((33, 6), (257, 12), (4096, 20), (5000, 1), (4100, 37), (4099, 49), (4098, 130), (45000, 3), (524304, 2)):   # from (4100, 37) on: as in test_merkle_tree_matches_oracle
         rng = np.random.default_rng(height + width)
         rows = rng.integers(0, P, size=height * width, dtype=np.uint64)
         t = zk.MerkleTreeBN128(field=bls); t.merkelize(rows, width, height)

@@ -62,7 +62,7 @@ def run(seed, rounds, verbose=True):
             for fld in ("bn128", "bls12381"):                                   # ragged heights, extreme words; every 100th round a level of more than 16 384 parents
                 big = r % 100 == 0
                 h = int(rng.integers(262145, 270000)) if big else int(rng.integers(4097, 9000))
-                w = int(rng.integers(1, 5)) if big else int(rng.integers(5, 49))
+                w = int(rng.integers(1, 5)) if big else int(rng.integers(5, 49)) if rng.integers(0, 3) else int(rng.integers(49, 200))
                 rows = R(h * w)
                 for k in range(int(rng.integers(0, 6))):
                     rows[int(rng.integers(0, h * w))] = [0, P - 1, 0xFFFFFFFF, 0x8080808080808080 % P, 1][int(rng.integers(0, 5))]
