@@ -7,12 +7,14 @@
 // (digest.rs:45-53); that is the format of every node buffer here.
 //
 // Mapping, by how many permutations a launch holds (frhash_impl.hip.h): one lane per permutation with the state
-// (t <= 17 elements of 9 x 29-bit limbs) in registers where throughput binds (leaves of one sponge step, levels above 32 768 parents),
-// eight lanes per permutation for levels of 2 561..32 768 parents, one wave per permutation (sparse rounds as a linear recurrence over
+// in registers where throughput binds (leaves on more than 4096 rows -- one sponge step, or the full steps of a wide row and then its last --,
+// levels above 16 384 parents): since round 6 every linear step of these kernels (the dense layers M, P and the row / column products of the
+// sparse rounds) runs on the matrix pipe from digit tables built on the host (fr_mfma.hip.h), the vector pipe keeps the S-boxes;
+// eight lanes per permutation for levels of 2 561..16 384 parents, one wave per permutation (sparse rounds as a linear recurrence over
 // the lanes) where a chain's latency binds (small levels, few wide rows, the transcript).  The parameter tables (24 060 constants,
-// converted once per device to the internal Montgomery form, plus the cooperative form's coefficient tables built from them on the
-// device) live in global memory.  Integer-ALU bound: 5 457 Fr products per one-lane t = 17 permutation, 190-230 instructions each
-// (fe29_impl.hip.h).  Value bounds are stated where the sums are formed.
+// converted once per device to the internal Montgomery form, the cooperative form's coefficient tables built from them on the
+// device, the matrix-pipe fragments of t = 3..17: ~20 MB per field) live in global memory.  Integer-ALU bound: 325 k vector instructions per
+// one-lane t = 17 permutation (1 025 k before round 6), 126 k of them the 204 S-boxes (fe29_impl.hip.h).  Value bounds are stated where the sums are formed.
 #include "zk_internal.h"
 #include <cstdio>
 #include <cstdlib>
